@@ -1,0 +1,292 @@
+r"""Generate the committed golden fixtures from the LIVE reference and pin the oracle.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+For every case it (1) evaluates the real `zuko` (v1.6.0, imported read-only from
+/root/reference) on seeded inputs, (2) evaluates `oracle/zuko_oracle.py` on the same
+inputs and REQUIRES agreement (bitwise unless noted), (3) stores inputs + reference
+outputs in tests/golden/*.npz.  Flow weights are not stored: they are re-created from
+`torch.manual_seed(seed)` by the constructor, and only a SHA-256 of the state_dict is
+committed (tests check that zuko_amd's constructors reproduce it).
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import zuko  # noqa: E402  (the real reference)
+from oracle import zuko_oracle as O  # noqa: E402
+
+
+def sd_hash(sd: dict) -> str:
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        v = sd[k]
+        if v is None:
+            continue
+        h.update(k.encode())
+        h.update(str(tuple(v.shape)).encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def same(a: torch.Tensor, b: torch.Tensor, what: str, tol: float = 0.0) -> None:
+    a, b = a.detach(), b.detach()
+    if tol == 0.0:
+        ok = torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())
+    else:
+        ok = torch.allclose(a, b, rtol=tol, atol=tol, equal_nan=True)
+    if not ok:
+        raise SystemExit(f"ORACLE != REFERENCE for {what}: max |d| = {(a - b).abs().nan_to_num().max().item():.3e}")
+
+
+def adversarial_x(hor: torch.Tensor, n: int, dtype) -> torch.Tensor:
+    """Edge inputs of SURVEY 8(d): +-B, +-B(1+-2^-23), interior knots, +-6, NaN, +-inf."""
+    eps = 2.0**-23
+    vals = [5.0, -5.0, 5.0 * (1 + eps), 5.0 * (1 - eps), -5.0 * (1 + eps), -5.0 * (1 - eps), 6.0, -6.0, float("nan"), float("inf"), float("-inf"), 0.0]
+    return torch.tensor(vals, dtype=dtype)
+
+
+def save(name: str, **arrays) -> None:
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"wrote {name}: " + ", ".join(f"{k}{tuple(np.shape(v))}" for k, v in out.items()))
+
+
+# --------------------------------------------------------------------------------------
+
+
+def gen_rqs(dtype, tag: str) -> None:
+    g = torch.Generator().manual_seed(11)
+    N, D, K = 48, 5, 8
+    w = torch.randn(N, D, K, generator=g, dtype=dtype) * 2
+    h = torch.randn(N, D, K, generator=g, dtype=dtype) * 2
+    d = torch.randn(N, D, K - 1, generator=g, dtype=dtype) * 2
+    x = torch.randn(N, D, generator=g, dtype=dtype) * 2.5
+    t = zuko.transforms.MonotonicRQSTransform(w, h, d)
+    # place edge inputs (incl. exact interior knots) in the first rows
+    adv = adversarial_x(t.horizontal, N, dtype)
+    x[: len(adv), 0] = adv
+    for i in range(2 * K):  # x exactly ON interior knots (belongs to the left bin)
+        x[i, 1] = t.horizontal[i, 1, 1 + (i % (K - 1))]
+    y, ladj = t.call_and_ladj(x)
+    k = t.searchsorted(t.horizontal, x) - 1
+    yin = torch.randn(N, D, generator=g, dtype=dtype) * 2.5
+    yin[: len(adv), 0] = adv
+    xinv = t.inv(yin)
+    kinv = t.searchsorted(t.vertical, yin) - 1
+    # oracle pin
+    hor, ver, der = O.rqs_knots(w, h, d)
+    same(hor, t.horizontal, "rqs horizontal")
+    same(ver, t.vertical, "rqs vertical")
+    same(der, t.derivatives, "rqs derivatives")
+    oy, ol, ok = O.rqs_forward_from_knots(hor, ver, der, x)
+    same(oy, y, "rqs y")
+    same(ol, ladj, "rqs ladj")
+    assert torch.equal(ok, k)
+    ox, okk = O.rqs_inverse_from_knots(hor, ver, der, yin)
+    same(ox, xinv, "rqs inverse")
+    assert torch.equal(okk, kinv)
+    # broadcast (unbatched params) case of tests/test_transforms.py:12-32
+    w1, h1, d1 = w[0, 0], h[0, 0], d[0, 0]
+    xl = torch.linspace(-5.0, 5.0, 256, dtype=dtype)
+    t1 = zuko.transforms.MonotonicRQSTransform(w1, h1, d1)
+    y1, l1 = t1.call_and_ladj(xl)
+    oy1, ol1 = O.rqs_forward(w1, h1, d1, xl)
+    same(oy1, y1, "rqs y (unbatched)")
+    same(ol1, l1, "rqs ladj (unbatched)")
+    save(
+        f"rqs_{tag}.npz", widths=w, heights=h, derivatives=d, x=x, y=y, ladj=ladj, k=k,
+        horizontal=t.horizontal, vertical=t.vertical, slopes=t.derivatives,
+        y_in=yin, x_inv=xinv, k_inv=kinv, x_lin=xl, y_lin=y1, ladj_lin=l1,
+    )
+
+
+def gen_affine(dtype, tag: str) -> None:
+    g = torch.Generator().manual_seed(12)
+    N, D = 40, 7
+    shift = torch.randn(N, D, generator=g, dtype=dtype)
+    scale = torch.randn(N, D, generator=g, dtype=dtype) * 4
+    scale[0, 0], scale[0, 1], scale[0, 2] = 50.0, -50.0, 0.0
+    x = torch.randn(N, D, generator=g, dtype=dtype) * 3
+    x[1, 0], x[1, 1], x[1, 2] = float("nan"), float("inf"), float("-inf")
+    t = zuko.transforms.MonotonicAffineTransform(shift, scale)
+    y, ladj = t.call_and_ladj(x)
+    xinv = t.inv(x)
+    oy, ol = O.affine_forward(shift, scale, x)
+    same(oy, y, "affine y")
+    same(ol, ladj, "affine ladj")
+    same(O.affine_inverse(shift, scale, x), xinv, "affine inverse")
+    save(f"affine_{tag}.npz", shift=shift, scale=scale, x=x, y=y, ladj=ladj, x_inv=xinv)
+
+
+def gen_sos(dtype, tag: str) -> None:
+    g = torch.Generator().manual_seed(13)
+    N, D = 32, 4
+    a = torch.randn(N, D, 3, 5, generator=g, dtype=dtype)
+    x = torch.randn(N, D, generator=g, dtype=dtype) * 3
+    x[0, 0], x[0, 1], x[0, 2] = 0.0, 9.5, -9.5
+    t = zuko.transforms.SOSPolynomialTransform(a)
+    y, ladj = t.call_and_ladj(x)
+    xinv = t.inv(y)
+    oy, ol = O.sos_forward(a, x)
+    same(oy, y, "sos y")
+    same(ol, ladj, "sos ladj")
+    same(O.sos_inverse(a, y), xinv, "sos inverse")
+    nodes, weights = np.polynomial.legendre.leggauss(5)
+    save(f"sos_{tag}.npz", a=a, x=x, y=y, ladj=ladj, x_inv=xinv, gl_nodes01=(nodes + 1) / 2, gl_weights01=weights / 2)
+
+
+def gen_bernstein(dtype, tag: str) -> None:
+    g = torch.Generator().manual_seed(14)
+    N, D = 32, 4
+    for bounded, name, M in ((False, "bern", 16), (True, "bbern", 17)):
+        th = torch.randn(N, D, M, generator=g, dtype=dtype)
+        x = torch.randn(N, D, generator=g, dtype=dtype) * 2.5
+        x[0, 0], x[0, 1], x[0, 2], x[0, 3] = 5.0, -5.0, 6.5, -6.5
+        x[1, 0], x[1, 1] = 4.99999, -4.99999
+        cls = zuko.transforms.BoundedBernsteinTransform if bounded else zuko.transforms.BernsteinTransform
+        t = cls(th)
+        y, ladj = t.call_and_ladj(x)
+        xinv = t.inv(y)
+        oy, ol = O.bern_forward(th, x, bounded)
+        same(oy, y, f"{name} y")
+        same(ol, ladj, f"{name} ladj")
+        same(O.bern_inverse(th, y, bounded), xinv, f"{name} inverse")
+        save(f"{name}_{tag}.npz", theta=th, x=x, y=y.detach(), ladj=ladj.detach(), x_inv=xinv.detach(), theta_constrained=t.theta.detach())
+
+
+def gen_masks() -> None:
+    """MaskedMLP / autoregressive adjacency structure (host logic)."""
+    out = {}
+    cases = {
+        "ar64": dict(features=64, context=0, total=23, hidden=(256, 256, 256), order=None, passes=None),
+        "ar3c5": dict(features=3, context=5, total=23, hidden=(128, 128, 128), order=None, passes=None),
+        "ar6desc": dict(features=6, context=2, total=2, hidden=(32, 48), order=list(range(5, -1, -1)), passes=None),
+        "ar8p2": dict(features=8, context=0, total=2, hidden=(24, 24), order=None, passes=2),
+    }
+    for name, cfg in cases.items():
+        t = zuko.flows.MaskedAutoregressiveTransform(
+            cfg["features"], cfg["context"], passes=cfg["passes"], order=cfg["order"],
+            shapes=[(cfg["total"],)] if cfg["total"] != 2 else ((), ()), hidden_features=cfg["hidden"],
+            univariate=(lambda *a: None),
+        )
+        ref_masks = [m.mask for m in t.hyper if hasattr(m, "mask")]
+        adj, order, passes = O.ar_adjacency(cfg["features"], cfg["context"], cfg["total"], cfg["order"], cfg["passes"])
+        assert torch.equal(order, t.order) and passes == t.passes
+        mine = O.masked_mlp_masks(adj, cfg["hidden"])
+        assert len(mine) == len(ref_masks)
+        for a, b in zip(mine, ref_masks):
+            assert torch.equal(a, b), name
+        for i, m in enumerate(ref_masks):
+            out[f"{name}_mask{i}"] = np.packbits(m.numpy(), axis=None)
+            out[f"{name}_shape{i}"] = np.array(m.shape)
+        out[f"{name}_order"] = t.order.numpy()
+    # free-form adjacency of tests/test_nn.py:41-60 style
+    g = torch.Generator().manual_seed(15)
+    A = torch.randn(5, 3, generator=g) < 0
+    A[0, 0] = True
+    net = zuko.nn.MaskedMLP(A, hidden_features=(16, 32))
+    ref_masks = [m.mask for m in net if hasattr(m, "mask")]
+    mine = O.masked_mlp_masks(A, (16, 32))
+    for a, b in zip(mine, ref_masks):
+        assert torch.equal(a, b)
+    out["free_adjacency"] = A.numpy()
+    for i, m in enumerate(ref_masks):
+        out[f"free_mask{i}"] = m.numpy()
+    np.savez_compressed(os.path.join(HERE, "masks.npz"), **out)
+    print("wrote masks.npz", len(out), "arrays")
+
+
+FLOWS = {
+    # name: (constructor, kwargs, seed, batch, context, oracle kind, univariate, extra spec kwargs)
+    "nsf_cfg1": (zuko.flows.NSF, dict(features=3, context=5, transforms=3, bins=8, hidden_features=[128] * 3), 0, 512, 5, "ar", O.uni_rqs(8), {}),
+    "nsf_cfg2": (zuko.flows.NSF, dict(features=64, context=0, transforms=8, bins=8, hidden_features=[256] * 3), 0, 256, 0, "ar", O.uni_rqs(8), {}),
+    "maf_cfg3": (zuko.flows.MAF, dict(features=64, context=0, transforms=8, hidden_features=[256] * 3), 0, 256, 0, "ar", O.UNI_AFFINE, {}),
+    "realnvp_cfg4": (zuko.flows.RealNVP, dict(features=256, context=0, transforms=16, hidden_features=[512] * 3), 0, 64, 0, "coupling", O.UNI_AFFINE, {}),
+    "maf_doc": (zuko.flows.MAF, dict(features=3, context=4, transforms=3), 0, 64, 4, "ar", O.UNI_AFFINE, {}),
+    "nsf_p2": (zuko.flows.NSF, dict(features=6, context=2, transforms=2, bins=4, passes=2, hidden_features=[32, 32]), 3, 64, 2, "ar", O.uni_rqs(4), dict(passes=2)),
+    "nice_small": (zuko.flows.NICE, dict(features=5, context=3, transforms=3, hidden_features=[32, 32]), 4, 64, 3, "coupling", O.UNI_AFFINE, {}),
+    "sospf_small": (zuko.flows.SOSPF, dict(features=4, context=2, transforms=2, hidden_features=[32, 32]), 5, 64, 2, "ar", O.uni_sos(), dict(softclip=11.0)),
+    "bpf_small": (zuko.flows.BPF, dict(features=4, context=2, transforms=2, hidden_features=[32, 32]), 6, 64, 2, "ar", O.uni_bpf(), {}),
+}
+
+
+def gen_flows() -> None:
+    for name, (ctor, kw, seed, batch, ctx, kind, uni, extra) in FLOWS.items():
+        torch.manual_seed(seed)
+        flow = ctor(**kw)
+        sd = {k: v for k, v in flow.state_dict().items() if v is not None}
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(batch, kw["features"], generator=g)
+        c = torch.randn(batch, ctx, generator=g) if ctx else None
+        with torch.no_grad():
+            dist = flow(c)
+            lp = dist.log_prob(x)
+            z, ladj = dist.transform.call_and_ladj(x)
+            ninv = min(batch, 16)
+            xr = dist.transform.inv(z[:ninv]) if c is None else flow(c[:ninv]).transform.inv(z[:ninv])
+        spec = O.spec_from_state_dict(sd, kind, uni, kw["features"], **extra)
+        with torch.no_grad():
+            oz, ol = O.flow_forward(spec, x, c)
+            olp = O.flow_log_prob(spec, x, c)
+            oxr = O.flow_inverse(spec, z[:ninv], None if c is None else c[:ninv])
+        tol = 0.0 if uni.kind not in ("bbernstein", "bernstein") else 0.0
+        same(oz, z, f"{name} z", tol)
+        same(ol, ladj, f"{name} ladj", tol)
+        same(olp, lp, f"{name} log_prob", tol)
+        same(oxr, xr, f"{name} inverse", tol)
+        arrays = dict(x=x, log_prob=lp, z=z, ladj=ladj, x_rec=xr, sd_sha256=np.array(sd_hash(sd)), seed=np.array(seed))
+        if c is not None:
+            arrays["c"] = c
+        save(f"flow_{name}.npz", **arrays)
+
+
+def gen_doctest_kats() -> None:
+    """The reference's only literal known answers (doctests):
+    flows/autoregressive.py:278-283 -- MAF(3, 4, transforms=3), seed 0, after the repr
+    (whose extra_repr draws 2 scalars per transform, autoregressive.py:188)."""
+    torch.manual_seed(0)
+    flow = zuko.flows.MAF(3, 4, transforms=3)
+    repr(flow)
+    c = torch.randn(4)
+    x = flow(c).sample()
+    lp = flow(c).log_prob(x)
+    assert torch.allclose(x, torch.tensor([-0.5012, -1.6298, 0.3803]), atol=1e-4), x
+    assert abs(lp.item() - (-3.7514)) < 1e-4, lp
+    sd = {k: v for k, v in flow.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "ar", O.UNI_AFFINE, 3)
+    with torch.no_grad():
+        z = flow(c).transform(x)
+        same(O.flow_log_prob(spec, x, c), lp, "doctest KAT log_prob")
+        same(O.flow_inverse(spec, z, c), flow(c).transform.inv(z), "doctest KAT inverse")
+    save("kat_maf_doctest.npz", c=c, x=x.detach(), z=z.detach(), log_prob=lp.detach(), literal_x=np.array([-0.5012, -1.6298, 0.3803]), literal_log_prob=np.array(-3.7514))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        gen_rqs(dtype, tag)
+        gen_affine(dtype, tag)
+        gen_sos(dtype, tag)
+        gen_bernstein(dtype, tag)
+    gen_masks()
+    gen_flows()
+    gen_doctest_kats()
+    print("oracle pinned against reference; fixtures written")
