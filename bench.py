@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+r"""Headline benchmark: log_prob samples/s of NSF(features=64, context=0, transforms=8, bins=8,
+hidden=[256]*3) at batch 2^20 per GPU (BASELINE.json configs[1]), fp32, synthetic N(0,1) inputs
+resident in HBM, random-init weights from torch.manual_seed(0) (the reference's constructor order).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-log2 20] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path over the rank's batch: flow().log_prob(x) for all 2^20 rows,
+the f64 reduction to the mean NLL, and (N > 1) ONE all-reduce of that scalar over RCCL.  Multi-GPU
+is weak scaling: every rank owns its own 2^20-row shard; nothing but the scalar crosses xGMI.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured with events on the launch
+stream) and `cpu_baseline` (the CPU oracle = the reference's algorithm on PyTorch-CPU ops, timed on
+this host's cores on a bounded sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FEATURES, TRANSFORMS, BINS, HIDDEN = 64, 8, 8, [256, 256, 256]
+# dense conditioner FLOPs per sample per transform = 2 * (64*256 + 256*256*2 + 256*1472)
+FLOP_PER_SAMPLE_TRANSFORM = 2 * (64 * 256 + 256 * 256 * 2 + 256 * 1472)
+NNZ_FLOP_PER_SAMPLE_TRANSFORM = 2 * 265784  # mask-aware (non-zero weights only), reported alongside
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0
+RQS_BYTES_PER_SAMPLE_TRANSFORM = 64 * (4 + 92 + 4) + 4  # x + phi + y per element, + ladj
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(flow_cpu, seconds: float) -> dict:
+    """The oracle (a restatement of the reference on PyTorch-CPU ops, bitwise equal to it in the
+    build container) timed on this host: chunks of 2^12 rows of the same workload, all cores."""
+    from oracle import zuko_oracle as O
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = {k: v for k, v in flow_cpu.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(BINS), FEATURES)
+    chunk = 1 << 12
+    x = torch.randn(chunk, FEATURES, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        O.flow_log_prob(spec, x)  # warm-up
+        times = []
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end or len(times) < 3:
+            t0 = time.perf_counter()
+            O.flow_log_prob(spec, x)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": chunk / med,
+        "unit": "samples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{len(times)} x chunk of 2^12 rows (median), same model; reference degrades at larger chunks (SURVEY 6)",
+        "cpu_model": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown"),
+    }
+
+
+def main() -> None:
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import zuko_amd
+    from zuko_amd import _C, ops
+    from zuko_amd.flows import NSF
+
+    torch.manual_seed(0)
+    flow_cpu = NSF(FEATURES, 0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
+    flow = NSF(FEATURES, 0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
+    flow.load_state_dict(flow_cpu.state_dict())
+    flow = flow.to(dev)
+    B = 1 << args.batch_log2
+    x = torch.randn(B, FEATURES, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+
+    def step():
+        with torch.no_grad():
+            lp = flow().log_prob(x)
+            nll = ops.sum_f64(lp, -1.0 / (B * world))
+            if dist is not None:
+                dist.all_reduce(nll)  # the only collective: one f64 scalar over RCCL/xGMI
+        return nll
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        nll = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nll = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    ms = dt / args.steps * 1e3
+    value = B * world / (dt / args.steps)
+
+    # per-kernel durations over extra (profiled) steps: events on the launch stream
+    roof = None
+    kernels = {}
+    if rank == 0:
+        _C.PROFILE = {}
+        for _ in range(min(3, args.steps)):
+            step()
+        torch.cuda.synchronize()
+        prof, _C.PROFILE = _C.PROFILE, None
+        for name, recs in prof.items():
+            groups = {}
+            for a, b, cargs in recs:
+                key = (name,) + tuple(v for v in cargs[1:4] if isinstance(v, int))
+                groups.setdefault(key, []).append(a.elapsed_time(b))
+            for key, ts in groups.items():
+                kernels[" ".join(map(str, key))] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts)}
+        roof, extra = zuko_amd_roofline(kernels, B)
+
+    if rank == 0:
+        out = {
+            "metric": "log_prob samples/sec, NSF d=64 K=8 bins=8 batch=2^20",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"NSF(features=64, context=0, transforms=8, bins=8, hidden=[256]*3) log_prob, batch=2^{args.batch_log2} per GPU, x~N(0,1), seed-0 init",
+                "batch_per_gpu": B,
+                "global_batch": B * world,
+                "parallelism": f"batch-sharded x{world}, one RCCL all-reduce of the scalar NLL",
+            },
+            "roofline": roof,
+            "end_to_end": {
+                "flop_per_sample": FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS,
+                "achieved_tflops_dense_equiv": value / world * FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12,
+                "frac_of_f32_mfma_peak": value / world * FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "mask_aware_tflops": value / world * NNZ_FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12,
+            },
+            "kernels": extra,
+            "nll": float(nll.item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flow_cpu, args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def zuko_amd_roofline(kernels: dict, B: int):
+    """Roofline object for the dominant kernel + a per-kernel table (all measured in this run)."""
+    table = []
+    for name, rec in kernels.items():
+        row = {"kernel": name, **rec}
+        parts = name.split()
+        if parts[0] == "zk_linear":
+            n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
+            flops = 2.0 * n * fin * fout
+            row.update(bound="mfma", achieved=flops / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+        elif parts[0] == "zk_ar_forward":
+            flops = float(B) * FLOP_PER_SAMPLE_TRANSFORM
+            row.update(bound="mfma", achieved=flops / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+        elif parts[0] == "zk_rqs_forward":
+            byts = float(B) * RQS_BYTES_PER_SAMPLE_TRANSFORM
+            row.update(bound="hbm", achieved=byts / (rec["avg_ms"] * 1e-3) / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
+        if "achieved" in row:
+            row["frac"] = row["achieved"] / row["peak"]
+        row["total_ms_per_step"] = rec["avg_ms"] * rec["calls"] / max(1, min(3, rec["calls"]))
+        table.append(row)
+    # dominant = largest total time per step
+    per_step = {}
+    for row in table:
+        per_step[row["kernel"]] = row["avg_ms"] * row["calls"]
+    dom = max(table, key=lambda r: r["avg_ms"] * r["calls"])
+    roof = None
+    if "achieved" in dom:
+        roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": None,
+                "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]}
+    for row in table:
+        row.pop("total_ms_per_step", None)
+    return roof, table
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+/* zuko_amd — C ABI of the MI355X-native zuko transform hot path (libzuko_amd.so).
+ *
+ * The reference (probabilists/zuko v1.6.0) is pure Python on PyTorch and has NO FFI of its own;
+ * its extension points are Python constructor hooks.  Each entry point below
+ * therefore replaces a *sequence of ATen ops* at a named place in the reference, and is what a
+ * ctypes binding in `zuko/transforms.py` / `zuko/nn.py` would call.
+ *
+ * Conventions (all entry points):
+ *   - return value: hipError_t as int, 0 = success (hipErrorInvalidValue for unsupported arguments);
+ *     the Python side raises RuntimeError on non-zero.  Value-domain problems (NaN, out-of-range x)
+ *     are never errors: they propagate exactly as in the reference (Distribution._validate_args =
+ *     False, zuko/distributions.py:35).
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocates); the library
+ *     allocates nothing, keeps no global state, never synchronises, and only enqueues work on
+ *     `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - dtype: ZK_DTYPE_F32 (0) or ZK_DTYPE_F64 (1); all tensors of one call share it.
+ *   - x / y are row-major contiguous [N, D].  Parameter tensors are addressed as
+ *         p[n * sN + d * sD + j],   j contiguous,
+ *     with element strides (sN, sD); 0 = broadcast.  When the segments of a transform form one
+ *     packed buffer phi[N, D, total] — the layout the conditioner's last layer emits
+ *     (zuko/flows/autoregressive.py:149,212-213; zuko/utils.py:616-622) — the LDS-staged streaming
+ *     kernel is used, otherwise a strided-gather instantiation.
+ *   - ladj: if `ladj_reduced` the output is ladj[N] summed over D (what
+ *     DependentTransform(., 1) returns, zuko/transforms.py:210-214), else ladj[N, D]
+ *     (Transform.log_abs_det_jacobian).
+ */
+#ifndef ZUKO_AMD_H
+#define ZUKO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_DTYPE_F32 0
+#define ZK_DTYPE_F64 1
+
+/* activations of zk_linear / zk_ar_* (zuko/nn.py:168-169: ReLU is the default) */
+#define ZK_ACT_NONE 0
+#define ZK_ACT_RELU 1
+#define ZK_ACT_ELU 2
+#define ZK_ACT_TANH 3
+#define ZK_ACT_SILU 4
+#define ZK_ACT_GELU 5
+#define ZK_ACT_SIGMOID 6
+#define ZK_ACT_LEAKY 7
+
+/* ---- MonotonicRQSTransform ------------------------------------------------------------------ */
+
+/* Replaces MonotonicRQSTransform.__init__ + call_and_ladj (zuko/transforms.py:469-490, 554-567):
+ * softclip, softmax, pad, cumsum, exp, bin search (strict <), gathers, rational-quadratic value and
+ * log-derivative in one pass.  widths/heights are [N, D, K], derivs [N, D, K-1].
+ * bin_out (optional, int32 [N, D]) receives k = #(knots < x) - 1 in [-1, K]. */
+int zk_rqs_forward(int dtype, int64_t N, int64_t D, int K, double bound, double slope, const void* x,
+                   const void* widths, int64_t w_sN, int64_t w_sD, const void* heights, int64_t h_sN, int64_t h_sD,
+                   const void* derivs, int64_t d_sN, int64_t d_sD, void* y, void* ladj, int ladj_reduced,
+                   int32_t* bin_out, void* stream);
+
+/* Replaces MonotonicRQSTransform.__init__ + _inverse (zuko/transforms.py:469-490, 534-548). */
+int zk_rqs_inverse(int dtype, int64_t N, int64_t D, int K, double bound, double slope, const void* y,
+                   const void* widths, int64_t w_sN, int64_t w_sD, const void* heights, int64_t h_sN, int64_t h_sD,
+                   const void* derivs, int64_t d_sN, int64_t d_sD, void* x, int32_t* bin_out, void* stream);
+
+/* Test entry: same evaluation from ALREADY-CONSTRAINED knots (horizontal, vertical, slopes, each
+ * [N, D, K+1] with common strides) — zuko/transforms.py:521-567 only.  Used to assert the
+ * bit-exact bin index on knots shared with the oracle. */
+int zk_rqs_from_knots(int dtype, int inverse, int64_t N, int64_t D, int K, const void* in, const void* horizontal,
+                      const void* vertical, const void* slopes, int64_t k_sN, int64_t k_sD, void* out, void* ladj,
+                      int32_t* bin_out, void* stream);
+
+/* ---- MonotonicAffineTransform (zuko/transforms.py:412-446) -------------------------------------- */
+int zk_affine_forward(int dtype, int64_t N, int64_t D, double slope, const void* x, const void* shift, int64_t s_sN,
+                      int64_t s_sD, const void* scale, int64_t c_sN, int64_t c_sD, void* y, void* ladj, int ladj_reduced,
+                      void* stream);
+int zk_affine_inverse(int dtype, int64_t N, int64_t D, double slope, const void* y, const void* shift, int64_t s_sN,
+                      int64_t s_sD, const void* scale, int64_t c_sN, int64_t c_sD, void* x, void* stream);
+
+/* ---- SOSPolynomialTransform (zuko/transforms.py:927-963, zuko/utils.py:349-363, :170-180) ------- *
+ * a_coef is [N, D, P, L1] (L1 = degree + 1 = number of Gauss-Legendre nodes); gl_nodes01 /
+ * gl_weights01 are HOST arrays of L1 nodes / weights on [0, 1] (numpy leggauss, utils.py:337-339).
+ * `constant` (optional, [N, D]) is the additive shift of flows/polynomial.py:23-29. */
+int zk_sos_forward(int dtype, int64_t N, int64_t D, int P, int L1, double slope, const double* gl_nodes01,
+                   const double* gl_weights01, const void* x, const void* a_coef, int64_t a_sN, int64_t a_sD,
+                   const void* constant, int64_t c_sN, int64_t c_sD, void* y, void* ladj, int ladj_reduced, void* stream);
+int zk_sos_inverse(int dtype, int64_t N, int64_t D, int P, int L1, double slope, const double* gl_nodes01,
+                   const double* gl_weights01, int n_bisect, const void* y, const void* a_coef, int64_t a_sN,
+                   int64_t a_sD, const void* constant, int64_t c_sN, int64_t c_sD, void* x, void* stream);
+
+/* ---- BernsteinTransform / BoundedBernsteinTransform (zuko/transforms.py:640-831) ---------------- *
+ * theta is the UNCONSTRAINED [N, D, M]; M + 2 (unbounded) or M + 5 (bounded) must be one of
+ * {6, 8, 10, 13, 14, 18, 21, 22, 34, 37} (register-resident de Casteljau instantiations). */
+int zk_bernstein_forward(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, const void* x,
+                         const void* theta, int64_t t_sN, int64_t t_sD, void* y, void* ladj, int ladj_reduced, void* stream);
+int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, int n_bisect, const void* y,
+                         const void* theta, int64_t t_sN, int64_t t_sD, void* x, void* stream);
+
+/* ---- conditioner layer: F.linear(x, mask * weight, bias) + activation (zuko/nn.py:217-218, 13-15) - *
+ * x [N, in] with row stride ldx, weight [out, in] contiguous, mask (uint8/bool [out, in]) and bias
+ * optional, y [N, out] with row stride ldy.  fp32 runs on v_mfma_f32_32x32x2_f32. */
+int zk_linear(int dtype, int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight,
+              const uint8_t* mask, const void* bias, int act, void* y, int64_t ldy, void* stream);
+
+/* ---- base density + final reduction (zuko/distributions.py:115-119, 337-363) ---------------------- *
+ * out[n] = sum_d Normal(loc[d], scale[d]).log_prob(z[n, d]) (+ ladj[n] if ladj != NULL). */
+int zk_diag_normal_log_prob(int dtype, int64_t N, int64_t D, const void* z, const void* loc, const void* scale,
+                            const void* ladj, void* out, void* stream);
+/* out[0] = scale * sum_i v[i] in f64 (per-rank partial NLL for the RCCL all-reduce);
+ * workspace: >= 1024 doubles of device memory. */
+int zk_sum_f64(int dtype, int64_t N, const void* v, double scale, double* workspace, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZUKO_AMD_H */

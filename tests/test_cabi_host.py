@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library loads and exports every symbol include/zuko_amd.h declares; host-side
+logic (module trees, state_dict keys, masks, loud failure on CPU tensors).  No kernel is launched."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, T, golden
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "zuko_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(zk_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import zuko_amd._C as C
+
+    lib = ctypes.CDLL(C.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/zuko_amd.h but not exported"
+    # and the Python binding table covers exactly the declared surface
+    assert sorted(C.SIGNATURES) == syms
+
+
+def test_import_fails_loudly_without_library(monkeypatch):
+    import zuko_amd._C as C
+
+    with pytest.raises(ImportError, match="no CPU"):
+        C._Lib("/nonexistent/libzuko_amd.so")
+
+
+def test_cpu_tensors_are_rejected():
+    import zuko_amd.transforms as ZT
+    from zuko_amd import ops
+
+    t = ZT.MonotonicRQSTransform(torch.randn(8), torch.randn(8), torch.randn(7))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        t(torch.randn(4))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.linear(torch.randn(2, 3), torch.randn(4, 3))
+
+
+def test_masks_and_module_tree():
+    import zuko_amd.flows as F
+    from zuko_amd.nn import MaskedLinear, masked_mlp_masks
+
+    g = golden("masks.npz")
+    t = F.MaskedAutoregressiveTransform(64, 0, shapes=[(8,), (8,), (7,)], hidden_features=(256, 256, 256))
+    layers = [m for m in t.hyper if isinstance(m, MaskedLinear)]
+    assert [tuple(m.weight.shape) for m in layers] == [(256, 64), (256, 256), (256, 256), (1472, 256)]
+    for i, m in enumerate(layers):
+        shape = tuple(g[f"ar64_shape{i}"])
+        ref = np.unpackbits(g[f"ar64_mask{i}"])[: shape[0] * shape[1]].reshape(shape).astype(bool)
+        assert np.array_equal(m.mask.numpy(), ref)
+    assert int(sum(m.mask.sum() for m in layers)) == 265784  # nnz of the cfg2 conditioner
+    keys = set(t.state_dict())
+    assert {"order", "hyper.0.weight", "hyper.0.bias", "hyper.0.mask", "hyper.6.mask"} <= keys
+    A = T(g["free_adjacency"])
+    for i, m in enumerate(masked_mlp_masks(A, (16, 32))):
+        assert np.array_equal(m.numpy(), g[f"free_mask{i}"])
+    with pytest.raises(ValueError, match="null Jacobian"):
+        masked_mlp_masks(torch.zeros(3, 3, dtype=bool), (8,))
+
+
+def test_constructor_assertions_match_reference_messages():
+    import zuko_amd.flows as F
+
+    with pytest.raises(AssertionError, match="'order' should have 3 elements"):
+        F.MaskedAutoregressiveTransform(3, order=[0, 1])
+    with pytest.raises(AssertionError, match="ones on the diagonal"):
+        F.MaskedAutoregressiveTransform(3, adjacency=torch.zeros(3, 3, dtype=bool))
+    with pytest.raises(AssertionError, match="cycles"):
+        F.MaskedAutoregressiveTransform(3, adjacency=torch.ones(3, 3, dtype=bool))
+    t = F.MaskedAutoregressiveTransform(4, adjacency=torch.tril(torch.ones(4, 4, dtype=bool)))
+    assert t.passes == 4
+    t = F.MaskedAutoregressiveTransform(6, passes=2)
+    assert t.passes == 2 and t.order.tolist() == [0, 0, 0, 1, 1, 1]
+    assert isinstance(F.MaskedAutoregressiveTransform(1, 3), F.ElementWiseTransform)
+
+
+def test_flow_state_dict_layout_and_pickle(tmp_path):
+    import zuko_amd.flows as F
+
+    torch.manual_seed(0)
+    flow = F.NSF(3, 5, transforms=2, hidden_features=[16, 16])
+    keys = list(flow.state_dict())
+    assert "transform.transforms.0.order" in keys and "transform.transforms.1.hyper.4.mask" in keys
+    assert "base.loc" in keys and "base.scale" in keys
+    p = tmp_path / "flow.pt"
+    torch.save(flow, p)  # whole-module pickle, as tests/test_flows.py:78-91 of the reference does
+    again = torch.load(p, weights_only=False)
+    for (k1, v1), (k2, v2) in zip(flow.state_dict().items(), again.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert "MaskedAutoregressiveTransform" in repr(flow)

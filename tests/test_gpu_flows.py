@@ -1,0 +1,99 @@
+"""GPU parity: conditioner GEMM and whole flows (log_prob / z / ladj / inverse) against the golden
+vectors of the reference, plus size-independent properties at the BASELINE batch sizes."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, build_flow, flow_registry, golden, oracle_spec
+from oracle import zuko_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_close(a, b, what, rtol=1e-5, atol=1e-5):
+    a = a.detach().cpu()
+    b = T(b) if isinstance(b, np.ndarray) else b.detach().cpu()
+    assert a.shape == b.shape, f"{what}: {tuple(a.shape)} vs {tuple(b.shape)}"
+    if not torch.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True):
+        d = (a - b).abs().nan_to_num()
+        raise AssertionError(f"{what}: max|d|={d.max():.3e}, max rel={(d / b.abs().clamp_min(1e-30)).max():.3e}")
+
+
+@pytest.mark.parametrize("N,IN,OUT,masked,act", [(1000, 64, 256, True, 1), (513, 256, 1472, True, 0), (300, 8, 128, True, 1), (257, 7, 33, False, 3), (64, 128, 512, False, 1), (0, 16, 16, False, 0)])
+def test_linear_vs_oracle(dev, N, IN, OUT, masked, act):
+    from zuko_amd import ops
+
+    gen = torch.Generator().manual_seed(N + IN)
+    x = torch.randn(N, IN, generator=gen)
+    W = torch.randn(OUT, IN, generator=gen) / IN**0.5
+    b = torch.randn(OUT, generator=gen)
+    m = (torch.rand(OUT, IN, generator=gen) < 0.5) if masked else None
+    fn = {0: lambda v: v, 1: torch.relu, 3: torch.tanh}[act]
+    ref = fn(torch.nn.functional.linear(x, W if m is None else m * W, b))
+    with torch.no_grad():
+        y = ops.linear(x.to(dev), W.to(dev), b.to(dev), None if m is None else m.to(dev), act)
+    rel_close(y, ref, "linear", 1e-5, 2e-5)
+    if N:
+        y64 = ops.linear(x.double().to(dev), W.double().to(dev), b.double().to(dev), None if m is None else m.to(dev), act)
+        rel_close(y64, fn(torch.nn.functional.linear(x.double(), (W if m is None else m * W).double(), b.double())), "linear f64", 1e-12, 1e-12)
+
+
+@pytest.mark.parametrize("name", list(flow_registry()))
+def test_flow_golden(dev, name):
+    """north_star parity bar: log_prob rel 1e-5; y / ladj allclose(1e-5, 1e-5) (fp32)."""
+    g = golden(f"flow_{name}.npz")
+    flow, entry = build_flow(name)
+    flow = flow.to(dev)
+    x = T(g["x"], dev)
+    c = T(g["c"], dev) if "c" in g else None
+    loose = entry[4].kind in ("sos", "bbernstein")
+    with torch.no_grad():
+        dist = flow(c)
+        lp = dist.log_prob(x)
+        z, ladj = dist.transform.call_and_ladj(x)
+        n = g["x_rec"].shape[0]
+        xr = (flow(None if c is None else c[:n])).transform.inv(T(g["z"], dev)[:n])
+    rel_close(lp, g["log_prob"], "log_prob", 1e-5 if not loose else 1e-4, 1e-5 if not loose else 1e-4)
+    rel_close(z, g["z"], "z", 1e-5, 2e-5 if not loose else 2e-4)
+    rel_close(ladj, g["ladj"], "ladj", 1e-5, 5e-5 if not loose else 5e-4)
+    rel_close(xr, g["x_rec"], "inverse", 1e-4, 1e-4)
+
+
+def test_doctest_known_answer_on_gpu(dev):
+    """zuko/flows/autoregressive.py:278-283 literal: log_prob = -3.7514 at x = [-0.5012, -1.6298, 0.3803]."""
+    import zuko_amd.flows as F
+
+    g = golden("kat_maf_doctest.npz")
+    torch.manual_seed(0)
+    flow = F.MAF(3, 4, transforms=3).to(dev)
+    with torch.no_grad():
+        lp = flow(T(g["c"], dev)).log_prob(T(g["x"], dev))
+        x = flow(T(g["c"], dev)).transform.inv(T(g["z"], dev))
+    assert abs(lp.item() - (-3.7514)) < 1e-4
+    assert np.allclose(x.cpu().numpy(), [-0.5012, -1.6298, 0.3803], atol=1e-4)
+
+
+@pytest.mark.parametrize("name,batch", [("nsf_cfg2", 1 << 16), ("maf_cfg3", 1 << 16), ("realnvp_cfg4", 1 << 14)])
+def test_flow_properties_large_batch(dev, name, batch):
+    """Size-independent properties at large batch: (a) batch rows are independent — a permutation
+    of the rows permutes the outputs bit for bit; (b) chunked == monolithic; (c) inverse(forward) = id."""
+    flow, entry = build_flow(name)
+    flow = flow.to(dev)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(batch, entry[1]["features"], generator=gen).to(dev)
+    with torch.no_grad():
+        lp = flow().log_prob(x)
+        perm = torch.randperm(batch, generator=gen).to(dev)
+        assert torch.equal(flow().log_prob(x[perm]), lp[perm])
+        parts = torch.cat([flow().log_prob(p) for p in x.split(batch // 8 + 13)])
+        assert torch.equal(parts, lp)
+        assert torch.isfinite(lp).all()
+        z = flow().transform(x[:2048])
+        xr = flow().transform.inv(z)
+    assert (xr - x[:2048]).abs().max() < 2e-3
+    # spot-check a slice against the oracle
+    spec = oracle_spec(flow, entry)
+    with torch.no_grad():
+        ref = O.flow_log_prob(spec, x[:256].cpu())
+    rel_close(lp[:256], ref, "log_prob vs oracle", 1e-5, 1e-5)

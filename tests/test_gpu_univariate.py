@@ -1,0 +1,180 @@
+"""GPU parity: univariate transform kernels (through the C-ABI) against the golden vectors of the
+reference and against the CPU oracle on fresh seeded inputs.
+
+Tolerances (north_star): fp32 allclose(rtol=1e-5, atol=1e-5) on y / ladj / inverse, bit-exact
+spline bin index on shared knots; fp64 1e-12."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, golden
+from oracle import zuko_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 1e-5, "f64": 1e-12}
+
+
+def close(a, b, what, tol):
+    a = a.detach().cpu()
+    b = T(b) if isinstance(b, np.ndarray) else b.detach().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    ok = torch.allclose(a, b, rtol=tol, atol=tol, equal_nan=True)
+    if not ok:
+        d = (a - b).abs().nan_to_num()
+        i = d.argmax()
+        raise AssertionError(f"{what}: max|d|={d.max():.3e} at {np.unravel_index(int(i), a.shape)}: {a.flatten()[i]} vs {b.flatten()[i]}; nan mismatch={int((a.isnan() != b.isnan()).sum())}")
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_rqs_golden(dev, tag):
+    from zuko_amd import ops
+    import zuko_amd.transforms as ZT
+
+    g = golden(f"rqs_{tag}.npz")
+    tol = TOL[tag]
+    w, h, d, x = (T(g[n], dev) for n in ("widths", "heights", "derivatives", "x"))
+    with torch.no_grad():
+        # 1) shared knots: bin index must be bit-exact, values to tolerance
+        y, ladj, k = ops.rqs_from_knots(x, T(g["horizontal"], dev), T(g["vertical"], dev), T(g["slopes"], dev))
+        assert torch.equal(k.cpu().long(), T(g["k"])), "bin index differs on shared knots"
+        close(y, g["y"], "y (shared knots)", tol)
+        close(ladj, g["ladj"], "ladj (shared knots)", tol)
+        xi, _, ki = ops.rqs_from_knots(T(g["y_in"], dev), T(g["horizontal"], dev), T(g["vertical"], dev), T(g["slopes"], dev), inverse=True)
+        assert torch.equal(ki.cpu().long(), T(g["k_inv"]))
+        close(xi, g["x_inv"], "x_inv (shared knots)", tol)
+        # 2) from unconstrained parameters (device expf vs Sleef: knots may move by an ulp)
+        t = ZT.MonotonicRQSTransform(w, h, d)
+        y2, l2 = t.call_and_ladj(x)
+        k2 = t.bin_index(x)
+        flips = int((k2.cpu().long() != T(g["k"])).sum())
+        edge = np.isin(np.arange(x.shape[0]), np.arange(16))[:, None] & np.ones_like(g["k"], bool)
+        assert int(((k2.cpu().long() != T(g["k"])) & ~T(edge)).sum()) == 0, "bin flips away from the adversarial rows"
+        same = k2.cpu().long() == T(g["k"])
+        close(torch.where(same.to(dev), y2, T(g["y"], dev)), g["y"], "y", tol)
+        close(torch.where(same.to(dev), l2, T(g["ladj"], dev)), g["ladj"], "ladj", 10 * tol if tag == "f32" else tol)
+        print(f"rqs[{tag}] end-to-end bin flips on adversarial set: {flips}")
+        close(t.log_abs_det_jacobian(x, y2), l2, "ladj method", 0)
+        xi2 = t.inv(T(g["y_in"], dev))
+        same_i = (ops.rqs_inverse(T(g["y_in"], dev), w, h, d, want_bins=True)[1].cpu().long() == T(g["k_inv"])).to(dev)
+        close(torch.where(same_i, xi2, T(g["x_inv"], dev)), g["x_inv"], "inverse", tol)
+        # 3) feature-reduced ladj
+        yr, lr = t.call_and_ladj_reduced(x)
+        close(yr, y2, "reduced y", 0)
+        close(lr, l2.sum(-1), "reduced ladj", 10 * tol if tag == "f32" else 1e-11)
+        # 4) unbatched parameters broadcast against x (tests/test_transforms.py:12-32 of the reference)
+        t1 = ZT.MonotonicRQSTransform(w[0, 0], h[0, 0], d[0, 0])
+        yl, ll = t1.call_and_ladj(T(g["x_lin"], dev))
+        close(yl, g["y_lin"], "y_lin", tol)
+        close(ll, g["ladj_lin"], "ladj_lin", tol)
+        close(t1.inv(yl), g["x_lin"], "roundtrip", 1e-4 if tag == "f32" else 1e-9)
+
+
+@pytest.mark.parametrize("shape,K", [((1000, 64), 8), ((257, 3), 8), ((33, 200), 8), ((5, 7, 11), 4), ((64, 16), 16), ((40, 6), 5), ((0, 8), 8), ((3, 1), 8)])
+def test_rqs_vs_oracle_shapes(dev, shape, K):
+    """Packed phi (LDS-staged path), ragged / non-power-of-two feature counts, D > 64, 3-d batches,
+    generic bin counts, empty input."""
+    import zuko_amd.transforms as ZT
+    from zuko_amd.utils import unpack
+
+    gen = torch.Generator().manual_seed(hash((shape, K)) % 2**31)
+    phi = torch.randn(*shape, 3 * K - 1, generator=gen) * 1.5
+    x = torch.randn(*shape, generator=gen) * 2.2
+    w, h, d = unpack(phi, [(K,), (K,), (K - 1,)])
+    hor, ver, der = O.rqs_knots(w, h, d)
+    phig = phi.to(dev)
+    wg, hg, dg = unpack(phig, [(K,), (K,), (K - 1,)])  # views of ONE packed buffer
+    t = ZT.MonotonicRQSTransform(wg, hg, dg)
+    with torch.no_grad():
+        y, ladj = t.call_and_ladj(x.to(dev))
+        if x.numel() == 0:
+            assert y.shape == x.shape
+            return
+        k = t.bin_index(x.to(dev)).cpu().long()
+        oy, ol, ok = O.rqs_forward_from_knots(hor, ver, der, x)
+        same = k == ok
+        assert (~same).float().mean() < 1e-4
+        close(torch.where(same, y.cpu(), oy), oy, "y", 1e-5)
+        close(torch.where(same, ladj.cpu(), ol), ol, "ladj", 2e-5)
+        yr, lr = t.call_and_ladj_reduced(x.to(dev))
+        close(lr, ladj.sum(-1), "reduced", 1e-4)
+        xr = t.inv(y)
+        close(xr, x, "roundtrip", 1e-4)
+        # strided (non-packed) parameters take the other instantiation: same numbers
+        t2 = ZT.MonotonicRQSTransform(wg.contiguous(), hg.contiguous(), dg.contiguous())
+        y2, l2 = t2.call_and_ladj(x.to(dev))
+        close(y2, y, "strided y", 0)
+        close(l2, ladj, "strided ladj", 0)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_affine_golden(dev, tag):
+    import zuko_amd.transforms as ZT
+
+    g = golden(f"affine_{tag}.npz")
+    tol = TOL[tag]
+    t = ZT.MonotonicAffineTransform(T(g["shift"], dev), T(g["scale"], dev))
+    with torch.no_grad():
+        y, ladj = t.call_and_ladj(T(g["x"], dev))
+        close(y, g["y"], "y", tol)
+        close(ladj, g["ladj"], "ladj", tol)
+        close(t.inv(T(g["x"], dev)), g["x_inv"], "inverse", tol)
+        _, lr = t.call_and_ladj_reduced(T(g["x"], dev))
+        close(lr, T(g["ladj"]).sum(-1), "reduced", 10 * tol)
+        # packed [shift, scale] pairs as the MAF conditioner emits them
+        phi = torch.stack((T(g["shift"]), T(g["scale"])), dim=-1).to(dev)
+        tp = ZT.MonotonicAffineTransform(phi[..., 0], phi[..., 1])
+        yp, lp = tp.call_and_ladj(T(g["x"], dev))
+        close(yp, y, "packed y", 0)
+        close(lp, ladj, "packed ladj", 0)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_sos_golden(dev, tag):
+    import zuko_amd.transforms as ZT
+
+    g = golden(f"sos_{tag}.npz")
+    tol = 2e-5 if tag == "f32" else 1e-11
+    t = ZT.SOSPolynomialTransform(T(g["a"], dev))
+    with torch.no_grad():
+        y, ladj = t.call_and_ladj(T(g["x"], dev))
+        close(y, g["y"], "y", tol)
+        close(ladj, g["ladj"], "ladj", tol)
+        close(t.inv(T(g["y"], dev)), g["x_inv"], "inverse", 1e-4 if tag == "f32" else 1e-6)
+        c = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(3), dtype=T(g["x"]).dtype).to(dev)
+        ts = ZT.ShiftedSOSPolynomialTransform(T(g["a"], dev), c)
+        ys, ls = ts.call_and_ladj(T(g["x"], dev))
+        close(ys, y + c, "shifted y", tol)
+        close(ts.inv(ys), g["x"], "shifted roundtrip", 1e-4)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["bern", "bbern"])
+def test_bernstein_golden(dev, tag, name):
+    import zuko_amd.transforms as ZT
+
+    g = golden(f"{name}_{tag}.npz")
+    cls = ZT.BoundedBernsteinTransform if name == "bbern" else ZT.BernsteinTransform
+    t = cls(T(g["theta"], dev))
+    tol = 5e-5 if tag == "f32" else 1e-9
+    with torch.no_grad():
+        y, ladj = t.call_and_ladj(T(g["x"], dev))
+        close(y, g["y"], "y", tol)
+        close(ladj, g["ladj"], "ladj", 2e-4 if tag == "f32" else 1e-8)
+        close(t.inv(T(g["y"], dev)), g["x_inv"], "inverse", 1e-4 if tag == "f32" else 1e-5)
+
+
+def test_normal_log_prob_and_sum(dev):
+    from zuko_amd import ops
+
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(1000, 64, generator=gen)
+    loc = torch.randn(64, generator=gen)
+    scale = torch.rand(64, generator=gen) + 0.5
+    ladj = torch.randn(1000, generator=gen)
+    ref = O.diag_normal_log_prob(z, loc, scale) + ladj
+    out = ops.diag_normal_log_prob(z.to(dev), loc.to(dev), scale.to(dev), ladj.to(dev))
+    close(out, ref, "normal log prob", 1e-5)
+    s = ops.sum_f64(out, -1.0 / 1000)
+    assert abs(s.item() - (-ref.double().mean().item())) < 1e-6

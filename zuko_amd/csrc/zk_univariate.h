@@ -1,0 +1,326 @@
+// zuko_amd — per-element device math of the univariate monotone transforms.
+//
+// Everything here works on ONE (sample, feature) element held in registers: the callers
+// (the standalone HBM-streaming kernels in elementwise.hip and the fused conditioner+spline
+// kernel in fused_ar.hip) decide where the parameters come from (LDS-staged packed phi,
+// strided global memory, or MFMA accumulators).
+//
+// Operation ORDER follows the reference expression trees so that results track the
+// PyTorch-CPU path to the last few ulps (translation units including this header are built
+// with -ffp-contract=off; expf/logf are the accurate ocml versions, never __expf/__logf):
+//   RQS        zuko/transforms.py:469-567     affine  zuko/transforms.py:412-446
+//   SOS        zuko/transforms.py:927-963 + zuko/utils.py:349-363 (Gauss-Legendre), :170-180 (bisection)
+//   Bernstein  zuko/transforms.py:640-831
+#pragma once
+
+#include "zk_common.h"
+
+namespace zk {
+
+// ---------------------------------------------------------------------------------------------
+// soft clipping of unconstrained parameters (transforms.py:436, :480-482)
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T softclip(T v, T ls) { return v / (T(1) + t_abs(v / ls)); }
+template <typename T> __device__ __forceinline__ T softclip2(T v, T ls) { return v / (T(1) + t_abs((T(2) * v) / ls)); }
+
+// ---------------------------------------------------------------------------------------------
+// monotonic affine (transforms.py:436-446)
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void affine_fwd(T shift, T scale, T ls, T x, T& y, T& ladj) {
+  T lsc = softclip(scale, ls);
+  y = x * t_exp(lsc) + shift;
+  ladj = lsc;
+}
+template <typename T> __device__ __forceinline__ T affine_inv(T shift, T scale, T ls, T y) {
+  T lsc = softclip(scale, ls);
+  return (y - shift) / t_exp(lsc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rational-quadratic spline
+// ---------------------------------------------------------------------------------------------
+
+// softmax over K soft-clipped values followed by the padded cumulative sum mapped to [-B, B]
+// (transforms.py:480-481, 484-485, 488-489).  `ld(j)` returns the j-th unconstrained value.
+template <typename T, int K, typename Ld> __device__ __forceinline__ void rqs_axis_knots(Ld ld, T bound, T ls, T (&knot)[K + 1]) {
+  T v[K];
+  T m;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    v[j] = softclip2<T>(ld(j), ls);
+    m = (j == 0) ? v[0] : (v[j] > m ? v[j] : m);
+  }
+  T s = T(0);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    v[j] = t_exp(v[j] - m);
+    s += v[j];
+  }
+  T r = T(1) / s;
+  T cum = T(0);
+  knot[0] = bound * (T(2) * cum - T(1));
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    cum += v[j] * r;
+    knot[j + 1] = bound * (T(2) * cum - T(1));
+  }
+}
+
+// knot slopes: exp(softclip(d)) inside, 1 at both ends (transforms.py:482, 486, 490)
+template <typename T, int K, typename Ld> __device__ __forceinline__ void rqs_slopes(Ld ld, T ls, T (&kd)[K + 1]) {
+  kd[0] = T(1);
+  kd[K] = T(1);
+#pragma unroll
+  for (int j = 1; j < K; ++j) kd[j] = t_exp(softclip<T>(ld(j - 1), ls));
+}
+
+// k = #(knots < v) - 1 with a STRICT compare (transforms.py:521-526); NaN compares false -> k = -1
+template <typename T, int K> __device__ __forceinline__ int rqs_bin(const T (&knot)[K + 1], T v) {
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j <= K; ++j) cnt += (knot[j] < v) ? 1 : 0;
+  return cnt - 1;
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void rqs_select(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], int k, bool& inside, T& x0, T& x1, T& y0,
+                                           T& y1, T& d0, T& d1) {
+  inside = (k >= 0) && (k < K);
+  int kw = k < 0 ? k + K : (k >= K ? k - K : k);  // python's k % K for k in [-1, K]  (transforms.py:502)
+  x0 = kx[0]; x1 = kx[1]; y0 = ky[0]; y1 = ky[1]; d0 = kd[0]; d1 = kd[1];
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    bool s = (kw == j);
+    x0 = s ? kx[j] : x0;
+    x1 = s ? kx[j + 1] : x1;
+    y0 = s ? ky[j] : y0;
+    y1 = s ? ky[j + 1] : y1;
+    d0 = s ? kd[j] : d0;
+    d1 = s ? kd[j + 1] : d1;
+  }
+}
+
+// forward value + log|dy/dx| (transforms.py:554-567).  Out-of-range / NaN / inf behaviour is
+// inherited from the literal `mask * ...` arithmetic of the reference.
+template <typename T, int K>
+__device__ __forceinline__ void rqs_fwd(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], T x, T& y, T& ladj, int& k) {
+  k = rqs_bin<T, K>(kx, x);
+  bool inside;
+  T x0, x1, y0, y1, d0, d1;
+  rqs_select<T, K>(kx, ky, kd, k, inside, x0, x1, y0, y1, d0, d1);
+  T m = inside ? T(1) : T(0);
+  T s = (y1 - y0) / (x1 - x0);
+  T z = (m * (x - x0)) / (x1 - x0);
+  T omz = T(1) - z;
+  T t = (d0 + d1) - T(2) * s;
+  T den = s + (t * z) * omz;
+  T num = s * (z * z) + (d0 * z) * omz;
+  T yy = y0 + ((y1 - y0) * num) / den;
+  T jac = ((s * s) * ((((T(2) * s) * z) * omz + d0 * (omz * omz)) + d1 * (z * z))) / (den * den);
+  y = inside ? yy : x;
+  ladj = m * t_log(jac);
+}
+
+// inverse value (transforms.py:534-548): bin search on the vertical knots, stable quadratic root
+template <typename T, int K>
+__device__ __forceinline__ void rqs_inv(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], T y, T& x, int& k) {
+  k = rqs_bin<T, K>(ky, y);
+  bool inside;
+  T x0, x1, y0, y1, d0, d1;
+  rqs_select<T, K>(kx, ky, kd, k, inside, x0, x1, y0, y1, d0, d1);
+  T m = inside ? T(1) : T(0);
+  T s = (y1 - y0) / (x1 - x0);
+  T y_ = m * (y - y0);
+  T t = (d0 + d1) - T(2) * s;
+  T a = (y1 - y0) * (s - d0) + y_ * t;
+  T b = (y1 - y0) * d0 - y_ * t;
+  T c = (-s) * y_;
+  T z = (T(2) * c) / ((-b) - t_sqrt(b * b - (T(4) * a) * c));
+  T xx = x0 + z * (x1 - x0);
+  x = inside ? xx : y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sum-of-squares polynomial.  Coefficients a[P][L1] are read through `ld(p*L1 + j)`.
+// ---------------------------------------------------------------------------------------------
+#define ZK_SOS_MAX_NODES 16
+
+template <typename T> struct SosConst {
+  T bound;     // 10 (MonotonicTransform default, transforms.py:593)
+  T slope;     // additive floor of g (transforms.py:963)
+  int P, L1;   // polynomials, degree+1 (= number of quadrature nodes, transforms.py:952)
+  T node[ZK_SOS_MAX_NODES];    // Gauss-Legendre nodes on [0,1]  (utils.py:337-339)
+  T weight[ZK_SOS_MAX_NODES];  // weights / 2
+};
+
+// g(x) = mean_p (1 + sum_j a_pj (x/B)^j)^2 + slope   (transforms.py:958-963)
+template <typename T, typename Ld> __device__ __forceinline__ T sos_g(const SosConst<T>& c, Ld ld, T x) {
+  T u = x / c.bound;
+  T acc = T(0);
+  for (int p = 0; p < c.P; ++p) {
+    T pw = T(1);  // u**0 == 1 for every u, NaN included (IEEE pow)
+    T dot = T(0);
+    for (int j = 0; j < c.L1; ++j) {
+      dot += ld(p * c.L1 + j) * pw;
+      pw *= u;
+    }
+    T q = T(1) + dot;
+    acc += q * q;
+  }
+  return acc / T(c.P) + c.slope;
+}
+
+// f(x) = int_0^x g  by Gauss-Legendre on [0, x]  (transforms.py:911-918, utils.py:349-363)
+template <typename T, typename Ld> __device__ __forceinline__ T sos_f(const SosConst<T>& c, Ld ld, T x) {
+  T acc = T(0);
+  for (int i = 0; i < c.L1; ++i) {
+    T w = c.node[i];
+    // torch.lerp(0, x, w): a + w*(b-a) below one half, b - (b-a)*(1-w) above
+    T pt = (w < T(0.5)) ? (T(0) + w * (x - T(0))) : (x - (x - T(0)) * (T(1) - w));
+    acc += c.weight[i] * sos_g<T>(c, ld, pt);
+  }
+  return (x - T(0)) * acc;
+}
+
+// fixed-count bisection on [-B, B] (utils.py:170-180; n = ceil(log2(2B/eps)), transforms.py:615)
+template <typename T, typename Ld> __device__ __forceinline__ T sos_inv(const SosConst<T>& c, Ld ld, T y, int n) {
+  T a = -c.bound, b = c.bound;
+  for (int it = 0; it < n; ++it) {
+    T mid = (a + b) / T(2);
+    bool below = sos_f<T>(c, ld, mid) < y;
+    a = below ? mid : a;
+    b = below ? b : mid;
+  }
+  return (a + b) / T(2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bernstein polynomial.  NC = number of CONSTRAINED coefficients (order M = NC-1).
+// ---------------------------------------------------------------------------------------------
+#define ZK_BERN_EPS 1e-6
+
+template <typename T> __device__ __forceinline__ T softplus(T v) {  // torch softplus, beta=1, threshold=20
+  return v > T(20) ? v : t_log1p(t_exp(v));
+}
+
+// unbounded: theta = cumsum([t0, sp(t1), sp(t1), sp(t2), ..., sp(t_last), sp(t_last)]) - log(2) * n / 2
+// (transforms.py:703-727); n unconstrained -> NC = n + 2
+template <typename T, int NC, typename Ld> __device__ __forceinline__ void bern_theta_unbounded(Ld ld, T (&th)[NC]) {
+  constexpr int n = NC - 2;
+  const T shift = T(0.69314718055994530942 * n / 2.0);
+  T cum = ld(0);
+  th[0] = cum - shift;
+  cum += softplus<T>(ld(1));
+  th[1] = cum - shift;
+#pragma unroll
+  for (int j = 1; j < n; ++j) {
+    cum += softplus<T>(ld(j));
+    th[j + 1] = cum - shift;
+  }
+  cum += softplus<T>(ld(n - 1));
+  th[n + 1] = cum - shift;
+}
+
+// bounded: theta = cumsum([-B, e, e, softmax(t) * (2B - 4e), e, e]),  e = 2B / (n + 4)
+// (transforms.py:797-818); n unconstrained -> NC = n + 5
+template <typename T, int NC, typename Ld> __device__ __forceinline__ void bern_theta_bounded(Ld ld, T bound, T (&th)[NC]) {
+  constexpr int n = NC - 5;
+  const T edge = (T(2) * bound) / T(n + 4);
+  const T span = T(2) * bound - T(4) * edge;
+  T v[n];
+  T m;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    v[j] = ld(j);
+    m = (j == 0) ? v[0] : (v[j] > m ? v[j] : m);
+  }
+  T s = T(0);
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    v[j] = t_exp(v[j] - m);
+    s += v[j];
+  }
+  T r = T(1) / s;
+  T cum = -bound;
+  th[0] = cum;
+  cum += edge; th[1] = cum;
+  cum += edge; th[2] = cum;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    cum += (v[j] * r) * span;
+    th[3 + j] = cum;
+  }
+  cum += edge; th[n + 3] = cum;
+  cum += edge; th[n + 4] = cum;
+}
+
+// de Casteljau: value B(u) = sum_i C(M,i) u^i (1-u)^(M-i) theta_i and derivative dB/du in one sweep
+// (closed form of transforms.py:736-740; equality with the Beta-pdf form verified in SURVEY 9.1)
+template <typename T, int NC> __device__ __forceinline__ void bern_eval(const T (&th)[NC], T u, T& val, T& dval) {
+  T b[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) b[i] = th[i];
+  const T v = T(1) - u;
+#pragma unroll
+  for (int r = 1; r < NC - 1; ++r) {
+#pragma unroll
+    for (int i = 0; i < NC - r; ++i) b[i] = v * b[i] + u * b[i + 1];
+  }
+  dval = T(NC - 1) * (b[1] - b[0]);
+  val = v * b[0] + u * b[1];
+}
+
+template <typename T> struct BernTails { T off0, off1, slp0, slp1; };
+
+// offsets/slopes of the linear continuation (transforms.py:685-701 unbounded, :820-831 bounded)
+template <typename T, int NC> __device__ __forceinline__ BernTails<T> bern_tails(const T (&th)[NC], bool bounded, T bound) {
+  BernTails<T> t;
+  if (bounded) {
+    t.off0 = -bound; t.off1 = bound; t.slp0 = T(2) * bound; t.slp1 = T(2) * bound;
+  } else {
+    bern_eval<T, NC>(th, T(ZK_BERN_EPS), t.off0, t.slp0);
+    bern_eval<T, NC>(th, T(1) - T(ZK_BERN_EPS), t.off1, t.slp1);
+  }
+  return t;
+}
+
+// y = f(x) and dy/dx (transforms.py:742-760; derivative = what autograd yields at :623-637)
+template <typename T, int NC>
+__device__ __forceinline__ void bern_fwd(const T (&th)[NC], const BernTails<T>& t, T bound, T x, T& y, T& dydx) {
+  const T eps = T(ZK_BERN_EPS);
+  T u = (x + bound) / (T(2) * bound);
+  bool lo = u <= eps;
+  bool hi = u >= T(1) - eps;
+  T safe = (lo || hi) ? T(0.5) : u;
+  T val, dval;
+  bern_eval<T, NC>(th, safe, val, dval);
+  T ylo = t.slp0 * (u - eps) + t.off0;
+  T yhi = t.slp1 * ((u - T(1)) + eps) + t.off1;
+  y = lo ? ylo : val;
+  y = hi ? yhi : y;
+  T du = lo ? t.slp0 : dval;
+  du = hi ? t.slp1 : du;
+  dydx = du / (T(2) * bound);
+}
+
+// x = f^{-1}(y): n-step bisection on [-B, B] + closed-form tails (transforms.py:762-777, :609-617)
+template <typename T, int NC> __device__ __forceinline__ T bern_inv(const T (&th)[NC], const BernTails<T>& t, T bound, T y, int n) {
+  const T eps = T(ZK_BERN_EPS);
+  T a = -bound, b = bound;
+  for (int it = 0; it < n; ++it) {
+    T mid = (a + b) / T(2);
+    T fy, d;
+    bern_fwd<T, NC>(th, t, bound, mid, fy, d);
+    bool below = fy < y;
+    a = below ? mid : a;
+    b = below ? b : mid;
+  }
+  T x = (a + b) / T(2);
+  T xlo = (((y - t.off0) / t.slp0 + eps) * T(2)) * bound - bound;
+  T xhi = ((((y - t.off1) / t.slp1 - eps) + T(1)) * T(2)) * bound - bound;
+  x = (y <= t.off0) ? xlo : x;
+  x = (y >= t.off1) ? xhi : x;
+  return x;
+}
+
+}  // namespace zk

@@ -1,0 +1,174 @@
+r"""Conditioner networks of the hot path: `MaskedMLP` (autoregressive) and `MLP` (coupling).
+
+Module trees, parameter names, initialisation order and mask construction match
+zuko/nn.py:51-192 (Linear, MLP) and :202-318 (MaskedLinear, MaskedMLP) so that
+`load_state_dict` from a reference flow works and `torch.manual_seed(s)` reproduces the
+reference's initial weights bit for bit.  The forward pass is one HIP GEMM per layer with the mask
+applied in the weight-staging path and bias + activation fused in the epilogue (zk_linear).
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+import torch.nn as nn
+from torch import BoolTensor, Tensor
+
+from . import ops
+
+__all__ = ["MLP", "Linear", "MaskedLinear", "MaskedMLP"]
+
+
+def _act_code(module: nn.Module | None) -> int | None:
+    """C-ABI activation code for modules the GEMM epilogue can fuse, else None."""
+    if module is None:
+        return 0
+    t = type(module)
+    if t is nn.ELU and module.alpha != 1.0:
+        return None
+    if t is nn.LeakyReLU and module.negative_slope != 0.01:
+        return None
+    if t is nn.GELU and getattr(module, "approximate", "none") != "none":
+        return None
+    return ops.ACTIVATIONS.get(t)
+
+
+class Linear(nn.Module):
+    r"""y = x W^T + b with U(-1/sqrt(in), 1/sqrt(in)) init.  Mirrors zuko/nn.py:51-119
+    (the `stack=` variant of the reference is outside the hot path and not provided)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, stack: int | None = None) -> None:
+        super().__init__()
+        if stack is not None:
+            raise NotImplementedError("zuko_amd.nn.Linear: stacked operators are outside the hot path")
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.in_features = in_features
+        self.out_features = out_features
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        bound = 1 / self.weight.shape[-1] ** 0.5
+        nn.init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
+
+    def forward(self, x: Tensor, act: int = 0) -> Tensor:
+        return ops.linear(x, self.weight, self.bias, None, act)
+
+
+class MaskedLinear(nn.Linear):
+    r"""y = x (W * A)^T + b for a boolean adjacency A[out, in].  Mirrors zuko/nn.py:202-218;
+    the product mask*W is never materialised (the mask gates the weight tile inside the GEMM)."""
+
+    def __init__(self, adjacency: BoolTensor, **kwargs) -> None:
+        super().__init__(adjacency.shape[1], adjacency.shape[0], **kwargs)
+        self.register_buffer("mask", adjacency)
+
+    def forward(self, x: Tensor, act: int = 0) -> Tensor:
+        return ops.linear(x, self.weight, self.bias, self.mask, act)
+
+
+class _FusedSequential(nn.Sequential):
+    """Sequential whose (linear, activation) pairs run as ONE kernel when the activation is one
+    the GEMM epilogue knows; other modules are applied as-is."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, (Linear, MaskedLinear)):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                code = _act_code(nxt) if nxt is not None and not isinstance(nxt, (Linear, MaskedLinear)) else None
+                if code is not None and nxt is not None:
+                    x = m(x, code)
+                    i += 2
+                    continue
+                x = m(x)
+            else:
+                x = m(x)
+            i += 1
+        return x
+
+
+class MLP(_FusedSequential):
+    r"""Dense multi-layer perceptron (coupling conditioner).  Mirrors zuko/nn.py:122-192
+    (`normalize=True` LayerNorm variant is outside the hot path)."""
+
+    def __init__(
+        self,
+        in_features: int,
+        out_features: int,
+        hidden_features: Sequence[int] = (64, 64),
+        activation: Callable[[], nn.Module] | None = None,
+        normalize: bool = False,
+        **kwargs,
+    ) -> None:
+        if normalize:
+            raise NotImplementedError("zuko_amd.nn.MLP: normalize=True is outside the hot path")
+        activation = nn.ReLU if activation is None else activation
+        widths = (in_features, *hidden_features, out_features)
+        layers: list[nn.Module] = []
+        for i, (a, b) in enumerate(zip(widths[:-1], widths[1:])):
+            layers.append(Linear(a, b, **kwargs))
+            if i + 2 < len(widths):
+                layers.append(activation())
+        super().__init__(*layers)
+        self.in_features = in_features
+        self.out_features = out_features
+
+
+def masked_mlp_masks(adjacency: BoolTensor, hidden_features: Sequence[int]) -> list[BoolTensor]:
+    r"""Layer masks of a masked MLP whose Jacobian dy_i/dx_j vanishes where adjacency[i, j] is False.
+
+    Follows zuko/nn.py:265-295: outputs with identical dependency sets are merged; a hidden unit is
+    tagged with one of the (non-empty) dependency sets, cycling through them; unit u may feed unit v
+    iff deps(u) is a subset of deps(v); the last layer maps tags back to output rows."""
+    rows, inverse = torch.unique(adjacency, dim=0, return_inverse=True)
+    counts = rows.sum(dim=-1)
+    subset = (rows.double() @ rows.double().t()) == counts  # subset[i, j]: deps(j) within deps(i)
+    masks: list[BoolTensor] = []
+    tags = None
+    n_hidden = len(hidden_features)
+    for depth, width in enumerate((*hidden_features, adjacency.shape[0])):
+        full = rows if depth == 0 else subset[:, tags]
+        if not full.any():
+            raise ValueError("The adjacency matrix leads to a null Jacobian.")
+        if depth < n_hidden:
+            usable = full.sum(dim=-1).nonzero().squeeze(dim=-1)
+            tags = usable[torch.arange(width) % len(usable)]
+            masks.append(full[tags])
+        else:
+            masks.append(full[inverse])
+    return masks
+
+
+class MaskedMLP(_FusedSequential):
+    r"""Masked MLP (autoregressive conditioner).  Mirrors zuko/nn.py:221-318 for residual=False;
+    `residual=True` is SURVEY 8(f) rank 4 and not provided yet."""
+
+    def __init__(
+        self,
+        adjacency: BoolTensor,
+        hidden_features: Sequence[int] = (64, 64),
+        activation: Callable[[], nn.Module] | None = None,
+        residual: bool = False,
+    ) -> None:
+        if residual:
+            raise NotImplementedError("zuko_amd.nn.MaskedMLP: residual=True is not part of the hot path yet")
+        activation = nn.ReLU if activation is None else activation
+        out_features, in_features = adjacency.shape
+        masks = masked_mlp_masks(adjacency, hidden_features)
+        layers: list[nn.Module] = []
+        for i, m in enumerate(masks):
+            layers.append(MaskedLinear(adjacency=m))
+            if i + 1 < len(masks):
+                layers.append(activation())
+        super().__init__(*layers)
+        self.in_features = in_features
+        self.out_features = out_features

@@ -1,0 +1,333 @@
+r"""Tensor-level wrappers around the C-ABI.  PyTorch is used for device memory, streams and
+shape bookkeeping only; every arithmetic result comes out of a HIP kernel in libzuko_amd.so.
+
+All functions require tensors on a HIP device (`tensor.is_cuda`) in float32 or float64 and raise
+otherwise — there is no CPU or eager-PyTorch fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+from functools import lru_cache
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _C
+
+ACTIVATIONS = {
+    None: 0,
+    torch.nn.Identity: 0,
+    torch.nn.ReLU: 1,
+    torch.nn.ELU: 2,
+    torch.nn.Tanh: 3,
+    torch.nn.SiLU: 4,
+    torch.nn.GELU: 5,
+    torch.nn.Sigmoid: 6,
+    torch.nn.LeakyReLU: 7,
+}
+
+
+def _dtype_code(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.float64:
+        return 1
+    raise TypeError(f"zuko_amd kernels support float32/float64, got {t.dtype}")
+
+
+def _require_device(*ts: Tensor) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "zuko_amd: tensors must live on a HIP device (got a CPU tensor). "
+                "This package has no CPU path; use the reference implementation for CPU work."
+            )
+
+
+def _no_grad_only(*ts: Tensor) -> None:
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
+        raise NotImplementedError(
+            "zuko_amd kernels are forward-only in this release (SURVEY 8f: backward is the next row); "
+            "call them under torch.no_grad() or with tensors that do not require grad."
+        )
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Tensor | None):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _lead_collapse(t: Tensor) -> tuple[Tensor, int, int]:
+    """View an expanded parameter tensor of shape (*lead, D, K) as strides (sN, sD) over a
+    flattened leading index, copying only if the leading strides do not collapse."""
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        t = t.contiguous()
+    *lead, D, _ = t.shape
+    sD = t.stride(-2) if D > 1 else 0
+    dims = [(n, s) for n, s in zip(lead, t.stride()[: len(lead)]) if n > 1]
+    if not dims:
+        return t, 0, sD
+    ok = True
+    for (n0, s0), (n1, s1) in zip(dims[:-1], dims[1:]):
+        if s0 != s1 * n1:
+            ok = False
+            break
+    if ok:
+        return t, dims[-1][1], sD
+    t = t.contiguous()
+    return t, t.stride(-3) if t.dim() >= 3 else 0, t.stride(-2) if D > 1 else 0
+
+
+def _bshape(x: Tensor, *params: Tensor) -> torch.Size:
+    """Broadcast of x against the parameters' batch shapes (everything but their last `k` dims)."""
+    return torch.broadcast_shapes(x.shape, *[p for p in params])
+
+
+class _Prepared:
+    """x expanded to the broadcast shape as a contiguous [N, D] block + per-parameter strides."""
+
+    def __init__(self, x: Tensor, params: list[tuple[Tensor, int]]):
+        # params: (tensor, number of trailing "parameter" dims)
+        _require_device(x, *[p for p, _ in params])
+        _no_grad_only(x, *[p for p, _ in params])
+        dt = x.dtype
+        for p, _ in params:
+            if p.dtype != dt or p.device != x.device:
+                raise TypeError("zuko_amd: x and parameters must share dtype and device")
+        batch = torch.broadcast_shapes(x.shape, *[p.shape[: p.dim() - k] for p, k in params])
+        self.shape = batch
+        if len(batch) == 0:
+            shape2 = (1, 1)
+        else:
+            shape2 = (int(math.prod(batch[:-1])), int(batch[-1]))
+        self.N, self.D = shape2
+        self.x = x.expand(batch).contiguous()
+        self.params = []
+        for p, k in params:
+            tail = p.shape[p.dim() - k :]
+            flat = p.reshape(p.shape[: p.dim() - k] + (int(math.prod(tail)),)) if k != 1 else p
+            pe = flat.expand(batch + flat.shape[-1:])
+            if len(batch) == 0:
+                pe = pe.reshape(1, 1, -1)
+            elif len(batch) == 1:
+                pe = pe.unsqueeze(0)
+            t, sN, sD = _lead_collapse(pe)
+            self.params.append((t, sN, sD))
+        self.code = _dtype_code(x)
+
+    def out(self) -> Tensor:
+        return torch.empty(self.shape, dtype=self.x.dtype, device=self.x.device)
+
+    def out_ladj(self, reduced: bool) -> Tensor:
+        shape = self.shape[:-1] if reduced else self.shape
+        return torch.empty(shape, dtype=self.x.dtype, device=self.x.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# RQS
+# ------------------------------------------------------------------------------------------------
+
+
+def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor, bound: float = 5.0, slope: float = 1e-3,
+                reduce: bool = False, want_bins: bool = False):
+    """(y, ladj[, k]) — see include/zuko_amd.h:zk_rqs_forward."""
+    K = widths.shape[-1]
+    if heights.shape[-1] != K or derivatives.shape[-1] != K - 1:
+        raise ValueError("zuko_amd: widths/heights must have K entries and derivatives K-1")
+    pr = _Prepared(x, [(widths, 1), (heights, 1), (derivatives, 1)])
+    if reduce and len(pr.shape) == 0:
+        raise ValueError("zuko_amd: cannot reduce ladj of a 0-d input")
+    y, ladj = pr.out(), pr.out_ladj(reduce)
+    bins = torch.empty(pr.shape, dtype=torch.int32, device=x.device) if want_bins else None
+    (w, wn, wd), (h, hn, hd), (d, dn, dd) = pr.params
+    err = _C.lib().zk_rqs_forward(pr.code, pr.N, pr.D, K, bound, slope, _ptr(pr.x), _ptr(w), wn, wd, _ptr(h), hn, hd, _ptr(d), dn, dd,
+                                  _ptr(y), _ptr(ladj), int(reduce), _ptr(bins), _stream())
+    _C.check(err, "zk_rqs_forward")
+    return (y, ladj, bins) if want_bins else (y, ladj)
+
+
+def rqs_inverse(y: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor, bound: float = 5.0, slope: float = 1e-3, want_bins: bool = False):
+    K = widths.shape[-1]
+    pr = _Prepared(y, [(widths, 1), (heights, 1), (derivatives, 1)])
+    x = pr.out()
+    bins = torch.empty(pr.shape, dtype=torch.int32, device=y.device) if want_bins else None
+    (w, wn, wd), (h, hn, hd), (d, dn, dd) = pr.params
+    err = _C.lib().zk_rqs_inverse(pr.code, pr.N, pr.D, K, bound, slope, _ptr(pr.x), _ptr(w), wn, wd, _ptr(h), hn, hd, _ptr(d), dn, dd,
+                                  _ptr(x), _ptr(bins), _stream())
+    _C.check(err, "zk_rqs_inverse")
+    return (x, bins) if want_bins else x
+
+
+def rqs_from_knots(v: Tensor, horizontal: Tensor, vertical: Tensor, slopes: Tensor, inverse: bool = False):
+    """Test entry: evaluate from constrained knots; returns (out, ladj, k)."""
+    K = horizontal.shape[-1] - 1
+    pr = _Prepared(v, [(horizontal.contiguous(), 1), (vertical.contiguous(), 1), (slopes.contiguous(), 1)])
+    out, ladj = pr.out(), pr.out_ladj(False)
+    bins = torch.empty(pr.shape, dtype=torch.int32, device=v.device)
+    (h, hn, hd), (ve, vn, vd), (s, sn, sd) = pr.params
+    if (hn, hd) != (vn, vd) or (hn, hd) != (sn, sd):
+        raise ValueError("zuko_amd: knots must share strides")
+    err = _C.lib().zk_rqs_from_knots(pr.code, int(inverse), pr.N, pr.D, K, _ptr(pr.x), _ptr(h), _ptr(ve), _ptr(s), hn, hd, _ptr(out), _ptr(ladj),
+                                     _ptr(bins), _stream())
+    _C.check(err, "zk_rqs_from_knots")
+    return out, ladj, bins
+
+
+# ------------------------------------------------------------------------------------------------
+# affine
+# ------------------------------------------------------------------------------------------------
+
+
+def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3, reduce: bool = False):
+    pr = _Prepared(x, [(shift.unsqueeze(-1), 1), (scale.unsqueeze(-1), 1)])
+    y, ladj = pr.out(), pr.out_ladj(reduce)
+    (s, sn, sd), (c, cn, cd) = pr.params
+    err = _C.lib().zk_affine_forward(pr.code, pr.N, pr.D, slope, _ptr(pr.x), _ptr(s), sn, sd, _ptr(c), cn, cd, _ptr(y), _ptr(ladj), int(reduce), _stream())
+    _C.check(err, "zk_affine_forward")
+    return y, ladj
+
+
+def affine_inverse(y: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3) -> Tensor:
+    pr = _Prepared(y, [(shift.unsqueeze(-1), 1), (scale.unsqueeze(-1), 1)])
+    x = pr.out()
+    (s, sn, sd), (c, cn, cd) = pr.params
+    err = _C.lib().zk_affine_inverse(pr.code, pr.N, pr.D, slope, _ptr(pr.x), _ptr(s), sn, sd, _ptr(c), cn, cd, _ptr(x), _stream())
+    _C.check(err, "zk_affine_inverse")
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# SOS polynomial
+# ------------------------------------------------------------------------------------------------
+
+
+@lru_cache(maxsize=None)
+def _leggauss01(n: int):
+    """Gauss-Legendre nodes / weights mapped to [0, 1] (zuko/utils.py:328-347)."""
+    nodes, weights = np.polynomial.legendre.leggauss(n)
+    nodes = (nodes + 1) / 2
+    weights = weights / 2
+    return (ctypes.c_double * n)(*nodes.tolist()), (ctypes.c_double * n)(*weights.tolist())
+
+
+SOS_BOUND = 10.0
+SOS_EPS = 1e-6
+
+
+def sos_forward(x: Tensor, a: Tensor, constant: Tensor | None = None, slope: float = 1e-3, reduce: bool = False):
+    P, L1 = a.shape[-2:]
+    plist = [(a, 2)] + ([(constant.unsqueeze(-1), 1)] if constant is not None else [])
+    pr = _Prepared(x, plist)
+    y, ladj = pr.out(), pr.out_ladj(reduce)
+    nodes, weights = _leggauss01(L1)
+    (at, an, ad) = pr.params[0]
+    ct, cn, cd = pr.params[1] if constant is not None else (None, 0, 0)
+    err = _C.lib().zk_sos_forward(pr.code, pr.N, pr.D, P, L1, slope, nodes, weights, _ptr(pr.x), _ptr(at), an, ad, _ptr(ct), cn, cd, _ptr(y), _ptr(ladj),
+                                  int(reduce), _stream())
+    _C.check(err, "zk_sos_forward")
+    return y, ladj
+
+
+def sos_inverse(y: Tensor, a: Tensor, constant: Tensor | None = None, slope: float = 1e-3) -> Tensor:
+    P, L1 = a.shape[-2:]
+    plist = [(a, 2)] + ([(constant.unsqueeze(-1), 1)] if constant is not None else [])
+    pr = _Prepared(y, plist)
+    x = pr.out()
+    nodes, weights = _leggauss01(L1)
+    n_bisect = math.ceil(math.log2(2 * SOS_BOUND / SOS_EPS))  # transforms.py:615
+    (at, an, ad) = pr.params[0]
+    ct, cn, cd = pr.params[1] if constant is not None else (None, 0, 0)
+    err = _C.lib().zk_sos_inverse(pr.code, pr.N, pr.D, P, L1, slope, nodes, weights, n_bisect, _ptr(pr.x), _ptr(at), an, ad, _ptr(ct), cn, cd, _ptr(x),
+                                  _stream())
+    _C.check(err, "zk_sos_inverse")
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# Bernstein polynomial
+# ------------------------------------------------------------------------------------------------
+
+BERN_EPS = 1e-6
+
+
+def bernstein_forward(x: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0, reduce: bool = False):
+    M = theta.shape[-1]
+    pr = _Prepared(x, [(theta, 1)])
+    y, ladj = pr.out(), pr.out_ladj(reduce)
+    (t, tn, td) = pr.params[0]
+    err = _C.lib().zk_bernstein_forward(pr.code, pr.N, pr.D, M, int(bounded), bound, _ptr(pr.x), _ptr(t), tn, td, _ptr(y), _ptr(ladj), int(reduce), _stream())
+    _C.check(err, "zk_bernstein_forward")
+    return y, ladj
+
+
+def bernstein_inverse(y: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0) -> Tensor:
+    M = theta.shape[-1]
+    pr = _Prepared(y, [(theta, 1)])
+    x = pr.out()
+    n_bisect = math.ceil(math.log2(2 * bound / BERN_EPS))  # transforms.py:615
+    (t, tn, td) = pr.params[0]
+    err = _C.lib().zk_bernstein_inverse(pr.code, pr.N, pr.D, M, int(bounded), bound, n_bisect, _ptr(pr.x), _ptr(t), tn, td, _ptr(x), _stream())
+    _C.check(err, "zk_bernstein_inverse")
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# conditioner layer, base density, reduction
+# ------------------------------------------------------------------------------------------------
+
+
+def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, act: int = 0) -> Tensor:
+    """act(x @ (mask * weight).T + bias) over the last dim of x (zuko/nn.py:217-218)."""
+    _require_device(x, weight, bias, mask)
+    _no_grad_only(x, weight, bias)
+    out_f, in_f = weight.shape
+    if x.shape[-1] != in_f:
+        raise ValueError(f"zuko_amd.linear: expected last dim {in_f}, got {x.shape[-1]}")
+    x2 = x.reshape(-1, in_f)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    w = weight.contiguous()
+    m = None
+    if mask is not None:
+        m = mask.contiguous()
+        if m.dtype == torch.bool:
+            m = m.view(torch.uint8)
+        elif m.dtype != torch.uint8:
+            raise TypeError("zuko_amd.linear: mask must be bool or uint8")
+    b = None if bias is None else bias.contiguous()
+    y = torch.empty((x2.shape[0], out_f), dtype=x.dtype, device=x.device)
+    err = _C.lib().zk_linear(_dtype_code(x), x2.shape[0], in_f, out_f, _ptr(x2), x2.stride(0) if x2.shape[0] > 1 else in_f, _ptr(w), _ptr(m), _ptr(b), act,
+                             _ptr(y), out_f, _stream())
+    _C.check(err, "zk_linear")
+    return y.reshape(x.shape[:-1] + (out_f,))
+
+
+def diag_normal_log_prob(z: Tensor, loc: Tensor, scale: Tensor, ladj: Tensor | None = None) -> Tensor:
+    _require_device(z, loc, scale, ladj)
+    _no_grad_only(z, loc, scale, ladj)
+    D = z.shape[-1]
+    z2 = z.reshape(-1, D).contiguous()
+    out = torch.empty(z2.shape[0], dtype=z.dtype, device=z.device)
+    la = None if ladj is None else ladj.expand(z.shape[:-1]).reshape(-1).contiguous()
+    err = _C.lib().zk_diag_normal_log_prob(_dtype_code(z), z2.shape[0], D, _ptr(z2), _ptr(loc.contiguous()), _ptr(scale.contiguous()), _ptr(la), _ptr(out), _stream())
+    _C.check(err, "zk_diag_normal_log_prob")
+    return out.reshape(z.shape[:-1])
+
+
+def sum_f64(v: Tensor, scale: float = 1.0) -> Tensor:
+    """scale * sum(v) accumulated in float64; returns a 0-d float64 device tensor."""
+    _require_device(v)
+    v1 = v.reshape(-1).contiguous()
+    ws = torch.empty(1024, dtype=torch.float64, device=v.device)
+    out = torch.empty((), dtype=torch.float64, device=v.device)
+    err = _C.lib().zk_sum_f64(_dtype_code(v), v1.numel(), _ptr(v1), scale, _ptr(ws), _ptr(out), _stream())
+    _C.check(err, "zk_sum_f64")
+    return out
