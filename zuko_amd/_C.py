@@ -9,7 +9,9 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_double, c_int, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, c_double, c_int, c_int64, c_void_p
+
+import torch  # noqa: F401  MUST precede the dlopen below: libzuko_amd.so shares torch's libamdhip64.so
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZUKO_AMD_LIB", os.path.join(_HERE, "lib", "libzuko_amd.so"))

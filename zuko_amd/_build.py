@@ -38,6 +38,18 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def _torch_lib_dir() -> str:
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        raise RuntimeError("zuko_amd build: PyTorch-ROCm is required (its libamdhip64.so is the HIP runtime we link against)")
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    if not os.path.exists(os.path.join(d, "libamdhip64.so")):
+        raise RuntimeError(f"zuko_amd build: {d}/libamdhip64.so not found (need a ROCm build of PyTorch)")
+    return d
+
+
 def _digest(path: str, flags: list[str]) -> str:
     h = hashlib.sha256()
     h.update(" ".join(flags).encode())
@@ -86,7 +98,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
             list(ex.map(compile_one, jobs))
     out = lib_path()
     if jobs or not os.path.exists(out):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out]
+        # Link against the SAME HIP runtime PyTorch uses (its bundled libamdhip64.so, soname
+        # "libamdhip64.so"), never the system one (soname "libamdhip64.so.7"): two runtimes in one
+        # process would give our kernels their own, unordered null stream.  No rpath is recorded;
+        # zuko_amd._C imports torch first so the soname is already resident when we are dlopen'ed.
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-no-hip-rt", *objs, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", out]
         if verbose:
             print("[zuko_amd build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
