@@ -101,6 +101,32 @@ int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, do
 int zk_linear(int dtype, int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight,
               const uint8_t* mask, const void* bias, int act, void* y, int64_t ldy, void* stream);
 
+/* ---- fused masked-autoregressive layer (the dominant kernel of NSF / MAF log_prob) ----------------- *
+ * Replaces, for one MaskedAutoregressiveTransform (zuko/flows/autoregressive.py:207-218 `meta` +
+ * zuko/transforms.py:1005-1007 `call_and_ladj`):  phi = MaskedMLP(cat(x, c)) (zuko/nn.py:217-218 per
+ * layer + activations), univariate(*unpack(phi)).call_and_ladj(x) (zuko/transforms.py:554-567 RQS /
+ * :436-446 affine) and the feature sum of zuko/transforms.py:210-214 — one launch, fp32,
+ * v_mfma_f32_16x16x4_f32, activations register-resident, phi never written to HBM.
+ *
+ *   uni_kind  0 = MonotonicAffineTransform (total 2), 1 = MonotonicRQSTransform with 8 bins (total 23)
+ *   x         [N, DIN] row-major, row stride ldx (elements, multiple of 4), 16-byte aligned:
+ *             cat(x, c) zero-padded to DIN % 4 == 0; the first D columns are the features
+ *   y         [N, D] (row stride ldy); ladj [N] (may be NULL); accumulate != 0 adds to ladj
+ *   wstream / bias / skip / featmap / n_layers / n_groups / n_chunks: the plan of zuko_amd/fused.py
+ *             (degree-sorted, tile-skipped weight stream of 1 KiB MFMA A-operand images, bias image,
+ *             per-group skip bitmasks, feature regrouping of the last layer); wstream and bias are
+ *             produced on the device by zk_gather_f32 from the module's weight / mask / bias tensors.
+ *   limits    DIN <= 256, every hidden width <= 256, >= 1 hidden layer.                             */
+int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
+                  int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
+                  const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
+                  void* stream);
+/* dynamic LDS bytes zk_ar_forward will request for a bias image of `bias_floats` floats (host query). */
+int zk_ar_lds_bytes(int bias_floats);
+/* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
+ * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
+int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);
+
 /* ---- base density + final reduction (zuko/distributions.py:115-119, 337-363) ---------------------- *
  * out[n] = sum_d Normal(loc[d], scale[d]).log_prob(z[n, d]) (+ ladj[n] if ladj != NULL). */
 int zk_diag_normal_log_prob(int dtype, int64_t N, int64_t D, const void* z, const void* loc, const void* scale,

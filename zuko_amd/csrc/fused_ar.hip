@@ -1,0 +1,327 @@
+// zuko_amd — fused masked-autoregressive transform: conditioner + univariate transform + ladj.
+//
+// Replaces, for one autoregressive layer of MAF / NSF (zuko/flows/autoregressive.py:207-218),
+//     phi = MaskedMLP(cat(x, c));  y, ladj = univariate(*unpack(phi)).call_and_ladj(x);  ladj.sum(-1)
+// i.e. zuko/nn.py:217-218 (x4), ReLU (x3), zuko/transforms.py:469-490 + 554-567 (RQS) or
+// :436-446 (affine) and the feature reduction of :210-214 — ONE launch, phi never touches HBM.
+//
+// Execution model (gfx950):
+//   * a workgroup = 8 wavefronts = 128 samples; a wavefront owns 16 samples for the whole network.
+//   * every layer is computed TRANSPOSED, H^T = W . X^T, on v_mfma_f32_16x16x4_f32 (exact fp32):
+//     A = 16x4 slice of W (rows = out units), B = 4x16 slice of the activations (cols = samples).
+//     The D fragment (lane (j, q) holds out units 4q..4q+3 of sample j) has exactly the layout the
+//     NEXT layer needs as its B operand (lane (j, q) supplies k = q of a 4-deep step) once the k
+//     axis is enumerated as k-step r <-> units {r, 4+r, 8+r, 12+r}; the weight stream is laid out
+//     accordingly on the host, so activations stay in VGPRs from the input load to the spline.
+//   * weights (1.2 MB per transform after tile skipping, L2-resident) are streamed through a
+//     3 x 24 KiB LDS ring with global_load_lds_dwordx4 (one 1 KiB tile image per wave-instruction),
+//     shared by the 8 waves and refilled two chunks ahead; A fragments are conflict-free
+//     ds_read_b128 (lane-linear image).
+//   * hidden units are sorted by MADE degree on the host => masks are block lower-triangular and
+//     all-zero 16x16 tiles are skipped via per-group bitmasks (44% of the tiles at cfg2).
+//   * last layer: rows are regrouped so lane (j, q) accumulates all `total` parameters of one
+//     (RQS) or two (affine) features of sample j; the univariate transform runs on those
+//     registers; y is stored, ladj reduced over q with two shuffles and over groups in a register.
+//
+// Host-side planning (permutations, stream order, skip masks): zuko_amd/fused.py.
+#include "zk_univariate.h"
+
+namespace zk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AR_CH 24
+#define AR_RING 3
+#define AR_TF 256 /* floats per tile image */
+#define AR_WAVES 8
+#define AR_T 16   /* activation tiles (256 units) */
+
+struct ArArgs {
+  int64_t N;
+  int D, DIN;               // features, conditioner inputs (features + context), DIN % 4 == 0
+  const float* x; int64_t ldx;  // [N, DIN] = cat(x, c) zero-padded to a multiple of 4; rows 16-byte aligned
+  float* y; int64_t ldy;
+  float* ladj; int accumulate;
+  const float* stream;
+  const float* bias;
+  const uint32_t* skip;
+  const int32_t* featmap;
+  int L, NG, n_chunks, act, bias_floats;
+  float bound, ls;
+  int64_t n_tiles;
+};
+
+__device__ __forceinline__ float act_f32(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? v : 0.f;
+    case 2: return v > 0.f ? v : expm1f(v);
+    case 3: return tanhf(v);
+    case 4: return v / (1.f + expf(-v));
+    case 5: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case 6: return 1.f / (1.f + expf(-v));
+    case 7: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+struct Ring {
+  float* lds;
+  const float* stream;
+  int n_chunks, pos, slot, load_chunk, load_slot, wave, lane;
+
+  __device__ __forceinline__ void issue() {
+#pragma unroll
+    for (int i = 0; i < AR_CH / AR_WAVES; ++i) {
+      const int bi = i * AR_WAVES + wave;
+      const float* g = stream + ((size_t)load_chunk * AR_CH + bi) * AR_TF + lane * 4;
+      float* l = lds + (load_slot * AR_CH + bi) * AR_TF;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
+    load_slot = (load_slot + 1 == AR_RING) ? 0 : load_slot + 1;
+  }
+  // all 8 waves call this at the same point of the (uniform) control flow
+  __device__ __forceinline__ void advance() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my own tile DMAs have landed
+    __syncthreads();                                   // everyone's have; previous chunk fully consumed
+    issue();                                           // refill the slot that was just released
+    slot = (slot + 1 == AR_RING) ? 0 : slot + 1;
+    pos = 0;
+  }
+  __device__ __forceinline__ f32x4 tile(int t) const {
+    return *reinterpret_cast<const f32x4*>(lds + (slot * AR_CH + pos + t) * AR_TF + lane * 4);
+  }
+  __device__ __forceinline__ void end_layer() {
+    if (pos != 0) pos = AR_CH;
+  }
+};
+
+// ---- univariate epilogues -------------------------------------------------------------------------
+struct UniAffine {
+  static constexpr int TOTAL = 2, FPL = 2, NT = 1;
+  template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {
+    affine_fwd<float>(p(base + 0), p(base + 1), ls, x, y, lj);
+  }
+  template <typename P> static __device__ __forceinline__ float inv(const P& p, int base, float bound, float ls, float y) {
+    return affine_inv<float>(p(base + 0), p(base + 1), ls, y);
+  }
+};
+
+struct UniRqs8 {
+  static constexpr int TOTAL = 23, FPL = 1, NT = 6;
+  template <typename P> static __device__ __forceinline__ void knots(const P& p, int base, float bound, float ls, float (&kx)[9], float (&ky)[9], float (&kd)[9]) {
+    rqs_axis_knots<float, 8>([&](int j) { return p(base + j); }, bound, ls, kx);
+    rqs_axis_knots<float, 8>([&](int j) { return p(base + 8 + j); }, bound, ls, ky);
+    rqs_slopes<float, 8>([&](int j) { return p(base + 16 + j); }, ls, kd);
+  }
+  template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {
+    float kx[9], ky[9], kd[9];
+    knots(p, base, bound, ls, kx, ky, kd);
+    int k;
+    rqs_fwd<float, 8>(kx, ky, kd, x, y, lj, k);
+  }
+  template <typename P> static __device__ __forceinline__ float inv(const P& p, int base, float bound, float ls, float y) {
+    float kx[9], ky[9], kd[9];
+    knots(p, base, bound, ls, kx, ky, kd);
+    int k;
+    float x;
+    rqs_inv<float, 8>(kx, ky, kd, y, x, k);
+    return x;
+  }
+};
+
+extern __shared__ __attribute__((aligned(16))) float ar_lds[];
+
+// one masked layer with <= 256 inputs / outputs: out = W in, tiles skipped per (group of 4 out tiles, in tile)
+__device__ __forceinline__ void hidden_layer(Ring& ring, const uint32_t* __restrict__ skip4, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T]) {
+#pragma unroll
+  for (int otg = 0; otg < 4; ++otg) {
+    const uint32_t bits = skip4[otg];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[otg * 4 + t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < AR_T; ++it) {
+      if (bits & (1u << it)) {
+        if (ring.pos == AR_CH) ring.advance();
+        f32x4 a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = ring.tile(t);
+        ring.pos += 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][r], in[it][r], out[otg * 4 + t], 0, 0, 0);
+      }
+    }
+  }
+  ring.end_layer();
+}
+
+template <typename Uni, bool INVERSE> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
+  constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  float* ring_lds = ar_lds;
+  float* bias_lds = ar_lds + AR_RING * AR_CH * AR_TF;
+
+  Ring ring;
+  ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < AR_RING - 1; ++i) ring.issue();
+  ring.slot = AR_RING - 1;
+  ring.pos = AR_CH;
+
+  for (int i = tid; i < a.bias_floats; i += 512) bias_lds[i] = a.bias[i];
+  __syncthreads();
+
+  const uint32_t* skip_last = a.skip + (a.L - 1) * 4;
+  const float* bias_last = bias_lds + (a.L - 1) * 256;
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n = tile * 128 + wave * 16 + j;
+    const bool live = n < a.N;
+    const int64_t nc = live ? n : a.N - 1;
+    const float* xrow = a.x + nc * a.ldx;
+
+    // ---- input tile -> B-operand registers: in[it][r] = input[16 it + 4 q + r] --------------------
+    f32x4 in[AR_T], out[AR_T];
+#pragma unroll
+    for (int it = 0; it < AR_T; ++it) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (it * 16 < a.DIN) {
+        const int i0 = it * 16 + 4 * q;
+        if (i0 < a.DIN) v = *reinterpret_cast<const f32x4*>(xrow + i0);
+      }
+      in[it] = v;
+    }
+
+    // ---- hidden layers ---------------------------------------------------------------------------
+    for (int l = 0; l < a.L - 1; ++l) {
+      hidden_layer(ring, a.skip + l * 4, in, out);
+      const float* bl = bias_lds + l * 256 + 4 * q;
+#pragma unroll
+      for (int t = 0; t < AR_T; ++t) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + t * 16);
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = act_f32(out[t][r] + b[r], a.act);
+        in[t] = h;
+      }
+    }
+
+    // ---- last layer + univariate transform, one group of 4*FPL features at a time ----------------
+    float lacc = 0.f;
+    for (int g = 0; g < a.NG; ++g) {
+      const uint32_t bits = skip_last[g];
+      f32x4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < AR_T; ++it) {
+        if (bits & (1u << it)) {
+          if (ring.pos == AR_CH) ring.advance();
+          f32x4 w[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) w[t] = ring.tile(t);
+          ring.pos += NT;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][r], in[it][r], acc[t], 0, 0, 0);
+        }
+      }
+      float p[4 * NT];
+      const float* bg = bias_last + (g * NT) * 16 + 4 * q;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bg + t * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r] + b[r];
+      }
+      auto ld = [&](int i) { return p[i]; };
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) {
+        const int f = a.featmap[(g * 4 + q) * FPL + fi];
+        if (f >= 0) {
+          const float xv = xrow[f];
+          float yv, lj;
+          if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
+          else Uni::fwd(ld, fi * TOTAL, a.bound, a.ls, xv, yv, lj);
+          if (live) a.y[n * a.ldy + f] = yv;
+          lacc += lj;
+        }
+      }
+    }
+    ring.end_layer();
+    if (!INVERSE && a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead DMAs before the LDS is released
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, const int32_t* __restrict__ idx, int64_t n, float* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int32_t k = idx[i];
+    float v = 0.f;
+    if (k >= 0 && (!mask || mask[k])) v = src[k];
+    dst[i] = v;
+  }
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+// dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]])   (weight-stream / bias-image prep)
+int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream) {
+  if (n <= 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, (const float*)src, mask, idx, n, (float*)dst);
+  return ZK_LAUNCH_CHECK();
+}
+
+int zk_ar_lds_bytes(int bias_floats) { return (AR_RING * AR_CH * AR_TF + bias_floats) * (int)sizeof(float); }
+
+// uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23).  inverse: x <- f^{-1}(y | x_cond)
+// where the conditioner sees `x` (cond) and the univariate inverse is applied to `y_in`... see
+// include/zuko_amd.h for the exact contract.
+int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
+                  int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers,
+                  int n_groups, int n_chunks, int act, double bound, double slope, void* stream) {
+  if (N <= 0) return 0;
+  if (n_layers < 2 || DIN > 256 || DIN < D || DIN % 4 || ldx % 4 || ((uintptr_t)x % 16) || n_chunks < 1) return ZK_EINVAL;
+  ArArgs a{};
+  a.N = N; a.D = D; a.DIN = DIN;
+  a.x = (const float*)x; a.ldx = ldx;
+  a.y = (float*)y; a.ldy = ldy; a.ladj = (float*)ladj; a.accumulate = accumulate;
+  a.stream = (const float*)wstream; a.bias = (const float*)bias; a.skip = skip; a.featmap = featmap;
+  a.L = n_layers; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
+  a.bound = (float)bound; a.ls = (float)log(slope);
+  a.n_tiles = (N + 127) / 128;
+  const int lds = zk_ar_lds_bytes(bias_floats);
+  if (lds > 160 * 1024) return ZK_EINVAL;
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  hipError_t e;
+  if (uni_kind == 0) {
+    e = hipFuncSetAttribute((const void*)ar_kernel<UniAffine, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((ar_kernel<UniAffine, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  } else if (uni_kind == 1) {
+    e = hipFuncSetAttribute((const void*)ar_kernel<UniRqs8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((ar_kernel<UniRqs8, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  } else {
+    return ZK_EINVAL;
+  }
+  return ZK_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -16,10 +16,15 @@ import torch
 from torch import BoolTensor, LongTensor, Size, Tensor
 from torch.distributions import Transform
 
+import weakref
+
+import torch.nn as nn
+
+from .. import fused
 from ..distributions import DiagNormal
 from ..lazy import Flow, LazyTransform, UnconditionalDistribution
-from ..nn import MaskedMLP
-from ..transforms import AutoregressiveTransform, DependentTransform, MonotonicAffineTransform
+from ..nn import MaskedLinear, MaskedMLP, _act_code
+from ..transforms import AutoregressiveTransform, DependentTransform, MonotonicAffineTransform, MonotonicRQSTransform
 from ..utils import broadcast, unpack
 from .elementwise import ElementWiseTransform
 
@@ -130,7 +135,103 @@ class MaskedAutoregressiveTransform(LazyTransform):
         return DependentTransform(self.univariate(*unpack(phi, self.shapes)), 1)
 
     def forward(self, c: Tensor | None = None) -> Transform:
-        return AutoregressiveTransform(partial(self.meta, c), self.passes)
+        return FusedAutoregressiveTransform(self, c)
+
+    # ---- fused-kernel support ----------------------------------------------------------------
+
+    def _fusable_layout(self):
+        """(UniLayout, bound, slope) if conditioner + univariate fit csrc/fused_ar.hip, else None."""
+        u = self.univariate
+        f, kw = (u.func, dict(u.keywords)) if isinstance(u, partial) else (u, {})
+        if isinstance(u, partial) and u.args:
+            return None
+        shapes = [tuple(s) for s in self.shapes]
+        slope = kw.pop("slope", 1e-3)
+        if f is MonotonicAffineTransform and shapes == [(), ()] and not kw:
+            return fused.uni_layout("affine", 2), 5.0, slope
+        if f is MonotonicRQSTransform and len(shapes) == 3 and shapes[0] == shapes[1] and shapes[2] == (shapes[0][0] - 1,):
+            bound = kw.pop("bound", 5.0)
+            lay = fused.uni_layout("rqs", self.total, shapes[0][0])
+            if lay is not None and not kw:
+                return lay, bound, slope
+        return None
+
+    def fused_state(self, device: torch.device):
+        """Plan + device tables of the fused kernel (built once per device), or None."""
+        cache = _FUSED_CACHE.setdefault(self, {})
+        key = str(device)
+        if key not in cache:
+            state = None
+            lay = self._fusable_layout()
+            mods = list(self.hyper)
+            lins = [m for m in mods if isinstance(m, MaskedLinear)]
+            acts = [m for m in mods if not isinstance(m, MaskedLinear)]
+            simple = all(isinstance(a, MaskedLinear) != (i % 2 == 1) for i, a in enumerate(mods))  # lin, act, lin, ...
+            codes = {_act_code(a) for a in acts}
+            if lay is not None and simple and len(codes) == 1 and None not in codes and all(l.weight.dtype == torch.float32 for l in lins):
+                plan = fused.build_plan([l.mask for l in lins], self.features, lay[0])
+                if plan is not None:
+                    state = fused.FusedAR(plan, device, codes.pop(), lay[1], lay[2])
+            cache[key] = state
+        return cache[key]
+
+
+_FUSED_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+class FusedAutoregressiveTransform(AutoregressiveTransform):
+    r"""The Transform `MaskedAutoregressiveTransform.forward(c)` returns.
+
+    Same interface and semantics as zuko's `AutoregressiveTransform(partial(meta, c), passes)`
+    (zuko/transforms.py:966-1007), but `call_and_ladj` / `_call` / `log_abs_det_jacobian` run the
+    conditioner, the univariate transform and the feature-sum of log|det J| in ONE kernel
+    (zk_ar_forward) whenever the layer fits it (fp32, widths <= 256, affine or 8-bin RQS, fusable
+    activation); otherwise the layer-by-layer kernels are used through `meta`."""
+
+    def __init__(self, lazy: MaskedAutoregressiveTransform, c: Tensor | None) -> None:
+        super().__init__(partial(lazy.meta, c), lazy.passes)
+        self.lazy = lazy
+        self.c = c
+
+    def _fused(self, x: Tensor):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1):
+            return None
+        if torch.is_grad_enabled() and (x.requires_grad or (self.c is not None and self.c.requires_grad) or any(p.requires_grad for p in self.lazy.hyper.parameters())):
+            return None
+        return self.lazy.fused_state(x.device)
+
+    def call_and_ladj(self, x: Tensor):
+        st = self._fused(x)
+        if st is None:
+            return super().call_and_ladj(x)
+        lazy, c = self.lazy, self.c
+        D = lazy.features
+        if c is not None:
+            xb, cb = broadcast(x, c, ignore=1)
+        else:
+            xb, cb = x, None
+        batch = xb.shape[:-1]
+        x2 = xb.reshape(-1, D)
+        din = D + (0 if cb is None else cb.shape[-1])
+        dinp = -(-din // 4) * 4
+        if cb is None and dinp == D and x2.stride(-1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0:
+            inp = x2
+        else:
+            inp = x2.new_zeros((x2.shape[0], dinp))
+            inp[:, :D] = x2
+            if cb is not None:
+                inp[:, D:din] = cb.reshape(-1, cb.shape[-1])
+        y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
+        ladj = torch.empty(x2.shape[0], dtype=x.dtype, device=x.device)
+        st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+        st.run(inp, y, ladj, False)
+        return y.reshape(batch + (D,)), ladj.reshape(batch)
+
+    def _call(self, x: Tensor) -> Tensor:
+        return self.call_and_ladj(x)[0]
+
+    def log_abs_det_jacobian(self, x: Tensor, y: Tensor) -> Tensor:
+        return self.call_and_ladj(x)[1]
 
 
 class MAF(Flow):

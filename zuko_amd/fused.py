@@ -1,0 +1,344 @@
+r"""Host-side planning for the fused autoregressive kernel (csrc/fused_ar.hip).
+
+The kernel evaluates, for a tile of samples, the whole masked conditioner
+(zuko/nn.py:217-218, :279-315) followed by the univariate transform + log|det J|
+(zuko/transforms.py:554-567 / :436-446) with the activations held in MFMA accumulator
+registers from the first layer to the spline epilogue.  This module turns a `MaskedMLP` into what
+that kernel consumes:
+
+* a permutation of every hidden layer's units by the size of their dependency set (the "degree"
+  of MADE), applied to the rows of W_l and the columns of W_{l+1}: results are unchanged up to
+  summation order, but the masks become block lower-triangular so that whole 16x16 weight tiles
+  vanish and are skipped;
+* the WEIGHT STREAM: the surviving 16x16 tiles, each stored as the 1 KiB image the 64 lanes of a
+  wavefront read back as their `v_mfma_f32_16x16x4_f32` A operand (lane (i, q) <- W[row i][col 4q..4q+3]),
+  in exactly the order the kernel consumes them, every layer padded to a whole number of
+  24-tile chunks (the granularity of the LDS ring the tiles are DMA'd through);
+* per tile-group skip bitmasks, the bias image, and the feature map of the last layer, whose
+  output rows are regrouped so that ONE lane ends up holding all `total` parameters of a feature.
+
+Everything here is integer bookkeeping on the CPU (done once per module); the per-call work —
+gathering mask*W into the stream — is a HIP kernel (zk_gather_f32).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+from torch import Tensor
+
+TILE = 16
+CHUNK = 24  # tiles per LDS-ring chunk; multiple of every group size used (4 and 6)
+GROUP_HIDDEN = 4  # out tiles processed together in the hidden layers
+MAX_WIDTH = 256  # activations live in 16 tiles x 4 registers per lane
+
+
+@dataclass
+class UniLayout:
+    """How the last layer's rows are regrouped for a univariate transform with `total` params."""
+
+    kind: int  # 0 = affine, 1 = rqs
+    total: int
+    fpl: int  # features per lane
+    nt: int  # 16-row output tiles per group of 4*fpl features
+    bins: int = 0
+
+
+def uni_layout(kind: str, total: int, bins: int = 0) -> UniLayout | None:
+    if kind == "affine" and total == 2:
+        return UniLayout(0, 2, 2, 1)
+    if kind == "rqs" and bins == 8 and total == 23:
+        return UniLayout(1, 23, 1, 6, 8)
+    return None
+
+
+@dataclass
+class ArPlan:
+    layout: UniLayout
+    n_layers: int  # linear layers (hidden + 1)
+    din: int  # input width (features + context)
+    features: int
+    n_groups: int  # groups of 4*fpl features in the last layer
+    n_chunks: int
+    gather: list  # per layer: int32 index into W_l.flatten() (-1 -> 0), length = blocks*256
+    layer_block0: list  # first stream block of each layer
+    bias_gather: list  # per layer: int32 index into b_l (-1 -> 0)
+    bias_off: list  # offset of each layer's bias image in the bias buffer
+    skip: np.ndarray  # uint32 [(n_layers-1)*4 + n_groups]
+    featmap: np.ndarray  # int32 [n_groups*4*fpl] original feature index or -1
+    n_blocks: int
+    dense_tiles: int  # tile pairs a dense evaluation would touch (for reporting)
+    kept_tiles: int
+
+
+def _deps(masks: list[np.ndarray]) -> list[np.ndarray]:
+    """Input-dependency sets of every layer's units (boolean products of the masks)."""
+    out = []
+    cur = masks[0].astype(bool)
+    out.append(cur)
+    for m in masks[1:]:
+        cur = (m.astype(np.int64) @ cur.astype(np.int64)) > 0
+        out.append(cur)
+    return out
+
+
+def build_plan(masks: list[Tensor], features: int, layout: UniLayout) -> ArPlan | None:
+    """masks[l]: bool [out_l, in_l] of the conditioner's linear layers (last: features*total rows)."""
+    M = [m.detach().cpu().numpy().astype(bool) for m in masks]
+    L = len(M)
+    if L < 2:
+        return None
+    din = M[0].shape[1]
+    widths = [m.shape[0] for m in M[:-1]]
+    if din > MAX_WIDTH or any(w > MAX_WIDTH for w in widths) or M[-1].shape[0] != features * layout.total:
+        return None
+    deps = _deps(M)
+
+    # unit permutations (stable sort by dependency count) and padded index lists (-1 = padding)
+    def padded(idx: np.ndarray, mult: int) -> np.ndarray:
+        n = -(-len(idx) // mult) * mult
+        return np.concatenate([idx, -np.ones(n - len(idx), dtype=np.int64)])
+
+    cols = padded(np.arange(din), TILE)  # layer-0 input order is the natural one
+    perms = []
+    for l in range(L - 1):
+        key = deps[l].sum(axis=1)
+        perms.append(padded(np.argsort(key, kind="stable"), TILE))
+
+    fkey = deps[-1][:: layout.total].sum(axis=1)
+    per_group = 4 * layout.fpl
+    featmap = padded(np.argsort(fkey, kind="stable"), per_group).astype(np.int32)
+    n_groups = len(featmap) // per_group
+
+    gather, layer_block0, bias_gather, bias_off, skip = [], [], [], [], []
+    block_cursor = 0
+    bias_cursor = 0
+    dense_tiles = kept_tiles = 0
+
+    lane = np.arange(64)
+    li, lq = lane % 16, lane // 16
+
+    def block_index(rows: np.ndarray, ccols: np.ndarray, in_width: int) -> np.ndarray:
+        """1 KiB tile image: element (lane, r) <- W[rows[lane%16], ccols[4*(lane//16) + r]]."""
+        r = rows[li][:, None]  # [64, 1]
+        c = ccols[(4 * lq)[:, None] + np.arange(4)[None, :]]  # [64, 4]
+        idx = r * in_width + c
+        idx[(r < 0) | (c < 0)] = -1
+        return idx.reshape(-1)
+
+    def tile_nonzero(mask: np.ndarray, rows: np.ndarray, ccols: np.ndarray) -> bool:
+        rr, cc = rows[rows >= 0], ccols[ccols >= 0]
+        return bool(rr.size and cc.size and mask[np.ix_(rr, cc)].any())
+
+    def finish_layer(blocks: list[np.ndarray]) -> None:
+        nonlocal block_cursor
+        n = len(blocks)
+        pad = -(-n // CHUNK) * CHUNK - n
+        blocks = blocks + [-np.ones(256, dtype=np.int64)] * pad
+        gather.append(np.concatenate(blocks).astype(np.int32) if blocks else np.zeros(0, np.int32))
+        layer_block0.append(block_cursor)
+        block_cursor += len(blocks)
+
+    in_cols = cols
+    for l in range(L - 1):
+        rows_all = perms[l]
+        n_ot = len(rows_all) // TILE
+        n_it = len(in_cols) // TILE
+        blocks = []
+        for otg in range(MAX_WIDTH // TILE // GROUP_HIDDEN):
+            bits = 0
+            ots = [otg * GROUP_HIDDEN + t for t in range(GROUP_HIDDEN)]
+            if ots[0] < n_ot:
+                for it in range(n_it):
+                    cc = in_cols[it * TILE : (it + 1) * TILE]
+                    nz = False
+                    for ot in ots:
+                        if ot < n_ot:
+                            dense_tiles += 1
+                            if tile_nonzero(M[l], rows_all[ot * TILE : (ot + 1) * TILE], cc):
+                                nz = True
+                    if nz:
+                        bits |= 1 << it
+                        for ot in ots:
+                            rr = rows_all[ot * TILE : (ot + 1) * TILE] if ot < n_ot else -np.ones(TILE, dtype=np.int64)
+                            blocks.append(block_index(rr, cc, M[l].shape[1]))
+                            kept_tiles += 1
+            skip.append(bits)
+        finish_layer(blocks)
+        b = -np.ones(MAX_WIDTH, dtype=np.int64)
+        b[: len(rows_all)] = rows_all
+        bias_gather.append(b.astype(np.int32))
+        bias_off.append(bias_cursor)
+        bias_cursor += MAX_WIDTH
+        in_cols = rows_all
+
+    # last layer: group g, tile t, tile row i  <->  feature slot / parameter
+    n_it = len(in_cols) // TILE
+    blocks = []
+    bias_last = []
+    for g in range(n_groups):
+        tiles_rows = []
+        for t in range(layout.nt):
+            rows = -np.ones(TILE, dtype=np.int64)
+            for i in range(TILE):
+                m = 4 * t + (i & 3)
+                fi, p = divmod(m, layout.total)
+                if fi < layout.fpl:
+                    f = featmap[g * per_group + (i >> 2) * layout.fpl + fi]
+                    if f >= 0:
+                        rows[i] = f * layout.total + p
+            tiles_rows.append(rows)
+            bias_last.append(rows)
+        bits = 0
+        for it in range(n_it):
+            cc = in_cols[it * TILE : (it + 1) * TILE]
+            dense_tiles += layout.nt
+            if any(tile_nonzero(M[-1], rows, cc) for rows in tiles_rows):
+                bits |= 1 << it
+                for rows in tiles_rows:
+                    blocks.append(block_index(rows, cc, M[-1].shape[1]))
+                    kept_tiles += 1
+        skip.append(bits)
+    finish_layer(blocks)
+    bias_gather.append(np.concatenate(bias_last).astype(np.int32))
+    bias_off.append(bias_cursor)
+
+    return ArPlan(
+        layout=layout,
+        n_layers=L,
+        din=din,
+        features=features,
+        n_groups=n_groups,
+        n_chunks=block_cursor // CHUNK,
+        gather=gather,
+        layer_block0=layer_block0,
+        bias_gather=bias_gather,
+        bias_off=bias_off,
+        skip=np.asarray(skip, dtype=np.uint32),
+        featmap=featmap,
+        n_blocks=block_cursor,
+        dense_tiles=dense_tiles,
+        kept_tiles=kept_tiles,
+    )
+
+
+def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], masks: list[np.ndarray], inp: np.ndarray, act) -> np.ndarray:
+    """Pure-numpy walk through the SAME stream / tables the kernel uses (tile order, skip bits,
+    chunk padding, feature regrouping) for a [n, din] input; returns phi[n, features, total].
+    Used by the CPU tests to validate the plan without a GPU."""
+    stream = []
+    for l, g in enumerate(plan.gather):
+        w = (weights[l] * masks[l]).reshape(-1)
+        s = np.where(g >= 0, w[np.maximum(g, 0)], 0.0)
+        stream.append(s)
+    stream = np.concatenate(stream).reshape(-1, 64, 4)  # [block][lane][r]
+    bias_img = []
+    for l, g in enumerate(plan.bias_gather):
+        bias_img.append(np.where(g >= 0, biases[l][np.maximum(g, 0)], 0.0))
+    n = inp.shape[0]
+    cur = np.zeros((n, MAX_WIDTH))
+    cur[:, : plan.din] = inp
+    lay = plan.layout
+    for l in range(plan.n_layers - 1):
+        b = plan.layer_block0[l]
+        out = np.zeros((n, MAX_WIDTH))
+        for otg in range(4):
+            bits = int(plan.skip[l * 4 + otg])
+            for it in range(16):
+                if bits >> it & 1:
+                    for t in range(GROUP_HIDDEN):
+                        ot = otg * GROUP_HIDDEN + t
+                        blk = stream[b]
+                        b += 1
+                        # lane (i, q), r: A[i][k = 4q + r]
+                        A = blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)  # [i][4q+r]
+                        out[:, ot * 16 : ot * 16 + 16] += cur[:, it * 16 : it * 16 + 16] @ A.T
+        cur = act(out + bias_img[l][None, :])
+    b = plan.layer_block0[-1]
+    phi = np.zeros((n, plan.features, lay.total))
+    per_group = 4 * lay.fpl
+    for g in range(plan.n_groups):
+        acc = np.zeros((n, lay.nt, 16))
+        bits = int(plan.skip[(plan.n_layers - 1) * 4 + g])
+        for it in range(16):
+            if bits >> it & 1:
+                for t in range(lay.nt):
+                    blk = stream[b]
+                    b += 1
+                    A = blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)
+                    acc[:, t, :] += cur[:, it * 16 : it * 16 + 16] @ A.T
+        acc += bias_img[-1].reshape(plan.n_groups, lay.nt, 16)[g][None]
+        for t in range(lay.nt):
+            for i in range(16):
+                m = 4 * t + (i & 3)
+                fi, p = divmod(m, lay.total)
+                if fi < lay.fpl:
+                    f = plan.featmap[g * per_group + (i >> 2) * lay.fpl + fi]
+                    if f >= 0:
+                        phi[:, f, p] = acc[:, t, i]
+    return phi
+
+
+# --------------------------------------------------------------------------------------------------
+# device-side state: plan tables + the gathered weight stream, refreshed when parameters change
+# --------------------------------------------------------------------------------------------------
+
+
+class FusedAR:
+    """Runs zk_ar_forward for one MaskedAutoregressiveTransform on one device."""
+
+    def __init__(self, plan: ArPlan, device: torch.device, act: int, bound: float, slope: float) -> None:
+        self.plan = plan
+        self.device = device
+        self.act = act
+        self.bound = bound
+        self.slope = slope
+        self.skip = torch.from_numpy(plan.skip.view(np.int32).copy()).to(device)
+        self.featmap = torch.from_numpy(plan.featmap.copy()).to(device)
+        self.gather = [torch.from_numpy(g).to(device) for g in plan.gather]
+        self.bias_gather = [torch.from_numpy(g).to(device) for g in plan.bias_gather]
+        self.stream = torch.empty(plan.n_blocks * 256, dtype=torch.float32, device=device)
+        self.bias_floats = plan.bias_off[-1] + len(plan.bias_gather[-1])
+        self.bias = torch.empty(self.bias_floats, dtype=torch.float32, device=device)
+        self._stamp = None
+
+    def refresh(self, linears) -> None:
+        """(Re)build the weight stream / bias image if any parameter changed since the last call."""
+        from . import _C
+        from .ops import _ptr, _stream
+
+        stamp = tuple((m.weight._version, m.weight.data_ptr(), m.bias._version if m.bias is not None else -1) for m in linears)
+        if stamp == self._stamp:
+            return
+        lib = _C.lib()
+        for l, m in enumerate(linears):
+            w = m.weight.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            mask = m.mask.contiguous().view(torch.uint8)
+            n = self.gather[l].numel()
+            dst = self.stream[self.plan.layer_block0[l] * 256 :]
+            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), n, _ptr(dst), _stream()), "zk_gather_f32")
+            nb = self.bias_gather[l].numel()
+            bdst = self.bias[self.plan.bias_off[l] :]
+            if m.bias is None:
+                bdst[:nb].zero_()
+            else:
+                _C.check(lib.zk_gather_f32(_ptr(m.bias.detach().contiguous()), None, _ptr(self.bias_gather[l]), nb, _ptr(bdst), _stream()), "zk_gather_f32")
+        self._stamp = stamp
+
+    def run(self, inp: Tensor, y: Tensor, ladj: Tensor | None, accumulate: bool) -> None:
+        """inp [N, DINP] (cat(x, c), zero-padded to a multiple of 4 columns), y [N, D], ladj [N]."""
+        from . import _C
+        from .ops import _ptr, _stream
+
+        p = self.plan
+        N = inp.shape[0]
+        err = _C.lib().zk_ar_forward(
+            p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
+            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
+            self.act, self.bound, self.slope, _stream(),
+        )
+        _C.check(err, "zk_ar_forward")
