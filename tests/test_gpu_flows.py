@@ -99,9 +99,10 @@ def test_flow_properties_large_batch(dev, name, batch):
     rel_close(lp[:256], ref, "log_prob vs oracle", 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("name", ["nsf_cfg1", "nsf_cfg2", "maf_cfg3", "maf_doc", "nsf_p2"])
 @pytest.mark.parametrize("N", [1, 127, 129, 1000])
-def test_fused_layer_vs_layerwise_kernels_and_oracle(dev, name, N):
+def test_fused_layer_vs_layerwise_kernels_and_oracle(dev, name, N, variant, monkeypatch):
     """The fused conditioner+transform kernel (zk_ar_forward) against (a) the layer-by-layer HIP
     kernels (zk_linear x L, zk_rqs_forward / zk_affine_forward) and (b) the CPU oracle, per layer,
     on ragged batch sizes (tail tiles, single row)."""
@@ -109,9 +110,8 @@ def test_fused_layer_vs_layerwise_kernels_and_oracle(dev, name, N):
 
     from zuko_amd.transforms import AutoregressiveTransform
 
+    monkeypatch.setenv("ZUKO_AMD_AR_VARIANT", str(variant))  # 0 = LDS ring, 1 = direct L2->VGPR feed
     flow, entry = build_flow(name)
-    if name == "nsf_p2":
-        pytest.skip("bins=4 is not a fused layout; covered by the layer-wise path") if False else None
     spec = oracle_spec(flow, entry)
     flow = flow.to(dev)
     gen = torch.Generator().manual_seed(N)

@@ -25,6 +25,7 @@
 //
 // Host-side planning (permutations, stream order, skip masks): zuko_amd/fused.py.
 #include "zk_univariate.h"
+#include <type_traits>
 
 namespace zk {
 
@@ -91,41 +92,80 @@ struct Ring {
   __device__ __forceinline__ f32x4 tile(int t) const {
     return *reinterpret_cast<const f32x4*>(lds + (slot * AR_CH + pos + t) * AR_TF + lane * 4);
   }
+  template <int G> __device__ __forceinline__ void begin() {
+    if (pos == AR_CH) advance();
+  }
+  template <int G> __device__ __forceinline__ void commit() { pos += G; }
   __device__ __forceinline__ void end_layer() {
     if (pos != 0) pos = AR_CH;
   }
+  __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// Variant B of the weight feed: no LDS, no workgroup synchronisation.  Every wavefront streams the
+// (L2-resident) tile images straight into VGPRs with global_load_dwordx4 — a tile image is exactly
+// one 16-byte load per lane — through a 12-tile register FIFO that runs two groups ahead of the
+// MFMAs.  The stream is consumed strictly linearly, so "the next group" is always the next G
+// images whatever (layer, out-group, in-tile) it belongs to; the stream carries no chunk padding.
+#define AR_FIFO 12
+struct Feed {
+  const f32x4* src;  // stream + lane
+  int head, n_blocks;
+  f32x4 q[AR_FIFO];
+  __device__ __forceinline__ f32x4 fetch() {
+    const f32x4 v = src[(size_t)head * 64];
+    head = (head + 1 == n_blocks) ? 0 : head + 1;
+    return v;
+  }
+  __device__ __forceinline__ void init(const float* stream, int lane, int nb) {
+    src = reinterpret_cast<const f32x4*>(stream) + lane;
+    head = 0;
+    n_blocks = nb;
+#pragma unroll
+    for (int i = 0; i < AR_FIFO; ++i) q[i] = fetch();
+  }
+  __device__ __forceinline__ f32x4 tile(int t) const { return q[t]; }
+  template <int G> __device__ __forceinline__ void begin() {}
+  template <int G> __device__ __forceinline__ void commit() {
+#pragma unroll
+    for (int i = 0; i + G < AR_FIFO; ++i) q[i] = q[i + G];
+#pragma unroll
+    for (int i = AR_FIFO - G; i < AR_FIFO; ++i) q[i] = fetch();
+  }
+  __device__ __forceinline__ void end_layer() {}
+  __device__ __forceinline__ void drain() {}
 };
 
 // ---- univariate epilogues -------------------------------------------------------------------------
 struct UniAffine {
   static constexpr int TOTAL = 2, FPL = 2, NT = 1;
   template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {
-    affine_fwd<float>(p(base + 0), p(base + 1), ls, x, y, lj);
+    affine_fwd<float, MathFast>(p(base + 0), p(base + 1), ls, x, y, lj);
   }
   template <typename P> static __device__ __forceinline__ float inv(const P& p, int base, float bound, float ls, float y) {
-    return affine_inv<float>(p(base + 0), p(base + 1), ls, y);
+    return affine_inv<float, MathFast>(p(base + 0), p(base + 1), ls, y);
   }
 };
 
 struct UniRqs8 {
   static constexpr int TOTAL = 23, FPL = 1, NT = 6;
   template <typename P> static __device__ __forceinline__ void knots(const P& p, int base, float bound, float ls, float (&kx)[9], float (&ky)[9], float (&kd)[9]) {
-    rqs_axis_knots<float, 8>([&](int j) { return p(base + j); }, bound, ls, kx);
-    rqs_axis_knots<float, 8>([&](int j) { return p(base + 8 + j); }, bound, ls, ky);
-    rqs_slopes<float, 8>([&](int j) { return p(base + 16 + j); }, ls, kd);
+    rqs_axis_knots<float, 8, MathFast>([&](int j) { return p(base + j); }, bound, ls, kx);
+    rqs_axis_knots<float, 8, MathFast>([&](int j) { return p(base + 8 + j); }, bound, ls, ky);
+    rqs_slopes<float, 8, MathFast>([&](int j) { return p(base + 16 + j); }, ls, kd);
   }
   template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {
     float kx[9], ky[9], kd[9];
     knots(p, base, bound, ls, kx, ky, kd);
     int k;
-    rqs_fwd<float, 8>(kx, ky, kd, x, y, lj, k);
+    rqs_fwd<float, 8, MathFast>(kx, ky, kd, x, y, lj, k);
   }
   template <typename P> static __device__ __forceinline__ float inv(const P& p, int base, float bound, float ls, float y) {
     float kx[9], ky[9], kd[9];
     knots(p, base, bound, ls, kx, ky, kd);
     int k;
     float x;
-    rqs_inv<float, 8>(kx, ky, kd, y, x, k);
+    rqs_inv<float, 8, MathFast>(kx, ky, kd, y, x, k);
     return x;
   }
 };
@@ -133,7 +173,7 @@ struct UniRqs8 {
 extern __shared__ __attribute__((aligned(16))) float ar_lds[];
 
 // one masked layer with <= 256 inputs / outputs: out = W in, tiles skipped per (group of 4 out tiles, in tile)
-__device__ __forceinline__ void hidden_layer(Ring& ring, const uint32_t* __restrict__ skip4, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T]) {
+template <class Src> __device__ __forceinline__ void hidden_layer(Src& ring, const uint32_t* __restrict__ skip4, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T]) {
 #pragma unroll
   for (int otg = 0; otg < 4; ++otg) {
     const uint32_t bits = skip4[otg];
@@ -142,11 +182,11 @@ __device__ __forceinline__ void hidden_layer(Ring& ring, const uint32_t* __restr
 #pragma unroll
     for (int it = 0; it < AR_T; ++it) {
       if (bits & (1u << it)) {
-        if (ring.pos == AR_CH) ring.advance();
+        ring.template begin<4>();
         f32x4 a[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) a[t] = ring.tile(t);
-        ring.pos += 4;
+        ring.template commit<4>();
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -157,22 +197,27 @@ __device__ __forceinline__ void hidden_layer(Ring& ring, const uint32_t* __restr
   ring.end_layer();
 }
 
-template <typename Uni, bool INVERSE> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
+template <typename Uni, bool INVERSE, bool DIRECT> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   float* ring_lds = ar_lds;
-  float* bias_lds = ar_lds + AR_RING * AR_CH * AR_TF;
+  float* bias_lds = ar_lds + AR_RING * AR_CH * AR_TF;  // (DIRECT: the bias image is the only LDS user)
 
-  Ring ring;
-  ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
-  ring.load_chunk = 0; ring.load_slot = 0;
+  typename std::conditional<DIRECT, Feed, Ring>::type ring;
+  if constexpr (DIRECT) {
+    ring.init(a.stream, lane, a.n_chunks);  // n_chunks == number of tile images (chunk size 1)
+    bias_lds = ar_lds;
+  } else {
+    ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+    ring.load_chunk = 0; ring.load_slot = 0;
 #pragma unroll
-  for (int i = 0; i < AR_RING - 1; ++i) ring.issue();
-  ring.slot = AR_RING - 1;
-  ring.pos = AR_CH;
+    for (int i = 0; i < AR_RING - 1; ++i) ring.issue();
+    ring.slot = AR_RING - 1;
+    ring.pos = AR_CH;
+  }
 
   for (int i = tid; i < a.bias_floats; i += 512) bias_lds[i] = a.bias[i];
   __syncthreads();
@@ -222,11 +267,11 @@ template <typename Uni, bool INVERSE> __global__ __launch_bounds__(512, 2) void 
 #pragma unroll
       for (int it = 0; it < AR_T; ++it) {
         if (bits & (1u << it)) {
-          if (ring.pos == AR_CH) ring.advance();
+          ring.template begin<NT>();
           f32x4 w[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) w[t] = ring.tile(t);
-          ring.pos += NT;
+          ring.template commit<NT>();
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -262,7 +307,7 @@ template <typename Uni, bool INVERSE> __global__ __launch_bounds__(512, 2) void 
       if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead DMAs before the LDS is released
+  ring.drain();  // look-ahead DMAs must land before the LDS is released
 }
 
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, const int32_t* __restrict__ idx, int64_t n, float* __restrict__ dst) {
@@ -295,7 +340,7 @@ int zk_ar_lds_bytes(int bias_floats) { return (AR_RING * AR_CH * AR_TF + bias_fl
 // include/zuko_amd.h for the exact contract.
 int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
                   int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers,
-                  int n_groups, int n_chunks, int act, double bound, double slope, void* stream) {
+                  int n_groups, int n_chunks, int act, double bound, double slope, int variant, void* stream) {
   if (N <= 0) return 0;
   if (n_layers < 2 || DIN > 256 || DIN < D || DIN % 4 || ldx % 4 || ((uintptr_t)x % 16) || n_chunks < 1) return ZK_EINVAL;
   ArArgs a{};
@@ -306,21 +351,19 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
   a.L = n_layers; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
   a.bound = (float)bound; a.ls = (float)log(slope);
   a.n_tiles = (N + 127) / 128;
-  const int lds = zk_ar_lds_bytes(bias_floats);
+  const bool direct = (variant == 1);
+  const int lds = direct ? bias_floats * (int)sizeof(float) : zk_ar_lds_bytes(bias_floats);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
-  hipError_t e;
-  if (uni_kind == 0) {
-    e = hipFuncSetAttribute((const void*)ar_kernel<UniAffine, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((ar_kernel<UniAffine, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-  } else if (uni_kind == 1) {
-    e = hipFuncSetAttribute((const void*)ar_kernel<UniRqs8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((ar_kernel<UniRqs8, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-  } else {
-    return ZK_EINVAL;
-  }
+  const void* fn = nullptr;
+  if (uni_kind == 0) fn = direct ? (const void*)ar_kernel<UniAffine, false, true> : (const void*)ar_kernel<UniAffine, false, false>;
+  else if (uni_kind == 1) fn = direct ? (const void*)ar_kernel<UniRqs8, false, true> : (const void*)ar_kernel<UniRqs8, false, false>;
+  else return ZK_EINVAL;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
+  void* kargs[] = {&a};
+  e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
   return ZK_LAUNCH_CHECK();
 }
 

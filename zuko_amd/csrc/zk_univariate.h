@@ -18,22 +18,40 @@
 namespace zk {
 
 // ---------------------------------------------------------------------------------------------
+// math policies.  MathIEEE: correctly rounded division, ocml expf/logf (<= 1 ulp) — used by the
+// standalone kernels, whose parameters are bit-identical to the reference's.  MathFast (fp32):
+// v_rcp/v_exp/v_log based (a few ulp) — used inside the fused conditioner kernel, where the
+// parameters already carry ~1e-6 relative GEMM summation-order noise and the ~1000-instruction
+// IEEE epilogue would otherwise idle the matrix pipe (profiles/r01: 4.4 VALU instructions per MFMA).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct MathIEEE {
+  static __device__ __forceinline__ T div(T a, T b) { return a / b; }
+  static __device__ __forceinline__ T exp(T v) { return t_exp(v); }
+  static __device__ __forceinline__ T log(T v) { return t_log(v); }
+};
+struct MathFast {
+  static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  static __device__ __forceinline__ float exp(float v) { return __expf(v); }
+  static __device__ __forceinline__ float log(float v) { return __logf(v); }
+};
+
+// ---------------------------------------------------------------------------------------------
 // soft clipping of unconstrained parameters (transforms.py:436, :480-482)
 // ---------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T softclip(T v, T ls) { return v / (T(1) + t_abs(v / ls)); }
-template <typename T> __device__ __forceinline__ T softclip2(T v, T ls) { return v / (T(1) + t_abs((T(2) * v) / ls)); }
+template <typename T, class M = MathIEEE<T>> __device__ __forceinline__ T softclip(T v, T ls) { return M::div(v, T(1) + t_abs(M::div(v, ls))); }
+template <typename T, class M = MathIEEE<T>> __device__ __forceinline__ T softclip2(T v, T ls) { return M::div(v, T(1) + t_abs(M::div(T(2) * v, ls))); }
 
 // ---------------------------------------------------------------------------------------------
 // monotonic affine (transforms.py:436-446)
 // ---------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void affine_fwd(T shift, T scale, T ls, T x, T& y, T& ladj) {
-  T lsc = softclip(scale, ls);
-  y = x * t_exp(lsc) + shift;
+template <typename T, class M = MathIEEE<T>> __device__ __forceinline__ void affine_fwd(T shift, T scale, T ls, T x, T& y, T& ladj) {
+  T lsc = softclip<T, M>(scale, ls);
+  y = x * M::exp(lsc) + shift;
   ladj = lsc;
 }
-template <typename T> __device__ __forceinline__ T affine_inv(T shift, T scale, T ls, T y) {
-  T lsc = softclip(scale, ls);
-  return (y - shift) / t_exp(lsc);
+template <typename T, class M = MathIEEE<T>> __device__ __forceinline__ T affine_inv(T shift, T scale, T ls, T y) {
+  T lsc = softclip<T, M>(scale, ls);
+  return M::div(y - shift, M::exp(lsc));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -42,21 +60,21 @@ template <typename T> __device__ __forceinline__ T affine_inv(T shift, T scale, 
 
 // softmax over K soft-clipped values followed by the padded cumulative sum mapped to [-B, B]
 // (transforms.py:480-481, 484-485, 488-489).  `ld(j)` returns the j-th unconstrained value.
-template <typename T, int K, typename Ld> __device__ __forceinline__ void rqs_axis_knots(Ld ld, T bound, T ls, T (&knot)[K + 1]) {
+template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __forceinline__ void rqs_axis_knots(Ld ld, T bound, T ls, T (&knot)[K + 1]) {
   T v[K];
   T m;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    v[j] = softclip2<T>(ld(j), ls);
+    v[j] = softclip2<T, M>(ld(j), ls);
     m = (j == 0) ? v[0] : (v[j] > m ? v[j] : m);
   }
   T s = T(0);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    v[j] = t_exp(v[j] - m);
+    v[j] = M::exp(v[j] - m);
     s += v[j];
   }
-  T r = T(1) / s;
+  T r = M::div(T(1), s);
   T cum = T(0);
   knot[0] = bound * (T(2) * cum - T(1));
 #pragma unroll
@@ -67,11 +85,11 @@ template <typename T, int K, typename Ld> __device__ __forceinline__ void rqs_ax
 }
 
 // knot slopes: exp(softclip(d)) inside, 1 at both ends (transforms.py:482, 486, 490)
-template <typename T, int K, typename Ld> __device__ __forceinline__ void rqs_slopes(Ld ld, T ls, T (&kd)[K + 1]) {
+template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __forceinline__ void rqs_slopes(Ld ld, T ls, T (&kd)[K + 1]) {
   kd[0] = T(1);
   kd[K] = T(1);
 #pragma unroll
-  for (int j = 1; j < K; ++j) kd[j] = t_exp(softclip<T>(ld(j - 1), ls));
+  for (int j = 1; j < K; ++j) kd[j] = M::exp(softclip<T, M>(ld(j - 1), ls));
 }
 
 // k = #(knots < v) - 1 with a STRICT compare (transforms.py:521-526); NaN compares false -> k = -1
@@ -102,40 +120,40 @@ __device__ __forceinline__ void rqs_select(const T (&kx)[K + 1], const T (&ky)[K
 
 // forward value + log|dy/dx| (transforms.py:554-567).  Out-of-range / NaN / inf behaviour is
 // inherited from the literal `mask * ...` arithmetic of the reference.
-template <typename T, int K>
+template <typename T, int K, class M = MathIEEE<T>>
 __device__ __forceinline__ void rqs_fwd(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], T x, T& y, T& ladj, int& k) {
   k = rqs_bin<T, K>(kx, x);
   bool inside;
   T x0, x1, y0, y1, d0, d1;
   rqs_select<T, K>(kx, ky, kd, k, inside, x0, x1, y0, y1, d0, d1);
   T m = inside ? T(1) : T(0);
-  T s = (y1 - y0) / (x1 - x0);
-  T z = (m * (x - x0)) / (x1 - x0);
+  T s = M::div(y1 - y0, x1 - x0);
+  T z = M::div(m * (x - x0), x1 - x0);
   T omz = T(1) - z;
   T t = (d0 + d1) - T(2) * s;
   T den = s + (t * z) * omz;
   T num = s * (z * z) + (d0 * z) * omz;
-  T yy = y0 + ((y1 - y0) * num) / den;
-  T jac = ((s * s) * ((((T(2) * s) * z) * omz + d0 * (omz * omz)) + d1 * (z * z))) / (den * den);
+  T yy = y0 + M::div((y1 - y0) * num, den);
+  T jac = M::div((s * s) * ((((T(2) * s) * z) * omz + d0 * (omz * omz)) + d1 * (z * z)), den * den);
   y = inside ? yy : x;
-  ladj = m * t_log(jac);
+  ladj = m * M::log(jac);
 }
 
 // inverse value (transforms.py:534-548): bin search on the vertical knots, stable quadratic root
-template <typename T, int K>
+template <typename T, int K, class M = MathIEEE<T>>
 __device__ __forceinline__ void rqs_inv(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], T y, T& x, int& k) {
   k = rqs_bin<T, K>(ky, y);
   bool inside;
   T x0, x1, y0, y1, d0, d1;
   rqs_select<T, K>(kx, ky, kd, k, inside, x0, x1, y0, y1, d0, d1);
   T m = inside ? T(1) : T(0);
-  T s = (y1 - y0) / (x1 - x0);
+  T s = M::div(y1 - y0, x1 - x0);
   T y_ = m * (y - y0);
   T t = (d0 + d1) - T(2) * s;
   T a = (y1 - y0) * (s - d0) + y_ * t;
   T b = (y1 - y0) * d0 - y_ * t;
   T c = (-s) * y_;
-  T z = (T(2) * c) / ((-b) - t_sqrt(b * b - (T(4) * a) * c));
+  T z = M::div(T(2) * c, (-b) - t_sqrt(b * b - (T(4) * a) * c));
   T xx = x0 + z * (x1 - x0);
   x = inside ? xx : y;
 }

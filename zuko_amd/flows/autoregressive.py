@@ -169,9 +169,10 @@ class MaskedAutoregressiveTransform(LazyTransform):
             simple = all(isinstance(a, MaskedLinear) != (i % 2 == 1) for i, a in enumerate(mods))  # lin, act, lin, ...
             codes = {_act_code(a) for a in acts}
             if lay is not None and simple and len(codes) == 1 and None not in codes and all(l.weight.dtype == torch.float32 for l in lins):
-                plan = fused.build_plan([l.mask for l in lins], self.features, lay[0])
+                variant = fused.default_variant()
+                plan = fused.build_plan([l.mask for l in lins], self.features, lay[0], fused.chunk_of(variant))
                 if plan is not None:
-                    state = fused.FusedAR(plan, device, codes.pop(), lay[1], lay[2])
+                    state = fused.FusedAR(plan, device, codes.pop(), lay[1], lay[2], variant)
             cache[key] = state
         return cache[key]
 

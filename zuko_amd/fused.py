@@ -84,8 +84,9 @@ def _deps(masks: list[np.ndarray]) -> list[np.ndarray]:
     return out
 
 
-def build_plan(masks: list[Tensor], features: int, layout: UniLayout) -> ArPlan | None:
-    """masks[l]: bool [out_l, in_l] of the conditioner's linear layers (last: features*total rows)."""
+def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int = CHUNK) -> ArPlan | None:
+    """masks[l]: bool [out_l, in_l] of the conditioner's linear layers (last: features*total rows).
+    `chunk`: tiles per LDS-ring chunk each layer is padded to (1 = no padding, direct-feed variant)."""
     M = [m.detach().cpu().numpy().astype(bool) for m in masks]
     L = len(M)
     if L < 2:
@@ -135,7 +136,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout) -> ArPlan 
     def finish_layer(blocks: list[np.ndarray]) -> None:
         nonlocal block_cursor
         n = len(blocks)
-        pad = -(-n // CHUNK) * CHUNK - n
+        pad = -(-n // chunk) * chunk - n
         blocks = blocks + [-np.ones(256, dtype=np.int64)] * pad
         gather.append(np.concatenate(blocks).astype(np.int32) if blocks else np.zeros(0, np.int32))
         layer_block0.append(block_cursor)
@@ -211,7 +212,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout) -> ArPlan 
         din=din,
         features=features,
         n_groups=n_groups,
-        n_chunks=block_cursor // CHUNK,
+        n_chunks=block_cursor // chunk,
         gather=gather,
         layer_block0=layer_block0,
         bias_gather=bias_gather,
@@ -286,11 +287,26 @@ def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], 
 # --------------------------------------------------------------------------------------------------
 
 
+VARIANT_RING = 0  # weight tiles shared through an LDS ring (global_load_lds DMA, workgroup barriers)
+VARIANT_DIRECT = 1  # every wave streams its A operands L2 -> VGPR through a register FIFO, no LDS / barriers
+
+
+def default_variant() -> int:
+    import os
+
+    return int(os.environ.get("ZUKO_AMD_AR_VARIANT", VARIANT_DIRECT))
+
+
+def chunk_of(variant: int) -> int:
+    return CHUNK if variant == VARIANT_RING else 1
+
+
 class FusedAR:
     """Runs zk_ar_forward for one MaskedAutoregressiveTransform on one device."""
 
-    def __init__(self, plan: ArPlan, device: torch.device, act: int, bound: float, slope: float) -> None:
+    def __init__(self, plan: ArPlan, device: torch.device, act: int, bound: float, slope: float, variant: int = VARIANT_DIRECT) -> None:
         self.plan = plan
+        self.variant = variant
         self.device = device
         self.act = act
         self.bound = bound
@@ -339,6 +355,6 @@ class FusedAR:
         err = _C.lib().zk_ar_forward(
             p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
             _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, _stream(),
+            self.act, self.bound, self.slope, self.variant, _stream(),
         )
         _C.check(err, "zk_ar_forward")
