@@ -99,7 +99,7 @@ def test_flow_properties_large_batch(dev, name, batch):
     rel_close(lp[:256], ref, "log_prob vs oracle", 1e-5, 1e-5)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", ["nsf_cfg1", "nsf_cfg2", "maf_cfg3", "maf_doc", "nsf_p2"])
 @pytest.mark.parametrize("N", [1, 127, 129, 1000])
 def test_fused_layer_vs_layerwise_kernels_and_oracle(dev, name, N, variant, monkeypatch):

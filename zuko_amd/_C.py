@@ -36,7 +36,7 @@ SIGNATURES = {
     "zk_diag_normal_log_prob": [I, L, L, P, P, P, P, P, P],
     "zk_sum_f64": [I, L, P, F, P, P, P],
     "zk_gather_f32": [P, P, P, L, P, P],
-    "zk_ar_lds_bytes": [I],
+    "zk_ar_lds_bytes": [I, I],
     "zk_ar_forward": [I, L, I, I, P, L, P, L, P, I, P, P, I, P, P, I, I, I, I, F, F, I, P],
 }
 

@@ -31,8 +31,6 @@ namespace zk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define AR_CH 24
-#define AR_RING 3
 #define AR_TF 256 /* floats per tile image */
 #define AR_WAVES 8
 #define AR_T 16   /* activation tiles (256 units) */
@@ -65,39 +63,40 @@ __device__ __forceinline__ float act_f32(float v, int act) {
   }
 }
 
-struct Ring {
+template <int CH, int NR> struct RingT {
+  static constexpr int kChunk = CH, kSlots = NR;
   float* lds;
   const float* stream;
   int n_chunks, pos, slot, load_chunk, load_slot, wave, lane;
 
   __device__ __forceinline__ void issue() {
 #pragma unroll
-    for (int i = 0; i < AR_CH / AR_WAVES; ++i) {
+    for (int i = 0; i < CH / AR_WAVES; ++i) {
       const int bi = i * AR_WAVES + wave;
-      const float* g = stream + ((size_t)load_chunk * AR_CH + bi) * AR_TF + lane * 4;
-      float* l = lds + (load_slot * AR_CH + bi) * AR_TF;
+      const float* g = stream + ((size_t)load_chunk * CH + bi) * AR_TF + lane * 4;
+      float* l = lds + (load_slot * CH + bi) * AR_TF;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     }
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
-    load_slot = (load_slot + 1 == AR_RING) ? 0 : load_slot + 1;
+    load_slot = (load_slot + 1 == NR) ? 0 : load_slot + 1;
   }
   // all 8 waves call this at the same point of the (uniform) control flow
   __device__ __forceinline__ void advance() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my own tile DMAs have landed
     __syncthreads();                                   // everyone's have; previous chunk fully consumed
     issue();                                           // refill the slot that was just released
-    slot = (slot + 1 == AR_RING) ? 0 : slot + 1;
+    slot = (slot + 1 == NR) ? 0 : slot + 1;
     pos = 0;
   }
   __device__ __forceinline__ f32x4 tile(int t) const {
-    return *reinterpret_cast<const f32x4*>(lds + (slot * AR_CH + pos + t) * AR_TF + lane * 4);
+    return *reinterpret_cast<const f32x4*>(lds + (slot * CH + pos + t) * AR_TF + lane * 4);
   }
   template <int G> __device__ __forceinline__ void begin() {
-    if (pos == AR_CH) advance();
+    if (pos == CH) advance();
   }
   template <int G> __device__ __forceinline__ void commit() { pos += G; }
   __device__ __forceinline__ void end_layer() {
-    if (pos != 0) pos = AR_CH;
+    if (pos != 0) pos = CH;
   }
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -197,26 +196,27 @@ template <class Src> __device__ __forceinline__ void hidden_layer(Src& ring, con
   ring.end_layer();
 }
 
-template <typename Uni, bool INVERSE, bool DIRECT> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
+template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
+  constexpr bool DIRECT = std::is_same<Src, Feed>::value;
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   float* ring_lds = ar_lds;
-  float* bias_lds = ar_lds + AR_RING * AR_CH * AR_TF;  // (DIRECT: the bias image is the only LDS user)
+  float* bias_lds = ar_lds;  // (DIRECT: the bias image is the only LDS user)
 
-  typename std::conditional<DIRECT, Feed, Ring>::type ring;
+  Src ring;
   if constexpr (DIRECT) {
     ring.init(a.stream, lane, a.n_chunks);  // n_chunks == number of tile images (chunk size 1)
-    bias_lds = ar_lds;
   } else {
+    bias_lds = ar_lds + Src::kSlots * Src::kChunk * AR_TF;
     ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
     ring.load_chunk = 0; ring.load_slot = 0;
 #pragma unroll
-    for (int i = 0; i < AR_RING - 1; ++i) ring.issue();
-    ring.slot = AR_RING - 1;
-    ring.pos = AR_CH;
+    for (int i = 0; i < Src::kSlots - 1; ++i) ring.issue();
+    ring.slot = Src::kSlots - 1;
+    ring.pos = Src::kChunk;
   }
 
   for (int i = tid; i < a.bias_floats; i += 512) bias_lds[i] = a.bias[i];
@@ -333,7 +333,12 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
   return ZK_LAUNCH_CHECK();
 }
 
-int zk_ar_lds_bytes(int bias_floats) { return (AR_RING * AR_CH * AR_TF + bias_floats) * (int)sizeof(float); }
+// ring geometry per variant: 0 -> 3 x 24 tiles, 1 -> direct feed (no ring), 2 -> 2 x 48, 3 -> 3 x 48 tiles
+typedef RingT<24, 3> Ring24x3;
+typedef RingT<48, 2> Ring48x2;
+typedef RingT<48, 3> Ring48x3;
+static int ring_tiles(int variant) { return variant == 0 ? 72 : variant == 2 ? 96 : variant == 3 ? 144 : 0; }
+int zk_ar_lds_bytes(int variant, int bias_floats) { return (ring_tiles(variant) * AR_TF + bias_floats) * (int)sizeof(float); }
 
 // uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23).  inverse: x <- f^{-1}(y | x_cond)
 // where the conditioner sees `x` (cond) and the univariate inverse is applied to `y_in`... see
@@ -351,13 +356,18 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
   a.L = n_layers; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
   a.bound = (float)bound; a.ls = (float)log(slope);
   a.n_tiles = (N + 127) / 128;
-  const bool direct = (variant == 1);
-  const int lds = direct ? bias_floats * (int)sizeof(float) : zk_ar_lds_bytes(bias_floats);
+  if (variant < 0 || variant > 3) return ZK_EINVAL;
+  const int lds = zk_ar_lds_bytes(variant, bias_floats);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
   const void* fn = nullptr;
-  if (uni_kind == 0) fn = direct ? (const void*)ar_kernel<UniAffine, false, true> : (const void*)ar_kernel<UniAffine, false, false>;
-  else if (uni_kind == 1) fn = direct ? (const void*)ar_kernel<UniRqs8, false, true> : (const void*)ar_kernel<UniRqs8, false, false>;
+#define ZK_AR_PICK(UNI)                                                              \
+  (variant == 0   ? (const void*)ar_kernel<UNI, false, Ring24x3>                     \
+   : variant == 1 ? (const void*)ar_kernel<UNI, false, Feed>                         \
+   : variant == 2 ? (const void*)ar_kernel<UNI, false, Ring48x2>                     \
+                  : (const void*)ar_kernel<UNI, false, Ring48x3>)
+  if (uni_kind == 0) fn = ZK_AR_PICK(UniAffine);
+  else if (uni_kind == 1) fn = ZK_AR_PICK(UniRqs8);
   else return ZK_EINVAL;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;

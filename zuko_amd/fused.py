@@ -298,7 +298,8 @@ def default_variant() -> int:
 
 
 def chunk_of(variant: int) -> int:
-    return CHUNK if variant == VARIANT_RING else 1
+    """Tiles per chunk the stream is padded to: ring variants 0 (3 x 24), 2 (2 x 48), 3 (3 x 48); 1 = direct."""
+    return {0: 24, 1: 1, 2: 48, 3: 48}[variant]
 
 
 class FusedAR:
