@@ -23,6 +23,8 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+pmc act SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_MFMA
+pmc ifetch SQ_IFETCH SQ_IFETCH_LEVEL SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_CYCLES SQ_BUSY_CU_CYCLES
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 rm -rf $OUT/trace/*/*.db $OUT/pmc_*/ 2>/dev/null
 du -sh $OUT

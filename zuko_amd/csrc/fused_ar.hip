@@ -248,12 +248,25 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
       hidden_layer(ring, a.skip + l * 4, in, out);
       const float* bl = bias_lds + l * 256 + 4 * q;
 #pragma unroll
-      for (int t = 0; t < AR_T; ++t) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + t * 16);
-        f32x4 h;
+      for (int t = 0; t < AR_T; ++t) in[t] = out[t] + *reinterpret_cast<const f32x4*>(bl + t * 16);
+      // the activation id is wave-uniform: ONE switch around 64-element loops (not 64 switches)
+      switch (a.act) {
+        case 1:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = act_f32(out[t][r] + b[r], a.act);
-        in[t] = h;
+          for (int t = 0; t < AR_T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in[t][r] = in[t][r] > 0.f ? in[t][r] : 0.f;
+          break;
+        case 0: break;
+        default:
+#pragma unroll 1
+          for (int rep = 0; rep < 1; ++rep) {
+#pragma unroll
+            for (int t = 0; t < AR_T; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) in[t][r] = act_f32(in[t][r], a.act);
+          }
+          break;
       }
     }
 

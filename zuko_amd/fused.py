@@ -294,7 +294,7 @@ VARIANT_DIRECT = 1  # every wave streams its A operands L2 -> VGPR through a reg
 def default_variant() -> int:
     import os
 
-    return int(os.environ.get("ZUKO_AMD_AR_VARIANT", VARIANT_DIRECT))
+    return int(os.environ.get("ZUKO_AMD_AR_VARIANT", VARIANT_RING))  # ring measured faster than direct (profiles/)
 
 
 def chunk_of(variant: int) -> int:
@@ -305,7 +305,7 @@ def chunk_of(variant: int) -> int:
 class FusedAR:
     """Runs zk_ar_forward for one MaskedAutoregressiveTransform on one device."""
 
-    def __init__(self, plan: ArPlan, device: torch.device, act: int, bound: float, slope: float, variant: int = VARIANT_DIRECT) -> None:
+    def __init__(self, plan: ArPlan, device: torch.device, act: int, bound: float, slope: float, variant: int = VARIANT_RING) -> None:
         self.plan = plan
         self.variant = variant
         self.device = device
