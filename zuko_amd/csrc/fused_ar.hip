@@ -45,7 +45,7 @@ struct ArArgs {
   const float* bias;
   const uint32_t* skip;
   const int32_t* featmap;
-  int L, NG, n_chunks, act, bias_floats;
+  int L, NG, n_chunks, act, bias_floats, dbg;
   float bound, ls;
   int64_t n_tiles;
 };
@@ -67,7 +67,7 @@ template <int CH, int NR> struct RingT {
   static constexpr int kChunk = CH, kSlots = NR;
   float* lds;
   const float* stream;
-  int n_chunks, pos, slot, load_chunk, load_slot, wave, lane;
+  int n_chunks, pos, slot, load_chunk, load_slot, wave, lane, dbg;
 
   __device__ __forceinline__ void issue() {
 #pragma unroll
@@ -82,6 +82,7 @@ template <int CH, int NR> struct RingT {
   }
   // all 8 waves call this at the same point of the (uniform) control flow
   __device__ __forceinline__ void advance() {
+    if (dbg & 2) { slot = (slot + 1 == NR) ? 0 : slot + 1; pos = 0; return; }  // ablation: no DMA / barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my own tile DMAs have landed
     __syncthreads();                                   // everyone's have; previous chunk fully consumed
     issue();                                           // refill the slot that was just released
@@ -89,6 +90,7 @@ template <int CH, int NR> struct RingT {
     pos = 0;
   }
   __device__ __forceinline__ f32x4 tile(int t) const {
+    if (dbg & 4) { const float v = (float)(pos + t); return f32x4{v, v, v, v}; }  // ablation: no LDS read
     return *reinterpret_cast<const f32x4*>(lds + (slot * CH + pos + t) * AR_TF + lane * 4);
   }
   template <int G> __device__ __forceinline__ void begin() {
@@ -211,7 +213,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
     ring.init(a.stream, lane, a.n_chunks);  // n_chunks == number of tile images (chunk size 1)
   } else {
     bias_lds = ar_lds + Src::kSlots * Src::kChunk * AR_TF;
-    ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+    ring.dbg = a.dbg; ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
     ring.load_chunk = 0; ring.load_slot = 0;
 #pragma unroll
     for (int i = 0; i < Src::kSlots - 1; ++i) ring.issue();
@@ -306,7 +308,8 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
         if (f >= 0) {
           const float xv = xrow[f];
           float yv, lj;
-          if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
+          if (a.dbg & 1) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
+          else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
           else Uni::fwd(ld, fi * TOTAL, a.bound, a.ls, xv, yv, lj);
           if (live) a.y[n * a.ldy + f] = yv;
           lacc += lj;
@@ -369,6 +372,8 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
   a.L = n_layers; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
   a.bound = (float)bound; a.ls = (float)log(slope);
   a.n_tiles = (N + 127) / 128;
+  a.dbg = (variant >> 8) & 0xff;  // undocumented ablation switches for profiling runs
+  variant &= 0xff;
   if (variant < 0 || variant > 3) return ZK_EINVAL;
   const int lds = zk_ar_lds_bytes(variant, bias_floats);
   if (lds > 160 * 1024) return ZK_EINVAL;

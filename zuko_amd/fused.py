@@ -129,8 +129,14 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         idx[(r < 0) | (c < 0)] = -1
         return idx.reshape(-1)
 
+    import os
+
+    dense = os.environ.get("ZUKO_AMD_AR_DENSE", "0") == "1"  # profiling aid: keep every tile (no skipping)
+
     def tile_nonzero(mask: np.ndarray, rows: np.ndarray, ccols: np.ndarray) -> bool:
         rr, cc = rows[rows >= 0], ccols[ccols >= 0]
+        if dense:
+            return bool(rr.size and cc.size)
         return bool(rr.size and cc.size and mask[np.ix_(rr, cc)].any())
 
     def finish_layer(blocks: list[np.ndarray]) -> None:
@@ -297,6 +303,12 @@ def default_variant() -> int:
     return int(os.environ.get("ZUKO_AMD_AR_VARIANT", VARIANT_RING))  # ring measured faster than direct (profiles/)
 
 
+def _debug_flags() -> int:
+    import os
+
+    return int(os.environ.get("ZUKO_AMD_AR_DEBUG", 0))
+
+
 def chunk_of(variant: int) -> int:
     """Tiles per chunk the stream is padded to: ring variants 0 (3 x 24), 2 (2 x 48), 3 (3 x 48); 1 = direct."""
     return {0: 24, 1: 1, 2: 48, 3: 48}[variant]
@@ -356,6 +368,6 @@ class FusedAR:
         err = _C.lib().zk_ar_forward(
             p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
             _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, self.variant, _stream(),
+            self.act, self.bound, self.slope, self.variant | (_debug_flags() << 8), _stream(),
         )
         _C.check(err, "zk_ar_forward")
