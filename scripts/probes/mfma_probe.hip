@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // MODE 2: ds_reads for the NEXT iteration issued before this iteration's MFMAs (manual double buffer)
 // MODE 3: MODE 1 + a data-dependent uniform branch per group (skip-mask test), never skipped
 // MODE 4: 6 accumulators / 24 MFMAs per group, 6 ds_reads (last-layer shape)
-template <int MODE, int THREADS> __global__ __launch_bounds__(THREADS) void probe(float* out, const unsigned* bits, int iters) {
+template <int MODE, int THREADS, int UNROLL = 1> __global__ __launch_bounds__(THREADS) void probe(float* out, const unsigned* bits, int iters) {
   __shared__ __attribute__((aligned(16))) float lds[24 * 256 * 2];
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 24 * 256 * 2; i += THREADS) lds[i] = (float)(i & 7) * 0.125f;
@@ -24,6 +24,7 @@ template <int MODE, int THREADS> __global__ __launch_bounds__(THREADS) void prob
   int pos = 0;
   if (MODE == 2) for (int t = 0; t < G; ++t) nxt[t] = *reinterpret_cast<f32x4*>(lds + (pos + t) * 256 + lane * 4);
   const unsigned mask = bits[0];
+#pragma unroll UNROLL
   for (int it = 0; it < iters; ++it) {
     if (MODE == 3) { if (!(mask & (1u << (it & 15)))) continue; }
     if (MODE == 1 || MODE == 3 || MODE == 4) {
@@ -48,14 +49,14 @@ template <int MODE, int THREADS> __global__ __launch_bounds__(THREADS) void prob
   out[blockIdx.x * THREADS + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-template <int MODE, int THREADS> void run(const char* name, float* out, unsigned* bits) {
+template <int MODE, int THREADS, int UNROLL = 1> void run(const char* name, float* out, unsigned* bits) {
   const int blocks = 256;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<MODE, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, out, bits, 64);
+  hipLaunchKernelGGL((probe<MODE, THREADS, UNROLL>), dim3(blocks), dim3(THREADS), 0, 0, out, bits, 64);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((probe<MODE, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, out, bits, ITERS);
+  hipLaunchKernelGGL((probe<MODE, THREADS, UNROLL>), dim3(blocks), dim3(THREADS), 0, 0, out, bits, ITERS);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -70,6 +71,11 @@ int main() {
   float* out; unsigned* bits;
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&bits, 4);
   unsigned h = 0xffffffffu; hipMemcpy(bits, &h, 4, hipMemcpyHostToDevice);
+  run<0, 512, 16>("pure MFMA, 2 waves, unroll 16 (2 KB)", out, bits);
+  run<0, 512, 128>("pure MFMA, 2 waves, unroll 128 (16 KB)", out, bits);
+  run<0, 512, 512>("pure MFMA, 2 waves, unroll 512 (64 KB)", out, bits);
+  run<0, 256, 512>("pure MFMA, 1 wave, unroll 512 (64 KB)", out, bits);
+  run<1, 512, 128>("ds_read+16 MFMA, 2 waves, unroll 128", out, bits);
   run<0, 256>("pure MFMA, 1 wave/SIMD", out, bits);
   run<0, 512>("pure MFMA, 2 waves/SIMD", out, bits);
   run<1, 256>("ds_read x4 + wait + 16 MFMA, 1 wave/SIMD", out, bits);

@@ -82,7 +82,6 @@ template <int CH, int NR> struct RingT {
   }
   // all 8 waves call this at the same point of the (uniform) control flow
   __device__ __forceinline__ void advance() {
-    if (dbg & 2) { slot = (slot + 1 == NR) ? 0 : slot + 1; pos = 0; return; }  // ablation: no DMA / barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my own tile DMAs have landed
     __syncthreads();                                   // everyone's have; previous chunk fully consumed
     issue();                                           // refill the slot that was just released
@@ -90,7 +89,6 @@ template <int CH, int NR> struct RingT {
     pos = 0;
   }
   __device__ __forceinline__ f32x4 tile(int t) const {
-    if (dbg & 4) { const float v = (float)(pos + t); return f32x4{v, v, v, v}; }  // ablation: no LDS read
     return *reinterpret_cast<const f32x4*>(lds + (slot * CH + pos + t) * AR_TF + lane * 4);
   }
   template <int G> __device__ __forceinline__ void begin() {
@@ -222,6 +220,8 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
   }
 
   for (int i = tid; i < a.bias_floats; i += 512) bias_lds[i] = a.bias[i];
+  int* fmap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);  // feature map of the last layer
+  for (int i = tid; i < a.NG * 4 * FPL; i += 512) fmap_lds[i] = a.featmap[i];
   __syncthreads();
 
   const uint32_t* skip_last = a.skip + (a.L - 1) * 4;
@@ -246,8 +246,12 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
     }
 
     // ---- hidden layers ---------------------------------------------------------------------------
+    unsigned long long tstamp[6];  // dbg bit3: phase timestamps (s_memtime) printed by two waves of block 0
+    const bool tprobe = (a.dbg & 8) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && (wave == 0 || wave == 4);
+    if (a.dbg & 8) tstamp[0] = __builtin_amdgcn_s_memtime();
     for (int l = 0; l < a.L - 1; ++l) {
       hidden_layer(ring, a.skip + l * 4, in, out);
+      if (a.dbg & 8) tstamp[1 + (l < 3 ? l : 3)] = __builtin_amdgcn_s_memtime();
       const float* bl = bias_lds + l * 256 + 4 * q;
 #pragma unroll
       for (int t = 0; t < AR_T; ++t) in[t] = out[t] + *reinterpret_cast<const f32x4*>(bl + t * 16);
@@ -276,6 +280,21 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
     float lacc = 0.f;
     for (int g = 0; g < a.NG; ++g) {
       const uint32_t bits = skip_last[g];
+      // operands of the epilogue are requested BEFORE the group's MFMAs so their latency is hidden:
+      // feature ids + bias from LDS, x[n, f] from global/L2 (one dependent load)
+      int fid[FPL];
+      float xin[FPL];
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) {
+        fid[fi] = fmap_lds[(g * 4 + q) * FPL + fi];
+        xin[fi] = xrow[fid[fi] < 0 ? 0 : fid[fi]];
+      }
+      f32x4 bgrp[NT];
+      {
+        const float* bg = bias_last + (g * NT) * 16 + 4 * q;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bgrp[t] = *reinterpret_cast<const f32x4*>(bg + t * 16);
+      }
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -294,19 +313,16 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
         }
       }
       float p[4 * NT];
-      const float* bg = bias_last + (g * NT) * 16 + 4 * q;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bg + t * 16);
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r] + b[r];
-      }
+        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r] + bgrp[t][r];
       auto ld = [&](int i) { return p[i]; };
 #pragma unroll
       for (int fi = 0; fi < FPL; ++fi) {
-        const int f = a.featmap[(g * 4 + q) * FPL + fi];
+        const int f = fid[fi];
         if (f >= 0) {
-          const float xv = xrow[f];
+          const float xv = xin[fi];
           float yv, lj;
           if (a.dbg & 1) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
           else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
@@ -317,6 +333,12 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
       }
     }
     ring.end_layer();
+    if (a.dbg & 8) {
+      tstamp[5] = __builtin_amdgcn_s_memtime();
+      if (tprobe)
+        printf("wave %d: L1 %llu  L2 %llu  L3 %llu  (+bias/act each)  last layer + 16 epilogues %llu   total %llu cycles\n", wave, tstamp[1] - tstamp[0],
+               tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[5] - tstamp[3], tstamp[5] - tstamp[0]);
+    }
     if (!INVERSE && a.ladj) {
       lacc += __shfl_xor(lacc, 16, 64);
       lacc += __shfl_xor(lacc, 32, 64);
@@ -354,7 +376,7 @@ typedef RingT<24, 3> Ring24x3;
 typedef RingT<48, 2> Ring48x2;
 typedef RingT<48, 3> Ring48x3;
 static int ring_tiles(int variant) { return variant == 0 ? 72 : variant == 2 ? 96 : variant == 3 ? 144 : 0; }
-int zk_ar_lds_bytes(int variant, int bias_floats) { return (ring_tiles(variant) * AR_TF + bias_floats) * (int)sizeof(float); }
+int zk_ar_lds_bytes(int variant, int bias_floats) { return (ring_tiles(variant) * AR_TF + bias_floats + 1024) * (int)sizeof(float); }  // + feature map (<= 1024 ints)
 
 // uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23).  inverse: x <- f^{-1}(y | x_cond)
 // where the conditioner sees `x` (cond) and the univariate inverse is applied to `y_in`... see
@@ -363,6 +385,7 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
                   int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers,
                   int n_groups, int n_chunks, int act, double bound, double slope, int variant, void* stream) {
   if (N <= 0) return 0;
+  if (n_groups * 8 > 1024) return ZK_EINVAL;
   if (n_layers < 2 || DIN > 256 || DIN < D || DIN % 4 || ldx % 4 || ((uintptr_t)x % 16) || n_chunks < 1) return ZK_EINVAL;
   ArArgs a{};
   a.N = N; a.D = D; a.DIN = DIN;
