@@ -205,6 +205,21 @@ def main() -> None:
         dist.destroy_process_group()
 
 
+def _pmc_traffic(B: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/traffic.json; collected as MI355X_MICROARCH.md prescribes) — only valid for the
+    default 2^20 workload they were taken on."""
+    import glob
+
+    if B != 1 << 20:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+
+
 def zuko_amd_roofline(kernels: dict, B: int):
     """Roofline object for the dominant kernel + a per-kernel table (all measured in this run)."""
     table = []
@@ -232,7 +247,7 @@ def zuko_amd_roofline(kernels: dict, B: int):
     dom = max(table, key=lambda r: r["avg_ms"] * r["calls"])
     roof = None
     if "achieved" in dom:
-        roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": None,
+        roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": _pmc_traffic(B),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]}
     for row in table:
         row.pop("total_ms_per_step", None)
