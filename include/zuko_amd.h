@@ -116,16 +116,21 @@ int zk_linear(int dtype, int64_t N, int in_features, int out_features, const voi
  *             (degree-sorted, tile-skipped weight stream of 1 KiB MFMA A-operand images, bias image,
  *             per-group skip bitmasks, feature regrouping of the last layer); wstream and bias are
  *             produced on the device by zk_gather_f32 from the module's weight / mask / bias tensors.
- *   variant   0 / 2 / 3: weight tiles shared by the workgroup through an LDS ring of 3 x 24 / 2 x 48 /
- *                3 x 48 tile images (global_load_lds DMA; the plan pads every layer to whole chunks of
- *                24 / 48 / 48 tiles, n_chunks = chunks);
- *             1: no LDS — every wavefront streams its MFMA A operands L2 -> VGPR through a register
- *                FIFO (plan built with chunk = 1, n_chunks = number of tile images).
+ *   variant   must be 0 (the LDS-ring weight feed; alternatives were measured and dropped)
  *   limits    DIN <= 256, every hidden width <= 256, >= 1 hidden layer.                             */
 int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
                   int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
                   const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
                   int variant, void* stream);
+/* One sweep of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000, the body of its loop):
+ *     x_out = univariate(*unpack(MaskedMLP(x_cond))).inv(y)
+ * x_cond [N, DIN] as `x` of zk_ar_forward (features first, context after), y [N, D] the values to
+ * invert, x_out [N, D] (row stride ldo); x_out may alias x_cond, so `passes` sweeps over one
+ * zero-initialised buffer reproduce the reference loop.  Other arguments as zk_ar_forward. */
+int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy,
+                        void* x_out, int64_t ldo, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
+                        const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
+                        int variant, void* stream);
 /* dynamic LDS bytes zk_ar_forward will request for `variant` and a bias image of `bias_floats` floats. */
 int zk_ar_lds_bytes(int variant, int bias_floats);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream

@@ -99,7 +99,7 @@ def test_flow_properties_large_batch(dev, name, batch):
     rel_close(lp[:256], ref, "log_prob vs oracle", 1e-5, 1e-5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("name", ["nsf_cfg1", "nsf_cfg2", "maf_cfg3", "maf_doc", "nsf_p2"])
 @pytest.mark.parametrize("N", [1, 127, 129, 1000])
 def test_fused_layer_vs_layerwise_kernels_and_oracle(dev, name, N, variant, monkeypatch):
@@ -132,3 +132,9 @@ def test_fused_layer_vs_layerwise_kernels_and_oracle(dev, name, N, variant, monk
             rel_close(ladj, ladj2, f"layer {i} ladj fused vs layerwise", 1e-5, 5e-5)
             if name != "nsf_p2":
                 assert used_fused, "expected the fused kernel to be selected"
+            # inverse: `passes` fused sweeps vs the same loop on the layer-wise kernels vs the oracle
+            xr = fused_t.inv(y)
+            rel_close(xr, x, f"layer {i} inverse(forward(x))", 1e-4, 2e-4)
+            if N <= 129:
+                xo = O.layer_inverse(spec.layers[i], oy, c)
+                rel_close(fused_t.inv(oy.to(dev)), xo, f"layer {i} inverse vs oracle", 1e-4, 2e-4)

@@ -55,12 +55,13 @@ template <typename T, int K, bool INV> struct RqsOp {
   static constexpr int NSEG = 3;
   static __device__ __forceinline__ int off(int s, int) { return s * K; }  // packed offsets 0, K, 2K
   template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
+    typedef typename MathStd<T>::type M;
     T kx[K + 1], ky[K + 1], kd[K + 1];
-    rqs_axis_knots<T, K>(ld[0], T(a.bound), T(a.ls), kx);
-    rqs_axis_knots<T, K>(ld[1], T(a.bound), T(a.ls), ky);
-    rqs_slopes<T, K>(ld[2], T(a.ls), kd);
-    if (INV) { rqs_inv<T, K>(kx, ky, kd, in, out, k); ladj = T(0); }
-    else rqs_fwd<T, K>(kx, ky, kd, in, out, ladj, k);
+    rqs_axis_knots<T, K, M>(ld[0], T(a.bound), T(a.ls), kx);
+    rqs_axis_knots<T, K, M>(ld[1], T(a.bound), T(a.ls), ky);
+    rqs_slopes<T, K, M>(ld[2], T(a.ls), kd);
+    if (INV) { rqs_inv<T, K, M>(kx, ky, kd, in, out, k); ladj = T(0); }
+    else rqs_fwd<T, K, M>(kx, ky, kd, in, out, ladj, k);
   }
 };
 
@@ -135,8 +136,9 @@ template <typename T, bool INV> struct AffineOp {
   static __device__ __forceinline__ int off(int s, int) { return s; }  // packed: [shift, scale]
   template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
     k = 0;
-    if (INV) { out = affine_inv<T>(ld[0](0), ld[1](0), T(a.ls), in); ladj = T(0); }
-    else affine_fwd<T>(ld[0](0), ld[1](0), T(a.ls), in, out, ladj);
+    typedef typename MathStd<T>::type M;
+    if (INV) { out = affine_inv<T, M>(ld[0](0), ld[1](0), T(a.ls), in); ladj = T(0); }
+    else affine_fwd<T, M>(ld[0](0), ld[1](0), T(a.ls), in, out, ladj);
   }
 };
 

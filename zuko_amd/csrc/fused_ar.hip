@@ -40,6 +40,7 @@ struct ArArgs {
   int D, DIN;               // features, conditioner inputs (features + context), DIN % 4 == 0
   const float* x; int64_t ldx;  // [N, DIN] = cat(x, c) zero-padded to a multiple of 4; rows 16-byte aligned
   float* y; int64_t ldy;
+  const float* yin; int64_t ldyin;  // INVERSE only: the values to invert (y of the forward map)
   float* ladj; int accumulate;
   const float* stream;
   const float* bias;
@@ -99,40 +100,6 @@ template <int CH, int NR> struct RingT {
     if (pos != 0) pos = CH;
   }
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-};
-
-// Variant B of the weight feed: no LDS, no workgroup synchronisation.  Every wavefront streams the
-// (L2-resident) tile images straight into VGPRs with global_load_dwordx4 — a tile image is exactly
-// one 16-byte load per lane — through a 12-tile register FIFO that runs two groups ahead of the
-// MFMAs.  The stream is consumed strictly linearly, so "the next group" is always the next G
-// images whatever (layer, out-group, in-tile) it belongs to; the stream carries no chunk padding.
-#define AR_FIFO 12
-struct Feed {
-  const f32x4* src;  // stream + lane
-  int head, n_blocks;
-  f32x4 q[AR_FIFO];
-  __device__ __forceinline__ f32x4 fetch() {
-    const f32x4 v = src[(size_t)head * 64];
-    head = (head + 1 == n_blocks) ? 0 : head + 1;
-    return v;
-  }
-  __device__ __forceinline__ void init(const float* stream, int lane, int nb) {
-    src = reinterpret_cast<const f32x4*>(stream) + lane;
-    head = 0;
-    n_blocks = nb;
-#pragma unroll
-    for (int i = 0; i < AR_FIFO; ++i) q[i] = fetch();
-  }
-  __device__ __forceinline__ f32x4 tile(int t) const { return q[t]; }
-  template <int G> __device__ __forceinline__ void begin() {}
-  template <int G> __device__ __forceinline__ void commit() {
-#pragma unroll
-    for (int i = 0; i + G < AR_FIFO; ++i) q[i] = q[i + G];
-#pragma unroll
-    for (int i = AR_FIFO - G; i < AR_FIFO; ++i) q[i] = fetch();
-  }
-  __device__ __forceinline__ void end_layer() {}
-  __device__ __forceinline__ void drain() {}
 };
 
 // ---- univariate epilogues -------------------------------------------------------------------------
@@ -197,7 +164,7 @@ template <class Src> __device__ __forceinline__ void hidden_layer(Src& ring, con
 }
 
 template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
-  constexpr bool DIRECT = std::is_same<Src, Feed>::value;
+  constexpr bool DIRECT = false;
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -287,7 +254,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
 #pragma unroll
       for (int fi = 0; fi < FPL; ++fi) {
         fid[fi] = fmap_lds[(g * 4 + q) * FPL + fi];
-        xin[fi] = xrow[fid[fi] < 0 ? 0 : fid[fi]];
+        xin[fi] = INVERSE ? a.yin[nc * a.ldyin + (fid[fi] < 0 ? 0 : fid[fi])] : xrow[fid[fi] < 0 ? 0 : fid[fi]];
       }
       f32x4 bgrp[NT];
       {
@@ -371,44 +338,33 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
   return ZK_LAUNCH_CHECK();
 }
 
-// ring geometry per variant: 0 -> 3 x 24 tiles, 1 -> direct feed (no ring), 2 -> 2 x 48, 3 -> 3 x 48 tiles
-typedef RingT<24, 3> Ring24x3;
-typedef RingT<48, 2> Ring48x2;
-typedef RingT<48, 3> Ring48x3;
-static int ring_tiles(int variant) { return variant == 0 ? 72 : variant == 2 ? 96 : variant == 3 ? 144 : 0; }
-int zk_ar_lds_bytes(int variant, int bias_floats) { return (ring_tiles(variant) * AR_TF + bias_floats + 1024) * (int)sizeof(float); }  // + feature map (<= 1024 ints)
+typedef RingT<24, 3> Ring24x3;  // 3 x 24 KiB; 2 x 48 and 3 x 48 tiles measured within +-1 %
+int zk_ar_lds_bytes(int variant, int bias_floats) { return (72 * AR_TF + bias_floats + 1024) * (int)sizeof(float); }  // ring + bias + feature map
 
-// uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23).  inverse: x <- f^{-1}(y | x_cond)
-// where the conditioner sees `x` (cond) and the univariate inverse is applied to `y_in`... see
-// include/zuko_amd.h for the exact contract.
-int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
-                  int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers,
-                  int n_groups, int n_chunks, int act, double bound, double slope, int variant, void* stream) {
+// uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23); contract in include/zuko_amd.h.
+static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, const void* yin, int64_t ldyin, void* y, int64_t ldy,
+                     void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap,
+                     int n_layers, int n_groups, int n_chunks, int act, double bound, double slope, int variant, void* stream) {
   if (N <= 0) return 0;
   if (n_groups * 8 > 1024) return ZK_EINVAL;
   if (n_layers < 2 || DIN > 256 || DIN < D || DIN % 4 || ldx % 4 || ((uintptr_t)x % 16) || n_chunks < 1) return ZK_EINVAL;
   ArArgs a{};
   a.N = N; a.D = D; a.DIN = DIN;
   a.x = (const float*)x; a.ldx = ldx;
+  a.yin = (const float*)yin; a.ldyin = ldyin;
   a.y = (float*)y; a.ldy = ldy; a.ladj = (float*)ladj; a.accumulate = accumulate;
   a.stream = (const float*)wstream; a.bias = (const float*)bias; a.skip = skip; a.featmap = featmap;
   a.L = n_layers; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
   a.bound = (float)bound; a.ls = (float)log(slope);
   a.n_tiles = (N + 127) / 128;
-  a.dbg = (variant >> 8) & 0xff;  // undocumented ablation switches for profiling runs
-  variant &= 0xff;
-  if (variant < 0 || variant > 3) return ZK_EINVAL;
-  const int lds = zk_ar_lds_bytes(variant, bias_floats);
+  a.dbg = (variant >> 8) & 0xff;  // undocumented profiling switches (bit0: skip univariate math, bit3: phase timestamps)
+  if ((variant & 0xff) != 0) return ZK_EINVAL;
+  const int lds = zk_ar_lds_bytes(0, bias_floats);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
   const void* fn = nullptr;
-#define ZK_AR_PICK(UNI)                                                              \
-  (variant == 0   ? (const void*)ar_kernel<UNI, false, Ring24x3>                     \
-   : variant == 1 ? (const void*)ar_kernel<UNI, false, Feed>                         \
-   : variant == 2 ? (const void*)ar_kernel<UNI, false, Ring48x2>                     \
-                  : (const void*)ar_kernel<UNI, false, Ring48x3>)
-  if (uni_kind == 0) fn = ZK_AR_PICK(UniAffine);
-  else if (uni_kind == 1) fn = ZK_AR_PICK(UniRqs8);
+  if (uni_kind == 0) fn = inverse ? (const void*)ar_kernel<UniAffine, true, Ring24x3> : (const void*)ar_kernel<UniAffine, false, Ring24x3>;
+  else if (uni_kind == 1) fn = inverse ? (const void*)ar_kernel<UniRqs8, true, Ring24x3> : (const void*)ar_kernel<UniRqs8, false, Ring24x3>;
   else return ZK_EINVAL;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
@@ -416,6 +372,22 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
   e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   return ZK_LAUNCH_CHECK();
+}
+
+int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj, int accumulate, const void* wstream,
+                  const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act,
+                  double bound, double slope, int variant, void* stream) {
+  return ar_launch(false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
+                   n_chunks, act, bound, slope, variant, stream);
+}
+
+// One sweep of the autoregressive inverse (zuko/transforms.py:997-998): x_out = univariate(conditioner(x_cond)).inv(y).
+// x_out may alias x_cond (a wave reads its rows of x_cond completely before it writes them).
+int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy, void* x_out, int64_t ldo,
+                        const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups,
+                        int n_chunks, int act, double bound, double slope, int variant, void* stream) {
+  return ar_launch(true, uni_kind, N, D, DIN, x_cond, ldx, y, ldy, x_out, ldo, nullptr, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
+                   n_chunks, act, bound, slope, variant, stream);
 }
 
 }  // extern "C"

@@ -29,6 +29,29 @@ template <typename T> struct MathIEEE {
   static __device__ __forceinline__ T exp(T v) { return t_exp(v); }
   static __device__ __forceinline__ T log(T v) { return t_log(v); }
 };
+// MathTight (fp32): within ~1.5 ulp of MathIEEE at a third of the instruction count — division by
+// v_rcp_f32 + one Newton step on the quotient (correctly rounded except in rare ties; operands here
+// are far from the exponent extremes v_div_scale/v_div_fixup exist for), exp by v_exp_f32 on a
+// compensated x*log2(e) product.  Used by the standalone fp32 kernels: their ~1000-instruction
+// IEEE epilogue made them VALU-bound (34 % of HBM peak, profiles/r01); log stays ocml (one per element).
+struct MathTight {
+  static __device__ __forceinline__ float div(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+  }
+  static __device__ __forceinline__ float exp(float v) {
+    const float l2e = 1.44269504088896340736f, l2e_lo = 1.92596299112661746e-08f, ln2 = 0.69314718055994530942f;
+    const float hi = v * l2e;
+    const float lo = fmaf(v, l2e, -hi) + v * l2e_lo;
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return fmaf(e, lo * ln2, e);
+  }
+  static __device__ __forceinline__ float log(float v) { return logf(v); }
+};
+template <typename T> struct MathStd { typedef MathIEEE<T> type; };
+template <> struct MathStd<float> { typedef MathTight type; };  // policy of the standalone kernels
+
 struct MathFast {
   static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
   static __device__ __forceinline__ float exp(float v) { return __expf(v); }

@@ -234,6 +234,29 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
     def log_abs_det_jacobian(self, x: Tensor, y: Tensor) -> Tensor:
         return self.call_and_ladj(x)[1]
 
+    def _inverse(self, y: Tensor) -> Tensor:
+        """`passes` sweeps x <- meta(x).inv(y) from x = 0 (zuko/transforms.py:994-1000); each sweep is
+        one fused launch (conditioner + univariate inverse), updating the buffer in place."""
+        st = self._fused(y)
+        if st is None:
+            return super()._inverse(y)
+        lazy, c = self.lazy, self.c
+        D = lazy.features
+        if c is not None:
+            yb, cb = broadcast(y, c, ignore=1)
+        else:
+            yb, cb = y, None
+        batch = yb.shape[:-1]
+        y2 = yb.reshape(-1, D).contiguous()
+        din = D + (0 if cb is None else cb.shape[-1])
+        buf = y2.new_zeros((y2.shape[0], -(-din // 4) * 4))
+        if cb is not None:
+            buf[:, D:din] = cb.reshape(-1, cb.shape[-1])
+        st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+        for _ in range(self.passes):
+            st.run_inverse_sweep(buf, y2)
+        return buf[:, :D].reshape(batch + (D,)).contiguous() if buf.shape[1] != D else buf.reshape(batch + (D,))
+
 
 class MAF(Flow):
     r"""Masked autoregressive flow: `transforms` autoregressive layers with alternating

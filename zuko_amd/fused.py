@@ -294,7 +294,6 @@ def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], 
 
 
 VARIANT_RING = 0  # weight tiles shared through an LDS ring (global_load_lds DMA, workgroup barriers)
-VARIANT_DIRECT = 1  # every wave streams its A operands L2 -> VGPR through a register FIFO, no LDS / barriers
 
 
 def default_variant() -> int:
@@ -310,8 +309,8 @@ def _debug_flags() -> int:
 
 
 def chunk_of(variant: int) -> int:
-    """Tiles per chunk the stream is padded to: ring variants 0 (3 x 24), 2 (2 x 48), 3 (3 x 48); 1 = direct."""
-    return {0: 24, 1: 1, 2: 48, 3: 48}[variant]
+    """Tiles per chunk the stream is padded to (variant 0: 3 x 24-tile LDS ring)."""
+    return {0: 24}[variant]
 
 
 class FusedAR:
@@ -371,3 +370,16 @@ class FusedAR:
             self.act, self.bound, self.slope, self.variant | (_debug_flags() << 8), _stream(),
         )
         _C.check(err, "zk_ar_forward")
+
+    def run_inverse_sweep(self, buf: Tensor, y: Tensor) -> None:
+        """One sweep x <- f^{-1}(y | x) in place: buf [N, DINP] holds cat(x, c, 0-pad), y [N, D]."""
+        from . import _C
+        from .ops import _ptr, _stream
+
+        p = self.plan
+        err = _C.lib().zk_ar_inverse_sweep(
+            p.layout.kind, buf.shape[0], p.features, buf.shape[1], _ptr(buf), buf.stride(0), _ptr(y), y.stride(0), _ptr(buf), buf.stride(0),
+            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
+            self.act, self.bound, self.slope, self.variant | (_debug_flags() << 8), _stream(),
+        )
+        _C.check(err, "zk_ar_inverse_sweep")
