@@ -212,8 +212,14 @@ __device__ __forceinline__ void uni_driver(const UniArgs& a, T* sh, RunFn run) {
   T* yg = (T*)a.y;
   T* lg = (T*)a.ladj;
 
+  // Each wavefront owns a CONTIGUOUS run of `iters` wave tiles: its phi stream is one long sequential
+  // read, and (one row per tile, D == 64) the per-row ladj sums are parked in lane (it % 64) and written
+  // back 64 rows at a time as one coalesced 256-byte store instead of 64 single-lane stores.
+  const int64_t wt0 = ((int64_t)blockIdx.x * 4 + wave) * a.iters;
+  const bool park = lg && a.reduced && a.segs == 1 && sizeof(T) == 4 && D == 64;
+  float parked = 0.f;
   for (int64_t it = 0; it < a.iters; ++it) {
-    const int64_t wt = (it * gridDim.x + blockIdx.x) * 4 + wave;  // wave tile
+    const int64_t wt = wt0 + it;  // wave tile
     const int64_t row0 = wt * RW;
     T lacc = T(0);
     for (int sgm = 0; sgm < a.segs; ++sgm) {
@@ -232,9 +238,13 @@ __device__ __forceinline__ void uni_driver(const UniArgs& a, T* sh, RunFn run) {
         else { cnt = (row0 < a.N) ? (D - (int64_t)sgm * 64) : 0; cnt = cnt > 64 ? 64 : cnt; }
         const T* src = (const T*)a.seg[0].p + e0 * total;
         shift = (int)(((uintptr_t)src / sizeof(T)) % VEC);
-        __syncthreads();  // previous step's readers are done with the LDS image
+        // The LDS image is private to this wavefront and a wave's DS operations execute in order, so
+        // no workgroup barrier is needed: fence the compiler and drain the staging stores only.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous step's reads have returned
+        __builtin_amdgcn_wave_barrier();
         if (cnt > 0) stage_contiguous<T>(src, wsh, cnt * total, lane);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
       }
       T out = T(0), lj = T(0);
       int k = 0;
@@ -258,8 +268,18 @@ __device__ __forceinline__ void uni_driver(const UniArgs& a, T* sh, RunFn run) {
       if (lg && a.reduced) {
         if (a.segs == 1) {
           T v = valid ? lj : T(0);
-          v = segment_sum<T>(v, (int)D, d);
-          if (valid && d == 0) lg[row] = v;
+          if (park) {  // one row per tile: DPP reduction (result in lane 63), parked in lane it % 64
+            const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_dpp_to_lane63((float)v)), 63));
+            const int slot = (int)(it & 63);
+            if (lane == slot) parked = tot;
+            if (slot == 63 || it + 1 == a.iters) {
+              const int64_t rbase = row0 - slot;  // rows are consecutive over `it` (RW == 1)
+              if (lane <= slot && rbase + lane < a.N) lg[rbase + lane] = (T)parked;
+            }
+          } else {
+            v = segment_sum<T>(v, (int)D, d);
+            if (valid && d == 0) lg[row] = v;
+          }
         } else {
           lacc += valid ? lj : T(0);
         }
@@ -301,11 +321,16 @@ template <typename T> static Plan plan(UniArgs& a, bool packed) {
   const int64_t wave_tiles = (a.N + a.rows_per_wave - 1) / a.rows_per_wave;
   const int64_t blocks = (wave_tiles + 3) / 4;
   Plan p;
-  p.grid = dim3((unsigned)grid_for(blocks));
-  a.iters = (blocks + p.grid.x - 1) / p.grid.x;
   constexpr int VEC = 16 / sizeof(T);
   const size_t per_wave = (((size_t)64 * a.total + 2 * VEC + VEC - 1) / VEC * VEC);
   p.lds = packed ? 4 * per_wave * sizeof(T) : 0;
+  // persistent grid = exactly what is co-resident (256 CUs x blocks/CU by LDS and wave slots), so the
+  // grid-stride loop has no partially filled second round
+  int64_t per_cu = p.lds ? (int64_t)(160 * 1024) / (int64_t)p.lds : 8;
+  per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+  const int64_t cap = 256 * per_cu;
+  p.grid = dim3((unsigned)(blocks < cap ? blocks : cap));
+  a.iters = (blocks + p.grid.x - 1) / p.grid.x;
   return p;
 }
 

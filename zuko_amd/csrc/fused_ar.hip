@@ -47,6 +47,8 @@ struct ArArgs {
   const uint32_t* skip;
   const int32_t* featmap;
   int L, NG, n_chunks, act, bias_floats, dbg;
+  int xlds;  // x (or y_in) and the result tile are staged in a wave-private LDS region (stride xs words)
+  int xs;
   float bound, ls;
   int64_t n_tiles;
 };
@@ -188,6 +190,11 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
 
   for (int i = tid; i < a.bias_floats; i += 512) bias_lds[i] = a.bias[i];
   int* fmap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);  // feature map of the last layer
+  // wave-private [16 samples x D] tile: the epilogue's input values on the way in, the results on the
+  // way out.  Keeps the per-group operand fetch on the LDS (lgkmcnt) queue — a global load there would
+  // have to be waited for with vmcnt(0), i.e. behind the ring DMAs in flight (measured: 5 k cycles per
+  // group) — and turns 4-byte scattered result stores into coalesced 16-byte row stores.
+  float* xr = reinterpret_cast<float*>(fmap_lds + 1024) + wave * 16 * a.xs + j * a.xs;
   for (int i = tid; i < a.NG * 4 * FPL; i += 512) fmap_lds[i] = a.featmap[i];
   __syncthreads();
 
@@ -210,6 +217,21 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
         if (i0 < a.DIN) v = *reinterpret_cast<const f32x4*>(xrow + i0);
       }
       in[it] = v;
+    }
+    if (a.xlds) {
+#pragma unroll
+      for (int it = 0; it < AR_T; ++it) {
+        if (it * 16 < a.D) {
+          const int i0 = it * 16 + 4 * q;
+          if (i0 < a.D) {
+            f32x4 v = in[it];
+            if (INVERSE) v = *reinterpret_cast<const f32x4*>(a.yin + nc * a.ldyin + i0);
+            *reinterpret_cast<f32x4*>(xr + i0) = v;
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
 
     // ---- hidden layers ---------------------------------------------------------------------------
@@ -247,6 +269,8 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
     float lacc = 0.f;
     for (int g = 0; g < a.NG; ++g) {
       const uint32_t bits = skip_last[g];
+      unsigned long long tg0 = 0, tg1 = 0;
+      if (a.dbg & 16) tg0 = __builtin_amdgcn_s_memtime();
       // operands of the epilogue are requested BEFORE the group's MFMAs so their latency is hidden:
       // feature ids + bias from LDS, x[n, f] from global/L2 (one dependent load)
       int fid[FPL];
@@ -254,7 +278,9 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
 #pragma unroll
       for (int fi = 0; fi < FPL; ++fi) {
         fid[fi] = fmap_lds[(g * 4 + q) * FPL + fi];
-        xin[fi] = INVERSE ? a.yin[nc * a.ldyin + (fid[fi] < 0 ? 0 : fid[fi])] : xrow[fid[fi] < 0 ? 0 : fid[fi]];
+        const int fc = fid[fi] < 0 ? 0 : fid[fi];
+        if (a.xlds) xin[fi] = xr[fc];
+        else xin[fi] = INVERSE ? a.yin[nc * a.ldyin + fc] : xrow[fc];
       }
       f32x4 bgrp[NT];
       {
@@ -279,6 +305,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][r], in[it][r], acc[t], 0, 0, 0);
         }
       }
+      if (a.dbg & 16) tg1 = __builtin_amdgcn_s_memtime();
       float p[4 * NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -294,12 +321,28 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
           if (a.dbg & 1) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
           else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
           else Uni::fwd(ld, fi * TOTAL, a.bound, a.ls, xv, yv, lj);
-          if (live) a.y[n * a.ldy + f] = yv;
+          if (a.xlds) xr[f] = yv;
+          else if (live) a.y[n * a.ldy + f] = yv;
           lacc += lj;
         }
       }
+      if ((a.dbg & 16) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && wave == 4) {
+        const unsigned long long tg2 = __builtin_amdgcn_s_memtime();
+        printf("grp %2d bits %04x: mfma %llu  epilogue %llu\n", g, bits, tg1 - tg0, tg2 - tg1);
+      }
     }
     ring.end_layer();
+    if (a.xlds) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < AR_T; ++it) {
+        if (it * 16 < a.D) {
+          const int i0 = it * 16 + 4 * q;
+          if (i0 < a.D && live) *reinterpret_cast<f32x4*>(a.y + n * a.ldy + i0) = *reinterpret_cast<const f32x4*>(xr + i0);
+        }
+      }
+    }
     if (a.dbg & 8) {
       tstamp[5] = __builtin_amdgcn_s_memtime();
       if (tprobe)
@@ -338,8 +381,13 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
   return ZK_LAUNCH_CHECK();
 }
 
-typedef RingT<24, 3> Ring24x3;  // 3 x 24 KiB; 2 x 48 and 3 x 48 tiles measured within +-1 %
-int zk_ar_lds_bytes(int variant, int bias_floats) { return (72 * AR_TF + bias_floats + 1024) * (int)sizeof(float); }  // ring + bias + feature map
+#ifndef AR_CH
+#define AR_CH 24
+#define AR_NR 3
+#endif
+typedef RingT<AR_CH, AR_NR> Ring24x3;  // 3 x 24 KiB; 2 x 48 and 3 x 48 tiles measured within +-1 %
+static int ar_base_lds_floats(int bias_floats) { return AR_CH * AR_NR * AR_TF + bias_floats + 1024; }  // ring + bias + feature map
+int zk_ar_lds_bytes(int variant, int bias_floats) { return (ar_base_lds_floats(bias_floats) + 8 * 16 * 260) * (int)sizeof(float); }  // upper bound incl. x/y tiles
 
 // uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23); contract in include/zuko_amd.h.
 static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, const void* yin, int64_t ldyin, void* y, int64_t ldy,
@@ -359,7 +407,11 @@ static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, cons
   a.n_tiles = (N + 127) / 128;
   a.dbg = (variant >> 8) & 0xff;  // undocumented profiling switches (bit0: skip univariate math, bit3: phase timestamps)
   if ((variant & 0xff) != 0) return ZK_EINVAL;
-  const int lds = zk_ar_lds_bytes(0, bias_floats);
+  // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
+  a.xs = ((D + 3) / 4) * 4 + 4;  // +4 words: 16-byte aligned rows whose stride is not a multiple of 32 banks
+  const bool vec_ok = (D % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)y % 16 == 0) && (!inverse || ((ldyin % 4 == 0) && ((uintptr_t)yin % 16 == 0)));
+  a.xlds = vec_ok && (ar_base_lds_floats(bias_floats) + 8 * 16 * a.xs) * 4 <= 160 * 1024;
+  const int lds = (ar_base_lds_floats(bias_floats) + (a.xlds ? 8 * 16 * a.xs : 0)) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
   const void* fn = nullptr;

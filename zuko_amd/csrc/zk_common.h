@@ -42,6 +42,20 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Full-wave sum on the DPP cross-lane network (no LDS crossbar traffic): quad swaps, row mirrors, then
+// row broadcasts; the total ends up in lane 63.
+#define ZK_DPP_ADD(v, ctrl, rmask) \
+  (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, true))
+__device__ __forceinline__ float wave_sum_dpp_to_lane63(float v) {
+  ZK_DPP_ADD(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+  ZK_DPP_ADD(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+  ZK_DPP_ADD(v, 0x141, 0xf);  // row_half_mirror
+  ZK_DPP_ADD(v, 0x140, 0xf);  // row_mirror          -> every lane of a 16-lane row holds the row sum
+  ZK_DPP_ADD(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  ZK_DPP_ADD(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return v;
+}
+
 // Sum over contiguous lane segments of length `seg` (seg <= 64, segments start at multiples of seg
 // counted from lane 0).  After the call the FIRST lane of each segment holds the segment's sum.
 template <typename T> __device__ __forceinline__ T segment_sum(T v, int seg, int lane_in_seg) {

@@ -26,8 +26,11 @@ namespace zk {
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct MathIEEE {
   static __device__ __forceinline__ T div(T a, T b) { return a / b; }
+  static __device__ __forceinline__ T div_safe(T a, T b) { return a / b; }
   static __device__ __forceinline__ T exp(T v) { return t_exp(v); }
   static __device__ __forceinline__ T log(T v) { return t_log(v); }
+  static __device__ __forceinline__ T max(T a, T b) { return b > a ? b : a; }              // NaN in `a` sticks, as torch.max
+  static __device__ __forceinline__ T knot(T cum, T bound) { return bound * (T(2) * cum - T(1)); }  // transforms.py:488-489, literally
 };
 // MathTight (fp32): within ~1.5 ulp of MathIEEE at a third of the instruction count — division by
 // v_rcp_f32 + one Newton step on the quotient (correctly rounded except in rare ties; operands here
@@ -35,25 +38,39 @@ template <typename T> struct MathIEEE {
 // compensated x*log2(e) product.  Used by the standalone fp32 kernels: their ~1000-instruction
 // IEEE epilogue made them VALU-bound (34 % of HBM peak, profiles/r01); log stays ocml (one per element).
 struct MathTight {
+  // a/b for FINITE operands (NaN propagates; an infinite operand yields NaN instead of inf/0 — every
+  // use in the spline/softclip math is one where the reference itself produces NaN for such inputs)
   static __device__ __forceinline__ float div(float a, float b) {
     const float r = __builtin_amdgcn_rcpf(b);
     const float q = a * r;
     return fmaf(fmaf(-b, q, a), r, q);
   }
+  // same, but keeps IEEE results for infinite operands (affine inverse of y = +-inf)
+  static __device__ __forceinline__ float div_safe(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    const float e = fmaf(-b, q, a);
+    return (e - e == 0.f) ? fmaf(e, r, q) : q;
+  }
   static __device__ __forceinline__ float exp(float v) {
-    const float l2e = 1.44269504088896340736f, l2e_lo = 1.92596299112661746e-08f, ln2 = 0.69314718055994530942f;
+    const float l2e = 1.44269504088896340736f, ln2 = 0.69314718055994530942f;
     const float hi = v * l2e;
-    const float lo = fmaf(v, l2e, -hi) + v * l2e_lo;
+    const float lo = fmaf(v, l2e, -hi);  // rounding error of the product (exact); l2e's own 1.3e-8 relative error is dropped
     const float e = __builtin_amdgcn_exp2f(hi);
     return fmaf(e, lo * ln2, e);
   }
   static __device__ __forceinline__ float log(float v) { return logf(v); }
+  static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+  static __device__ __forceinline__ float knot(float cum, float bound) { return fmaf(cum, 2.f * bound, -bound); }
 };
 template <typename T> struct MathStd { typedef MathIEEE<T> type; };
 template <> struct MathStd<float> { typedef MathTight type; };  // policy of the standalone kernels
 
 struct MathFast {
   static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  static __device__ __forceinline__ float div_safe(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+  static __device__ __forceinline__ float knot(float cum, float bound) { return fmaf(cum, 2.f * bound, -bound); }
   static __device__ __forceinline__ float exp(float v) { return __expf(v); }
   static __device__ __forceinline__ float log(float v) { return __logf(v); }
 };
@@ -74,7 +91,7 @@ template <typename T, class M = MathIEEE<T>> __device__ __forceinline__ void aff
 }
 template <typename T, class M = MathIEEE<T>> __device__ __forceinline__ T affine_inv(T shift, T scale, T ls, T y) {
   T lsc = softclip<T, M>(scale, ls);
-  return M::div(y - shift, M::exp(lsc));
+  return M::div_safe(y - shift, M::exp(lsc));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -89,7 +106,7 @@ template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __fo
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     v[j] = softclip2<T, M>(ld(j), ls);
-    m = (j == 0) ? v[0] : (v[j] > m ? v[j] : m);
+    m = (j == 0) ? v[0] : M::max(m, v[j]);
   }
   T s = T(0);
 #pragma unroll
@@ -99,11 +116,11 @@ template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __fo
   }
   T r = M::div(T(1), s);
   T cum = T(0);
-  knot[0] = bound * (T(2) * cum - T(1));
+  knot[0] = M::knot(cum, bound);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     cum += v[j] * r;
-    knot[j + 1] = bound * (T(2) * cum - T(1));
+    knot[j + 1] = M::knot(cum, bound);
   }
 }
 
@@ -141,14 +158,41 @@ __device__ __forceinline__ void rqs_select(const T (&kx)[K + 1], const T (&ky)[K
   }
 }
 
+// Bin search and corner gather in one sweep: k = #(search knots < v) - 1 (strict compare,
+// transforms.py:521-526) and the corners of the bin selected by the SAME compares — the knots are
+// increasing, so "knot j < v" is a prefix property and the last true j is the bin.  For v outside
+// [first, last] knot (k = -1 or K, or NaN) the reference gathers the wrapped bin k % K
+// (transforms.py:502) and then masks the result; any finite bin gives the same masked outputs
+// (y = v, ladj = 0 * log(finite) or NaN for non-finite v), so the first / last bin is used here.
+template <typename T, int K>
+__device__ __forceinline__ int rqs_locate(const T (&ks)[K + 1], const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], T v, bool& inside, T& x0,
+                                          T& x1, T& y0, T& y1, T& d0, T& d1) {
+  int cnt = (ks[0] < v) ? 1 : 0;
+  x0 = kx[0]; x1 = kx[1]; y0 = ky[0]; y1 = ky[1]; d0 = kd[0]; d1 = kd[1];
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const bool c = ks[j] < v;
+    cnt += c ? 1 : 0;
+    x0 = c ? kx[j] : x0;
+    x1 = c ? kx[j + 1] : x1;
+    y0 = c ? ky[j] : y0;
+    y1 = c ? ky[j + 1] : y1;
+    d0 = c ? kd[j] : d0;
+    d1 = c ? kd[j + 1] : d1;
+  }
+  cnt += (ks[K] < v) ? 1 : 0;
+  const int k = cnt - 1;
+  inside = (k >= 0) && (k < K);
+  return k;
+}
+
 // forward value + log|dy/dx| (transforms.py:554-567).  Out-of-range / NaN / inf behaviour is
 // inherited from the literal `mask * ...` arithmetic of the reference.
 template <typename T, int K, class M = MathIEEE<T>>
 __device__ __forceinline__ void rqs_fwd(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], T x, T& y, T& ladj, int& k) {
-  k = rqs_bin<T, K>(kx, x);
   bool inside;
   T x0, x1, y0, y1, d0, d1;
-  rqs_select<T, K>(kx, ky, kd, k, inside, x0, x1, y0, y1, d0, d1);
+  k = rqs_locate<T, K>(kx, kx, ky, kd, x, inside, x0, x1, y0, y1, d0, d1);
   T m = inside ? T(1) : T(0);
   T s = M::div(y1 - y0, x1 - x0);
   T z = M::div(m * (x - x0), x1 - x0);
@@ -165,10 +209,9 @@ __device__ __forceinline__ void rqs_fwd(const T (&kx)[K + 1], const T (&ky)[K + 
 // inverse value (transforms.py:534-548): bin search on the vertical knots, stable quadratic root
 template <typename T, int K, class M = MathIEEE<T>>
 __device__ __forceinline__ void rqs_inv(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], T y, T& x, int& k) {
-  k = rqs_bin<T, K>(ky, y);
   bool inside;
   T x0, x1, y0, y1, d0, d1;
-  rqs_select<T, K>(kx, ky, kd, k, inside, x0, x1, y0, y1, d0, d1);
+  k = rqs_locate<T, K>(ky, kx, ky, kd, y, inside, x0, x1, y0, y1, d0, d1);
   T m = inside ? T(1) : T(0);
   T s = M::div(y1 - y0, x1 - x0);
   T y_ = m * (y - y0);

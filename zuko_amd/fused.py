@@ -310,7 +310,9 @@ def _debug_flags() -> int:
 
 def chunk_of(variant: int) -> int:
     """Tiles per chunk the stream is padded to (variant 0: 3 x 24-tile LDS ring)."""
-    return {0: 24}[variant]
+    import os
+
+    return int(os.environ.get("ZUKO_AMD_AR_CH", 24))  # must match the AR_CH the library was built with
 
 
 class FusedAR:
