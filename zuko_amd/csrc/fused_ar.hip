@@ -27,6 +27,11 @@
 #include "zk_univariate.h"
 #include <type_traits>
 
+// -DZK_AR_TIMING=1 compiles in the s_memtime/printf phase probes (dbg bits 3 and 4); off in the product build
+#ifndef ZK_AR_TIMING
+#define ZK_AR_TIMING 0
+#endif
+
 namespace zk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -165,7 +170,7 @@ template <class Src> __device__ __forceinline__ void hidden_layer(Src& ring, con
   ring.end_layer();
 }
 
-template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
+template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
   constexpr bool DIRECT = false;
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   const int tid = threadIdx.x;
@@ -218,7 +223,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
       }
       in[it] = v;
     }
-    if (a.xlds) {
+    if (XLDS) {
 #pragma unroll
       for (int it = 0; it < AR_T; ++it) {
         if (it * 16 < a.D) {
@@ -236,11 +241,11 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
 
     // ---- hidden layers ---------------------------------------------------------------------------
     unsigned long long tstamp[6];  // dbg bit3: phase timestamps (s_memtime) printed by two waves of block 0
-    const bool tprobe = (a.dbg & 8) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && (wave == 0 || wave == 4);
-    if (a.dbg & 8) tstamp[0] = __builtin_amdgcn_s_memtime();
+    const bool tprobe = ZK_AR_TIMING && (a.dbg & 8) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && (wave == 0 || wave == 4);
+    if (ZK_AR_TIMING && (a.dbg & 8)) tstamp[0] = __builtin_amdgcn_s_memtime();
     for (int l = 0; l < a.L - 1; ++l) {
       hidden_layer(ring, a.skip + l * 4, in, out);
-      if (a.dbg & 8) tstamp[1 + (l < 3 ? l : 3)] = __builtin_amdgcn_s_memtime();
+      if (ZK_AR_TIMING && (a.dbg & 8)) tstamp[1 + (l < 3 ? l : 3)] = __builtin_amdgcn_s_memtime();
       const float* bl = bias_lds + l * 256 + 4 * q;
 #pragma unroll
       for (int t = 0; t < AR_T; ++t) in[t] = out[t] + *reinterpret_cast<const f32x4*>(bl + t * 16);
@@ -270,7 +275,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
     for (int g = 0; g < a.NG; ++g) {
       const uint32_t bits = skip_last[g];
       unsigned long long tg0 = 0, tg1 = 0;
-      if (a.dbg & 16) tg0 = __builtin_amdgcn_s_memtime();
+      if (ZK_AR_TIMING && (a.dbg & 16)) tg0 = __builtin_amdgcn_s_memtime();
       // operands of the epilogue are requested BEFORE the group's MFMAs so their latency is hidden:
       // feature ids + bias from LDS, x[n, f] from global/L2 (one dependent load)
       int fid[FPL];
@@ -279,7 +284,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
       for (int fi = 0; fi < FPL; ++fi) {
         fid[fi] = fmap_lds[(g * 4 + q) * FPL + fi];
         const int fc = fid[fi] < 0 ? 0 : fid[fi];
-        if (a.xlds) xin[fi] = xr[fc];
+        if (XLDS) xin[fi] = xr[fc];
         else xin[fi] = INVERSE ? a.yin[nc * a.ldyin + fc] : xrow[fc];
       }
       f32x4 bgrp[NT];
@@ -305,7 +310,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][r], in[it][r], acc[t], 0, 0, 0);
         }
       }
-      if (a.dbg & 16) tg1 = __builtin_amdgcn_s_memtime();
+      if (ZK_AR_TIMING && (a.dbg & 16)) tg1 = __builtin_amdgcn_s_memtime();
       float p[4 * NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -321,18 +326,18 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
           if (a.dbg & 1) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
           else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
           else Uni::fwd(ld, fi * TOTAL, a.bound, a.ls, xv, yv, lj);
-          if (a.xlds) xr[f] = yv;
+          if (XLDS) xr[f] = yv;
           else if (live) a.y[n * a.ldy + f] = yv;
           lacc += lj;
         }
       }
-      if ((a.dbg & 16) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && wave == 4) {
+      if ((ZK_AR_TIMING && (a.dbg & 16)) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && wave == 4) {
         const unsigned long long tg2 = __builtin_amdgcn_s_memtime();
         printf("grp %2d bits %04x: mfma %llu  epilogue %llu\n", g, bits, tg1 - tg0, tg2 - tg1);
       }
     }
     ring.end_layer();
-    if (a.xlds) {
+    if (XLDS) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -343,7 +348,7 @@ template <typename Uni, bool INVERSE, class Src> __global__ __launch_bounds__(51
         }
       }
     }
-    if (a.dbg & 8) {
+    if (ZK_AR_TIMING && (a.dbg & 8)) {
       tstamp[5] = __builtin_amdgcn_s_memtime();
       if (tprobe)
         printf("wave %d: L1 %llu  L2 %llu  L3 %llu  (+bias/act each)  last layer + 16 epilogues %llu   total %llu cycles\n", wave, tstamp[1] - tstamp[0],
@@ -415,8 +420,11 @@ static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, cons
   if (lds > 160 * 1024) return ZK_EINVAL;
   const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
   const void* fn = nullptr;
-  if (uni_kind == 0) fn = inverse ? (const void*)ar_kernel<UniAffine, true, Ring24x3> : (const void*)ar_kernel<UniAffine, false, Ring24x3>;
-  else if (uni_kind == 1) fn = inverse ? (const void*)ar_kernel<UniRqs8, true, Ring24x3> : (const void*)ar_kernel<UniRqs8, false, Ring24x3>;
+#define ZK_AR_PICK(UNI)                                                                                                                     \
+  (inverse ? (a.xlds ? (const void*)ar_kernel<UNI, true, Ring24x3, true> : (const void*)ar_kernel<UNI, true, Ring24x3, false>)            \
+           : (a.xlds ? (const void*)ar_kernel<UNI, false, Ring24x3, true> : (const void*)ar_kernel<UNI, false, Ring24x3, false>))
+  if (uni_kind == 0) fn = ZK_AR_PICK(UniAffine);
+  else if (uni_kind == 1) fn = ZK_AR_PICK(UniRqs8);
   else return ZK_EINVAL;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
