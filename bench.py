@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+                    help="cfg2 = the headline NSF workload (default, the only graded line); cfg3 = MAF(64,T=8,H=256x3); "
+                         "cfg4 = RealNVP(256,T=16,H=512x3) — side measurements quoted in DESIGN.md")
     return ap.parse_args()
 
 
@@ -111,11 +114,22 @@ def main() -> None:
 
     import zuko_amd
     from zuko_amd import _C, ops
-    from zuko_amd.flows import NSF
+    from zuko_amd.flows import MAF, NSF, RealNVP
 
+    global FEATURES, FLOP_PER_SAMPLE_TRANSFORM, TRANSFORMS
+    if args.config == "cfg3":
+        make = lambda: MAF(64, 0, transforms=8, hidden_features=HIDDEN)
+        FLOP_PER_SAMPLE_TRANSFORM, workload = 2 * (64 * 256 + 2 * 256 * 256 + 256 * 128), "MAF(features=64, transforms=8, hidden=[256]*3) log_prob"
+    elif args.config == "cfg4":
+        make = lambda: RealNVP(256, 0, transforms=16, hidden_features=[512] * 3)
+        FEATURES, TRANSFORMS = 256, 16
+        FLOP_PER_SAMPLE_TRANSFORM, workload = 2 * (128 * 512 + 2 * 512 * 512 + 512 * 256), "RealNVP(features=256, transforms=16, hidden=[512]*3) log_prob"
+    else:
+        make = lambda: NSF(FEATURES, 0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
+        workload = "NSF(features=64, context=0, transforms=8, bins=8, hidden=[256]*3) log_prob"
     torch.manual_seed(0)
-    flow_cpu = NSF(FEATURES, 0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
-    flow = NSF(FEATURES, 0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
+    flow_cpu = make()
+    flow = make()
     flow.load_state_dict(flow_cpu.state_dict())
     flow = flow.to(dev)
     B = 1 << args.batch_log2
@@ -168,6 +182,8 @@ def main() -> None:
         # the standalone (phi-in-HBM) spline kernel is not on the fused path: time it on its own so its
         # HBM fraction (the bandwidth-bound roofline of north_star) is measured in the same run
         try:
+            if args.config != "cfg2":
+                raise RuntimeError("side measurement only taken on the headline config")
             gen = torch.Generator(device=dev).manual_seed(3)
             phi = torch.randn(B, FEATURES, 3 * BINS - 1, generator=gen, device=dev)
             w, h, d = phi[..., :BINS], phi[..., BINS : 2 * BINS], phi[..., 2 * BINS :]
@@ -188,7 +204,7 @@ def main() -> None:
 
     if rank == 0:
         out = {
-            "metric": "log_prob samples/sec, NSF d=64 K=8 bins=8 batch=2^20",
+            "metric": "log_prob samples/sec, NSF d=64 K=8 bins=8 batch=2^20" if args.config == "cfg2" else f"log_prob samples/sec, {args.config}",
             "value": value,
             "unit": "samples/s",
             "n_gpus": world,
@@ -201,7 +217,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"NSF(features=64, context=0, transforms=8, bins=8, hidden=[256]*3) log_prob, batch=2^{args.batch_log2} per GPU, x~N(0,1), seed-0 init",
+                "workload": f"{workload}, batch=2^{args.batch_log2} per GPU, x~N(0,1), seed-0 init",
                 "batch_per_gpu": B,
                 "global_batch": B * world,
                 "parallelism": f"batch-sharded x{world}, one RCCL all-reduce of the scalar NLL",
@@ -216,7 +232,7 @@ def main() -> None:
             "kernels": extra,
             "nll": float(nll.item()),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             out["cpu_baseline"] = cpu_baseline(flow_cpu, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
