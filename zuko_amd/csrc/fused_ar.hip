@@ -60,7 +60,7 @@ struct ArArgs {
 
 __device__ __forceinline__ float act_f32(float v, int act) {
   switch (act) {
-    case 1: return v > 0.f ? v : 0.f;
+    case 1: return v < 0.f ? 0.f : v;
     case 2: return v > 0.f ? v : expm1f(v);
     case 3: return tanhf(v);
     case 4: return v / (1.f + expf(-v));
@@ -223,6 +223,20 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
       }
       in[it] = v;
     }
+    // The reference multiplies every input by (mask * W): a NaN or +-inf input therefore turns ALL
+    // parameters of its sample into NaN (x * 0 = NaN), including those whose mask excludes that input
+    // (zuko/nn.py:217-218).  Skipped tiles would not reproduce that, so the sample is flagged instead.
+    float poison = 0.f;
+    {
+      int bad = 0;
+#pragma unroll
+      for (int it = 0; it < AR_T; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= !(fabsf(in[it][r]) < __builtin_inff());
+      bad |= __shfl_xor(bad, 16, 64);
+      bad |= __shfl_xor(bad, 32, 64);
+      if (bad) poison = __builtin_nanf("");
+    }
     if (XLDS) {
 #pragma unroll
       for (int it = 0; it < AR_T; ++it) {
@@ -255,7 +269,7 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
 #pragma unroll
           for (int t = 0; t < AR_T; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) in[t][r] = in[t][r] > 0.f ? in[t][r] : 0.f;
+            for (int r = 0; r < 4; ++r) in[t][r] = in[t][r] < 0.f ? 0.f : in[t][r];  // NaN stays NaN, as torch.relu
           break;
         case 0: break;
         default:
@@ -315,7 +329,7 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r] + bgrp[t][r];
+        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r] + bgrp[t][r] + poison;
       auto ld = [&](int i) { return p[i]; };
 #pragma unroll
       for (int fi = 0; fi < FPL; ++fi) {

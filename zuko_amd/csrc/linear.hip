@@ -20,7 +20,7 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_TANH = 3, ACT_SILU = 4, 
 
 template <typename T> __device__ __forceinline__ T apply_act(T v, int act) {
   switch (act) {
-    case ACT_RELU: return v > T(0) ? v : T(0);
+    case ACT_RELU: return v < T(0) ? T(0) : v;  // NaN stays NaN, as torch.relu
     case ACT_ELU: return v > T(0) ? v : (T)expm1((double)v);
     case ACT_TANH: return (T)tanh((double)v);
     case ACT_SILU: return v / (T(1) + t_exp(-v));

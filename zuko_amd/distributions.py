@@ -80,8 +80,9 @@ class NormalizingFlow(Distribution):
             if loc.dim() > 1:
                 if any(s != 0 for s in loc.stride()[:-1]) or any(s != 0 for s in scale.stride()[:-1]):
                     return None
-                loc = loc[(0,) * (loc.dim() - 1)]
-                scale = scale[(0,) * (scale.dim() - 1)]
+                # (works for empty batch shapes too: view the last axis of the underlying vector)
+                loc = loc.as_strided((D,), (loc.stride(-1),))
+                scale = scale.as_strided((D,), (scale.stride(-1),))
             return loc, scale
         return None
 
