@@ -137,6 +137,20 @@ int zk_ar_lds_bytes(int variant, int bias_floats);
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
 int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);
 
+/* ---- backward (vector-Jacobian products; fp32).  The reference has no backward code: autograd runs
+ *      through the ATen ops of zuko/transforms.py:480-490,554-567 (spline), :436-446 (affine),
+ *      torch Normal.log_prob (zuko/distributions.py:115-119) and the activations of zuko/nn.py. --------- */
+/* kind 0 = affine (phi [N, D, 2] = [shift, scale]), 1 = RQS (phi [N, D, 3K-1], K in {4, 8, 16}).
+ * phi / gphi packed and contiguous with the same 16-byte alignment; gy [N, D] (may be NULL);
+ * gl [N] if gl_reduced else [N, D] (may be NULL); outputs gx [N, D], gphi [N, D, total]. */
+int zk_univariate_backward(int kind, int64_t N, int64_t D, int K, double bound, double slope, const void* x, const void* phi,
+                           const void* gy, const void* gl, int gl_reduced, void* gx, void* gphi, void* stream);
+/* gz[n, d] = -g[n] * (z[n, d] - loc[d]) / scale[d]^2 */
+int zk_diag_normal_backward(int64_t N, int64_t D, const void* z, const void* loc, const void* scale, const void* g, void* gz,
+                            void* stream);
+/* gin = gout * act'(.) written in terms of the activation OUTPUT y; act in {NONE, RELU, ELU, TANH, SIGMOID, LEAKY}. */
+int zk_act_backward(int64_t n, const void* y, const void* gout, int act, void* gin, void* stream);
+
 /* ---- base density + final reduction (zuko/distributions.py:115-119, 337-363) ---------------------- *
  * out[n] = sum_d Normal(loc[d], scale[d]).log_prob(z[n, d]) (+ ladj[n] if ladj != NULL). */
 int zk_diag_normal_log_prob(int dtype, int64_t N, int64_t D, const void* z, const void* loc, const void* scale,

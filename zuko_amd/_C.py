@@ -36,6 +36,9 @@ SIGNATURES = {
     "zk_diag_normal_log_prob": [I, L, L, P, P, P, P, P, P],
     "zk_sum_f64": [I, L, P, F, P, P, P],
     "zk_gather_f32": [P, P, P, L, P, P],
+    "zk_univariate_backward": [I, L, L, I, F, F, P, P, P, P, I, P, P, P],
+    "zk_diag_normal_backward": [L, L, P, P, P, P, P, P],
+    "zk_act_backward": [L, P, P, I, P, P],
     "zk_ar_lds_bytes": [I, I],
     "zk_ar_forward": [I, L, I, I, P, L, P, L, P, I, P, P, I, P, P, I, I, I, I, F, F, I, P],
     "zk_ar_inverse_sweep": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, I, P],

@@ -27,6 +27,7 @@ SOURCES = {
     "elementwise.hip": ["-ffp-contract=off"],
     "linear.hip": [],
     "fused_ar.hip": ["-ffp-contract=off"],
+    "backward.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 

@@ -1,0 +1,285 @@
+// zuko_amd — backward (vector-Jacobian product) kernels of the univariate transforms, the base
+// density and the activations: SURVEY 8(f) rank 1.  The reference has no backward code of its own —
+// `loss.backward()` runs PyTorch autograd through every ATen op of the forward
+// (zuko/transforms.py:480-490, 554-567 for the spline; :436-446 affine) — so these kernels are the
+// fused adjoints of those op sequences.
+//
+// Spline: given gy[N, D] and gl (the gradient w.r.t. log|det J|, per row when the forward reduced over
+// features), produce gx[N, D] and g_phi[N, D, 3K-1] for the PACKED parameter layout.  Per element the
+// forward is recomputed from phi (same device functions as the forward kernels), the local map
+//   (x, x0, x1, y0, y1, d0, d1) -> (y, ladj)
+// is differentiated with 7-wide forward-mode dual numbers (no hand-derived formulas to get wrong), and
+// the adjoint is pushed back through bin gather -> cumsum -> softmax -> softclip / exp by hand (those
+// are sparse: only the two knots of the active bin receive gradient).
+// Data movement mirrors the forward kernel: a wave owns 64 consecutive elements, phi comes in and
+// g_phi goes out through a wave-private LDS image with 16-byte global accesses.
+#include "zk_univariate.h"
+
+namespace zk {
+
+struct Dual7 {
+  float v;
+  float d[7];
+};
+__device__ __forceinline__ Dual7 dconst(float c) { Dual7 r; r.v = c;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.d[i] = 0.f; return r; }
+__device__ __forceinline__ Dual7 dvar(float c, int i) { Dual7 r = dconst(c); r.d[i] = 1.f; return r; }
+__device__ __forceinline__ Dual7 operator+(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator-(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator*(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator/(const Dual7& a, const Dual7& b) { Dual7 r; const float ib = 1.f / b.v; r.v = a.v * ib;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+__device__ __forceinline__ Dual7 dlog(const Dual7& a) { Dual7 r; r.v = logf(a.v); const float ia = 1.f / a.v;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * ia; return r; }
+
+__device__ __forceinline__ float softclip_grad(float v, float c_abs) {  // d/dv [ v / (1 + |v| / c) ]
+  const float t = 1.f + fabsf(v) / c_abs;
+  return 1.f / (t * t);
+}
+
+struct BwdArgs {
+  int64_t N, D;
+  const float* x;
+  const float* phi;   // [N, D, total] packed
+  const float* gy;    // [N, D]
+  const float* gl;    // [N] (reduced) or [N, D]
+  int gl_reduced;
+  float* gx;          // [N, D]
+  float* gphi;        // [N, D, total]
+  float bound, ls;
+  int64_t iters;
+};
+
+template <int K> __device__ __forceinline__ void rqs_backward_element(const float* p, float x, float gyv, float glv, float bound, float ls, float& gxv, float* g) {
+  typedef MathIEEE<float> M;
+  constexpr int TOTAL = 3 * K - 1;
+  float kx[K + 1], ky[K + 1], kd[K + 1], pw[K], ph[K];
+  // forward recompute, keeping the softmax probabilities
+  auto axis = [&](int off, float (&knot)[K + 1], float (&prob)[K]) {
+    float v[K], m;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { v[j] = softclip2<float, M>(p[off + j], ls); m = (j == 0) ? v[0] : fmaxf(m, v[j]); }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { v[j] = expf(v[j] - m); s += v[j]; }
+    const float r = 1.f / s;
+    float cum = 0.f;
+    knot[0] = -bound;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { prob[j] = v[j] * r; cum += prob[j]; knot[j + 1] = bound * (2.f * cum - 1.f); }
+  };
+  axis(0, kx, pw);
+  axis(K, ky, ph);
+  rqs_slopes<float, K, M>([&](int j) { return p[2 * K + j]; }, ls, kd);
+  bool inside;
+  float x0, x1, y0, y1, d0, d1;
+  const int k = rqs_locate<float, K>(kx, kx, ky, kd, x, inside, x0, x1, y0, y1, d0, d1);
+#pragma unroll
+  for (int i = 0; i < TOTAL; ++i) g[i] = 0.f;
+  if (!inside) { gxv = gyv; return; }  // identity outside [-B, B]: y = x, ladj = 0, no parameter gradient
+  // local map in dual numbers: variables 0..6 = x, x0, x1, y0, y1, d0, d1
+  const Dual7 X = dvar(x, 0), X0 = dvar(x0, 1), X1 = dvar(x1, 2), Y0 = dvar(y0, 3), Y1 = dvar(y1, 4), D0 = dvar(d0, 5), D1 = dvar(d1, 6);
+  const Dual7 one = dconst(1.f), two = dconst(2.f);
+  const Dual7 w = X1 - X0, h = Y1 - Y0;
+  const Dual7 s = h / w;
+  const Dual7 z = (X - X0) / w;
+  const Dual7 omz = one - z;
+  const Dual7 zz = z * omz;
+  const Dual7 den = s + (D0 + D1 - two * s) * zz;
+  const Dual7 num = s * z * z + D0 * zz;
+  const Dual7 y = Y0 + h * num / den;
+  const Dual7 jac = s * s * (two * s * zz + D0 * omz * omz + D1 * z * z) / (den * den);
+  const Dual7 lad = dlog(jac);
+  float gv[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) gv[i] = gyv * y.d[i] + glv * lad.d[i];
+  gxv = gv[0];
+  // knots -> softmax probabilities: kx_j = B (2 sum_{i<j} p_i - 1): only knots k and k+1 carry gradient
+  const float twoB = 2.f * bound;
+  float gpw[K], gph[K], dotw = 0.f, doth = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    gpw[i] = twoB * ((i < k ? gv[1] : 0.f) + (i <= k ? gv[2] : 0.f));
+    gph[i] = twoB * ((i < k ? gv[3] : 0.f) + (i <= k ? gv[4] : 0.f));
+    dotw += pw[i] * gpw[i];
+    doth += ph[i] * gph[i];
+  }
+  const float cw = fabsf(ls) * 0.5f, cd = fabsf(ls);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    g[i] = pw[i] * (gpw[i] - dotw) * softclip_grad(p[i], cw);
+    g[K + i] = ph[i] * (gph[i] - doth) * softclip_grad(p[K + i], cw);
+  }
+  // slopes: kd_j = exp(softclip(ud_{j-1})), j = 1..K-1 (ends are the constant 1)
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const float gk = (j == k ? gv[5] : 0.f) + (j == k + 1 ? gv[6] : 0.f);
+    g[2 * K + j - 1] = gk * kd[j] * softclip_grad(p[2 * K + j - 1], cd);
+  }
+}
+
+__device__ __forceinline__ void affine_backward_element(const float* p, float x, float gyv, float glv, float ls, float& gxv, float* g) {
+  const float lsc = softclip<float>(p[1], ls);
+  const float e = expf(lsc);
+  gxv = gyv * e;
+  g[0] = gyv;                                                       // shift
+  g[1] = (gyv * x * e + glv) * softclip_grad(p[1], fabsf(ls));      // unconstrained log-scale
+}
+
+extern __shared__ __attribute__((aligned(16))) float bw_lds[];
+
+// KIND 0: affine (total 2), 1: RQS with K bins.  Requires 16-byte aligned phi / gphi and D*total*... any D.
+template <int KIND, int K> __global__ __launch_bounds__(256) void uni_backward_kernel(BwdArgs a) {
+  constexpr int TOTAL = KIND == 0 ? 2 : 3 * K - 1;
+  constexpr int PER_WAVE = 64 * TOTAL + 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wsh = bw_lds + wave * PER_WAVE;
+  const int64_t total_elems = a.N * a.D;
+  const int64_t wt0 = ((int64_t)blockIdx.x * 4 + wave) * a.iters;
+  for (int64_t it = 0; it < a.iters; ++it) {
+    const int64_t e0 = (wt0 + it) * 64;
+    if (e0 >= total_elems) break;  // wave-uniform
+    const int64_t cnt = (total_elems - e0) < 64 ? (total_elems - e0) : 64;
+    const float* src = a.phi + e0 * TOTAL;
+    const int shift = (int)(((uintptr_t)src / 4) % 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // stage phi (alignment-preserving image, as the forward kernel)
+    {
+      const int64_t n = cnt * TOTAL;
+      int head = shift ? 4 - shift : 0;
+      if (head > n) head = (int)n;
+      if (lane < head) wsh[shift + lane] = src[lane];
+      const int64_t body = (n - head) / 4;
+      const float4* vs = reinterpret_cast<const float4*>(src + head);
+      float4* vd = reinterpret_cast<float4*>(wsh + shift + head);
+      for (int64_t i = lane; i < body; i += 64) vd[i] = vs[i];
+      const int64_t done = head + body * 4;
+      if (lane < n - done) wsh[shift + done + lane] = src[done + lane];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const bool valid = lane < cnt;
+    float g[TOTAL];
+    float gxv = 0.f;
+    if (valid) {
+      const int64_t e = e0 + lane;
+      float p[TOTAL];
+#pragma unroll
+      for (int i = 0; i < TOTAL; ++i) p[i] = wsh[shift + lane * TOTAL + i];
+      const float glv = a.gl ? (a.gl_reduced ? a.gl[e / a.D] : a.gl[e]) : 0.f;
+      const float gyv = a.gy ? a.gy[e] : 0.f;
+      if (KIND == 0) affine_backward_element(p, a.x[e], gyv, glv, a.ls, gxv, g);
+      else rqs_backward_element<K>(p, a.x[e], gyv, glv, a.bound, a.ls, gxv, g);
+      a.gx[e] = gxv;
+    }
+    // g_phi out through the same LDS image (same shift: gphi has the alignment of phi by contract)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < TOTAL; ++i) wsh[shift + lane * TOTAL + i] = g[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+      float* dst = a.gphi + e0 * TOTAL;
+      const int64_t n = cnt * TOTAL;
+      int head = shift ? 4 - shift : 0;
+      if (head > n) head = (int)n;
+      if (lane < head) dst[lane] = wsh[shift + lane];
+      const int64_t body = (n - head) / 4;
+      float4* vd = reinterpret_cast<float4*>(dst + head);
+      const float4* vs = reinterpret_cast<const float4*>(wsh + shift + head);
+      for (int64_t i = lane; i < body; i += 64) vd[i] = vs[i];
+      const int64_t done = head + body * 4;
+      if (lane < n - done) dst[done + lane] = wsh[shift + done + lane];
+    }
+  }
+}
+
+// gz[n, d] = -g[n] (z - loc) / scale^2 ; the ladj gradient is g itself (done by the caller)
+__global__ __launch_bounds__(256) void normal_backward_kernel(int64_t N, int64_t D, const float* z, const float* loc, const float* scale, const float* g, float* gz) {
+  const int64_t total = N * D;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t d = e % D;
+    const float s = scale[d];
+    gz[e] = -g[e / D] * (z[e] - loc[d]) / (s * s);
+  }
+}
+
+// gin = gout * act'(.) expressed through the activation's OUTPUT y (relu, elu, tanh, sigmoid, leaky relu)
+__global__ __launch_bounds__(256) void act_backward_kernel(int64_t n, const float* y, const float* gout, int act, float* gin) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float v = y[e], g = gout[e];
+    float d = 1.f;
+    switch (act) {
+      case 1: d = v > 0.f ? 1.f : 0.f; break;
+      case 2: d = v > 0.f ? 1.f : v + 1.f; break;
+      case 3: d = 1.f - v * v; break;
+      case 6: d = v * (1.f - v); break;
+      case 7: d = v > 0.f ? 1.f : 0.01f; break;
+      default: break;
+    }
+    gin[e] = g * d;
+  }
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+// kind 0 = affine (phi [N, D, 2] = [shift, scale]), 1 = RQS (phi [N, D, 3K-1], K in {4, 8, 16}); fp32, packed phi/gphi.
+int zk_univariate_backward(int kind, int64_t N, int64_t D, int K, double bound, double slope, const void* x, const void* phi, const void* gy, const void* gl,
+                           int gl_reduced, void* gx, void* gphi, void* stream) {
+  if (N <= 0 || D <= 0) return 0;
+  BwdArgs a{};
+  a.N = N; a.D = D; a.x = (const float*)x; a.phi = (const float*)phi; a.gy = (const float*)gy; a.gl = (const float*)gl; a.gl_reduced = gl_reduced;
+  a.gx = (float*)gx; a.gphi = (float*)gphi; a.bound = (float)bound; a.ls = (float)log(slope);
+  if ((((uintptr_t)phi ^ (uintptr_t)gphi) % 16) != 0) return ZK_EINVAL;
+  const int total = kind == 0 ? 2 : 3 * K - 1;
+  const int64_t tiles = (N * D + 63) / 64;
+  const int64_t blocks = (tiles + 3) / 4;
+  const size_t lds = 4 * (size_t)(64 * total + 8) * sizeof(float);
+  int64_t per_cu = (160 * 1024) / (int64_t)lds;
+  per_cu = per_cu > 8 ? 8 : per_cu;
+  const int64_t cap = 256 * per_cu;
+  const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+  a.iters = (tiles + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0) hipLaunchKernelGGL((uni_backward_kernel<0, 1>), dim3(grid), dim3(256), lds, st, a);
+  else if (kind == 1 && K == 4) hipLaunchKernelGGL((uni_backward_kernel<1, 4>), dim3(grid), dim3(256), lds, st, a);
+  else if (kind == 1 && K == 8) hipLaunchKernelGGL((uni_backward_kernel<1, 8>), dim3(grid), dim3(256), lds, st, a);
+  else if (kind == 1 && K == 16) hipLaunchKernelGGL((uni_backward_kernel<1, 16>), dim3(grid), dim3(256), lds, st, a);
+  else return ZK_EINVAL;
+  return ZK_LAUNCH_CHECK();
+}
+
+int zk_diag_normal_backward(int64_t N, int64_t D, const void* z, const void* loc, const void* scale, const void* g, void* gz, void* stream) {
+  if (N <= 0 || D <= 0) return 0;
+  const int64_t nb = (N * D + 255) / 256;
+  hipLaunchKernelGGL(normal_backward_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, N, D, (const float*)z, (const float*)loc,
+                     (const float*)scale, (const float*)g, (float*)gz);
+  return ZK_LAUNCH_CHECK();
+}
+
+int zk_act_backward(int64_t n, const void* y, const void* gout, int act, void* gin, void* stream) {
+  if (n <= 0) return 0;
+  if (!(act == 0 || act == 1 || act == 2 || act == 3 || act == 6 || act == 7)) return ZK_EINVAL;
+  const int64_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(act_backward_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, n, (const float*)y, (const float*)gout, act, (float*)gin);
+  return ZK_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -85,6 +85,8 @@ class _FusedSequential(nn.Sequential):
             if isinstance(m, (Linear, MaskedLinear)):
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
                 code = _act_code(nxt) if nxt is not None and not isinstance(nxt, (Linear, MaskedLinear)) else None
+                if code is not None and torch.is_grad_enabled() and code not in (0, 1, 2, 3, 6, 7):
+                    code = None  # SiLU / GELU need the pre-activation for their derivative: leave them to torch
                 if code is not None and nxt is not None:
                     x = m(x, code)
                     i += 2

@@ -52,8 +52,8 @@ def _require_device(*ts: Tensor) -> None:
 def _no_grad_only(*ts: Tensor) -> None:
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
         raise NotImplementedError(
-            "zuko_amd kernels are forward-only in this release (SURVEY 8f: backward is the next row); "
-            "call them under torch.no_grad() or with tensors that do not require grad."
+            "zuko_amd: no backward kernel for this operation yet (autograd covers log_prob of affine / RQS "
+            "flows, see zuko_amd/autograd.py); call it under torch.no_grad()."
         )
 
 
@@ -142,6 +142,13 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
     K = widths.shape[-1]
     if heights.shape[-1] != K or derivatives.shape[-1] != K - 1:
         raise ValueError("zuko_amd: widths/heights must have K entries and derivatives K-1")
+    from . import autograd as AG
+
+    if not want_bins and AG.needs_grad(x, widths, heights, derivatives):
+        _require_device(x, widths, heights, derivatives)
+        if K not in (4, 8, 16):
+            raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
+        return AG.UnivariateFn.apply(1, bound, slope, reduce, x, widths, heights, derivatives)
     pr = _Prepared(x, [(widths, 1), (heights, 1), (derivatives, 1)])
     if reduce and len(pr.shape) == 0:
         raise ValueError("zuko_amd: cannot reduce ladj of a 0-d input")
@@ -187,6 +194,11 @@ def rqs_from_knots(v: Tensor, horizontal: Tensor, vertical: Tensor, slopes: Tens
 
 
 def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3, reduce: bool = False):
+    from . import autograd as AG
+
+    if AG.needs_grad(x, shift, scale):
+        _require_device(x, shift, scale)
+        return AG.UnivariateFn.apply(0, 5.0, slope, reduce, x, shift, scale)
     pr = _Prepared(x, [(shift.unsqueeze(-1), 1), (scale.unsqueeze(-1), 1)])
     y, ladj = pr.out(), pr.out_ladj(reduce)
     (s, sn, sd), (c, cn, cd) = pr.params
@@ -287,7 +299,12 @@ def bernstein_inverse(y: Tensor, theta: Tensor, bounded: bool, bound: float = 5.
 def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, act: int = 0) -> Tensor:
     """act(x @ (mask * weight).T + bias) over the last dim of x (zuko/nn.py:217-218)."""
     _require_device(x, weight, bias, mask)
-    _no_grad_only(x, weight, bias)
+    from . import autograd as AG
+
+    if AG.needs_grad(x, weight, bias):
+        if act not in AG.BACKWARD_ACTS:
+            raise NotImplementedError("zuko_amd: this activation cannot be fused when gradients are required")
+        return AG.LinearFn.apply(x, weight, bias, mask, act)
     out_f, in_f = weight.shape
     if x.shape[-1] != in_f:
         raise ValueError(f"zuko_amd.linear: expected last dim {in_f}, got {x.shape[-1]}")
@@ -312,7 +329,10 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor |
 
 def diag_normal_log_prob(z: Tensor, loc: Tensor, scale: Tensor, ladj: Tensor | None = None) -> Tensor:
     _require_device(z, loc, scale, ladj)
-    _no_grad_only(z, loc, scale, ladj)
+    from . import autograd as AG
+
+    if AG.needs_grad(z, ladj):
+        return AG.DiagNormalLogProbFn.apply(z, loc, scale, ladj)
     D = z.shape[-1]
     z2 = z.reshape(-1, D).contiguous()
     out = torch.empty(z2.shape[0], dtype=z.dtype, device=z.device)
