@@ -57,8 +57,12 @@ template <typename T, int K, bool INV> struct RqsOp {
   template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
     typedef typename MathStd<T>::type M;
     T kx[K + 1], ky[K + 1], kd[K + 1];
-    rqs_axis_knots<T, K, M>(ld[0], T(a.bound), T(a.ls), kx);
-    rqs_axis_knots<T, K, M>(ld[1], T(a.bound), T(a.ls), ky);
+    if constexpr (sizeof(T) == 4) {
+      rqs_axes_knots_packed_tight<K>(ld[0], ld[1], (float)a.bound, (float)a.ls, kx, ky);
+    } else {
+      rqs_axis_knots<T, K, M>(ld[0], T(a.bound), T(a.ls), kx);
+      rqs_axis_knots<T, K, M>(ld[1], T(a.bound), T(a.ls), ky);
+    }
     rqs_slopes<T, K, M>(ld[2], T(a.ls), kd);
     if (INV) { rqs_inv<T, K, M>(kx, ky, kd, in, out, k); ladj = T(0); }
     else rqs_fwd<T, K, M>(kx, ky, kd, in, out, ladj, k);

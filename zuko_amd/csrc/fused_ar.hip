@@ -123,8 +123,7 @@ struct UniAffine {
 struct UniRqs8 {
   static constexpr int TOTAL = 23, FPL = 1, NT = 6;
   template <typename P> static __device__ __forceinline__ void knots(const P& p, int base, float bound, float ls, float (&kx)[9], float (&ky)[9], float (&kd)[9]) {
-    rqs_axis_knots<float, 8, MathFast>([&](int j) { return p(base + j); }, bound, ls, kx);
-    rqs_axis_knots<float, 8, MathFast>([&](int j) { return p(base + 8 + j); }, bound, ls, ky);
+    rqs_axes_knots_packed<8>([&](int j) { return p(base + j); }, [&](int j) { return p(base + 8 + j); }, bound, ls, kx, ky);
     rqs_slopes<float, 8, MathFast>([&](int j) { return p(base + 16 + j); }, ls, kd);
   }
   template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {

@@ -124,6 +124,91 @@ template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __fo
   }
 }
 
+// Both axes at once on 2-wide vectors (fast-math policy only): the width and height pipelines are
+// identical, so every multiply / add / fma of the softclip, softmax and cumulative sum is issued once
+// as a packed v_pk_*_f32 instruction instead of twice; v_rcp / v_exp remain per component.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int K, typename LdW, typename LdH>
+__device__ __forceinline__ void rqs_axes_knots_packed(LdW ldw, LdH ldh, float bound, float ls, float (&kx)[K + 1], float (&ky)[K + 1]) {
+  const float inv_c = 2.f * __builtin_amdgcn_rcpf(fabsf(ls));  // |2 v / ls| = |v| * inv_c
+  f32x2_t v[K];
+  f32x2_t m;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const f32x2_t u = {ldw(j), ldh(j)};
+    const f32x2_t a = {fabsf(u.x), fabsf(u.y)};
+    const f32x2_t den = a * inv_c + 1.f;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    v[j] = u * r;
+    m = (j == 0) ? v[0] : f32x2_t{fmaxf(m.x, v[j].x), fmaxf(m.y, v[j].y)};
+  }
+  const float l2e = 1.44269504088896340736f;
+  f32x2_t s = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const f32x2_t t = (v[j] - m) * l2e;
+    v[j] = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    s += v[j];
+  }
+  const f32x2_t r = {__builtin_amdgcn_rcpf(s.x), __builtin_amdgcn_rcpf(s.y)};
+  const f32x2_t scale = r * (2.f * bound);
+  f32x2_t cum = {-bound, -bound};
+  kx[0] = -bound;
+  ky[0] = -bound;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    cum += v[j] * scale;  // knot_{j+1} = -B + 2B * sum_{i<=j} p_i
+    kx[j + 1] = cum.x;
+    ky[j + 1] = cum.y;
+  }
+}
+
+// Same two-axis packing with the MathTight operations (Newton-refined reciprocal, compensated exp2,
+// knot = fma(cum, 2B, -B)): used by the standalone fp32 kernels.
+template <int K, typename LdW, typename LdH>
+__device__ __forceinline__ void rqs_axes_knots_packed_tight(LdW ldw, LdH ldh, float bound, float ls, float (&kx)[K + 1], float (&ky)[K + 1]) {
+  f32x2_t v[K];
+  f32x2_t m;
+  const float twoinv = 2.f / ls;  // hoisted by the compiler (ls is uniform); |2 v / ls| up to one rounding of the reference's
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const f32x2_t u = {ldw(j), ldh(j)};
+    // inner quotient 2v/ls with one Newton correction, as MathTight::div
+    f32x2_t q = u * twoinv;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(f32x2_t{-ls, -ls}, q, u * 2.f), f32x2_t{0.5f * twoinv, 0.5f * twoinv}, q);
+    const f32x2_t den = f32x2_t{fabsf(q.x), fabsf(q.y)} + 1.f;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2_t o = u * r;
+    o = __builtin_elementwise_fma(__builtin_elementwise_fma(-den, o, u), r, o);
+    v[j] = o;
+    m = (j == 0) ? v[0] : f32x2_t{fmaxf(m.x, v[j].x), fmaxf(m.y, v[j].y)};
+  }
+  const float l2e = 1.44269504088896340736f, ln2 = 0.69314718055994530942f;
+  f32x2_t s = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const f32x2_t d = v[j] - m;
+    const f32x2_t hi = d * l2e;
+    const f32x2_t lo = __builtin_elementwise_fma(d, f32x2_t{l2e, l2e}, -hi);
+    const f32x2_t e = {__builtin_amdgcn_exp2f(hi.x), __builtin_amdgcn_exp2f(hi.y)};
+    v[j] = __builtin_elementwise_fma(e, lo * ln2, e);
+    s += v[j];
+  }
+  f32x2_t r = {__builtin_amdgcn_rcpf(s.x), __builtin_amdgcn_rcpf(s.y)};
+  r = __builtin_elementwise_fma(__builtin_elementwise_fma(-s, r, f32x2_t{1.f, 1.f}), r, r);  // 1/s, refined
+  f32x2_t cum = {0.f, 0.f};
+  kx[0] = -bound;
+  ky[0] = -bound;
+  const f32x2_t twoB = {2.f * bound, 2.f * bound}, negB = {-bound, -bound};
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    cum += v[j] * r;
+    const f32x2_t kn = __builtin_elementwise_fma(cum, twoB, negB);
+    kx[j + 1] = kn.x;
+    ky[j + 1] = kn.y;
+  }
+}
+
 // knot slopes: exp(softclip(d)) inside, 1 at both ends (transforms.py:482, 486, 490)
 template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __forceinline__ void rqs_slopes(Ld ld, T ls, T (&kd)[K + 1]) {
   kd[0] = T(1);
