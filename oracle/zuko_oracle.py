@@ -354,13 +354,28 @@ def ar_adjacency(features: int, context: int, total: int, order: Tensor | None =
     return torch.repeat_interleave(adj, repeats=total, dim=0), order, passes
 
 
-def mlp_forward(x: Tensor, weights, biases, masks=None, act=torch.relu) -> Tensor:
-    """Linear stack; with masks: F.linear(x, mask*W, b) per layer (nn.py:217-218), else dense (nn.py:13-15)."""
-    n = len(weights)
-    for i in range(n):
+def mlp_forward(x: Tensor, weights, biases, masks=None, act=torch.relu, plan=None) -> Tensor:
+    """Linear stack; with masks: F.linear(x, mask*W, b) per layer (nn.py:217-218), else dense (nn.py:13-15).
+
+    `plan` (residual=True networks, nn.py:297-309): a list of ("lin", i) / ("res", i, j) / ("act",) steps over
+    the flat parameter lists; "res" is x + lin_j(act(lin_i(x))) (nn.py:195-199)."""
+    def lin(i, v):
         W = weights[i] if masks is None else masks[i] * weights[i]
-        x = F.linear(x, W, biases[i])
-        if i + 1 < n:
+        return F.linear(v, W, biases[i])
+
+    if plan is None:
+        n = len(weights)
+        for i in range(n):
+            x = lin(i, x)
+            if i + 1 < n:
+                x = act(x)
+        return x
+    for step in plan:
+        if step[0] == "lin":
+            x = lin(step[1], x)
+        elif step[0] == "res":
+            x = x + lin(step[2], act(lin(step[1], x)))
+        else:
             x = act(x)
     return x
 
@@ -391,6 +406,9 @@ def univariate_forward(u: Univariate, phi: Tensor, x: Tensor):
         return affine_forward(p[0], p[1], x, u.slope)
     if u.kind == "rqs":
         return rqs_forward(p[0], p[1], p[2], x, u.bound, u.slope)
+    if u.kind == "crqs":  # flows/spline.py:65-72: circular shift, then RQS on [-pi, pi]
+        xs = torch.remainder(x, 2 * math.pi) - math.pi
+        return rqs_forward(p[0], p[1], p[2], xs, math.pi, u.slope)
     if u.kind == "sos":  # flows/polynomial.py:23-29: SOS then + constant
         y, l = sos_forward(p[0], x, u.slope)
         return y + p[1], l
@@ -405,6 +423,9 @@ def univariate_inverse(u: Univariate, phi: Tensor, y: Tensor) -> Tensor:
         return affine_inverse(p[0], p[1], y, u.slope)
     if u.kind == "rqs":
         return rqs_inverse(p[0], p[1], p[2], y, u.bound, u.slope)
+    if u.kind == "crqs":
+        xs = rqs_inverse(p[0], p[1], p[2], y, math.pi, u.slope)
+        return torch.remainder(xs, 2 * math.pi) - math.pi
     if u.kind == "sos":
         return sos_inverse(p[0], y - p[1], u.slope)
     if u.kind in ("bernstein", "bbernstein"):
@@ -422,6 +443,7 @@ class ARLayer:
     masks: list
     passes: int
     features: int
+    plan: list | None = None  # module sequence for residual conditioners
 
 
 @dataclass
@@ -444,7 +466,7 @@ class SoftclipLayer:
 def _ar_phi(layer: ARLayer, x: Tensor, c: Tensor | None) -> Tensor:
     """Conditioner call + unflatten. flows/autoregressive.py:207-213."""
     inp = x if c is None else torch.cat(bcast(x, c, ignore=1), dim=-1)
-    phi = mlp_forward(inp, layer.weights, layer.biases, layer.masks)
+    phi = mlp_forward(inp, layer.weights, layer.biases, layer.masks, plan=layer.plan)
     return phi.unflatten(-1, (-1, layer.uni.total))
 
 
@@ -521,14 +543,22 @@ def diag_normal_log_prob(z: Tensor, loc: Tensor, scale: Tensor) -> Tensor:
     return lp.sum(dim=-1)
 
 
+def box_uniform_log_prob(z: Tensor, lower: Tensor, upper: Tensor) -> Tensor:
+    """Independent(Uniform(lower, upper)).log_prob as torch/distributions/uniform.py computes it
+    (zuko/distributions.py:366-396): log(1[l <= z < u]) - log(u - l), summed over the last dim."""
+    inside = lower.le(z).type_as(lower) * upper.gt(z).type_as(lower)
+    return (torch.log(inside) - torch.log(upper - lower)).sum(dim=-1)
+
+
 @dataclass
 class FlowSpec:
-    """A composed flow with a diagonal-normal base (lazy.py:131-172, distributions.py:39-138)."""
+    """A composed flow with a diagonal-normal (or box-uniform, NCSF) base (lazy.py:131-172, distributions.py:39-138)."""
 
     layers: list
     loc: Tensor
     scale: Tensor
     meta: dict = field(default_factory=dict)
+    box: tuple | None = None  # (lower, upper) when the base is a BoxUniform
 
 
 def flow_forward(spec: FlowSpec, x: Tensor, c: Tensor | None = None):
@@ -543,6 +573,8 @@ def flow_forward(spec: FlowSpec, x: Tensor, c: Tensor | None = None):
 def flow_log_prob(spec: FlowSpec, x: Tensor, c: Tensor | None = None) -> Tensor:
     """base.log_prob(f(x)) + ladj.  distributions.py:115-119."""
     z, ladj = flow_forward(spec, x, c)
+    if spec.box is not None:
+        return box_uniform_log_prob(z, *spec.box) + ladj
     return diag_normal_log_prob(z, spec.loc, spec.scale) + ladj
 
 
@@ -565,6 +597,10 @@ def uni_rqs(bins: int = 8, slope: float = 1e-3) -> Univariate:
     return Univariate("rqs", ((bins,), (bins,), (bins - 1,)), slope=slope)
 
 
+def uni_crqs(bins: int = 8, slope: float = 1e-3) -> Univariate:
+    return Univariate("crqs", ((bins,), (bins,), (bins - 1,)), slope=slope)
+
+
 def uni_sos(degree: int = 4, polynomials: int = 3, slope: float = 1e-3) -> Univariate:
     return Univariate("sos", ((polynomials, degree + 1), ()), slope=slope)
 
@@ -578,15 +614,31 @@ def spec_from_state_dict(sd: dict, kind: str, uni: Univariate, features: int, pa
     idx = sorted({int(k.split(".")[2]) for k in sd if k.startswith("transform.transforms.") and ".hyper." in k})
     layers = []
     for n, i in enumerate(idx):
-        pre = f"transform.transforms.{i}."
-        lin = sorted({int(k[len(pre + "hyper.") :].split(".")[0]) for k in sd if k.startswith(pre + "hyper.")})
-        W = [sd[f"{pre}hyper.{j}.weight"] for j in lin]
-        b = [sd[f"{pre}hyper.{j}.bias"] for j in lin]
+        pre = f"transform.transforms.{i}.hyper."
+        mods = sorted({int(k[len(pre) :].split(".")[0]) for k in sd if k.startswith(pre)})
+        W, b, M, plan = [], [], [], []
+        residual = any(f"{pre}{j}.0.weight" in sd for j in mods)
+        prev = None
+        for j in mods:
+            if prev is not None and j - prev == 2:
+                plan.append(("act",))  # a parameter-free activation module sits between the two
+            prev = j
+            if f"{pre}{j}.weight" in sd:
+                names = [f"{pre}{j}"]
+                plan.append(("lin", len(W)))
+            else:
+                names = [f"{pre}{j}.0", f"{pre}{j}.2"]
+                plan.append(("res", len(W), len(W) + 1))
+            for nm in names:
+                W.append(sd[nm + ".weight"])
+                b.append(sd[nm + ".bias"])
+                M.append(sd.get(nm + ".mask"))
         if kind == "ar":
-            M = [sd[f"{pre}hyper.{j}.mask"] for j in lin]
-            layers.append(ARLayer(uni, W, b, M, passes if passes is not None else features, features))
+            layers.append(ARLayer(uni, W, b, M, passes if passes is not None else features, features, plan if residual else None))
         else:
-            layers.append(CouplingLayer(uni, W, b, sd[f"{pre}mask"]))
+            layers.append(CouplingLayer(uni, W, b, sd[f"transform.transforms.{i}.mask"]))
         if softclip is not None and n + 1 < len(idx):
             layers.append(SoftclipLayer(softclip))
-    return FlowSpec(layers, sd["base.loc"], sd["base.scale"])
+    if "base.loc" in sd:
+        return FlowSpec(layers, sd["base.loc"], sd["base.scale"])
+    return FlowSpec(layers, None, None, box=(sd["base.lower"], sd["base.upper"]))

@@ -56,6 +56,8 @@ def flow_registry():
         "nsf_p2": (F.NSF, dict(features=6, context=2, transforms=2, bins=4, passes=2, hidden_features=[32, 32]), 3, "ar", O.uni_rqs(4), dict(passes=2)),
         "nice_small": (F.NICE, dict(features=5, context=3, transforms=3, hidden_features=[32, 32]), 4, "coupling", O.UNI_AFFINE, {}),
         "sospf_small": (F.SOSPF, dict(features=4, context=2, transforms=2, hidden_features=[32, 32]), 5, "ar", O.uni_sos(), dict(softclip=11.0)),
+        "maf_res": (F.MAF, dict(features=5, context=2, transforms=2, hidden_features=[24, 32, 32], residual=True), 7, "ar", O.UNI_AFFINE, {}),
+        "ncsf_small": (F.NCSF, dict(features=3, context=2, transforms=2, hidden_features=[16, 16]), 8, "ar", O.uni_crqs(8), {}),
         "bpf_small": (F.BPF, dict(features=4, context=2, transforms=2, hidden_features=[32, 32]), 6, "ar", O.uni_bpf(), {}),
     }
 

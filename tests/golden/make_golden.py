@@ -224,6 +224,8 @@ FLOWS = {
     "nsf_p2": (zuko.flows.NSF, dict(features=6, context=2, transforms=2, bins=4, passes=2, hidden_features=[32, 32]), 3, 64, 2, "ar", O.uni_rqs(4), dict(passes=2)),
     "nice_small": (zuko.flows.NICE, dict(features=5, context=3, transforms=3, hidden_features=[32, 32]), 4, 64, 3, "coupling", O.UNI_AFFINE, {}),
     "sospf_small": (zuko.flows.SOSPF, dict(features=4, context=2, transforms=2, hidden_features=[32, 32]), 5, 64, 2, "ar", O.uni_sos(), dict(softclip=11.0)),
+    "maf_res": (zuko.flows.MAF, dict(features=5, context=2, transforms=2, hidden_features=[24, 32, 32], residual=True), 7, 64, 2, "ar", O.UNI_AFFINE, {}),
+    "ncsf_small": (zuko.flows.NCSF, dict(features=3, context=2, transforms=2, hidden_features=[16, 16]), 8, 64, 2, "ar", O.uni_crqs(8), {}),
     "bpf_small": (zuko.flows.BPF, dict(features=4, context=2, transforms=2, hidden_features=[32, 32]), 6, 64, 2, "ar", O.uni_bpf(), {}),
 }
 
@@ -235,6 +237,8 @@ def gen_flows() -> None:
         sd = {k: v for k, v in flow.state_dict().items() if v is not None}
         g = torch.Generator().manual_seed(1)
         x = torch.randn(batch, kw["features"], generator=g)
+        if name.startswith("ncsf"):
+            x = x.clamp(-3.0, 3.0)  # NCSF features live in [-pi, pi[
         c = torch.randn(batch, ctx, generator=g) if ctx else None
         with torch.no_grad():
             dist = flow(c)

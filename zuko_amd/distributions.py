@@ -9,12 +9,12 @@ from __future__ import annotations
 
 import torch
 from torch import Size, Tensor
-from torch.distributions import Distribution, Independent, Normal, Transform
+from torch.distributions import Distribution, Independent, Normal, Transform, Uniform
 from torch.distributions.utils import _sum_rightmost
 
 from . import ops
 
-__all__ = ["DiagNormal", "NormalizingFlow"]
+__all__ = ["BoxUniform", "DiagNormal", "NormalizingFlow"]
 
 # the reference switches argument validation off globally (zuko/distributions.py:35-36); NaNs propagate
 Distribution._validate_args = False
@@ -32,6 +32,20 @@ class DiagNormal(Independent):
 
     def expand(self, batch_shape: Size, new: Distribution | None = None) -> Distribution:
         new = self._get_checked_instance(DiagNormal, new)
+        return super().expand(batch_shape, new)
+
+
+class BoxUniform(Independent):
+    """Independent(Uniform(lower, upper), ndims): the base of NCSF.  Mirrors zuko/distributions.py:366-396."""
+
+    def __init__(self, lower: Tensor, upper: Tensor, ndims: int = 1) -> None:
+        super().__init__(Uniform(torch.as_tensor(lower), torch.as_tensor(upper)), ndims)
+
+    def __repr__(self) -> str:
+        return "Box" + repr(self.base_dist)
+
+    def expand(self, batch_shape: Size, new: Distribution | None = None) -> Distribution:
+        new = self._get_checked_instance(BoxUniform, new)
         return super().expand(batch_shape, new)
 
 

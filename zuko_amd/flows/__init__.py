@@ -5,11 +5,12 @@ from .autoregressive import MAF, MaskedAutoregressiveTransform
 from .coupling import NICE, GeneralCouplingTransform, RealNVP
 from .elementwise import ElementWiseTransform
 from .polynomial import BPF, SOSPF
-from .spline import NSF
+from .spline import NCSF, NSF
 
 __all__ = [
     "BPF",
     "MAF",
+    "NCSF",
     "NICE",
     "NSF",
     "SOSPF",

@@ -17,7 +17,7 @@ from torch import BoolTensor, Tensor
 
 from . import ops
 
-__all__ = ["MLP", "Linear", "MaskedLinear", "MaskedMLP"]
+__all__ = ["MLP", "Linear", "MaskedLinear", "MaskedMLP", "Residual"]
 
 
 def _act_code(module: nn.Module | None) -> int | None:
@@ -125,7 +125,14 @@ class MLP(_FusedSequential):
         self.out_features = out_features
 
 
-def masked_mlp_masks(adjacency: BoolTensor, hidden_features: Sequence[int]) -> list[BoolTensor]:
+class Residual(_FusedSequential):
+    """x + block(x).  Mirrors zuko/nn.py:195-199."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return x + super().forward(x)
+
+
+def masked_mlp_masks(adjacency: BoolTensor, hidden_features: Sequence[int], residual_masks: list | None = None) -> list[BoolTensor]:
     r"""Layer masks of a masked MLP whose Jacobian dy_i/dx_j vanishes where adjacency[i, j] is False.
 
     Follows zuko/nn.py:265-295: outputs with identical dependency sets are merged; a hidden unit is
@@ -147,12 +154,16 @@ def masked_mlp_masks(adjacency: BoolTensor, hidden_features: Sequence[int]) -> l
             masks.append(full[tags])
         else:
             masks.append(full[inverse])
+        if residual_masks is not None:
+            residual_masks.append(subset[tags, :][:, tags])  # unit -> unit precedence inside the layer
     return masks
 
 
 class MaskedMLP(_FusedSequential):
-    r"""Masked MLP (autoregressive conditioner).  Mirrors zuko/nn.py:221-318 for residual=False;
-    `residual=True` is SURVEY 8(f) rank 4 and not provided yet."""
+    r"""Masked MLP (autoregressive conditioner).  Mirrors zuko/nn.py:221-318, including the
+    `residual=True` variant (zuko/nn.py:297-309): every layer is followed by a masked residual block
+    x + W2 act(W1 x), square hidden-to-hidden layers are replaced by their block; the modules are
+    created (and their initialisation drawn) in the reference's order so seeds reproduce its weights."""
 
     def __init__(
         self,
@@ -161,16 +172,21 @@ class MaskedMLP(_FusedSequential):
         activation: Callable[[], nn.Module] | None = None,
         residual: bool = False,
     ) -> None:
-        if residual:
-            raise NotImplementedError("zuko_amd.nn.MaskedMLP: residual=True is not part of the hot path yet")
         activation = nn.ReLU if activation is None else activation
         out_features, in_features = adjacency.shape
-        masks = masked_mlp_masks(adjacency, hidden_features)
+        inner: list = []
+        masks = masked_mlp_masks(adjacency, hidden_features, inner if residual else None)
         layers: list[nn.Module] = []
+        n_hidden = len(hidden_features)
         for i, m in enumerate(masks):
             layers.append(MaskedLinear(adjacency=m))
-            if i + 1 < len(masks):
+            if residual:
+                if 0 < i < n_hidden and m.shape[0] == m.shape[1]:
+                    layers.pop()  # (its parameters were still drawn, as in the reference)
+                layers.append(Residual(MaskedLinear(adjacency=inner[i]), activation(), MaskedLinear(adjacency=inner[i])))
+            else:
                 layers.append(activation())
+        layers.pop()
         super().__init__(*layers)
         self.in_features = in_features
         self.out_features = out_features

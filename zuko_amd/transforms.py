@@ -30,6 +30,7 @@ __all__ = [
     "AutoregressiveTransform",
     "BernsteinTransform",
     "BoundedBernsteinTransform",
+    "CircularShiftTransform",
     "ComposedTransform",
     "CouplingTransform",
     "DependentTransform",
@@ -204,6 +205,31 @@ class SoftclipTransform(Transform):
 
     def log_abs_det_jacobian(self, x, y):
         return -2 * torch.log1p(abs(x / self.bound))
+
+
+class CircularShiftTransform(Transform):
+    r"""(x mod 2B) - B on [-B, B], zero log|det J|.  Mirrors zuko/transforms.py:319-351 (NCSF glue,
+    one device `remainder`)."""
+
+    bijective = True
+
+    def __init__(self, bound: float = 1.0, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.bound = bound
+        self.domain = constraints.interval(-bound, bound)
+        self.codomain = constraints.interval(-bound, bound)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(bound={self.bound})"
+
+    def _call(self, x):
+        return torch.remainder(x, 2 * self.bound) - self.bound
+
+    def _inverse(self, y):
+        return torch.remainder(y, 2 * self.bound) - self.bound
+
+    def log_abs_det_jacobian(self, x, y):
+        return torch.zeros_like(x)
 
 
 class AdditiveTransform(Transform):
