@@ -108,7 +108,9 @@ int zk_linear(int dtype, int64_t N, int in_features, int out_features, const voi
  * :436-446 affine) and the feature sum of zuko/transforms.py:210-214 — one launch, fp32,
  * v_mfma_f32_16x16x4_f32, activations register-resident, phi never written to HBM.
  *
- *   uni_kind  0 = MonotonicAffineTransform (total 2), 1 = MonotonicRQSTransform with 8 bins (total 23)
+ *   uni_kind  0 = MonotonicAffineTransform (total 2); 1 / 2 / 3 = MonotonicRQSTransform with 8 / 4 / 16 bins;
+ *             4 = circular 8-bin spline of NCSF (zuko/flows/spline.py:65-72, bound = pi).  Kinds 2-4 need
+ *             D % 4 == 0 and D <= 128 (LDS-staged x / y tiles).
  *   x         [N, DIN] row-major, row stride ldx (elements, multiple of 4), 16-byte aligned:
  *             cat(x, c) zero-padded to DIN % 4 == 0; the first D columns are the features
  *   y         [N, D] (row stride ldy); ladj [N] (may be NULL); accumulate != 0 adds to ladj

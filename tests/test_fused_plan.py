@@ -17,6 +17,8 @@ from oracle import zuko_oracle as O
         ("maf64", "affine", 2, 0, 64, 0, dict(hidden_features=[256] * 3)),
         ("maf10", "affine", 2, 0, 10, 3, dict(hidden_features=[40, 72])),
         ("nsf_p2", "rqs", 23, 8, 12, 0, dict(hidden_features=[64, 64], passes=2)),
+        ("nsf_k4", "rqs", 11, 4, 8, 2, dict(hidden_features=[48, 48], bins=4)),
+        ("nsf_k16", "rqs", 47, 16, 8, 0, dict(hidden_features=[64], bins=16)),
     ],
 )
 def test_plan_simulation_matches_masked_mlp(name, kind, total, bins, D, C, kw):
@@ -44,7 +46,9 @@ def test_unsupported_shapes_fall_back():
     from zuko_amd import fused
     from zuko_amd.flows import NSF
 
-    assert fused.uni_layout("rqs", 3 * 16 - 1, 16) is None
+    assert fused.uni_layout("rqs", 3 * 32 - 1, 32) is None
+    assert fused.uni_layout("rqs", 47, 16).nt == 12 and fused.uni_layout("rqs", 11, 4).nt == 3
+    assert not fused.layout_supports(fused.uni_layout("rqs", 11, 4), 6)  # 4-bin layout needs float4 rows
     t = NSF(8, 0, transforms=1, hidden_features=[512]).transform.transforms[0]
     assert fused.build_plan([m.mask for m in t.hyper if hasattr(m, "mask")], 8, fused.uni_layout("rqs", 23, 8)) is None
     assert t._fusable_layout() is not None

@@ -196,3 +196,33 @@ def test_sampling_paths(dev, name):
         rel_close(x, xo, "sample == oracle inverse of its own latent", 1e-4, 5e-4)
         xs, lp = dist.rsample_and_log_prob((33,) if c is None else ())
         rel_close(lp, O.flow_log_prob(spec, xs.cpu(), c), "rsample_and_log_prob", 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("kind,kw", [("nsf", dict(features=8, context=2, transforms=2, bins=4, hidden_features=[48, 48])),
+                                      ("nsf", dict(features=16, context=0, transforms=2, bins=16, hidden_features=[64, 64])),
+                                      ("ncsf", dict(features=8, context=3, transforms=2, hidden_features=[40, 40]))])
+def test_fused_extra_spline_layouts(dev, kind, kw):
+    """4-bin, 16-bin and circular (NCSF) spline epilogues of the fused kernel against the CPU oracle
+    (forward, ladj, inverse), with the fused path asserted to be the one that ran."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(9)
+    flow = (F.NSF if kind == "nsf" else F.NCSF)(**kw)
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items() if v is not None}
+    uni = O.uni_rqs(kw.get("bins", 8)) if kind == "nsf" else O.uni_crqs(8)
+    spec = O.spec_from_state_dict(sd, "ar", uni, kw["features"])
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(300, kw["features"], generator=gen).clamp(-3, 3)
+    c = torch.randn(300, kw["context"], generator=gen) if kw["context"] else None
+    flow = flow.to(dev)
+    cg = None if c is None else c.to(dev)
+    with torch.no_grad():
+        t = flow.transform.transforms[0](cg)
+        assert t._fused(x.to(dev)) is not None
+        z, ladj = flow(cg).transform.call_and_ladj(x.to(dev))
+        oz, ol = O.flow_forward(spec, x, c)
+        rel_close(z, oz, "z", 1e-5, 3e-5)
+        rel_close(ladj, ol, "ladj", 1e-5, 1e-4)
+        rel_close(flow(cg).log_prob(x.to(dev)), O.flow_log_prob(spec, x, c), "log_prob", 1e-5, 1e-4)
+        xr = flow(cg).transform.inv(oz.to(dev))
+        rel_close(xr, O.flow_inverse(spec, oz, c), "inverse", 1e-4, 5e-4)

@@ -120,27 +120,39 @@ struct UniAffine {
   }
 };
 
-struct UniRqs8 {
-  static constexpr int TOTAL = 23, FPL = 1, NT = 6;
-  template <typename P> static __device__ __forceinline__ void knots(const P& p, int base, float bound, float ls, float (&kx)[9], float (&ky)[9], float (&kd)[9]) {
-    rqs_axes_knots_packed<8>([&](int j) { return p(base + j); }, [&](int j) { return p(base + 8 + j); }, bound, ls, kx, ky);
-    rqs_slopes<float, 8, MathFast>([&](int j) { return p(base + 16 + j); }, ls, kd);
+// K-bin rational-quadratic spline; CIRC: preceded by the circular shift of NCSF (zuko/flows/spline.py:65-72,
+// zuko/transforms.py:344-348: x -> remainder(x, 2B) - B with B = pi passed as `bound`).
+template <int K, bool CIRC> struct UniRqs {
+  static constexpr int TOTAL = 3 * K - 1, FPL = 1, NT = (TOTAL + 3) / 4;
+  static __device__ __forceinline__ float shift(float v, float bound) {
+    const float period = 2.f * bound;
+    float r = fmodf(v, period);
+    r = (r < 0.f) ? r + period : r;  // torch.remainder: result takes the sign of the divisor
+    return r - bound;
+  }
+  template <typename P> static __device__ __forceinline__ void knots(const P& p, int base, float bound, float ls, float (&kx)[K + 1], float (&ky)[K + 1], float (&kd)[K + 1]) {
+    rqs_axes_knots_packed<K>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, bound, ls, kx, ky);
+    rqs_slopes<float, K, MathFast>([&](int j) { return p(base + 2 * K + j); }, ls, kd);
   }
   template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {
-    float kx[9], ky[9], kd[9];
+    float kx[K + 1], ky[K + 1], kd[K + 1];
     knots(p, base, bound, ls, kx, ky, kd);
     int k;
-    rqs_fwd<float, 8, MathFast>(kx, ky, kd, x, y, lj, k);
+    rqs_fwd<float, K, MathFast>(kx, ky, kd, CIRC ? shift(x, bound) : x, y, lj, k);
   }
   template <typename P> static __device__ __forceinline__ float inv(const P& p, int base, float bound, float ls, float y) {
-    float kx[9], ky[9], kd[9];
+    float kx[K + 1], ky[K + 1], kd[K + 1];
     knots(p, base, bound, ls, kx, ky, kd);
     int k;
     float x;
-    rqs_inv<float, 8, MathFast>(kx, ky, kd, y, x, k);
-    return x;
+    rqs_inv<float, K, MathFast>(kx, ky, kd, y, x, k);
+    return CIRC ? shift(x, bound) : x;
   }
 };
+typedef UniRqs<8, false> UniRqs8;
+typedef UniRqs<4, false> UniRqs4;
+typedef UniRqs<16, false> UniRqs16;
+typedef UniRqs<8, true> UniCircRqs8;
 
 extern __shared__ __attribute__((aligned(16))) float ar_lds[];
 
@@ -436,8 +448,14 @@ static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, cons
 #define ZK_AR_PICK(UNI)                                                                                                                     \
   (inverse ? (a.xlds ? (const void*)ar_kernel<UNI, true, Ring24x3, true> : (const void*)ar_kernel<UNI, true, Ring24x3, false>)            \
            : (a.xlds ? (const void*)ar_kernel<UNI, false, Ring24x3, true> : (const void*)ar_kernel<UNI, false, Ring24x3, false>))
+  // kinds 2-4 (4 / 16 bins, circular 8 bins) are built for the LDS-staged variant only
+#define ZK_AR_PICK_X(UNI) (inverse ? (const void*)ar_kernel<UNI, true, Ring24x3, true> : (const void*)ar_kernel<UNI, false, Ring24x3, true>)
   if (uni_kind == 0) fn = ZK_AR_PICK(UniAffine);
   else if (uni_kind == 1) fn = ZK_AR_PICK(UniRqs8);
+  else if (uni_kind >= 2 && uni_kind <= 4 && !a.xlds) return ZK_EINVAL;
+  else if (uni_kind == 2) fn = ZK_AR_PICK_X(UniRqs4);
+  else if (uni_kind == 3) fn = ZK_AR_PICK_X(UniRqs16);
+  else if (uni_kind == 4) fn = ZK_AR_PICK_X(UniCircRqs8);
   else return ZK_EINVAL;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;

@@ -9,6 +9,7 @@ univariate transform + feature-sum of log|det J| on the GPU.
 from __future__ import annotations
 
 from functools import partial
+import math
 from math import ceil, prod
 from typing import Callable, Sequence
 
@@ -149,11 +150,18 @@ class MaskedAutoregressiveTransform(LazyTransform):
         slope = kw.pop("slope", 1e-3)
         if f is MonotonicAffineTransform and shapes == [(), ()] and not kw:
             return fused.uni_layout("affine", 2), 5.0, slope
-        if f is MonotonicRQSTransform and len(shapes) == 3 and shapes[0] == shapes[1] and shapes[2] == (shapes[0][0] - 1,):
+        from .spline import CircularRQSTransform  # (spline.py imports this module)
+
+        spline_shapes = len(shapes) == 3 and len(shapes[0]) == 1 and shapes[0] == shapes[1] and shapes[2] == (shapes[0][0] - 1,)
+        if f is MonotonicRQSTransform and spline_shapes:
             bound = kw.pop("bound", 5.0)
             lay = fused.uni_layout("rqs", self.total, shapes[0][0])
-            if lay is not None and not kw:
+            if lay is not None and not kw and fused.layout_supports(lay, self.features):
                 return lay, bound, slope
+        if f is CircularRQSTransform and spline_shapes and not kw:
+            lay = fused.uni_layout("crqs", self.total, shapes[0][0])
+            if lay is not None and fused.layout_supports(lay, self.features):
+                return lay, math.pi, slope
         return None
 
     def fused_state(self, device: torch.device):

@@ -47,11 +47,20 @@ class UniLayout:
 
 
 def uni_layout(kind: str, total: int, bins: int = 0) -> UniLayout | None:
+    """C-ABI kind codes: 0 affine, 1 / 2 / 3 RQS with 8 / 4 / 16 bins, 4 circular RQS with 8 bins."""
     if kind == "affine" and total == 2:
         return UniLayout(0, 2, 2, 1)
-    if kind == "rqs" and bins == 8 and total == 23:
-        return UniLayout(1, 23, 1, 6, 8)
+    if kind == "rqs" and total == 3 * bins - 1 and bins in (8, 4, 16):
+        return UniLayout({8: 1, 4: 2, 16: 3}[bins], total, 1, (total + 3) // 4, bins)
+    if kind == "crqs" and bins == 8 and total == 23:
+        return UniLayout(4, 23, 1, 6, 8)
     return None
+
+
+def layout_supports(layout: UniLayout, features: int) -> bool:
+    """Kinds 2-4 are built only for the LDS-staged epilogue: rows of x must be float4-addressable and
+    the [128 x D] tile must fit beside the weight ring."""
+    return layout.kind in (0, 1) or (features % 4 == 0 and features <= 128)
 
 
 @dataclass
