@@ -133,6 +133,17 @@ int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_c
                         void* x_out, int64_t ldo, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
                         const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
                         int variant, void* stream);
+/* Partial inverse sweep (the "wavefront" form of AutoregressiveTransform._inverse, SURVEY 7 hard part 4):
+ * like zk_ar_inverse_sweep, but only the features of last-layer groups [g0, g1) are updated and only
+ * the prefix of the conditioner they depend on is evaluated.  The plan must be built with
+ * group-aligned chunks (zuko_amd/fused.py: build_plan(align_groups=True)); `sched` is a DEVICE array of
+ * n_sched stream-chunk ids in consumption order, `olim` a HOST array with, per hidden layer, the last
+ * out-group (of 4 tiles) to compute (fused.partial_schedule).  Running it for s = 0..passes-1 on the
+ * groups that hold the features of order s gives the same x as `passes` full sweeps. */
+int zk_ar_inverse_partial(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy,
+                          void* x_out, int64_t ldo, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
+                          const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
+                          const int32_t* sched, int n_sched, const int32_t* olim, int g0, int g1, int variant, void* stream);
 /* dynamic LDS bytes zk_ar_forward will request for `variant` and a bias image of `bias_floats` floats. */
 int zk_ar_lds_bytes(int variant, int bias_floats);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream

@@ -52,6 +52,10 @@ struct ArArgs {
   const uint32_t* skip;
   const int32_t* featmap;
   int L, NG, n_chunks, act, bias_floats, dbg;
+  const int* sched;  // optional chunk schedule (partial inverse sweeps): stream chunk ids in consumption order
+  int n_sched;
+  int olim[8];       // per hidden layer: last out-group (of 4 tiles) to evaluate; 3 = all
+  int g0, g1;        // last-layer groups [g0, g1) to evaluate
   int xlds;  // x (or y_in) and the result tile are staged in a wave-private LDS region (stride xs words)
   int xs;
   float bound, ls;
@@ -76,12 +80,14 @@ template <int CH, int NR> struct RingT {
   float* lds;
   const float* stream;
   int n_chunks, pos, slot, load_chunk, load_slot, wave, lane, dbg;
+  const int* sched;  // when set, load_chunk indexes this list (length n_chunks) instead of the stream
 
   __device__ __forceinline__ void issue() {
 #pragma unroll
     for (int i = 0; i < CH / AR_WAVES; ++i) {
       const int bi = i * AR_WAVES + wave;
-      const float* g = stream + ((size_t)load_chunk * CH + bi) * AR_TF + lane * 4;
+      const int chunk_id = sched ? sched[load_chunk] : load_chunk;
+      const float* g = stream + ((size_t)chunk_id * CH + bi) * AR_TF + lane * 4;
       float* l = lds + (load_slot * CH + bi) * AR_TF;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     }
@@ -157,10 +163,10 @@ typedef UniRqs<8, true> UniCircRqs8;
 extern __shared__ __attribute__((aligned(16))) float ar_lds[];
 
 // one masked layer with <= 256 inputs / outputs: out = W in, tiles skipped per (group of 4 out tiles, in tile)
-template <class Src> __device__ __forceinline__ void hidden_layer(Src& ring, const uint32_t* __restrict__ skip4, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T]) {
+template <class Src> __device__ __forceinline__ void hidden_layer(Src& ring, const uint32_t* __restrict__ skip4, int olim, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T]) {
 #pragma unroll
   for (int otg = 0; otg < 4; ++otg) {
-    const uint32_t bits = skip4[otg];
+    const uint32_t bits = otg <= olim ? skip4[otg] : 0u;  // partial sweeps evaluate a prefix of the out-groups
 #pragma unroll
     for (int t = 0; t < 4; ++t) out[otg * 4 + t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -196,7 +202,7 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
     ring.init(a.stream, lane, a.n_chunks);  // n_chunks == number of tile images (chunk size 1)
   } else {
     bias_lds = ar_lds + Src::kSlots * Src::kChunk * AR_TF;
-    ring.dbg = a.dbg; ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+    ring.dbg = a.dbg; ring.lds = ring_lds; ring.stream = a.stream; ring.sched = a.sched; ring.n_chunks = a.sched ? a.n_sched : a.n_chunks; ring.wave = wave; ring.lane = lane;
     ring.load_chunk = 0; ring.load_slot = 0;
 #pragma unroll
     for (int i = 0; i < Src::kSlots - 1; ++i) ring.issue();
@@ -269,7 +275,7 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
     const bool tprobe = ZK_AR_TIMING && (a.dbg & 8) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && (wave == 0 || wave == 4);
     if (ZK_AR_TIMING && (a.dbg & 8)) tstamp[0] = __builtin_amdgcn_s_memtime();
     for (int l = 0; l < a.L - 1; ++l) {
-      hidden_layer(ring, a.skip + l * 4, in, out);
+      hidden_layer(ring, a.skip + l * 4, a.olim[l < 8 ? l : 7], in, out);
       if (ZK_AR_TIMING && (a.dbg & 8)) tstamp[1 + (l < 3 ? l : 3)] = __builtin_amdgcn_s_memtime();
       const float* bl = bias_lds + l * 256 + 4 * q;
 #pragma unroll
@@ -297,8 +303,9 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
 
     // ---- last layer + univariate transform, one group of 4*FPL features at a time ----------------
     float lacc = 0.f;
-    for (int g = 0; g < a.NG; ++g) {
+    for (int g = a.g0; g < a.g1; ++g) {
       const uint32_t bits = skip_last[g];
+      if (a.sched) ring.end_layer();  // aligned plan: every group starts on a chunk boundary
       unsigned long long tg0 = 0, tg1 = 0;
       if (ZK_AR_TIMING && (a.dbg & 16)) tg0 = __builtin_amdgcn_s_memtime();
       // operands of the epilogue are requested BEFORE the group's MFMAs so their latency is hidden:
@@ -351,8 +358,8 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
           if (a.dbg & 1) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
           else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
           else Uni::fwd(ld, fi * TOTAL, a.bound, a.ls, xv, yv, lj);
-          if (XLDS) xr[f] = yv;
-          else if (live) a.y[n * a.ldy + f] = yv;
+          if (XLDS && !a.sched) xr[f] = yv;
+          else if (live) a.y[n * a.ldy + f] = yv;  // (partial sweeps touch a few features only: direct stores)
           lacc += lj;
         }
       }
@@ -362,7 +369,7 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
       }
     }
     ring.end_layer();
-    if (XLDS) {
+    if (XLDS && !a.sched) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -420,7 +427,14 @@ static int ar_base_lds_floats(int bias_floats) { return AR_CH * AR_NR * AR_TF + 
 int zk_ar_lds_bytes(int variant, int bias_floats) { return (ar_base_lds_floats(bias_floats) + 8 * 16 * 260) * (int)sizeof(float); }  // upper bound incl. x/y tiles
 
 // uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23); contract in include/zuko_amd.h.
-static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, const void* yin, int64_t ldyin, void* y, int64_t ldy,
+struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and the prefix of the network they depend on
+  const int* sched = nullptr;
+  int n_sched = 0;
+  const int* olim = nullptr;  // host array, one entry per hidden layer
+  int g0 = 0, g1 = -1;
+};
+
+static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, const void* yin, int64_t ldyin, void* y, int64_t ldy,
                      void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap,
                      int n_layers, int n_groups, int n_chunks, int act, double bound, double slope, int variant, void* stream) {
   if (N <= 0) return 0;
@@ -435,6 +449,13 @@ static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, cons
   a.L = n_layers; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
   a.bound = (float)bound; a.ls = (float)log(slope);
   a.n_tiles = (N + 127) / 128;
+  a.g0 = 0; a.g1 = n_groups;
+  for (int l = 0; l < 8; ++l) a.olim[l] = 3;
+  if (part.sched) {
+    if (part.n_sched < 2 || part.g0 < 0 || part.g1 > n_groups || part.g0 >= part.g1 || n_layers - 1 > 8) return ZK_EINVAL;
+    a.sched = part.sched; a.n_sched = part.n_sched; a.g0 = part.g0; a.g1 = part.g1;
+    for (int l = 0; l < n_layers - 1; ++l) a.olim[l] = part.olim[l];
+  }
   a.dbg = (variant >> 8) & 0xff;  // undocumented profiling switches (bit0: skip univariate math, bit3: phase timestamps)
   if ((variant & 0xff) != 0) return ZK_EINVAL;
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
@@ -468,7 +489,7 @@ static int ar_launch(bool inverse, int uni_kind, int64_t N, int D, int DIN, cons
 int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj, int accumulate, const void* wstream,
                   const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act,
                   double bound, double slope, int variant, void* stream) {
-  return ar_launch(false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
+  return ar_launch(ArPartial{}, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
                    n_chunks, act, bound, slope, variant, stream);
 }
 
@@ -477,7 +498,24 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
 int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy, void* x_out, int64_t ldo,
                         const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups,
                         int n_chunks, int act, double bound, double slope, int variant, void* stream) {
-  return ar_launch(true, uni_kind, N, D, DIN, x_cond, ldx, y, ldy, x_out, ldo, nullptr, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
+  return ar_launch(ArPartial{}, true, uni_kind, N, D, DIN, x_cond, ldx, y, ldy, x_out, ldo, nullptr, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
+                   n_chunks, act, bound, slope, variant, stream);
+}
+
+// Partial inverse sweep: as zk_ar_inverse_sweep, but only the features of last-layer groups [g0, g1)
+// are updated, and only the prefix of the conditioner they depend on is evaluated: `sched` (device,
+// n_sched chunk ids of a plan built with group-aligned chunks) lists the weight-stream chunks in
+// consumption order, `olim` (host, one int per hidden layer) the last out-group of 4 tiles to compute.
+// After sweep p of the reference loop only the features of order <= p are final and only they matter
+// to later sweeps, so running, for s = 0..passes-1, the partial sweep of the groups holding order s
+// yields the same x as `passes` full sweeps at a fraction of the work (hard part 4).
+int zk_ar_inverse_partial(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy, void* x_out, int64_t ldo,
+                          const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups,
+                          int n_chunks, int act, double bound, double slope, const int32_t* sched, int n_sched, const int32_t* olim, int g0, int g1,
+                          int variant, void* stream) {
+  ArPartial part;
+  part.sched = sched; part.n_sched = n_sched; part.olim = olim; part.g0 = g0; part.g1 = g1;
+  return ar_launch(part, true, uni_kind, N, D, DIN, x_cond, ldx, y, ldy, x_out, ldo, nullptr, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
                    n_chunks, act, bound, slope, variant, stream);
 }
 

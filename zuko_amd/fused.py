@@ -80,6 +80,10 @@ class ArPlan:
     n_blocks: int
     dense_tiles: int  # tile pairs a dense evaluation would touch (for reporting)
     kept_tiles: int
+    chunk: int = CHUNK
+    otg_blocks_end: list = None
+    group_chunk0: list = None  # (align_groups plans) first chunk / chunk count of every last-layer group
+    group_nchunks: list = None
 
 
 def _deps(masks: list[np.ndarray]) -> list[np.ndarray]:
@@ -93,9 +97,11 @@ def _deps(masks: list[np.ndarray]) -> list[np.ndarray]:
     return out
 
 
-def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int = CHUNK) -> ArPlan | None:
+def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int = CHUNK, align_groups: bool = False) -> ArPlan | None:
     """masks[l]: bool [out_l, in_l] of the conditioner's linear layers (last: features*total rows).
-    `chunk`: tiles per LDS-ring chunk each layer is padded to (1 = no padding, direct-feed variant)."""
+    `chunk`: tiles per LDS-ring chunk each layer is padded to.  `align_groups`: additionally start
+    every last-layer group on a chunk boundary and record per-group / per-out-group stream positions,
+    so that a sweep of the inverse can stream only the prefix of the network it needs."""
     M = [m.detach().cpu().numpy().astype(bool) for m in masks]
     L = len(M)
     if L < 2:
@@ -157,8 +163,12 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         layer_block0.append(block_cursor)
         block_cursor += len(blocks)
 
+    otg_blocks_end: list[list[int]] = []  # [layer][otg] blocks of the layer consumed once out-group otg is done
+    group_chunk0: list[int] = []
+    group_nchunks: list[int] = []
     in_cols = cols
     for l in range(L - 1):
+        otg_blocks_end.append([])
         rows_all = perms[l]
         n_ot = len(rows_all) // TILE
         n_it = len(in_cols) // TILE
@@ -182,6 +192,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
                             blocks.append(block_index(rr, cc, M[l].shape[1]))
                             kept_tiles += 1
             skip.append(bits)
+            otg_blocks_end[l].append(len(blocks))
         finish_layer(blocks)
         b = -np.ones(MAX_WIDTH, dtype=np.int64)
         b[: len(rows_all)] = rows_all
@@ -208,6 +219,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
             tiles_rows.append(rows)
             bias_last.append(rows)
         bits = 0
+        g_start = len(blocks)
         for it in range(n_it):
             cc = in_cols[it * TILE : (it + 1) * TILE]
             dense_tiles += layout.nt
@@ -217,6 +229,11 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
                     blocks.append(block_index(rows, cc, M[-1].shape[1]))
                     kept_tiles += 1
         skip.append(bits)
+        if align_groups:
+            n = len(blocks) - g_start
+            blocks += [-np.ones(256, dtype=np.int64)] * (-(-n // chunk) * chunk - n)
+            group_chunk0.append((block_cursor + g_start) // chunk)
+            group_nchunks.append((len(blocks) - g_start) // chunk)
     finish_layer(blocks)
     bias_gather.append(np.concatenate(bias_last).astype(np.int32))
     bias_off.append(bias_cursor)
@@ -237,7 +254,37 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         n_blocks=block_cursor,
         dense_tiles=dense_tiles,
         kept_tiles=kept_tiles,
+        chunk=chunk,
+        otg_blocks_end=otg_blocks_end,
+        group_chunk0=group_chunk0,
+        group_nchunks=group_nchunks,
     )
+
+
+def partial_schedule(plan: ArPlan, g_lo: int, g_hi: int):
+    """Chunk schedule + per-hidden-layer out-group limits for evaluating ONLY the last-layer groups
+    [g_lo, g_hi) (plan built with align_groups=True): walk the skip masks backwards to find which
+    hidden tiles those groups depend on, and keep the matching prefix of every layer's stream."""
+    L = plan.n_layers
+    need = 0
+    for g in range(g_lo, g_hi):
+        need |= int(plan.skip[(L - 1) * 4 + g])
+    olim = [0] * (L - 1)
+    for l in range(L - 2, -1, -1):
+        otgs = sorted({it // GROUP_HIDDEN for it in range(16) if need >> it & 1})
+        olim[l] = max(otgs) if otgs else -1
+        nxt = 0
+        for otg in range(olim[l] + 1):  # the stream is consumed as a prefix: every out-group up to the limit
+            nxt |= int(plan.skip[l * 4 + otg])
+        need = nxt
+    sched = []
+    for l in range(L - 1):
+        nblk = plan.otg_blocks_end[l][olim[l]] if olim[l] >= 0 else 0
+        c0 = plan.layer_block0[l] // plan.chunk
+        sched += list(range(c0, c0 + -(-nblk // plan.chunk)))
+    for g in range(g_lo, g_hi):
+        sched += list(range(plan.group_chunk0[g], plan.group_chunk0[g] + plan.group_nchunks[g]))
+    return sched, olim
 
 
 def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], masks: list[np.ndarray], inp: np.ndarray, act) -> np.ndarray:
@@ -394,3 +441,45 @@ class FusedAR:
             self.act, self.bound, self.slope, self.variant | (_debug_flags() << 8), _stream(),
         )
         _C.check(err, "zk_ar_inverse_sweep")
+
+    # ---- partial (wavefront) inverse ---------------------------------------------------------------
+
+    def set_sweeps(self, order: np.ndarray, passes: int) -> None:
+        """Pre-compute, for every sweep s of the inverse, the last-layer groups that hold the features of
+        order s and the chunk schedule / out-group limits of the network prefix they depend on
+        (plan must be group-aligned)."""
+        import ctypes
+
+        p = self.plan
+        per_group = 4 * p.layout.fpl
+        slot_order = np.where(p.featmap >= 0, order[np.maximum(p.featmap, 0)], -1)
+        self.sweeps = []
+        flat: list[int] = []
+        for s_ in range(passes):
+            slots = np.nonzero(slot_order == s_)[0]
+            if slots.size == 0:
+                self.sweeps.append(None)
+                continue
+            g0, g1 = int(slots.min() // per_group), int(slots.max() // per_group) + 1
+            sched, olim = partial_schedule(p, g0, g1)
+            self.sweeps.append((len(flat), len(sched), (ctypes.c_int * len(olim))(*olim), g0, g1))
+            flat += sched
+        self.sched_dev = torch.tensor(flat, dtype=torch.int32, device=self.device)
+
+    def run_inverse_partial(self, buf: Tensor, y: Tensor, sweep: int) -> None:
+        from . import _C
+        from .ops import _ptr, _stream
+        import ctypes
+
+        entry = self.sweeps[sweep]
+        if entry is None:
+            return
+        off, n_sched, olim, g0, g1 = entry
+        p = self.plan
+        sched_ptr = ctypes.c_void_p(self.sched_dev.data_ptr() + 4 * off)
+        err = _C.lib().zk_ar_inverse_partial(
+            p.layout.kind, buf.shape[0], p.features, buf.shape[1], _ptr(buf), buf.stride(0), _ptr(y), y.stride(0), _ptr(buf), buf.stride(0),
+            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
+            self.act, self.bound, self.slope, sched_ptr, n_sched, olim, g0, g1, self.variant | (_debug_flags() << 8), _stream(),
+        )
+        _C.check(err, "zk_ar_inverse_partial")
