@@ -179,7 +179,7 @@ def test_univariate_transforms(dev, batched):
 
     torch.manual_seed(4)
     b = (256,) if batched else ()
-    r = lambda *s: torch.randn(*s, device=dev)
+    r = lambda *s: torch.randn(s, device=dev)
     ts = [
         ZT.MonotonicAffineTransform(r(*b), r(*b)),
         ZT.MonotonicRQSTransform(r(*b, 8), r(*b, 8), r(*b, 7)),
