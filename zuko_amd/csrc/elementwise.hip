@@ -16,6 +16,8 @@
 //     matching DependentTransform(., 1) (zuko/transforms.py:210-214), or written un-reduced.
 // Parameters that are NOT packed (independent tensors, broadcast strides) take the `strided`
 // instantiation which reads them straight from global memory.
+#include <stdlib.h>
+
 #include "zk_univariate.h"
 
 namespace zk {
@@ -42,6 +44,7 @@ struct UniArgs {
   int bounded;
   int K;           // runtime bin count for the generic RQS path
   const void* extra;  // optional additive constant [N, D] strides in seg[2] (shifted SOS)
+  RqsLeanConst lc;    // fp32 spline constants (rqs_lean)
 };
 
 template <typename T> struct Ld {
@@ -57,15 +60,15 @@ template <typename T, int K, bool INV> struct RqsOp {
   template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
     typedef typename MathStd<T>::type M;
     T kx[K + 1], ky[K + 1], kd[K + 1];
-    if constexpr (sizeof(T) == 4) {
-      rqs_axes_knots_packed_tight<K>(ld[0], ld[1], (float)a.bound, (float)a.ls, kx, ky);
+    if constexpr (sizeof(T) == 4) {  // fp32: the same arithmetic as the stream kernel and the fused epilogue
+      rqs_lean<K, INV>(ld[0], ld[1], ld[2], a.lc, in, out, ladj, k);
     } else {
       rqs_axis_knots<T, K, M>(ld[0], T(a.bound), T(a.ls), kx);
       rqs_axis_knots<T, K, M>(ld[1], T(a.bound), T(a.ls), ky);
+      rqs_slopes<T, K, M>(ld[2], T(a.ls), kd);
+      if (INV) { rqs_inv<T, K, M>(kx, ky, kd, in, out, k); ladj = T(0); }
+      else rqs_fwd<T, K, M>(kx, ky, kd, in, out, ladj, k);
     }
-    rqs_slopes<T, K, M>(ld[2], T(a.ls), kd);
-    if (INV) { rqs_inv<T, K, M>(kx, ky, kd, in, out, k); ladj = T(0); }
-    else rqs_fwd<T, K, M>(kx, ky, kd, in, out, ladj, k);
   }
 };
 
@@ -432,6 +435,189 @@ static int launch_sos(UniArgs a, int P, int L1, double slope, const double* node
   return ZK_LAUNCH_CHECK();
 }
 
+// ---- the fp32 spline stream (K1 of SURVEY 2.1 at its benchmark shape) ---------------------------------
+// phi[N, D, 3K-1] packed and 16-byte aligned, N*D a multiple of 64 and D | 64 or 64 | D.  A wavefront walks
+// a contiguous run of 64-element tiles.  While tile t is evaluated out of the wave's private LDS image,
+// tile t+1's 64 x (3K-1) floats are already in flight as dwordx4 loads into registers (and its x values
+// with them); they are written to the LDS image once tile t's parameters have been read out.  No
+// workgroup barrier anywhere: a wave's LDS operations execute in order.  Arithmetic: rqs_lean.
+struct RqsStreamArgs {
+  const float* x;
+  const float* phi;
+  float* y;
+  float* ladj;       // null: none
+  int64_t tiles;     // N * D / 64
+  int64_t iters;     // tiles per wave (a multiple of D / 64 when D > 64)
+  int cs;            // >= 0: tiles are dealt to the waves in chunks of 2^cs consecutive tiles, round-robin; -1: one contiguous run per wave
+  int64_t N;
+  int D;
+  int reduced;
+  RqsLeanConst c;
+};
+
+// LM: 0 no ladj, 1 ladj[N, D], 2 ladj[N] with D == 64 (one row per tile), 3 ladj[N] for any other admissible D
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int K, bool INV, int LM> __global__ __launch_bounds__(256) void rqs_stream_kernel(RqsStreamArgs a) {
+  constexpr int TOTAL = 3 * K - 1;
+  constexpr int NV = (TOTAL + 3) / 4;          // dwordx4 loads per lane per tile (16 * TOTAL f32x4_t per tile)
+  constexpr int TILE_V = 16 * TOTAL;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* img = reinterpret_cast<float*>(zk_dyn_lds) + (size_t)wave * 64 * TOTAL;
+  f32x4_t* img4 = reinterpret_cast<f32x4_t*>(img);
+  const float* my = img + lane * TOTAL;
+  // k-th tile of this wave (increasing in k, so the first tile past the end terminates the wave)
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave, W = (int64_t)gridDim.x * 4;
+  const int cs = a.cs;
+  const int64_t cmask = cs >= 0 ? ((int64_t)1 << cs) - 1 : 0;
+  auto tile_of = [&](int64_t k) -> int64_t { return cs < 0 ? wid * a.iters + k : ((((k >> cs) * W + wid) << cs) | (k & cmask)); };
+  int64_t t = tile_of(0);
+  if (t >= a.tiles) return;
+  const f32x4_t* phi4 = reinterpret_cast<const f32x4_t*>(a.phi);
+
+  f32x4_t nxt[NV];
+  float xn;
+  // (the last dwordx4 round covers only part of the wave: out-of-range lanes re-read the tile's last vector)
+#define ZK_FETCH(t)                                                         \
+  {                                                                         \
+    const f32x4_t* src = phi4 + (t) * TILE_V;                                \
+    _Pragma("unroll") for (int r = 0; r < NV; ++r) {                        \
+      const int i = r * 64 + lane;                                          \
+      nxt[r] = src[((r + 1) * 64 <= TILE_V || i < TILE_V) ? i : TILE_V - 1]; \
+    }                                                                       \
+    xn = a.x[(t) * 64 + lane];                                              \
+  }
+#define ZK_STASH()                                                          \
+  {                                                                         \
+    _Pragma("unroll") for (int r = 0; r < NV; ++r) {                        \
+      const int i = r * 64 + lane;                                          \
+      if ((r + 1) * 64 <= TILE_V || i < TILE_V) img4[i] = nxt[r];           \
+    }                                                                       \
+  }
+  ZK_FETCH(t);
+  ZK_STASH();
+
+  const int D = a.D;
+  const int per_row = D >> 6;                       // tiles per row when D >= 64
+  float parked = 0.f, lacc = 0.f;
+  int row_left = per_row;                           // (a wave's run starts on a row boundary)
+  int slot = 0;                                     // LM == 2: parked row sums so far (rows t - slot .. t are consecutive)
+  for (int64_t k = 0; k < a.iters; ++k) {
+    const float xc = xn;
+    const int64_t tn = tile_of(k + 1);
+    const bool more = (k + 1 < a.iters) && (tn < a.tiles);   // wave-uniform
+    if (more) ZK_FETCH(tn);
+    float p[TOTAL];
+#pragma unroll
+    for (int j = 0; j < TOTAL; ++j) p[j] = my[j];
+    float out, lj;
+    rqs_lean<K, INV>([&](int j) { return p[j]; }, [&](int j) { return p[K + j]; }, [&](int j) { return p[2 * K + j]; }, a.c, xc, out, lj);
+    const int64_t e = t * 64 + lane;
+    a.y[e] = out;
+    if (LM == 1) {
+      a.ladj[e] = lj;
+    } else if (LM == 2) {  // DPP reduction; 64 row sums are parked in lanes and stored as one 256-byte line
+      const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_dpp_to_lane63(lj)), 63));
+      if (lane == slot) parked = tot;
+      if (slot == 63 || !more || tn != t + 1) {
+        if (lane <= slot) a.ladj[t - slot + lane] = parked;
+        slot = 0;
+      } else {
+        ++slot;
+      }
+    } else if (LM == 3) {
+      if (D < 64) {
+        const int sh = __builtin_ctz(D);            // D divides 64: a power of two
+        const float v = segment_sum<float>(lj, D, lane & (D - 1));
+        if ((lane & (D - 1)) == 0) a.ladj[e >> sh] = v;
+      } else {
+        lacc += lj;
+        if (--row_left == 0) {
+          const float v = wave_sum<float>(lacc);
+          if (lane == 0) a.ladj[(t + 1) / per_row - 1] = v;
+          lacc = 0.f;
+          row_left = per_row;
+        }
+      }
+    }
+    if (!more) break;
+    ZK_STASH();
+    t = tn;
+  }
+#undef ZK_FETCH
+#undef ZK_STASH
+}
+
+// Tiles are dealt to the waves round-robin in chunks of 2^cs consecutive tiles, so that at any moment the
+// resident waves sweep ONE compact window of phi (measured at N = 2^20, D = 64, K = 8: 5.6 TB/s against
+// 4.95 TB/s for one long run per wave).  Feature-reduced ladj wants 64 consecutive rows per wave (their
+// sums leave as one 256-byte store); the other modes are fastest with single tiles.
+// ZUKO_AMD_K1_CHUNK overrides cs (-1 = contiguous runs).
+static int zk_stream_chunk_shift(int lm) {
+  const char* e = getenv("ZUKO_AMD_K1_CHUNK");  // (read per call: the tests switch it)
+  return e ? atoi(e) : (lm == 2 ? 6 : 0);
+}
+
+template <int K, bool INV, int LM> static int launch_rqs_stream_k(RqsStreamArgs a, hipStream_t st) {
+  constexpr int TOTAL = 3 * K - 1;
+  const size_t lds = (size_t)4 * 64 * TOTAL * sizeof(float);
+  static int per_cu = 0;  // resident blocks per CU for this instantiation (device query, once)
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rqs_stream_kernel<K, INV, LM>, 256, lds) != hipSuccess || nb < 1) nb = 4;
+    per_cu = nb;
+  }
+  const int64_t per_row = a.D > 64 ? a.D / 64 : 1;
+  const int64_t waves_wanted = (a.tiles + per_row - 1) / per_row;     // a wave needs at least one whole row
+  int64_t blocks = (waves_wanted + 3) / 4;
+  const int64_t cap = (int64_t)256 * per_cu;
+  if (blocks > cap) blocks = cap;
+  const int64_t W = blocks * 4;
+  a.cs = (LM == 3) ? -1 : zk_stream_chunk_shift(LM);
+  while (a.cs > 0 && (a.tiles >> a.cs) < W) --a.cs;                   // small inputs: keep every wave busy
+  if (a.cs >= 0) {
+    const int64_t chunks = (a.tiles + ((int64_t)1 << a.cs) - 1) >> a.cs;
+    a.iters = ((chunks + W - 1) / W) << a.cs;
+  } else {
+    int64_t iters = (a.tiles + W - 1) / W;
+    a.iters = (iters + per_row - 1) / per_row * per_row;
+  }
+  hipLaunchKernelGGL((rqs_stream_kernel<K, INV, LM>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  return ZK_LAUNCH_CHECK();
+}
+template <int K> static int launch_rqs_stream_fwd(const RqsStreamArgs& a, hipStream_t st) {
+  if (!a.ladj) return launch_rqs_stream_k<K, false, 0>(a, st);
+  if (!a.reduced) return launch_rqs_stream_k<K, false, 1>(a, st);
+  return a.D == 64 ? launch_rqs_stream_k<K, false, 2>(a, st) : launch_rqs_stream_k<K, false, 3>(a, st);
+}
+
+// returns -1 when the call does not have the stream kernel's shape (caller falls back to uni_kernel)
+template <bool INV> static int try_rqs_stream(const UniArgs& u, int K, hipStream_t st) {
+  if (K != 4 && K != 8 && K != 16) return -1;
+  if (u.kout || u.N <= 0 || u.D <= 0) return -1;
+  const int64_t D = u.D, E = u.N * D;
+  if (E % 64 != 0 || !((D <= 64 && 64 % D == 0) || D % 64 == 0)) return -1;
+  const int lens[3] = {K, K, K - 1};
+  if (!is_packed(u, lens, 3, sizeof(float))) return -1;
+  if (((uintptr_t)u.seg[0].p & 15) != 0) return -1;
+  RqsStreamArgs a;
+  a.x = (const float*)u.x; a.phi = (const float*)u.seg[0].p; a.y = (float*)u.y; a.ladj = (float*)u.ladj;
+  a.tiles = E / 64; a.iters = 0; a.N = u.N; a.D = (int)D; a.reduced = u.reduced;
+  a.c = u.lc;
+  if (INV) {
+    switch (K) {
+      case 4: return launch_rqs_stream_k<4, true, 0>(a, st);
+      case 8: return launch_rqs_stream_k<8, true, 0>(a, st);
+      default: return launch_rqs_stream_k<16, true, 0>(a, st);
+    }
+  }
+  switch (K) {
+    case 4: return launch_rqs_stream_fwd<4>(a, st);
+    case 8: return launch_rqs_stream_fwd<8>(a, st);
+    default: return launch_rqs_stream_fwd<16>(a, st);
+  }
+}
+
 // ---- base density: Independent(Normal(loc, scale), 1).log_prob(z) + ladj --------------------------
 // (zuko/distributions.py:115-119, 337-363; torch/distributions/normal.py log_prob)
 template <typename T> __global__ __launch_bounds__(256) void normal_kernel(int64_t N, int64_t D, const T* z, const T* loc, const T* scale, const T* ladj, T* out, int64_t iters) {
@@ -496,6 +682,12 @@ static UniArgs base_args(int64_t N, int64_t D, const void* x, void* y, void* lad
 #define ZK_DISPATCH(dtype, CALL_F32, CALL_F64) \
   ((dtype) == ZK_DTYPE_F32 ? (CALL_F32) : ((dtype) == ZK_DTYPE_F64 ? (CALL_F64) : ZK_EINVAL))
 
+// ZUKO_AMD_NO_STREAM=1 routes every call through the general uni_kernel (A/B measurements, tests of both paths)
+static bool zk_no_stream() {
+  const char* e = getenv("ZUKO_AMD_NO_STREAM");  // (read per call: the tests switch it)
+  return e && e[0] == '1';
+}
+
 extern "C" {
 
 int zk_rqs_forward(int dtype, int64_t N, int64_t D, int K, double bound, double slope, const void* x, const void* widths, int64_t w_sN, int64_t w_sD,
@@ -503,7 +695,11 @@ int zk_rqs_forward(int dtype, int64_t N, int64_t D, int K, double bound, double 
                    int32_t* bin_out, void* stream) {
   UniArgs a = base_args(N, D, x, y, ladj, ladj_reduced, bin_out);
   a.seg[0] = {widths, w_sN, w_sD}; a.seg[1] = {heights, h_sN, h_sD}; a.seg[2] = {derivs, d_sN, d_sD};
-  a.bound = bound; a.ls = log(slope);
+  a.bound = bound; a.ls = log(slope); a.lc = rqs_lean_const(bound, a.ls);
+  if (dtype == ZK_DTYPE_F32 && !zk_no_stream()) {
+    const int rc = try_rqs_stream<false>(a, K, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   return ZK_DISPATCH(dtype, (launch_rqs<float, false>(a, K, (hipStream_t)stream)), (launch_rqs<double, false>(a, K, (hipStream_t)stream)));
 }
 
@@ -511,7 +707,11 @@ int zk_rqs_inverse(int dtype, int64_t N, int64_t D, int K, double bound, double 
                    const void* heights, int64_t h_sN, int64_t h_sD, const void* derivs, int64_t d_sN, int64_t d_sD, void* x, int32_t* bin_out, void* stream) {
   UniArgs a = base_args(N, D, y, x, nullptr, 0, bin_out);
   a.seg[0] = {widths, w_sN, w_sD}; a.seg[1] = {heights, h_sN, h_sD}; a.seg[2] = {derivs, d_sN, d_sD};
-  a.bound = bound; a.ls = log(slope);
+  a.bound = bound; a.ls = log(slope); a.lc = rqs_lean_const(bound, a.ls);
+  if (dtype == ZK_DTYPE_F32 && !zk_no_stream()) {
+    const int rc = try_rqs_stream<true>(a, K, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   return ZK_DISPATCH(dtype, (launch_rqs<float, true>(a, K, (hipStream_t)stream)), (launch_rqs<double, true>(a, K, (hipStream_t)stream)));
 }
 

@@ -59,6 +59,7 @@ struct ArArgs {
   int xlds;  // x (or y_in) and the result tile are staged in a wave-private LDS region (stride xs words)
   int xs;
   float bound, ls;
+  RqsLeanConst lc;   // spline epilogues: constants of rqs_lean
   int64_t n_tiles;
 };
 
@@ -118,11 +119,11 @@ template <int CH, int NR> struct RingT {
 // ---- univariate epilogues -------------------------------------------------------------------------
 struct UniAffine {
   static constexpr int TOTAL = 2, FPL = 2, NT = 1;
-  template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {
-    affine_fwd<float, MathFast>(p(base + 0), p(base + 1), ls, x, y, lj);
+  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj) {
+    affine_fwd<float, MathFast>(p(base + 0), p(base + 1), a.ls, x, y, lj);
   }
-  template <typename P> static __device__ __forceinline__ float inv(const P& p, int base, float bound, float ls, float y) {
-    return affine_inv<float, MathFast>(p(base + 0), p(base + 1), ls, y);
+  template <typename P, typename A> static __device__ __forceinline__ float inv(const P& p, int base, const A& a, float y) {
+    return affine_inv<float, MathFast>(p(base + 0), p(base + 1), a.ls, y);
   }
 };
 
@@ -136,23 +137,14 @@ template <int K, bool CIRC> struct UniRqs {
     r = (r < 0.f) ? r + period : r;  // torch.remainder: result takes the sign of the divisor
     return r - bound;
   }
-  template <typename P> static __device__ __forceinline__ void knots(const P& p, int base, float bound, float ls, float (&kx)[K + 1], float (&ky)[K + 1], float (&kd)[K + 1]) {
-    rqs_axes_knots_packed<K>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, bound, ls, kx, ky);
-    rqs_slopes<float, K, MathFast>([&](int j) { return p(base + 2 * K + j); }, ls, kd);
+  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj) {
+    rqs_lean<K, false>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, [&](int j) { return p(base + 2 * K + j); }, a.lc,
+                       CIRC ? shift(x, a.bound) : x, y, lj);
   }
-  template <typename P> static __device__ __forceinline__ void fwd(const P& p, int base, float bound, float ls, float x, float& y, float& lj) {
-    float kx[K + 1], ky[K + 1], kd[K + 1];
-    knots(p, base, bound, ls, kx, ky, kd);
-    int k;
-    rqs_fwd<float, K, MathFast>(kx, ky, kd, CIRC ? shift(x, bound) : x, y, lj, k);
-  }
-  template <typename P> static __device__ __forceinline__ float inv(const P& p, int base, float bound, float ls, float y) {
-    float kx[K + 1], ky[K + 1], kd[K + 1];
-    knots(p, base, bound, ls, kx, ky, kd);
-    int k;
-    float x;
-    rqs_inv<float, K, MathFast>(kx, ky, kd, y, x, k);
-    return CIRC ? shift(x, bound) : x;
+  template <typename P, typename A> static __device__ __forceinline__ float inv(const P& p, int base, const A& a, float y) {
+    float x, lj;
+    rqs_lean<K, true>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, [&](int j) { return p(base + 2 * K + j); }, a.lc, y, x, lj);
+    return CIRC ? shift(x, a.bound) : x;
   }
 };
 typedef UniRqs<8, false> UniRqs8;
@@ -356,8 +348,8 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
           const float xv = xin[fi];
           float yv, lj;
           if (a.dbg & 1) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
-          else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a.bound, a.ls, xv); lj = 0.f; }
-          else Uni::fwd(ld, fi * TOTAL, a.bound, a.ls, xv, yv, lj);
+          else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a, xv); lj = 0.f; }
+          else Uni::fwd(ld, fi * TOTAL, a, xv, yv, lj);
           if (XLDS && !a.sched) xr[f] = yv;
           else if (live) a.y[n * a.ldy + f] = yv;  // (partial sweeps touch a few features only: direct stores)
           lacc += lj;
@@ -448,6 +440,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   a.stream = (const float*)wstream; a.bias = (const float*)bias; a.skip = skip; a.featmap = featmap;
   a.L = n_layers; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
   a.bound = (float)bound; a.ls = (float)log(slope);
+  a.lc = rqs_lean_const(bound, log(slope));
   a.n_tiles = (N + 127) / 128;
   a.g0 = 0; a.g1 = n_groups;
   for (int l = 0; l < 8; ++l) a.olim[l] = 3;

@@ -5,9 +5,10 @@
 // kernel in fused_ar.hip) decide where the parameters come from (LDS-staged packed phi,
 // strided global memory, or MFMA accumulators).
 //
-// Operation ORDER follows the reference expression trees so that results track the
-// PyTorch-CPU path to the last few ulps (translation units including this header are built
-// with -ffp-contract=off; expf/logf are the accurate ocml versions, never __expf/__logf):
+// The fp64 paths (and fp32 affine / SOS / Bernstein) follow the ORDER of the reference expression
+// trees so that results track the PyTorch-CPU path to the last few ulps (translation units including
+// this header are built with -ffp-contract=off); the fp32 spline has one hardware-shaped
+// implementation, rqs_lean, shared by every kernel that evaluates it:
 //   RQS        zuko/transforms.py:469-567     affine  zuko/transforms.py:412-446
 //   SOS        zuko/transforms.py:927-963 + zuko/utils.py:349-363 (Gauss-Legendre), :170-180 (bisection)
 //   Bernstein  zuko/transforms.py:640-831
@@ -18,11 +19,10 @@
 namespace zk {
 
 // ---------------------------------------------------------------------------------------------
-// math policies.  MathIEEE: correctly rounded division, ocml expf/logf (<= 1 ulp) — used by the
-// standalone kernels, whose parameters are bit-identical to the reference's.  MathFast (fp32):
-// v_rcp/v_exp/v_log based (a few ulp) — used inside the fused conditioner kernel, where the
-// parameters already carry ~1e-6 relative GEMM summation-order noise and the ~1000-instruction
-// IEEE epilogue would otherwise idle the matrix pipe (profiles/r01: 4.4 VALU instructions per MFMA).
+// math policies.  MathIEEE: correctly rounded division, ocml exp/log (<= 1 ulp) — the fp64 kernels and
+// the generic-K fp32 spline.  MathFast (fp32): v_rcp/v_exp/v_log based (a few ulp) — the affine
+// epilogue of the fused conditioner kernel, whose parameters already carry ~1e-6 relative GEMM
+// summation-order noise.
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct MathIEEE {
   static __device__ __forceinline__ T div(T a, T b) { return a / b; }
@@ -35,8 +35,7 @@ template <typename T> struct MathIEEE {
 // MathTight (fp32): within ~1.5 ulp of MathIEEE at a third of the instruction count — division by
 // v_rcp_f32 + one Newton step on the quotient (correctly rounded except in rare ties; operands here
 // are far from the exponent extremes v_div_scale/v_div_fixup exist for), exp by v_exp_f32 on a
-// compensated x*log2(e) product.  Used by the standalone fp32 kernels: their ~1000-instruction
-// IEEE epilogue made them VALU-bound (34 % of HBM peak, profiles/r01); log stays ocml (one per element).
+// compensated x*log2(e) product.  Used by the standalone fp32 affine kernel; log stays ocml.
 struct MathTight {
   // a/b for FINITE operands (NaN propagates; an infinite operand yields NaN instead of inf/0 — every
   // use in the spline/softclip math is one where the reference itself produces NaN for such inputs)
@@ -124,90 +123,7 @@ template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __fo
   }
 }
 
-// Both axes at once on 2-wide vectors (fast-math policy only): the width and height pipelines are
-// identical, so every multiply / add / fma of the softclip, softmax and cumulative sum is issued once
-// as a packed v_pk_*_f32 instruction instead of twice; v_rcp / v_exp remain per component.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-template <int K, typename LdW, typename LdH>
-__device__ __forceinline__ void rqs_axes_knots_packed(LdW ldw, LdH ldh, float bound, float ls, float (&kx)[K + 1], float (&ky)[K + 1]) {
-  const float inv_c = 2.f * __builtin_amdgcn_rcpf(fabsf(ls));  // |2 v / ls| = |v| * inv_c
-  f32x2_t v[K];
-  f32x2_t m;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const f32x2_t u = {ldw(j), ldh(j)};
-    const f32x2_t a = {fabsf(u.x), fabsf(u.y)};
-    const f32x2_t den = a * inv_c + 1.f;
-    const f32x2_t r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-    v[j] = u * r;
-    m = (j == 0) ? v[0] : f32x2_t{fmaxf(m.x, v[j].x), fmaxf(m.y, v[j].y)};
-  }
-  const float l2e = 1.44269504088896340736f;
-  f32x2_t s = {0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const f32x2_t t = (v[j] - m) * l2e;
-    v[j] = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-    s += v[j];
-  }
-  const f32x2_t r = {__builtin_amdgcn_rcpf(s.x), __builtin_amdgcn_rcpf(s.y)};
-  const f32x2_t scale = r * (2.f * bound);
-  f32x2_t cum = {-bound, -bound};
-  kx[0] = -bound;
-  ky[0] = -bound;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    cum += v[j] * scale;  // knot_{j+1} = -B + 2B * sum_{i<=j} p_i
-    kx[j + 1] = cum.x;
-    ky[j + 1] = cum.y;
-  }
-}
-
-// Same two-axis packing with the MathTight operations (Newton-refined reciprocal, compensated exp2,
-// knot = fma(cum, 2B, -B)): used by the standalone fp32 kernels.
-template <int K, typename LdW, typename LdH>
-__device__ __forceinline__ void rqs_axes_knots_packed_tight(LdW ldw, LdH ldh, float bound, float ls, float (&kx)[K + 1], float (&ky)[K + 1]) {
-  f32x2_t v[K];
-  f32x2_t m;
-  const float twoinv = 2.f / ls;  // hoisted by the compiler (ls is uniform); |2 v / ls| up to one rounding of the reference's
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const f32x2_t u = {ldw(j), ldh(j)};
-    // inner quotient 2v/ls with one Newton correction, as MathTight::div
-    f32x2_t q = u * twoinv;
-    q = __builtin_elementwise_fma(__builtin_elementwise_fma(f32x2_t{-ls, -ls}, q, u * 2.f), f32x2_t{0.5f * twoinv, 0.5f * twoinv}, q);
-    const f32x2_t den = f32x2_t{fabsf(q.x), fabsf(q.y)} + 1.f;
-    const f32x2_t r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-    f32x2_t o = u * r;
-    o = __builtin_elementwise_fma(__builtin_elementwise_fma(-den, o, u), r, o);
-    v[j] = o;
-    m = (j == 0) ? v[0] : f32x2_t{fmaxf(m.x, v[j].x), fmaxf(m.y, v[j].y)};
-  }
-  const float l2e = 1.44269504088896340736f, ln2 = 0.69314718055994530942f;
-  f32x2_t s = {0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const f32x2_t d = v[j] - m;
-    const f32x2_t hi = d * l2e;
-    const f32x2_t lo = __builtin_elementwise_fma(d, f32x2_t{l2e, l2e}, -hi);
-    const f32x2_t e = {__builtin_amdgcn_exp2f(hi.x), __builtin_amdgcn_exp2f(hi.y)};
-    v[j] = __builtin_elementwise_fma(e, lo * ln2, e);
-    s += v[j];
-  }
-  f32x2_t r = {__builtin_amdgcn_rcpf(s.x), __builtin_amdgcn_rcpf(s.y)};
-  r = __builtin_elementwise_fma(__builtin_elementwise_fma(-s, r, f32x2_t{1.f, 1.f}), r, r);  // 1/s, refined
-  f32x2_t cum = {0.f, 0.f};
-  kx[0] = -bound;
-  ky[0] = -bound;
-  const f32x2_t twoB = {2.f * bound, 2.f * bound}, negB = {-bound, -bound};
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    cum += v[j] * r;
-    const f32x2_t kn = __builtin_elementwise_fma(cum, twoB, negB);
-    kx[j + 1] = kn.x;
-    ky[j + 1] = kn.y;
-  }
-}
 
 // knot slopes: exp(softclip(d)) inside, 1 at both ends (transforms.py:482, 486, 490)
 template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __forceinline__ void rqs_slopes(Ld ld, T ls, T (&kd)[K + 1]) {
@@ -307,6 +223,139 @@ __device__ __forceinline__ void rqs_inv(const T (&kx)[K + 1], const T (&ky)[K + 
   T z = M::div(T(2) * c, (-b) - t_sqrt(b * b - (T(4) * a) * c));
   T xx = x0 + z * (x1 - x0);
   x = inside ? xx : y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lean fp32 evaluation straight from the unconstrained parameters (fast-math policy).  Same map as
+// rqs_axis_knots + rqs_slopes + rqs_fwd / rqs_inv, organised around what the VALU has to issue:
+//   * softclip and the softmax exponent are one chain  e_j = 2^(u_j * r_j),  r_j = 1 / ((1 + |u_j| c) / log2 e),
+//     i.e. fma, v_rcp, (packed) mul, v_exp per value; no max-subtraction — the clipped exponent is
+//     confined to (-|ln slope|/2, |ln slope|/2) = (-3.45, 3.45), so nothing can overflow;
+//   * both axes ride the two halves of v_pk_{mul,add,fma}_f32;
+//   * the bin is found by bisection over the K+1 knots, each level halving the candidate knots of
+//     the search axis, of the other axis and of the (zero-padded, still unconstrained) derivative
+//     parameters with the same compare: 3 (K/2+1 + K/4+1 + ... + 2) v_cndmask instead of 6 (K-1);
+//     for increasing knots the selected bin is exactly #(knots < v) - 1 (transforms.py:521-526);
+//   * only the two selected derivative parameters are soft-clipped and exponentiated (the padded
+//     zeros give exp(0) = 1 at both ends, transforms.py:486, 490).
+// ---------------------------------------------------------------------------------------------
+struct RqsLeanConst {
+  float bound;
+  float c2l;   // (2 / |ln slope|) / log2(e)
+  float c1l;   // (1 / |ln slope|) / log2(e)
+  float il2e;  // 1 / log2(e) = ln 2
+};
+static inline RqsLeanConst rqs_lean_const(double bound, double ls) {
+  const double ln2 = 0.69314718055994530942, a = ls < 0 ? -ls : ls;
+  RqsLeanConst c;
+  c.bound = (float)bound; c.c2l = (float)(2.0 / a * ln2); c.c1l = (float)(1.0 / a * ln2); c.il2e = (float)ln2;
+  return c;
+}
+
+// one bisection level over M+1 candidates (M a power of two >= 2); returns the index of the selected bin
+template <int M> struct RqsBisect {
+  static __device__ __forceinline__ int run(float v, float (&ks)[M + 1], float (&ko)[M + 1], float (&kr)[M + 1], float& s0, float& s1, float& o0, float& o1,
+                                            float& r0, float& r1) {
+    const bool c = ks[M / 2] < v;
+    float ns[M / 2 + 1], no[M / 2 + 1], nr[M / 2 + 1];
+#pragma unroll
+    for (int i = 0; i <= M / 2; ++i) {
+      ns[i] = c ? ks[M / 2 + i] : ks[i];
+      no[i] = c ? ko[M / 2 + i] : ko[i];
+      nr[i] = c ? kr[M / 2 + i] : kr[i];
+    }
+    return (c ? M / 2 : 0) + RqsBisect<M / 2>::run(v, ns, no, nr, s0, s1, o0, o1, r0, r1);
+  }
+};
+template <> struct RqsBisect<1> {
+  static __device__ __forceinline__ int run(float, float (&ks)[2], float (&ko)[2], float (&kr)[2], float& s0, float& s1, float& o0, float& o1, float& r0,
+                                            float& r1) {
+    s0 = ks[0]; s1 = ks[1]; o0 = ko[0]; o1 = ko[1]; r0 = kr[0]; r1 = kr[1];
+    return 0;
+  }
+};
+
+template <int K, bool INV, typename LdW, typename LdH, typename LdD>
+__device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLeanConst& c, float v, float& out, float& ladj, int& k) {
+  static_assert((K & (K - 1)) == 0 && K >= 2, "bisection needs a power-of-two bin count");
+  float kx[K + 1], ky[K + 1], kr[K + 1];
+  f32x2_t acc = {0.f, 0.f};
+  f32x2_t cum[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const f32x2_t u = {ldw(j), ldh(j)};
+    const f32x2_t r = {__builtin_amdgcn_rcpf(fmaf(fabsf(u.x), c.c2l, c.il2e)), __builtin_amdgcn_rcpf(fmaf(fabsf(u.y), c.c2l, c.il2e))};
+    const f32x2_t t = u * r;
+    acc += f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    cum[j] = acc;
+  }
+  const f32x2_t scale = f32x2_t{__builtin_amdgcn_rcpf(acc.x), __builtin_amdgcn_rcpf(acc.y)} * (2.f * c.bound);
+  const f32x2_t negB = {-c.bound, -c.bound};
+  kx[0] = -c.bound; ky[0] = -c.bound;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const f32x2_t kn = __builtin_elementwise_fma(cum[j], scale, negB);
+    kx[j + 1] = kn.x; ky[j + 1] = kn.y;
+  }
+  kr[0] = 0.f; kr[K] = 0.f;
+#pragma unroll
+  for (int j = 1; j < K; ++j) kr[j] = ldd(j - 1);
+
+  float x0, x1, y0, y1, r0, r1;
+  bool inside, above;
+  int bin;
+  if (INV) {
+    above = ky[K] < v;
+    inside = (ky[0] < v) && !above;
+    bin = RqsBisect<K>::run(v, ky, kx, kr, y0, y1, x0, x1, r0, r1);
+  } else {
+    above = kx[K] < v;
+    inside = (kx[0] < v) && !above;
+    bin = RqsBisect<K>::run(v, kx, ky, kr, x0, x1, y0, y1, r0, r1);
+  }
+  k = inside ? bin : (above ? K : -1);  // #(knots < v) - 1, NaN -> -1 (dropped by the compiler where unused)
+  const f32x2_t rr = {r0, r1};
+  const f32x2_t td = rr * f32x2_t{__builtin_amdgcn_rcpf(fmaf(fabsf(r0), c.c1l, c.il2e)), __builtin_amdgcn_rcpf(fmaf(fabsf(r1), c.c1l, c.il2e))};
+  const float d0 = __builtin_amdgcn_exp2f(td.x), d1 = __builtin_amdgcn_exp2f(td.y);
+
+  const float m = inside ? 1.f : 0.f;
+  const float dx = x1 - x0, dy = y1 - y0;
+  const float rdx = __builtin_amdgcn_rcpf(dx);
+  float s = dy * rdx;
+  if (INV) s = fmaf(fmaf(-dx, s, dy), rdx, s);  // the inverse amplifies errors of s by 1 / slope: one Newton step
+  const float t = (d0 + d1) - 2.f * s;
+  if (INV) {
+    const float y_ = m * (v - y0);
+    const float yt = y_ * t;
+    const float qa = fmaf(dy, s - d0, yt);
+    const float qb = fmaf(dy, d0, -yt);
+    const float qc = -s * y_;
+    const float disc = fmaf(qb, qb, -4.f * qa * qc);
+    const float qd = -qb - __builtin_amdgcn_sqrtf(disc);
+    const float rq = __builtin_amdgcn_rcpf(qd);
+    float z = (2.f * qc) * rq;
+    z = fmaf(fmaf(-qd, z, 2.f * qc), rq, z);
+    out = inside ? fmaf(z, dx, x0) : v;
+    ladj = 0.f;
+  } else {
+    const float z = (m * (v - x0)) * rdx;
+    const float omz = 1.f - z;
+    const float zz = z * omz;
+    const float den = fmaf(t, zz, s);
+    const float rden = __builtin_amdgcn_rcpf(den);
+    const float num = fmaf(s * z, z, d0 * zz);
+    const float yy = fmaf(dy * num, rden, y0);
+    const float jn = fmaf(d1 * z, z, fmaf(d0 * omz, omz, (2.f * s) * zz));
+    const float sr = s * rden;
+    const float jac = (sr * sr) * jn;
+    out = inside ? yy : v;
+    ladj = m * (__builtin_amdgcn_logf(jac) * c.il2e);
+  }
+}
+template <int K, bool INV, typename LdW, typename LdH, typename LdD>
+__device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLeanConst& c, float v, float& out, float& ladj) {
+  int k;
+  rqs_lean<K, INV>(ldw, ldh, ldd, c, v, out, ladj, k);
 }
 
 // ---------------------------------------------------------------------------------------------
