@@ -208,11 +208,14 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
   // way out.  Keeps the per-group operand fetch on the LDS (lgkmcnt) queue — a global load there would
   // have to be waited for with vmcnt(0), i.e. behind the ring DMAs in flight (measured: 5 k cycles per
   // group) — and turns 4-byte scattered result stores into coalesced 16-byte row stores.
-  float* xr = reinterpret_cast<float*>(fmap_lds + 1024) + wave * 16 * a.xs + j * a.xs;
+  // skip words of the last layer's groups: read per group, so they must not come through a vector-memory
+  // load (its s_waitcnt vmcnt(0) would also drain the ring DMAs in flight) — LDS copy, lgkmcnt queue
+  int* skip_lds = fmap_lds + 1024;
+  float* xr = reinterpret_cast<float*>(fmap_lds + 1024 + 256) + wave * 16 * a.xs + j * a.xs;
   for (int i = tid; i < a.NG * 4 * FPL; i += 512) fmap_lds[i] = a.featmap[i];
+  for (int i = tid; i < a.NG; i += 512) skip_lds[i] = (int)a.skip[(a.L - 1) * 4 + i];
   __syncthreads();
 
-  const uint32_t* skip_last = a.skip + (a.L - 1) * 4;
   const float* bias_last = bias_lds + (a.L - 1) * 256;
 
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -296,7 +299,7 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
     // ---- last layer + univariate transform, one group of 4*FPL features at a time ----------------
     float lacc = 0.f;
     for (int g = a.g0; g < a.g1; ++g) {
-      const uint32_t bits = skip_last[g];
+      const uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane(skip_lds[g]);
       if (a.sched) ring.end_layer();  // aligned plan: every group starts on a chunk boundary
       unsigned long long tg0 = 0, tg1 = 0;
       if (ZK_AR_TIMING && (a.dbg & 16)) tg0 = __builtin_amdgcn_s_memtime();
@@ -415,7 +418,7 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
 #define AR_NR 3
 #endif
 typedef RingT<AR_CH, AR_NR> Ring24x3;  // 3 x 24 KiB; 2 x 48 and 3 x 48 tiles measured within +-1 %
-static int ar_base_lds_floats(int bias_floats) { return AR_CH * AR_NR * AR_TF + bias_floats + 1024; }  // ring + bias + feature map
+static int ar_base_lds_floats(int bias_floats) { return AR_CH * AR_NR * AR_TF + bias_floats + 1024 + 256; }  // ring + bias + feature map + skip words
 int zk_ar_lds_bytes(int variant, int bias_floats) { return (ar_base_lds_floats(bias_floats) + 8 * 16 * 260) * (int)sizeof(float); }  // upper bound incl. x/y tiles
 
 // uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23); contract in include/zuko_amd.h.
@@ -430,7 +433,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
                      void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap,
                      int n_layers, int n_groups, int n_chunks, int act, double bound, double slope, int variant, void* stream) {
   if (N <= 0) return 0;
-  if (n_groups * 8 > 1024) return ZK_EINVAL;
+  if (n_groups * 8 > 1024 || n_groups > 256) return ZK_EINVAL;
   if (n_layers < 2 || DIN > 256 || DIN < D || DIN % 4 || ldx % 4 || ((uintptr_t)x % 16) || n_chunks < 1) return ZK_EINVAL;
   ArArgs a{};
   a.N = N; a.D = D; a.DIN = DIN;
