@@ -33,6 +33,7 @@ FLOP_PER_SAMPLE_TRANSFORM = 2 * (64 * 256 + 256 * 256 * 2 + 256 * 1472)
 NNZ_FLOP_PER_SAMPLE_TRANSFORM = 2 * 265784  # mask-aware (non-zero weights only), reported alongside
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA, same guide
 RQS_BYTES_PER_SAMPLE_TRANSFORM = 64 * (4 + 92 + 4) + 4  # x + phi + y per element, + ladj
 
 
@@ -44,9 +45,10 @@ def parse():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = the headline NSF workload (default, the only graded line); cfg3 = MAF(64,T=8,H=256x3); "
-                         "cfg4 = RealNVP(256,T=16,H=512x3) — side measurements quoted in DESIGN.md")
+                         "cfg4 = RealNVP(256,T=16,H=512x3); cfg5 = NSF(1024,T=12,K=16,H=1024x3) in bf16 (use --batch-log2 19) — "
+                         "side measurements quoted in DESIGN.md")
     return ap.parse_args()
 
 
@@ -132,16 +134,26 @@ def main() -> None:
         make = lambda: RealNVP(256, 0, transforms=16, hidden_features=[512] * 3)
         FEATURES, TRANSFORMS = 256, 16
         FLOP_PER_SAMPLE_TRANSFORM, workload = 2 * (128 * 512 + 2 * 512 * 512 + 512 * 256), "RealNVP(features=256, transforms=16, hidden=[512]*3) log_prob"
+    elif args.config == "cfg5":
+        make = lambda: NSF(1024, 0, transforms=12, bins=16, hidden_features=[1024] * 3)
+        FEATURES, TRANSFORMS = 1024, 12
+        FLOP_PER_SAMPLE_TRANSFORM, workload = 2 * (3 * 1024 * 1024 + 1024 * 48128), "NSF(features=1024, transforms=12, bins=16, hidden=[1024]*3) bf16 log_prob"
     else:
         make = lambda: NSF(FEATURES, 0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
         workload = "NSF(features=64, context=0, transforms=8, bins=8, hidden=[256]*3) log_prob"
     torch.manual_seed(0)
+    bf16 = args.config == "cfg5"
     flow_cpu = make()
-    flow = make()
-    flow.load_state_dict(flow_cpu.state_dict())
-    flow = flow.to(dev)
+    if bf16:  # 629 M parameters: no second copy
+        flow, flow_cpu = flow_cpu.to(dev).to(torch.bfloat16), None
+    else:
+        flow = make()
+        flow.load_state_dict(flow_cpu.state_dict())
+        flow = flow.to(dev)
     B = 1 << args.batch_log2
     x = torch.randn(B, FEATURES, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    if bf16:
+        x = x.to(torch.bfloat16)
 
     def step(collective: bool = True):
         with torch.no_grad():
@@ -184,10 +196,11 @@ def main() -> None:
         for name, recs in prof.items():
             groups = {}
             for a, b, cargs in recs:
-                key = (name,) + tuple(v for v in cargs[1:4] if isinstance(v, int))
+                sizes = cargs[0:3] if name == "zk_linear_bf16" else cargs[1:4]  # (dtype-less signature)
+                key = (name,) + tuple(v for v in sizes if isinstance(v, int))
                 groups.setdefault(key, []).append(a.elapsed_time(b))
             for key, ts in groups.items():
-                kernels[" ".join(map(str, key))] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts)}
+                kernels[" ".join(map(str, key))] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), **({"bf16": True} if bf16 else {})}
         # the standalone (phi-in-HBM) spline kernel is not on the fused path: time it on its own so its
         # HBM fraction (the bandwidth-bound roofline of north_star) is measured in the same run
         try:
@@ -223,7 +236,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{workload}, batch=2^{args.batch_log2} per GPU, x~N(0,1), seed-0 init",
@@ -235,7 +248,7 @@ def main() -> None:
             "end_to_end": {
                 "flop_per_sample": FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS,
                 "achieved_tflops_dense_equiv": value / world * FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12,
-                "frac_of_f32_mfma_peak": value / world * FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "frac_of_mfma_peak": value / world * FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS),
                 "mask_aware_tflops": value / world * NNZ_FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12,
             },
             "kernels": extra,
@@ -270,7 +283,10 @@ def zuko_amd_roofline(kernels: dict, B: int):
     for name, rec in kernels.items():
         row = {"kernel": name, **rec}
         parts = name.split()
-        if parts[0] == "zk_linear":
+        if parts[0] == "zk_linear_bf16":
+            n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
+            row.update(bound="mfma", achieved=2.0 * n * fin * fout / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s")
+        elif parts[0] == "zk_linear":
             n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
             flops = 2.0 * n * fin * fout
             row.update(bound="mfma", achieved=flops / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
@@ -278,7 +294,9 @@ def zuko_amd_roofline(kernels: dict, B: int):
             flops = float(B) * FLOP_PER_SAMPLE_TRANSFORM
             row.update(bound="mfma", achieved=flops / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
         elif parts[0] == "zk_rqs_forward":
-            byts = float(B) * RQS_BYTES_PER_SAMPLE_TRANSFORM
+            n, d, k = int(parts[1]), int(parts[2]), int(parts[3])
+            esz = 2 if rec.get("bf16") else 4
+            byts = float(n) * (d * (esz + esz * (3 * k - 1) + esz) + 4)  # x + phi + y per element, + ladj per row
             row.update(bound="hbm", achieved=byts / (rec["avg_ms"] * 1e-3) / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
         if "achieved" in row:
             row["frac"] = row["achieved"] / row["peak"]

@@ -35,6 +35,8 @@ extern "C" {
 
 #define ZK_DTYPE_F32 0
 #define ZK_DTYPE_F64 1
+#define ZK_DTYPE_BF16 2 /* zk_rqs_forward / zk_rqs_inverse only: bf16 x / phi / y in HBM, fp32 arithmetic, fp32 ladj;
+                           packed 16-byte aligned phi, N*D % 64 == 0, D | 64 or 64 | D, K in {4, 8, 16} */
 
 /* activations of zk_linear / zk_ar_* (zuko/nn.py:168-169: ReLU is the default) */
 #define ZK_ACT_NONE 0
@@ -100,6 +102,15 @@ int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, do
  * optional, y [N, out] with row stride ldy.  fp32 runs on v_mfma_f32_32x32x2_f32. */
 int zk_linear(int dtype, int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight,
               const uint8_t* mask, const void* bias, int act, void* y, int64_t ldy, void* stream);
+
+/* bf16 conditioner layer (cfg5 of BASELINE.json: NSF(1024, K=16, H=[1024]^3) in bf16).  Same contract as
+ * zk_linear (zuko/nn.py:217-218 + the following activation) with bf16 x / weight / bias / y and fp32
+ * accumulation on v_mfma_f32_32x32x16_bf16.  `weight` is the ALREADY MASKED matrix (mask * W, one pass
+ * over the parameters); `tile_live` is null or one byte per [256 outputs x 64 inputs] weight tile, row-major
+ * over (ceil(out/256), in/64): 0 = the tile is entirely zero and is skipped.  Requires in_features % 64 == 0,
+ * ldx % 8 == 0 and 16-byte aligned x / weight; returns hipErrorInvalidValue otherwise. */
+int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight, const uint8_t* tile_live,
+                   const void* bias, int act, void* y, int64_t ldy, void* stream);
 
 /* ---- fused masked-autoregressive layer (the dominant kernel of NSF / MAF log_prob) ----------------- *
  * Replaces, for one MaskedAutoregressiveTransform (zuko/flows/autoregressive.py:207-218 `meta` +

@@ -226,3 +226,105 @@ def test_fused_extra_spline_layouts(dev, kind, kw):
         rel_close(flow(cg).log_prob(x.to(dev)), O.flow_log_prob(spec, x, c), "log_prob", 1e-5, 1e-4)
         xr = flow(cg).transform.inv(oz.to(dev))
         rel_close(xr, O.flow_inverse(spec, oz, c), "inverse", 1e-4, 5e-4)
+
+
+# ---- bf16 storage path (cfg5 of BASELINE.json) ---------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,IN,OUT,act,use_live", [(512, 128, 512, 1, False), (300, 64, 705, 0, False), (1024, 256, 1024, 1, True), (37, 192, 47, 2, True)])
+def test_linear_bf16_matches_float_reference(dev, N, IN, OUT, act, use_live):
+    """zk_linear_bf16 (bf16 in / out, fp32 accumulation) against the same product in float32 on the bf16
+    values: the only differences are the summation order and one final rounding to bf16."""
+    from zuko_amd import ops
+
+    g = torch.Generator().manual_seed(N + IN + OUT)
+    x = torch.randn(N, IN, generator=g).to(torch.bfloat16)
+    w = (torch.randn(OUT, IN, generator=g) / IN**0.5).to(torch.bfloat16)
+    b = torch.randn(OUT, generator=g).to(torch.bfloat16)
+    live = None
+    if use_live:  # zero whole 256 x 64 tiles and tell the kernel
+        rows, cols = -(-OUT // 256), IN // 64
+        live = torch.rand(rows, cols, generator=g) < 0.6
+        live[:, 0] = True
+        keep = live.repeat_interleave(256, 0)[:OUT].repeat_interleave(64, 1)
+        w = w * keep
+    ref = x.float() @ w.float().t() + b.float()
+    ref = {0: ref, 1: ref.relu(), 2: torch.nn.functional.elu(ref)}[act]
+    with torch.no_grad():
+        y = ops.linear_bf16(x.to(dev), w.to(dev), b.to(dev), None if live is None else live.to(torch.uint8).to(dev), act)
+    assert y.dtype == torch.bfloat16 and y.shape == (N, OUT)
+    err = (y.float().cpu() - ref).abs()
+    tol = 2.0**-8 * ref.abs() + 1e-2  # one bf16 rounding of the result + accumulation-order noise
+    assert (err <= tol).all(), f"max excess {(err - tol).max():.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,K", [(2048, 64, 16), (96, 128, 16), (512, 64, 8), (64, 1024, 16)])
+def test_rqs_bf16_storage_equals_fp32_kernel(dev, N, D, K):
+    """bf16 x / phi / y with fp32 arithmetic: exactly the fp32 kernel applied to the (exactly representable)
+    bf16 values, y rounded once to bf16; ladj is fp32 and bit-identical."""
+    from zuko_amd import ops
+
+    g = torch.Generator().manual_seed(N + D + K)
+    phi = (torch.randn(N, D, 3 * K - 1, generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    x = (torch.randn(N, D, generator=g) * 2.0).to(torch.bfloat16).to(dev)
+    w, h, d = phi[..., :K], phi[..., K : 2 * K], phi[..., 2 * K :]
+    pf = phi.float()
+    wf, hf, df = pf[..., :K], pf[..., K : 2 * K], pf[..., 2 * K :]
+    with torch.no_grad():
+        y, l = ops.rqs_forward(x, w, h, d)
+        y2, lr = ops.rqs_forward(x, w, h, d, reduce=True)
+        yf, lf = ops.rqs_forward(x.float(), wf, hf, df)
+        _, lrf = ops.rqs_forward(x.float(), wf, hf, df, reduce=True)
+        xi = ops.rqs_inverse(y, w, h, d)
+        xif = ops.rqs_inverse(y.float(), wf, hf, df)
+    assert y.dtype == torch.bfloat16 and l.dtype == torch.float32 and lr.dtype == torch.float32
+    assert torch.equal(y, yf.to(torch.bfloat16)) and torch.equal(y2, y)
+    assert torch.equal(l, lf)
+    assert torch.allclose(lr, lrf, rtol=0, atol=2e-6 * D)
+    assert torch.equal(xi, xif.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_nsf_bf16_log_prob(dev):
+    """NSF in bf16 (weights, activations, phi, x, y in bf16; accumulation, spline and ladj in fp32) against
+    (a) a float32 emulation of the same pipeline on the CPU (bf16 rounding after every layer and transform)
+    and (b) the fp32 oracle on the bf16-rounded weights."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(5)
+    D, K, T = 64, 16, 3
+    flow = F.NSF(D, 0, transforms=T, bins=K, hidden_features=[128, 128])
+    flow_b = F.NSF(D, 0, transforms=T, bins=K, hidden_features=[128, 128])
+    flow_b.load_state_dict(flow.state_dict())
+    flow_b = flow_b.to(dev).to(torch.bfloat16)
+    x = (torch.randn(512, D) * 0.9).to(torch.bfloat16)
+    with torch.no_grad():
+        lp = flow_b().log_prob(x.to(dev))
+    assert lp.shape == (512,) and lp.dtype == torch.float32 and torch.isfinite(lp).all()
+    plans = [t.hyper._bf16_plan() for t in flow_b.transform.transforms]
+    assert all(p is not None for p in plans)  # the bf16 plan (not a per-layer fallback) ran
+
+    # (a) float32 emulation with bf16 rounding at the same places
+    r = lambda t: t.to(torch.bfloat16).float()
+    z, ladj = x.float(), torch.zeros(512)
+    for t in flow.transform.transforms:
+        lins = [m for m in t.hyper if hasattr(m, "mask")]
+        hcur = z
+        for i, l in enumerate(lins):
+            hcur = hcur @ r(r(l.weight.detach()) * l.mask).t() + r(l.bias.detach())
+            hcur = r(hcur.relu() if i + 1 < len(lins) else hcur)
+        phi = hcur.unflatten(-1, (D, 3 * K - 1))
+        y64, l64, _ = O.rqs_forward_from_knots(*O.rqs_knots(phi[..., :K].double(), phi[..., K : 2 * K].double(), phi[..., 2 * K :].double()), z.double())
+        z, ladj = r(y64.float()), ladj + l64.sum(-1).float()
+    emu = (-0.5 * z.double() ** 2 - 0.5 * np.log(2 * np.pi)).sum(-1).float() + ladj
+    d = (lp.cpu() - emu).abs()
+    assert d.max() < 0.5 and d.mean() < 0.05, f"vs bf16 emulation: max {d.max():.3f} mean {d.mean():.3f}"
+
+    # (b) the fp32 oracle on the same (bf16-valued) weights: bf16-level agreement
+    flow32 = F.NSF(D, 0, transforms=T, bins=K, hidden_features=[128, 128])
+    flow32.load_state_dict({k: (r(v) if v.is_floating_point() else v) for k, v in flow.state_dict().items()})
+    with torch.no_grad():
+        lp32 = flow32.to(dev)().log_prob(x.float().to(dev)).cpu()
+    rel = ((lp.cpu() - lp32).abs() / lp32.abs().clamp_min(1.0))
+    assert rel.max() < 0.05 and rel.mean() < 0.01, f"vs fp32: max rel {rel.max():.3f} mean {rel.mean():.4f}"

@@ -33,6 +33,7 @@ SIGNATURES = {
     "zk_bernstein_forward": [I, L, L, I, I, F, P, P, L, L, P, P, I, P],
     "zk_bernstein_inverse": [I, L, L, I, I, F, I, P, P, L, L, P, P],
     "zk_linear": [I, L, I, I, P, L, P, P, P, I, P, L, P],
+    "zk_linear_bf16": [L, I, I, P, L, P, P, P, I, P, L, P],
     "zk_diag_normal_log_prob": [I, L, L, P, P, P, P, P, P],
     "zk_sum_f64": [I, L, P, F, P, P, P],
     "zk_gather_f32": [P, P, P, L, P, P],

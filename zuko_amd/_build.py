@@ -26,6 +26,7 @@ ARCH = "gfx950"
 SOURCES = {
     "elementwise.hip": ["-ffp-contract=off"],
     "linear.hip": [],
+    "linear_bf16.hip": [],
     "fused_ar.hip": ["-ffp-contract=off"],
     "backward.hip": [],
 }

@@ -442,9 +442,9 @@ static int launch_sos(UniArgs a, int P, int L1, double slope, const double* node
 // with them); they are written to the LDS image once tile t's parameters have been read out.  No
 // workgroup barrier anywhere: a wave's LDS operations execute in order.  Arithmetic: rqs_lean.
 struct RqsStreamArgs {
-  const float* x;
-  const float* phi;
-  float* y;
+  const void* x;     // float, or __bf16 in the BF instantiations (ladj stays float)
+  const void* phi;
+  void* y;
   float* ladj;       // null: none
   int64_t tiles;     // N * D / 64
   int64_t iters;     // tiles per wave (a multiple of D / 64 when D > 64)
@@ -455,12 +455,14 @@ struct RqsStreamArgs {
   RqsLeanConst c;
 };
 
-// LM: 0 no ladj, 1 ladj[N, D], 2 ladj[N] with D == 64 (one row per tile), 3 ladj[N] for any other admissible D
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <int K, bool INV, int LM> __global__ __launch_bounds__(256) void rqs_stream_kernel(RqsStreamArgs a) {
+typedef uint32_t uint32x4_t __attribute__((ext_vector_type(4)));
+// LM: 0 no ladj, 1 ladj[N, D], 2 ladj[N] with D == 64 (one row per tile), 3 ladj[N] for any other admissible D
+// BF: x, phi and y are bf16 in HBM (cfg5); the LDS image, the arithmetic and ladj stay fp32
+template <int K, bool INV, int LM, bool BF> __global__ __launch_bounds__(256) void rqs_stream_kernel(RqsStreamArgs a) {
   constexpr int TOTAL = 3 * K - 1;
-  constexpr int NV = (TOTAL + 3) / 4;          // dwordx4 loads per lane per tile (16 * TOTAL f32x4_t per tile)
-  constexpr int TILE_V = 16 * TOTAL;
+  constexpr int TILE_V = (BF ? 8 : 16) * TOTAL;  // 16-byte vectors per tile
+  constexpr int NV = (TILE_V + 63) / 64;         // dwordx4 loads per lane per tile
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float* img = reinterpret_cast<float*>(zk_dyn_lds) + (size_t)wave * 64 * TOTAL;
@@ -485,13 +487,23 @@ template <int K, bool INV, int LM> __global__ __launch_bounds__(256) void rqs_st
       const int i = r * 64 + lane;                                          \
       nxt[r] = src[((r + 1) * 64 <= TILE_V || i < TILE_V) ? i : TILE_V - 1]; \
     }                                                                       \
-    xn = a.x[(t) * 64 + lane];                                              \
+    xn = BF ? (float)((const __bf16*)a.x)[(t) * 64 + lane] : ((const float*)a.x)[(t) * 64 + lane]; \
   }
 #define ZK_STASH()                                                          \
   {                                                                         \
     _Pragma("unroll") for (int r = 0; r < NV; ++r) {                        \
       const int i = r * 64 + lane;                                          \
-      if ((r + 1) * 64 <= TILE_V || i < TILE_V) img4[i] = nxt[r];           \
+      if ((r + 1) * 64 <= TILE_V || i < TILE_V) {                           \
+        if (BF) {  /* 8 bf16 -> 8 floats: a bf16 is the high half of its float */ \
+          const uint32x4_t u = __builtin_bit_cast(uint32x4_t, nxt[r]);      \
+          const uint32x4_t lo = {u.x << 16, u.x & 0xffff0000u, u.y << 16, u.y & 0xffff0000u}; \
+          const uint32x4_t hi = {u.z << 16, u.z & 0xffff0000u, u.w << 16, u.w & 0xffff0000u}; \
+          img4[2 * i] = __builtin_bit_cast(f32x4_t, lo);                    \
+          img4[2 * i + 1] = __builtin_bit_cast(f32x4_t, hi);                \
+        } else {                                                            \
+          img4[i] = nxt[r];                                                 \
+        }                                                                   \
+      }                                                                     \
     }                                                                       \
   }
   ZK_FETCH(t);
@@ -513,7 +525,8 @@ template <int K, bool INV, int LM> __global__ __launch_bounds__(256) void rqs_st
     float out, lj;
     rqs_lean<K, INV>([&](int j) { return p[j]; }, [&](int j) { return p[K + j]; }, [&](int j) { return p[2 * K + j]; }, a.c, xc, out, lj);
     const int64_t e = t * 64 + lane;
-    a.y[e] = out;
+    if (BF) ((__bf16*)a.y)[e] = (__bf16)out;
+    else ((float*)a.y)[e] = out;
     if (LM == 1) {
       a.ladj[e] = lj;
     } else if (LM == 2) {  // DPP reduction; 64 row sums are parked in lanes and stored as one 256-byte line
@@ -558,13 +571,13 @@ static int zk_stream_chunk_shift(int lm) {
   return e ? atoi(e) : (lm == 2 ? 6 : 0);
 }
 
-template <int K, bool INV, int LM> static int launch_rqs_stream_k(RqsStreamArgs a, hipStream_t st) {
+template <int K, bool INV, int LM, bool BF = false> static int launch_rqs_stream_k(RqsStreamArgs a, hipStream_t st) {
   constexpr int TOTAL = 3 * K - 1;
   const size_t lds = (size_t)4 * 64 * TOTAL * sizeof(float);
   static int per_cu = 0;  // resident blocks per CU for this instantiation (device query, once)
   if (per_cu == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rqs_stream_kernel<K, INV, LM>, 256, lds) != hipSuccess || nb < 1) nb = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rqs_stream_kernel<K, INV, LM, BF>, 256, lds) != hipSuccess || nb < 1) nb = 4;
     per_cu = nb;
   }
   const int64_t per_row = a.D > 64 ? a.D / 64 : 1;
@@ -582,39 +595,39 @@ template <int K, bool INV, int LM> static int launch_rqs_stream_k(RqsStreamArgs 
     int64_t iters = (a.tiles + W - 1) / W;
     a.iters = (iters + per_row - 1) / per_row * per_row;
   }
-  hipLaunchKernelGGL((rqs_stream_kernel<K, INV, LM>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((rqs_stream_kernel<K, INV, LM, BF>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   return ZK_LAUNCH_CHECK();
 }
-template <int K> static int launch_rqs_stream_fwd(const RqsStreamArgs& a, hipStream_t st) {
-  if (!a.ladj) return launch_rqs_stream_k<K, false, 0>(a, st);
-  if (!a.reduced) return launch_rqs_stream_k<K, false, 1>(a, st);
-  return a.D == 64 ? launch_rqs_stream_k<K, false, 2>(a, st) : launch_rqs_stream_k<K, false, 3>(a, st);
+template <int K, bool BF = false> static int launch_rqs_stream_fwd(const RqsStreamArgs& a, hipStream_t st) {
+  if (!a.ladj) return launch_rqs_stream_k<K, false, 0, BF>(a, st);
+  if (!a.reduced) return launch_rqs_stream_k<K, false, 1, BF>(a, st);
+  return a.D == 64 ? launch_rqs_stream_k<K, false, 2, BF>(a, st) : launch_rqs_stream_k<K, false, 3, BF>(a, st);
 }
 
 // returns -1 when the call does not have the stream kernel's shape (caller falls back to uni_kernel)
-template <bool INV> static int try_rqs_stream(const UniArgs& u, int K, hipStream_t st) {
+template <bool INV, bool BF = false> static int try_rqs_stream(const UniArgs& u, int K, hipStream_t st) {
   if (K != 4 && K != 8 && K != 16) return -1;
   if (u.kout || u.N <= 0 || u.D <= 0) return -1;
   const int64_t D = u.D, E = u.N * D;
   if (E % 64 != 0 || !((D <= 64 && 64 % D == 0) || D % 64 == 0)) return -1;
   const int lens[3] = {K, K, K - 1};
-  if (!is_packed(u, lens, 3, sizeof(float))) return -1;
+  if (!is_packed(u, lens, 3, BF ? 2 : sizeof(float))) return -1;
   if (((uintptr_t)u.seg[0].p & 15) != 0) return -1;
   RqsStreamArgs a;
-  a.x = (const float*)u.x; a.phi = (const float*)u.seg[0].p; a.y = (float*)u.y; a.ladj = (float*)u.ladj;
+  a.x = u.x; a.phi = u.seg[0].p; a.y = u.y; a.ladj = (float*)u.ladj;
   a.tiles = E / 64; a.iters = 0; a.N = u.N; a.D = (int)D; a.reduced = u.reduced;
   a.c = u.lc;
   if (INV) {
     switch (K) {
-      case 4: return launch_rqs_stream_k<4, true, 0>(a, st);
-      case 8: return launch_rqs_stream_k<8, true, 0>(a, st);
-      default: return launch_rqs_stream_k<16, true, 0>(a, st);
+      case 4: return launch_rqs_stream_k<4, true, 0, BF>(a, st);
+      case 8: return launch_rqs_stream_k<8, true, 0, BF>(a, st);
+      default: return launch_rqs_stream_k<16, true, 0, BF>(a, st);
     }
   }
   switch (K) {
-    case 4: return launch_rqs_stream_fwd<4>(a, st);
-    case 8: return launch_rqs_stream_fwd<8>(a, st);
-    default: return launch_rqs_stream_fwd<16>(a, st);
+    case 4: return launch_rqs_stream_fwd<4, BF>(a, st);
+    case 8: return launch_rqs_stream_fwd<8, BF>(a, st);
+    default: return launch_rqs_stream_fwd<16, BF>(a, st);
   }
 }
 
@@ -696,6 +709,10 @@ int zk_rqs_forward(int dtype, int64_t N, int64_t D, int K, double bound, double 
   UniArgs a = base_args(N, D, x, y, ladj, ladj_reduced, bin_out);
   a.seg[0] = {widths, w_sN, w_sD}; a.seg[1] = {heights, h_sN, h_sD}; a.seg[2] = {derivs, d_sN, d_sD};
   a.bound = bound; a.ls = log(slope); a.lc = rqs_lean_const(bound, a.ls);
+  if (dtype == ZK_DTYPE_BF16) {  // bf16 x / phi / y, fp32 arithmetic and ladj: stream-kernel shapes only
+    const int rc = try_rqs_stream<false, true>(a, K, (hipStream_t)stream);
+    return rc >= 0 ? rc : ZK_EINVAL;
+  }
   if (dtype == ZK_DTYPE_F32 && !zk_no_stream()) {
     const int rc = try_rqs_stream<false>(a, K, (hipStream_t)stream);
     if (rc >= 0) return rc;
@@ -708,6 +725,10 @@ int zk_rqs_inverse(int dtype, int64_t N, int64_t D, int K, double bound, double 
   UniArgs a = base_args(N, D, y, x, nullptr, 0, bin_out);
   a.seg[0] = {widths, w_sN, w_sD}; a.seg[1] = {heights, h_sN, h_sD}; a.seg[2] = {derivs, d_sN, d_sD};
   a.bound = bound; a.ls = log(slope); a.lc = rqs_lean_const(bound, a.ls);
+  if (dtype == ZK_DTYPE_BF16) {
+    const int rc = try_rqs_stream<true, true>(a, K, (hipStream_t)stream);
+    return rc >= 0 ? rc : ZK_EINVAL;
+  }
   if (dtype == ZK_DTYPE_F32 && !zk_no_stream()) {
     const int rc = try_rqs_stream<true>(a, K, (hipStream_t)stream);
     if (rc >= 0) return rc;

@@ -6,6 +6,7 @@
 
 #define ZK_DTYPE_F32 0
 #define ZK_DTYPE_F64 1
+#define ZK_DTYPE_BF16 2  /* storage type of x / phi / y / weights; arithmetic and ladj stay fp32 */
 
 #define ZK_WAVE 64
 

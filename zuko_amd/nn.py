@@ -159,6 +159,65 @@ def masked_mlp_masks(adjacency: BoolTensor, hidden_features: Sequence[int], resi
     return masks
 
 
+class _Bf16Plan:
+    """Device-side tables for running a plain MaskedMLP (linear, activation, linear, ...) in bf16 through
+    zk_linear_bf16: hidden units of every layer are reordered by dependency count (a reparametrisation:
+    rows of W_l / b_l and columns of W_{l+1} move together, inputs and outputs keep their order), which
+    turns the masks of zuko/nn.py:265-295 into block-triangular matrices; `mask * W` is formed once per
+    parameter version in that order, and 256 x 64 weight tiles the mask zeroes completely are marked
+    dead so the kernel neither fetches nor multiplies them."""
+
+    def __init__(self, lins: Sequence["MaskedLinear"]):
+        masks = [l.mask for l in lins]
+        dev = masks[0].device
+        dep = torch.eye(masks[0].shape[1], dtype=torch.float64, device=dev)
+        self.perms: list[Tensor | None] = []
+        prev = None
+        self.live: list[Tensor | None] = []
+        self.masks_p: list[Tensor] = []
+        for i, m in enumerate(masks):
+            dep = ((m.double() @ dep) > 0).double()  # [units, inputs]: which inputs each unit can see
+            if i + 1 < len(masks):
+                perm = torch.argsort(dep.sum(dim=1), stable=True)
+                dep = dep[perm]
+            else:
+                perm = None  # the outputs keep the reference's column order f * total + j
+            mp = m if perm is None else m[perm]
+            mp = mp if prev is None else mp[:, prev]
+            self.perms.append(perm)
+            self.masks_p.append(mp.contiguous())
+            out_f, in_f = mp.shape
+            if in_f % 64 == 0:
+                pad = (-out_f) % 256
+                t = torch.nn.functional.pad(mp, (0, 0, 0, pad)) if pad else mp
+                self.live.append(t.reshape(-1, 256, in_f // 64, 64).any(dim=3).any(dim=1).to(torch.uint8).contiguous())
+            else:
+                self.live.append(None)
+            prev = perm
+        self.version = None
+        self.weights: list[Tensor] = []
+        self.biases: list[Tensor | None] = []
+
+    def refresh(self, lins: Sequence["MaskedLinear"]) -> None:
+        version = tuple((l.weight._version, l.weight.data_ptr(), -1 if l.bias is None else l.bias._version) for l in lins)
+        if version == self.version:
+            return
+        self.weights, self.biases = [], []
+        prev = None
+        for l, perm, mp in zip(lins, self.perms, self.masks_p):
+            w = l.weight.detach()
+            w = w if perm is None else w[perm]
+            w = w if prev is None else w[:, prev]
+            self.weights.append((w * mp).contiguous())
+            b = None if l.bias is None else l.bias.detach()
+            self.biases.append(b if (b is None or perm is None) else b[perm].contiguous())
+            prev = perm
+        self.version = version
+
+    def live_fraction(self) -> list[float]:
+        return [1.0 if t is None else float(t.float().mean()) for t in self.live]
+
+
 class MaskedMLP(_FusedSequential):
     r"""Masked MLP (autoregressive conditioner).  Mirrors zuko/nn.py:221-318, including the
     `residual=True` variant (zuko/nn.py:297-309): every layer is followed by a masked residual block
@@ -190,3 +249,33 @@ class MaskedMLP(_FusedSequential):
         super().__init__(*layers)
         self.in_features = in_features
         self.out_features = out_features
+
+    def _bf16_plan(self):
+        """Plan of the bf16 fast path, or None when the module tree is not (linear, fusable activation)*."""
+        plan = self.__dict__.get("_bf16_plan_cache")
+        if plan is None:
+            mods = list(self)
+            simple = all(isinstance(m, MaskedLinear) == (i % 2 == 0) for i, m in enumerate(mods))
+            codes = {_act_code(m) for i, m in enumerate(mods) if i % 2 == 1}
+            plan = False
+            if simple and len(codes) <= 1 and None not in codes and all(l.in_features % 64 == 0 for l in mods[0::2]):
+                plan = _Bf16Plan(mods[0::2])
+                plan.act = codes.pop() if codes else 0
+            self.__dict__["_bf16_plan_cache"] = plan
+        return plan or None
+
+    def _apply(self, fn, *args, **kwargs):  # device / dtype moves invalidate the bf16 tables
+        self.__dict__.pop("_bf16_plan_cache", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.dtype == torch.bfloat16 and x.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            plan = self._bf16_plan()
+            if plan is not None:
+                lins = list(self)[0::2]
+                plan.refresh(lins)
+                h = x
+                for i, (w, b, live) in enumerate(zip(plan.weights, plan.biases, plan.live)):
+                    h = ops.linear_bf16(h, w, b, live, plan.act if i + 1 < len(lins) else 0)
+                return h
+        return super().forward(x)

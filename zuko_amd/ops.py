@@ -35,7 +35,9 @@ def _dtype_code(t: Tensor) -> int:
         return 0
     if t.dtype == torch.float64:
         return 1
-    raise TypeError(f"zuko_amd kernels support float32/float64, got {t.dtype}")
+    if t.dtype == torch.bfloat16:
+        return 2  # storage type only (spline kernels, zk_linear_bf16): arithmetic and ladj are fp32
+    raise TypeError(f"zuko_amd kernels support float32/float64 (and bfloat16 storage for splines / linear layers), got {t.dtype}")
 
 
 def _require_device(*ts: Tensor) -> None:
@@ -128,7 +130,8 @@ class _Prepared:
 
     def out_ladj(self, reduced: bool) -> Tensor:
         shape = self.shape[:-1] if reduced else self.shape
-        return torch.empty(shape, dtype=self.x.dtype, device=self.x.device)
+        dt = torch.float32 if self.x.dtype == torch.bfloat16 else self.x.dtype  # bf16 is a storage type: ladj stays fp32
+        return torch.empty(shape, dtype=dt, device=self.x.device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -308,6 +311,9 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor |
     out_f, in_f = weight.shape
     if x.shape[-1] != in_f:
         raise ValueError(f"zuko_amd.linear: expected last dim {in_f}, got {x.shape[-1]}")
+    if x.dtype == torch.bfloat16:
+        w = weight if mask is None else weight * mask  # one pass over the parameters, not over the batch
+        return linear_bf16(x, w, bias, None, act)
     x2 = x.reshape(-1, in_f)
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
@@ -327,12 +333,37 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor |
     return y.reshape(x.shape[:-1] + (out_f,))
 
 
+def linear_bf16(x: Tensor, weight_masked: Tensor, bias: Tensor | None, tile_live: Tensor | None, act: int = 0) -> Tensor:
+    """bf16 act(x @ weight_masked.T + bias) with fp32 accumulation (zk_linear_bf16).  `tile_live`: uint8
+    [ceil(out/256), in/64], 0 where the (masked) weight tile is entirely zero."""
+    _require_device(x, weight_masked, bias, tile_live)
+    _no_grad_only(x, weight_masked, bias)
+    out_f, in_f = weight_masked.shape
+    if x.dtype != torch.bfloat16 or weight_masked.dtype != torch.bfloat16 or (bias is not None and bias.dtype != torch.bfloat16):
+        raise TypeError("zuko_amd.linear_bf16: x, weight and bias must be bfloat16")
+    if in_f % 64 != 0:
+        raise ValueError(f"zuko_amd.linear_bf16: in_features must be a multiple of 64 (got {in_f}); pad the conditioner input")
+    x2 = x.reshape(-1, in_f)
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) % 8 != 0) or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    w = weight_masked.contiguous()
+    b = None if bias is None else bias.contiguous()
+    y = torch.empty((x2.shape[0], out_f), dtype=x.dtype, device=x.device)
+    err = _C.lib().zk_linear_bf16(x2.shape[0], in_f, out_f, _ptr(x2), x2.stride(0) if x2.shape[0] > 1 else in_f, _ptr(w), _ptr(tile_live), _ptr(b), act,
+                                  _ptr(y), out_f, _stream())
+    _C.check(err, "zk_linear_bf16")
+    return y.reshape(x.shape[:-1] + (out_f,))
+
+
 def diag_normal_log_prob(z: Tensor, loc: Tensor, scale: Tensor, ladj: Tensor | None = None) -> Tensor:
     _require_device(z, loc, scale, ladj)
     from . import autograd as AG
 
     if AG.needs_grad(z, ladj):
         return AG.DiagNormalLogProbFn.apply(z, loc, scale, ladj)
+    if z.dtype == torch.bfloat16:  # bf16 is a storage type here: the density is evaluated and returned in fp32
+        z, loc, scale = z.float(), loc.float(), scale.float()
+        ladj = None if ladj is None else ladj.float()
     D = z.shape[-1]
     z2 = z.reshape(-1, D).contiguous()
     out = torch.empty(z2.shape[0], dtype=z.dtype, device=z.device)
