@@ -221,7 +221,8 @@ def main() -> None:
             kernels[f"zk_rqs_forward {B} {FEATURES} {BINS}"] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), "standalone": True}
             del phi, w, h, d
         except Exception as exc:  # never let the side measurement break the headline line
-            kernels["zk_rqs_forward (standalone)"] = {"calls": 0, "avg_ms": float("nan"), "error": repr(exc)}
+            if args.config == "cfg2":
+                kernels["zk_rqs_forward (standalone)"] = {"calls": 0, "avg_ms": float("nan"), "error": repr(exc)}
         roof, extra = zuko_amd_roofline(kernels, B)
 
     if rank == 0:
@@ -293,7 +294,7 @@ def zuko_amd_roofline(kernels: dict, B: int):
         elif parts[0] == "zk_ar_forward":
             flops = float(B) * FLOP_PER_SAMPLE_TRANSFORM
             row.update(bound="mfma", achieved=flops / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
-        elif parts[0] == "zk_rqs_forward":
+        elif parts[0] == "zk_rqs_forward" and len(parts) == 4 and parts[1].isdigit():
             n, d, k = int(parts[1]), int(parts[2]), int(parts[3])
             esz = 2 if rec.get("bf16") else 4
             byts = float(n) * (d * (esz + esz * (3 * k - 1) + esz) + 4)  # x + phi + y per element, + ladj per row

@@ -10,14 +10,14 @@
 // v_mfma_f32_32x32x16_bf16 accumulators (128 VGPRs).  Both operands are K-major in HBM, which is what
 // the MFMA wants (a lane holds 8 consecutive k of one row): tiles go HBM/L2 -> LDS with
 // global_load_lds_dwordx4 (no VGPR round trip, no ds_write), two stages of 64 KiB, one workgroup
-// barrier per stage.  LDS rows are 128 B; the 16-byte chunk c of row r is stored at slot
+// barrier per stage; the second stage doubles as the epilogue's transpose image.  LDS rows are 128 B; the 16-byte chunk c of row r is stored at slot
 // c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads conflict-free for every 16-lane
 // service group of CDNA4 (MI355X_MICROARCH.md, LDS table) — the swizzle is applied on the GLOBAL
 // address of the DMA, whose LDS side is fixed at lane * 16.
 //
-// Blocks are rasterised in super-tiles (SR row panels x SC column panels of consecutive logical ids)
-// so that the panels a set of co-resident blocks touches stay in L2 / MALL: a column sweep per row
-// panel would stream the 98.6 MB weight of cfg5's last layer once per 256 rows.
+// One persistent block per CU walks the tiles in super-tile raster order (SR row panels x SC column
+// panels of consecutive tile ids), so the panels the co-resident blocks touch stay in L2 / MALL: a
+// column sweep per row panel would stream the 98.6 MB weight of cfg5's last layer once per 256 rows.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -43,7 +43,9 @@ struct LinBf16Args {
   const __bf16* bias;       // [OUT] or null
   int act;
   __bf16* y; int64_t ldy;
-  int nbx, nby, sr, sc, nsc;  // block grid and super-tile shape (nsc super-tiles per row of super-tiles)
+  int nbx, nby, sr, sc, nsc;  // tile grid and super-tile shape (nsc super-tiles per row of super-tiles)
+  int dbg;                    // ZUKO_AMD_BF16_DEBUG (ablations: 1 = no result stores, 2 = no epilogue at all)
+  int ntiles;                 // raster length (super-tiles are padded: out-of-range tiles are filtered on the host)
 };
 
 __device__ __forceinline__ float act_bf(float v, int act) {
@@ -61,41 +63,75 @@ __device__ __forceinline__ float act_bf(float v, int act) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lin_bf16_lds[];
 
-__global__ __launch_bounds__(512, 2) void linear_bf16_kernel(LinBf16Args a) {
-  // ---- block -> (bx, by): XCD-contiguous logical ids, then super-tile rasterisation ---------------
-  const int nwg = gridDim.x;  // a multiple of 8
-  const int orig = blockIdx.x;
-  const int logical = (orig % 8) * (nwg / 8) + orig / 8;
-  const int per_st = a.sr * a.sc;
-  const int st = logical / per_st, within = logical - st * per_st;
-  const int bx = (st / a.nsc) * a.sr + within / a.sc;
-  const int by = (st % a.nsc) * a.sc + within % a.sc;
-  if (bx >= a.nbx || by >= a.nby) return;
+#define B_EPI_ROWB 144                       /* epilogue image: 64 cols of bf16 per row + 16 B pad */
+#define B_EPI_WAVE (64 * B_EPI_ROWB)         /* one wave's half sub-tile: 64 rows */
+#define B_LDS_BYTES (2 * B_STAGE_BYTES + 8 * B_EPI_WAVE - B_STAGE_BYTES)  /* stage 0 | stage 1 ∪ epilogue image */
 
+typedef unsigned int u32x2_b __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_b __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// Persistent: block b walks tiles b, b + G, b + 2G, ... of the super-tile raster.  The MFMA computes the
+// TRANSPOSED product (A operand = weight rows, B operand = activation rows), so a lane ends up with four
+// consecutive output columns of one sample per accumulator quad: bias + activation + bf16 packing happen
+// on 8-byte groups, the wave transposes its 128 x 64 sub-tile through a private LDS image and leaves
+// as full 128-byte row segments (dwordx4 per lane).  Between a tile's last MFMA and its epilogue the
+// first k-stage of the NEXT tile is already requested, so its DMA latency hides behind the stores.
+// GENERIC_ACT: activations other than none / ReLU are applied on the transposed bf16 image inside a rolled loop
+// (their inline expansions, unrolled over the 128 accumulators of a lane, made the epilogue instruction-cache bound)
+template <bool GENERIC_ACT> __global__ __launch_bounds__(512, 2) void linear_bf16_kernel(LinBf16Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // wave tile: rows [wm*128, +128), cols [wn*64, +64)
-  const int64_t row0 = (int64_t)bx * BBM;
-  const int col0 = by * BBN;
+  const int wm = wave >> 2, wn = wave & 3;  // wave tile: samples [wm*128, +128), outputs [wn*64, +64)
   const int KT = a.IN / BBK;
-  const uint8_t* live = a.live ? a.live + (size_t)by * KT : nullptr;
+  const int ntiles = a.ntiles;
+  const int drow = lane >> 3, dslot = lane & 7;   // DMA: row inside an 8-row group, LDS slot of this lane
+  const int fr = lane & 31, kg = lane >> 5;
 
-  // ---- DMA geometry: one wave-instruction moves 8 rows x 128 B; wave w fills rows [w*32, +32) of each panel
-  const int drow = lane >> 3;                       // row inside the 8-row group
-  const int dslot = lane & 7;                       // LDS slot written by this lane
+  // tile t of the super-tile raster -> (row panel, column panel); super-tiles at the right / bottom edge
+  // are clipped, so the raster enumerates exactly nbx * nby tiles
+  auto raster = [&](int t, int& bx, int& by) {
+    const int row_tiles = a.sr * a.nby;
+    const int R = t / row_tiles, rem = t - R * row_tiles;
+    const int hr = (a.nbx - R * a.sr) < a.sr ? (a.nbx - R * a.sr) : a.sr;
+    const int C = rem / (hr * a.sc), rem2 = rem - C * hr * a.sc;
+    const int wc = (a.nby - C * a.sc) < a.sc ? (a.nby - C * a.sc) : a.sc;
+    bx = R * a.sr + rem2 / wc;
+    by = C * a.sc + rem2 % wc;
+  };
+  // liveness of a column panel's k-tiles as a 64-bit wave-uniform mask (one byte per lane)
+  auto load_live = [&](int by) -> unsigned char { return (a.live && KT <= 64 && lane < KT) ? a.live[(size_t)by * KT + lane] : (unsigned char)1; };
+  auto mask_of = [&](unsigned char v) -> unsigned long long {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(v != 0);
+    if (KT < 64) m &= (1ull << KT) - 1;
+    return m;
+  };
+  auto next_live = [&](unsigned long long lmask, int kt) {  // first live k-tile >= kt (KT if none)
+    if (KT > 64) return kt < KT ? kt : KT;
+    if (kt >= 64) return KT;
+    const unsigned long long m = lmask >> kt;
+    return m ? kt + (int)__builtin_ctzll(m) : KT;
+  };
   const char* gA[4];
   const char* gB[4];
+  auto set_panels = [&](int bx, int by) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + drow;         // panel row
-    const int c = dslot ^ ((r >> 1) & 7);           // logical 16-byte chunk that lives in this slot
-    int64_t ra = row0 + r;
-    ra = ra < a.N ? ra : a.N - 1;                   // ragged edge: re-read the last row (results discarded)
-    int rb = col0 + r;
-    rb = rb < a.OUT ? rb : a.OUT - 1;
-    gA[i] = reinterpret_cast<const char*>(a.x + ra * a.ldx) + c * 16;
-    gB[i] = reinterpret_cast<const char*>(a.w + (int64_t)rb * a.IN) + c * 16;
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int r = wave * 32 + i * 8 + drow;       // panel row
+      const int c = dslot ^ ((r >> 1) & 7);         // logical 16-byte chunk that lives in this lane's slot
+      int64_t ra = (int64_t)bx * BBM + r;
+      ra = ra < a.N ? ra : a.N - 1;                 // ragged edge: re-read the last row (results discarded)
+      int rb = by * BBN + r;
+      rb = rb < a.OUT ? rb : a.OUT - 1;
+      gA[i] = reinterpret_cast<const char*>(a.x + ra * a.ldx) + c * 16;
+      gB[i] = reinterpret_cast<const char*>(a.w + (int64_t)rb * a.IN) + c * 16;
+    }
+  };
   auto issue = [&](int kt, int stage) {
     unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wave * 32) * 128;
     unsigned char* sB = sA + 256 * 128;
@@ -108,39 +144,41 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_kernel(LinBf16Args a) {
                                        (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
     }
   };
-  // liveness of this column panel's k-tiles as a 64-bit wave-uniform mask (one byte load per lane, once);
-  // more than 64 k-tiles (IN > 4096): every tile is treated as live
-  unsigned long long lmask = ~0ull;
-  if (live && KT <= 64) lmask = __builtin_amdgcn_ballot_w64(lane < KT && live[lane] != 0);
-  else if (KT < 64) lmask = (1ull << KT) - 1;
-  auto next_live = [&](int kt) {  // first live k-tile >= kt (KT if none)
-    if (kt >= 64) return kt < KT ? kt : KT;
-    const unsigned long long m = lmask >> kt;
-    if (KT > 64) return kt;
-    return m ? kt + (int)__builtin_ctzll(m) : KT;
-  };
-  // ---- fragment read offsets (bytes inside a panel), per 32-row sub-tile and k16 step -------------
-  const int fr = lane & 31, kg = lane >> 5;
-  f32x16_b acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int kt = next_live(0);
-  int stage = 0;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int bx, by;
+  raster(tile, bx, by);
+  set_panels(bx, by);
+  unsigned long long lmask = mask_of(load_live(by));
+  int kt = next_live(lmask, 0);
   if (kt < KT) issue(kt, 0);
-  while (kt < KT) {
-    const int ktn = next_live(kt + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMAs of this stage have landed
-    __syncthreads();                                   // everybody's have; the other stage is free again
-    if (ktn < KT) issue(ktn, stage ^ 1);
-    const unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wm * 128) * 128;
-    const unsigned char* sB = lin_bf16_lds + stage * B_STAGE_BYTES + 256 * 128 + (wn * 64) * 128;
-    // fragments of k16 step kk+1 are requested before the MFMAs of step kk (register double buffer)
-    bf16x8 fa[2][4], fb[2][2];
+
+  while (true) {
+    // ---- what the epilogue and the next tile will need, requested up front ------------------------
+    const int tile_n = tile + gridDim.x;
+    int bxn = 0, byn = 0;
+    if (tile_n < ntiles) raster(tile_n, bxn, byn);
+    const unsigned char live_n = (tile_n < ntiles) ? load_live(byn) : (unsigned char)0;
+    f32x16_b acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- k loop: two LDS stages, one barrier per live k-tile ---------------------------------------
+    int stage = 0;
+    while (kt < KT) {
+      const int ktn = next_live(lmask, kt + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMAs of this stage have landed (and my stores of the previous tile left)
+      __syncthreads();                                   // everybody's have; the other stage / the epilogue image is free again
+      if (ktn < KT) issue(ktn, stage ^ 1);
+      const unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wm * 128) * 128;
+      const unsigned char* sB = lin_bf16_lds + stage * B_STAGE_BYTES + 256 * 128 + (wn * 64) * 128;
+      // fragments of k16 step kk+1 are requested before the MFMAs of step kk (register double buffer)
+      bf16x8 fa[2][4], fb[2][2];
 #define ZK_BF16_FRAGS(buf, kk)                                                                              \
   {                                                                                                         \
     const int c_ = (kk) * 2 + kg;                                                                           \
@@ -153,36 +191,111 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_kernel(LinBf16Args a) {
       fb[buf][j] = *reinterpret_cast<const bf16x8*>(sB + r_ * 128 + ((c_ ^ ((r_ >> 1) & 7)) << 4));        \
     }                                                                                                       \
   }
-    ZK_BF16_FRAGS(0, 0);
+      ZK_BF16_FRAGS(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 3) ZK_BF16_FRAGS((kk + 1) & 1, kk + 1);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (the scheduler would sink it to its uses)
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) ZK_BF16_FRAGS((kk + 1) & 1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (the scheduler would sink it to its uses)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #undef ZK_BF16_FRAGS
-    stage ^= 1;
-    kt = ktn;
-  }
+      stage ^= 1;
+      kt = ktn;
+    }
 
-  // ---- epilogue: + bias, activation, bf16, store.  acc[i][j][r]: row (r/4)*8 + kg*4 + r%4, col fr ----
+    // ---- hand-over: the next tile's first stage goes out before this tile's epilogue ----------------
+    __syncthreads();  // every wave is done reading the stage buffers
+    const int bx_c = bx, by_c = by;
+    unsigned long long lmask_n = 0;
+    int kt_n = KT;
+    if (tile_n < ntiles) {
+      set_panels(bxn, byn);
+      lmask_n = mask_of(live_n);
+      kt_n = next_live(lmask_n, 0);
+      if (kt_n < KT) issue(kt_n, 0);
+    }
+
+    u32x2_b bias4[2][4];  // bias of outputs j*32 + q*8 + kg*4 .. +3 as four bf16
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = col0 + wn * 64 + j * 32 + fr;
-    const bool cok = col < a.OUT;
-    const float bv = (a.bias && cok) ? (float)a.bias[col] : 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int q = 0; q < 4; ++q) {
+        const int col = by_c * BBN + wn * 64 + j * 32 + q * 8 + kg * 4;
+        u32x2_b v = {0u, 0u};
+        if (a.bias) {
+          if (col + 4 <= a.OUT && (((uintptr_t)(a.bias + col)) & 7) == 0) v = *reinterpret_cast<const u32x2_b*>(a.bias + col);
+          else {
+            unsigned short e[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wm * 128 + i * 32 + (r >> 2) * 8 + kg * 4 + (r & 3);
-        if (cok && row < a.N) a.y[row * a.ldy + col] = (__bf16)act_bf(acc[i][j][r] + bv, a.act);
+            for (int t = 0; t < 4; ++t) e[t] = (col + t < a.OUT) ? reinterpret_cast<const unsigned short*>(a.bias)[col + t] : (unsigned short)0;
+            v = u32x2_b{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16)};
+          }
+        }
+        bias4[j][q] = v;
+      }
+
+    // ---- epilogue.  acc[i][j][r] = C[sample i*32 + fr][output j*32 + (r/4)*8 + kg*4 + r%4] ---------------
+    unsigned char* img = lin_bf16_lds + B_STAGE_BYTES + wave * B_EPI_WAVE;  // wave-private: 64 rows x 144 B
+    const int64_t row_w = (int64_t)bx_c * BBM + wm * 128;
+    const int col_w = by_c * BBN + wn * 64;
+    const bool vec_ok = (a.ldy % 8 == 0) && ((((uintptr_t)a.y) & 15) == 0);
+    const bool relu = a.act == 1;
+    if (!(a.dbg & 2))
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = h * 2 + ii;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x2_b bv = bias4[j][q];
+            const float b0 = __builtin_bit_cast(float, bv.x << 16), b1 = __builtin_bit_cast(float, bv.x & 0xffff0000u);
+            const float b2 = __builtin_bit_cast(float, bv.y << 16), b3 = __builtin_bit_cast(float, bv.y & 0xffff0000u);
+            float v0 = acc[i][j][4 * q + 0] + b0, v1 = acc[i][j][4 * q + 1] + b1, v2 = acc[i][j][4 * q + 2] + b2, v3 = acc[i][j][4 * q + 3] + b3;
+            if (!GENERIC_ACT && relu) {  // NaN stays NaN, as torch.relu
+              v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; v2 = v2 < 0.f ? 0.f : v2; v3 = v3 < 0.f ? 0.f : v3;
+            }
+            const u32x2_b pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+            *reinterpret_cast<u32x2_b*>(img + (ii * 32 + fr) * B_EPI_ROWB + (j * 32 + q * 8 + kg * 4) * 2) = pk;
+          }
+      }
+      // 64 rows x 128 B leave as 8 wave-stores of 8 rows: lane -> (row it*8 + lane/8, 16-byte chunk lane%8)
+#pragma unroll GENERIC_ACT ? 1 : 8
+      for (int it = 0; it < 8; ++it) {
+        const int rl = it * 8 + drow;
+        u32x4_b v = *reinterpret_cast<const u32x4_b*>(img + rl * B_EPI_ROWB + dslot * 16);
+        if (GENERIC_ACT) {  // (the reference also rounds the linear output to bf16 before its activation module)
+          unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float lo = act_bf(__builtin_bit_cast(float, w4[t] << 16), a.act), hi = act_bf(__builtin_bit_cast(float, w4[t] & 0xffff0000u), a.act);
+            w4[t] = pack_bf16x2(lo, hi);
+          }
+          v = u32x4_b{w4[0], w4[1], w4[2], w4[3]};
+        }
+        const int64_t row = row_w + h * 64 + rl;
+        const int col = col_w + dslot * 8;
+        if (row < a.N && !(a.dbg & 1)) {
+          __bf16* dst = a.y + row * a.ldy + col;
+          if (vec_ok && col + 8 <= a.OUT) *reinterpret_cast<u32x4_b*>(dst) = v;
+          else {
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              if (col + t < a.OUT) reinterpret_cast<unsigned short*>(dst)[t] = (unsigned short)(w4[t >> 1] >> ((t & 1) * 16));
+          }
+        }
       }
     }
+
+    if (tile_n >= ntiles) break;
+    tile = tile_n; bx = bxn; by = byn; lmask = lmask_n; kt = kt_n;
   }
 }
 
@@ -212,15 +325,20 @@ extern "C" int zk_linear_bf16(int64_t N, int in_features, int out_features, cons
   a.nby = (out_features + BBN - 1) / BBN;
   bf16_supertile(a.nbx, a.nby, a.sr, a.sc);
   a.nsc = (a.nby + a.sc - 1) / a.sc;
-  const int64_t nst = (int64_t)((a.nbx + a.sr - 1) / a.sr) * a.nsc;
-  int64_t grid = nst * a.sr * a.sc;
-  grid = (grid + 7) / 8 * 8;
-  if (grid > 0x7fffffff) return ZK_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B_STAGE_BYTES);
-    attr_set = true;
+  const int64_t ntiles = (int64_t)a.nbx * a.nby;
+  if (ntiles > 0x7fffffff) return ZK_EINVAL;
+  a.ntiles = (int)ntiles;
+  { const char* e = getenv("ZUKO_AMD_BF16_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+    n_cu = v;
   }
-  hipLaunchKernelGGL(linear_bf16_kernel, dim3((unsigned)grid), dim3(512), 2 * B_STAGE_BYTES, (hipStream_t)stream, a);
+  const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);  // persistent: one 8-wave block per CU
+  if (act <= 1) hipLaunchKernelGGL(linear_bf16_kernel<false>, dim3((unsigned)grid), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(linear_bf16_kernel<true>, dim3((unsigned)grid), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
   return ZK_LAUNCH_CHECK();
 }
