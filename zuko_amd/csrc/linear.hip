@@ -146,9 +146,12 @@ template <bool VEC4> __global__ __launch_bounds__(256) void linear_f32_mfma(LinA
     __syncthreads();
   }
 
-  // epilogue: D[row i = (r&3) + 8*(r>>2) + 4*(lane>>5)][col j = lane&31]
+  // epilogue: D[row i = (r&3) + 8*(r>>2) + 4*(lane>>5)][col j = lane&31].  None / ReLU are applied inline; the
+  // other activations run afterwards in a ROLLED loop over the values this thread just stored (their inline
+  // expansions, unrolled 64 times, made the epilogue instruction-cache bound — measured on the bf16 kernel).
   const float* bias = (const float*)a.bias;
   float* Y = (float*)a.y;
+  const bool relu = a.act == ACT_RELU;
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = col0 + wc * 64 + n * 32 + (lane & 31);
@@ -159,7 +162,21 @@ template <bool VEC4> __global__ __launch_bounds__(256) void linear_f32_mfma(LinA
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < a.N) Y[row * a.ldy + col] = apply_act<float>(acc[m][n][r] + bv, a.act);
+        float v = acc[m][n][r] + bv;
+        if (relu) v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
+        if (row < a.N) Y[row * a.ldy + col] = v;
+      }
+    }
+  }
+  if (a.act > ACT_RELU) {
+#pragma unroll 1
+    for (int e = 0; e < 64; ++e) {
+      const int n = e >> 5, m = (e >> 4) & 1, r = e & 15;
+      const int col = col0 + wc * 64 + n * 32 + (lane & 31);
+      const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (col < a.OUT && row < a.N) {
+        float* q = Y + row * a.ldy + col;
+        *q = apply_act<float>(*q, a.act);
       }
     }
   }
