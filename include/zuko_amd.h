@@ -106,10 +106,11 @@ int zk_linear(int dtype, int64_t N, int in_features, int out_features, const voi
 /* bf16 conditioner layer (cfg5 of BASELINE.json: NSF(1024, K=16, H=[1024]^3) in bf16).  Same contract as
  * zk_linear (zuko/nn.py:217-218 + the following activation) with bf16 x / weight / bias / y and fp32
  * accumulation on v_mfma_f32_32x32x16_bf16.  `weight` is the ALREADY MASKED matrix (mask * W, one pass
- * over the parameters); `tile_live` is null or one byte per [256 outputs x 64 inputs] weight tile, row-major
- * over (ceil(out/256), in/64): 0 = the tile is entirely zero and is skipped.  Requires in_features % 64 == 0,
- * ldx % 8 == 0 and 16-byte aligned x / weight; returns hipErrorInvalidValue otherwise. */
-int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight, const uint8_t* tile_live,
+ * over the parameters); `tile_live_mask` is null or one 64-bit word per panel of 256 outputs: bit k clear =
+ * the [256 outputs x inputs 64k .. 64k+63] weight tile is entirely zero and is skipped (in_features <= 4096).
+ * Requires in_features % 64 == 0, ldx % 8 == 0 and 16-byte aligned x / weight; returns hipErrorInvalidValue
+ * otherwise. */
+int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight, const uint64_t* tile_live_mask,
                    const void* bias, int act, void* y, int64_t ldy, void* stream);
 
 /* ---- fused masked-autoregressive layer (the dominant kernel of NSF / MAF log_prob) ----------------- *

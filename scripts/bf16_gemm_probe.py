@@ -30,6 +30,6 @@ for li in (3, 1):
             for _ in range(reps): y = ops.linear_bf16(x, w, b, live, 1)
             b_.record(); torch.cuda.synchronize()
         ms = a_.elapsed_time(b_) / reps
-        frac = 1.0 if live is None else float(live.float().mean())
+        frac = 1.0 if live is None else plan.live_fraction()[li]
         print(f"N=2^{N.bit_length()-1} {in_f}->{out_f} {name:9s}: {ms:8.3f} ms  dense-equiv {2*N*in_f*out_f/ms/1e9:7.1f} TF/s  executed {2*N*in_f*out_f*frac/ms/1e9:7.1f} TF/s ({2*N*in_f*out_f*frac/ms/1e9/2500*100:.1f}% of 2.5 PF)")
         del y

@@ -31,7 +31,9 @@ def test_bf16_plan_is_an_exact_reparametrisation(D, total, hidden, ctx):
             continue
         out_f, in_f = w.shape
         nz = torch.nn.functional.pad(w != 0, (0, 0, 0, (-out_f) % 256)).reshape(-1, 256, in_f // 64, 64).any(dim=3).any(dim=1)
-        assert not (nz & (live == 0)).any(), "a tile holding non-zero weights is marked dead"
+        bits = ((live.unsqueeze(-1) >> torch.arange(in_f // 64)) & 1).bool()
+        assert live.dtype == torch.int64 and bits.shape == nz.shape
+        assert not (nz & ~bits).any(), "a tile holding non-zero weights is marked dead"
     # a parameter update invalidates the cached masked weights
     with torch.no_grad():
         lins[0].weight.add_(1.0)

@@ -231,7 +231,7 @@ def test_fused_extra_spline_layouts(dev, kind, kw):
 # ---- bf16 storage path (cfg5 of BASELINE.json) ---------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,IN,OUT,act,use_live", [(512, 128, 512, 1, False), (300, 64, 705, 0, False), (1024, 256, 1024, 1, True), (37, 192, 47, 2, True)])
+@pytest.mark.parametrize("N,IN,OUT,act,use_live", [(512, 128, 512, 1, False), (300, 64, 705, 0, False), (1024, 256, 1024, 1, True), (37, 192, 47, 2, True), (2048, 1024, 1280, 1, True)])
 def test_linear_bf16_matches_float_reference(dev, N, IN, OUT, act, use_live):
     """zk_linear_bf16 (bf16 in / out, fp32 accumulation) against the same product in float32 on the bf16
     values: the only differences are the summation order and one final rounding to bf16."""
@@ -243,15 +243,19 @@ def test_linear_bf16_matches_float_reference(dev, N, IN, OUT, act, use_live):
     b = torch.randn(OUT, generator=g).to(torch.bfloat16)
     live = None
     if use_live:  # zero whole 256 x 64 tiles and tell the kernel
+        from zuko_amd.nn import live_tile_masks
+
         rows, cols = -(-OUT // 256), IN // 64
-        live = torch.rand(rows, cols, generator=g) < 0.6
-        live[:, 0] = True
-        keep = live.repeat_interleave(256, 0)[:OUT].repeat_interleave(64, 1)
+        keep_t = torch.rand(rows, cols, generator=g) < 0.6
+        keep_t[:, 0] = True
+        keep = keep_t.repeat_interleave(256, 0)[:OUT].repeat_interleave(64, 1)
         w = w * keep
+        live = live_tile_masks(keep)
+        assert live.tolist() == [sum(int(b) << k for k, b in enumerate(r)) for r in keep_t.tolist()]
     ref = x.float() @ w.float().t() + b.float()
     ref = {0: ref, 1: ref.relu(), 2: torch.nn.functional.elu(ref)}[act]
     with torch.no_grad():
-        y = ops.linear_bf16(x.to(dev), w.to(dev), b.to(dev), None if live is None else live.to(torch.uint8).to(dev), act)
+        y = ops.linear_bf16(x.to(dev), w.to(dev), b.to(dev), None if live is None else live.to(dev), act)
     assert y.dtype == torch.bfloat16 and y.shape == (N, OUT)
     err = (y.float().cpu() - ref).abs()
     tol = 2.0**-8 * ref.abs() + 1e-2  # one bf16 rounding of the result + accumulation-order noise

@@ -3,8 +3,8 @@
 //
 // Replaces `F.linear(x, mask * weight, bias)` + activation (zuko/nn.py:217-218, :13-15) for bf16
 // modules.  The caller passes the ALREADY MASKED weight (mask * W is one elementwise pass over the
-// parameters, not over the batch) and, optionally, a liveness byte per 256 x 64 weight tile: tiles
-// that the mask zeroes completely are neither fetched nor multiplied.
+// parameters, not over the batch) and, optionally, a liveness bit per 256 x 64 weight tile (one 64-bit word
+// per panel of 256 outputs): tiles that the mask zeroes completely are neither fetched nor multiplied.
 //
 // Block tile 256 x 256 x 64, 8 wavefronts (2 x 4), each owning 128 x 64 of the output as 4 x 2
 // v_mfma_f32_32x32x16_bf16 accumulators (128 VGPRs).  Both operands are K-major in HBM, which is what
@@ -39,7 +39,7 @@ struct LinBf16Args {
   int IN, OUT;
   const __bf16* x; int64_t ldx;
   const __bf16* w;          // [OUT, IN] row-major, already masked
-  const uint8_t* live;      // [ceil(OUT/256)][IN/64] or null
+  const unsigned long long* live;  // [ceil(OUT/256)]: bit k set = k-tile k (64 inputs) of the panel has non-zero weights; or null
   const __bf16* bias;       // [OUT] or null
   int act;
   __bf16* y; int64_t ldy;
@@ -104,10 +104,10 @@ template <bool GENERIC_ACT> __global__ __launch_bounds__(512, 2) void linear_bf1
     bx = R * a.sr + rem2 / wc;
     by = C * a.sc + rem2 % wc;
   };
-  // liveness of a column panel's k-tiles as a 64-bit wave-uniform mask (one byte per lane)
-  auto load_live = [&](int by) -> unsigned char { return (a.live && KT <= 64 && lane < KT) ? a.live[(size_t)by * KT + lane] : (unsigned char)1; };
-  auto mask_of = [&](unsigned char v) -> unsigned long long {
-    unsigned long long m = __builtin_amdgcn_ballot_w64(v != 0);
+  // liveness of a column panel's k-tiles: one 64-bit word per panel (all live without a table or beyond 64 k-tiles)
+  auto load_live = [&](int by) -> unsigned long long { return (a.live && KT <= 64) ? a.live[by] : ~0ull; };
+  auto mask_of = [&](unsigned long long v) -> unsigned long long {
+    unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     if (KT < 64) m &= (1ull << KT) - 1;
     return m;
   };
@@ -159,7 +159,7 @@ template <bool GENERIC_ACT> __global__ __launch_bounds__(512, 2) void linear_bf1
     const int tile_n = tile + gridDim.x;
     int bxn = 0, byn = 0;
     if (tile_n < ntiles) raster(tile_n, bxn, byn);
-    const unsigned char live_n = (tile_n < ntiles) ? load_live(byn) : (unsigned char)0;
+    const unsigned long long live_n = (tile_n < ntiles) ? load_live(byn) : 0ull;
     f32x16_b acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -312,14 +312,14 @@ static void bf16_supertile(int nbx, int nby, int& sr, int& sc) {
   if (sc > nby) sc = nby;
 }
 
-extern "C" int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight, const uint8_t* tile_live,
+extern "C" int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight, const uint64_t* tile_live_mask,
                               const void* bias, int act, void* y, int64_t ldy, void* stream) {
   if (N <= 0 || out_features <= 0) return 0;
   if (in_features <= 0 || in_features % BBK != 0 || act < 0 || act > 7) return ZK_EINVAL;
   if (ldx % 8 != 0 || (((uintptr_t)x | (uintptr_t)weight) & 15) != 0) return ZK_EINVAL;  // 16-byte DMA granules
   LinBf16Args a{};
   a.N = N; a.IN = in_features; a.OUT = out_features;
-  a.x = (const __bf16*)x; a.ldx = ldx; a.w = (const __bf16*)weight; a.live = tile_live; a.bias = (const __bf16*)bias; a.act = act;
+  a.x = (const __bf16*)x; a.ldx = ldx; a.w = (const __bf16*)weight; a.live = (const unsigned long long*)tile_live_mask; a.bias = (const __bf16*)bias; a.act = act;
   a.y = (__bf16*)y; a.ldy = ldy;
   a.nbx = (int)((N + BBM - 1) / BBM);
   a.nby = (out_features + BBN - 1) / BBN;

@@ -159,6 +159,20 @@ def masked_mlp_masks(adjacency: BoolTensor, hidden_features: Sequence[int], resi
     return masks
 
 
+def live_tile_masks(mask: Tensor) -> Tensor:
+    """int64 [ceil(out / 256)]: bit k of word p is set iff rows [256 p, 256 p + 256) x columns [64 k, 64 k + 64) of
+    `mask` (bool or numeric [out, in], in % 64 == 0, in <= 4096) hold a non-zero — the `tile_live_mask` argument of
+    zk_linear_bf16."""
+    out_f, in_f = mask.shape
+    kt = in_f // 64
+    pad = (-out_f) % 256
+    t = mask != 0
+    t = torch.nn.functional.pad(t, (0, 0, 0, pad)) if pad else t
+    live = t.reshape(-1, 256, kt, 64).any(dim=3).any(dim=1)  # [panels, kt]
+    weights = torch.ones(kt, dtype=torch.int64, device=mask.device) << torch.arange(kt, dtype=torch.int64, device=mask.device)
+    return (live.to(torch.int64) * weights).sum(dim=1).contiguous()  # (bit 63 lands in the sign bit: the kernel reads raw bits)
+
+
 class _Bf16Plan:
     """Device-side tables for running a plain MaskedMLP (linear, activation, linear, ...) in bf16 through
     zk_linear_bf16: hidden units of every layer are reordered by dependency count (a reparametrisation:
@@ -187,10 +201,8 @@ class _Bf16Plan:
             self.perms.append(perm)
             self.masks_p.append(mp.contiguous())
             out_f, in_f = mp.shape
-            if in_f % 64 == 0:
-                pad = (-out_f) % 256
-                t = torch.nn.functional.pad(mp, (0, 0, 0, pad)) if pad else mp
-                self.live.append(t.reshape(-1, 256, in_f // 64, 64).any(dim=3).any(dim=1).to(torch.uint8).contiguous())
+            if in_f % 64 == 0 and in_f // 64 <= 64:
+                self.live.append(live_tile_masks(mp))
             else:
                 self.live.append(None)
             prev = perm
@@ -215,7 +227,16 @@ class _Bf16Plan:
         self.version = version
 
     def live_fraction(self) -> list[float]:
-        return [1.0 if t is None else float(t.float().mean()) for t in self.live]
+        """Fraction of 256 x 64 weight tiles each layer actually multiplies."""
+        out = []
+        for t, mp in zip(self.live, self.masks_p):
+            if t is None:
+                out.append(1.0)
+                continue
+            kt = mp.shape[1] // 64
+            bits = (t.unsqueeze(-1) >> torch.arange(kt, device=t.device)) & 1
+            out.append(float(bits.double().mean()))
+        return out
 
 
 class MaskedMLP(_FusedSequential):

@@ -334,8 +334,8 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor |
 
 
 def linear_bf16(x: Tensor, weight_masked: Tensor, bias: Tensor | None, tile_live: Tensor | None, act: int = 0) -> Tensor:
-    """bf16 act(x @ weight_masked.T + bias) with fp32 accumulation (zk_linear_bf16).  `tile_live`: uint8
-    [ceil(out/256), in/64], 0 where the (masked) weight tile is entirely zero."""
+    """bf16 act(x @ weight_masked.T + bias) with fp32 accumulation (zk_linear_bf16).  `tile_live`: int64
+    [ceil(out/256)] bit masks (zuko_amd.nn.live_tile_masks), bit k clear where the 256 x 64 weight tile is entirely zero."""
     _require_device(x, weight_masked, bias, tile_live)
     _no_grad_only(x, weight_masked, bias)
     out_f, in_f = weight_masked.shape
@@ -343,6 +343,8 @@ def linear_bf16(x: Tensor, weight_masked: Tensor, bias: Tensor | None, tile_live
         raise TypeError("zuko_amd.linear_bf16: x, weight and bias must be bfloat16")
     if in_f % 64 != 0:
         raise ValueError(f"zuko_amd.linear_bf16: in_features must be a multiple of 64 (got {in_f}); pad the conditioner input")
+    if tile_live is not None and (tile_live.dtype != torch.int64 or tile_live.numel() != -(-out_f // 256) or in_f > 4096):
+        raise ValueError("zuko_amd.linear_bf16: tile_live must be int64 [ceil(out / 256)] (and in_features <= 4096)")
     x2 = x.reshape(-1, in_f)
     if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) % 8 != 0) or x2.data_ptr() % 16 != 0:
         x2 = x2.contiguous()
