@@ -137,34 +137,50 @@ template <bool VEC4> __global__ __launch_bounds__(256) void linear_f32_mfma(LinA
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
+          // transposed product (A operand = weight rows): a lane ends up with 4 consecutive outputs of one sample
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].x, af[m].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].y, af[m].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].z, af[m].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].w, af[m].w, acc[m][n], 0, 0, 0);
         }
     }
     __syncthreads();
   }
 
-  // epilogue: D[row i = (r&3) + 8*(r>>2) + 4*(lane>>5)][col j = lane&31].  None / ReLU are applied inline; the
-  // other activations run afterwards in a ROLLED loop over the values this thread just stored (their inline
-  // expansions, unrolled 64 times, made the epilogue instruction-cache bound — measured on the bf16 kernel).
+  // epilogue: acc[m][n][r] = Y[sample m*32 + (lane&31)][output n*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]: 16-byte stores of
+  // four consecutive outputs.  None / ReLU are applied inline; the other activations run afterwards in a ROLLED loop
+  // over the values this thread just stored (their inline expansions, unrolled 64 times, made the epilogue
+  // instruction-cache bound — measured on the bf16 kernel).
   const float* bias = (const float*)a.bias;
   float* Y = (float*)a.y;
   const bool relu = a.act == ACT_RELU;
+  const bool vec_ok = (a.ldy % 4 == 0) && ((((uintptr_t)Y) & 15) == 0);
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int col = col0 + wc * 64 + n * 32 + (lane & 31);
-    if (col >= a.OUT) continue;
-    const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int q = 0; q < 4; ++q) {
+      const int col = col0 + wc * 64 + n * 32 + 8 * q + 4 * (lane >> 5);
+      float bv[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[m][n][r] + bv;
-        if (relu) v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
-        if (row < a.N) Y[row * a.ldy + col] = v;
+      for (int t = 0; t < 4; ++t) bv[t] = (bias && col + t < a.OUT) ? bias[col + t] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int64_t row = row0 + wr * 64 + m * 32 + (lane & 31);
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          v[t] = acc[m][n][4 * q + t] + bv[t];
+          if (relu) v[t] = v[t] < 0.f ? 0.f : v[t];  // NaN stays NaN, as torch.relu
+        }
+        if (row < a.N) {
+          float* dst = Y + row * a.ldy + col;
+          if (vec_ok && col + 4 <= a.OUT) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (col + t < a.OUT) dst[t] = v[t];
+          }
+        }
       }
     }
   }
@@ -172,11 +188,11 @@ template <bool VEC4> __global__ __launch_bounds__(256) void linear_f32_mfma(LinA
 #pragma unroll 1
     for (int e = 0; e < 64; ++e) {
       const int n = e >> 5, m = (e >> 4) & 1, r = e & 15;
-      const int col = col0 + wc * 64 + n * 32 + (lane & 31);
-      const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int col = col0 + wc * 64 + n * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+      const int64_t row = row0 + wr * 64 + m * 32 + (lane & 31);
       if (col < a.OUT && row < a.N) {
-        float* q = Y + row * a.ldy + col;
-        *q = apply_act<float>(*q, a.act);
+        float* p = Y + row * a.ldy + col;
+        *p = apply_act<float>(*p, a.act);
       }
     }
   }
