@@ -128,21 +128,21 @@ template <bool VEC4> __global__ __launch_bounds__(256) void linear_f32_mfma(LinA
     const int fi = lane & 31, fh = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < LBK / 8; ++kk) {
-      float4 af[2], bf[2];
+      typedef float f32x4_l __attribute__((ext_vector_type(4)));
+      f32x4_l af[2], bf[2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const float4*>(&As[wr * 64 + m * 32 + fi][kk * 8 + 4 * fh]);
+      for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f32x4_l*>(&As[wr * 64 + m * 32 + fi][kk * 8 + 4 * fh]);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const float4*>(&Bs[wc * 64 + n * 32 + fi][kk * 8 + 4 * fh]);
+      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4_l*>(&Bs[wc * 64 + n * 32 + fi][kk * 8 + 4 * fh]);
+      // transposed product (A operand = weight rows): a lane ends up with 4 consecutive outputs of one sample.
+      // k element outermost: consecutive MFMAs go to four different accumulators (a dependent one would have to
+      // wait for its predecessor's 16 passes — measured: 70 % -> pipe busy with the accumulator-major order)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          // transposed product (A operand = weight rows): a lane ends up with 4 consecutive outputs of one sample
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].x, af[m].x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].y, af[m].y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].z, af[m].z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n].w, af[m].w, acc[m][n], 0, 0, 0);
-        }
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n][r], af[m][r], acc[m][n], 0, 0, 0);
     }
     __syncthreads();
   }
