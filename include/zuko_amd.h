@@ -113,6 +113,19 @@ int zk_linear(int dtype, int64_t N, int in_features, int out_features, const voi
 int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight, const uint64_t* tile_live_mask,
                    const void* bias, int act, void* y, int64_t ldy, void* stream);
 
+/* Last conditioner layer of a bf16 autoregressive SPLINE transform with the spline evaluated in the GEMM's
+ * epilogue — replaces `phi = hyper[-1](h)` + `MonotonicRQSTransform(*unpack(phi)).call_and_ladj(x)` + the
+ * feature sum (zuko/flows/autoregressive.py:211-218, zuko/transforms.py:469-567, :210-214) without writing
+ * phi[N, D, 3K-1] (50 GB per transform at cfg5).  `weight_panels` / `bias_panels` hold the (masked) weight rows
+ * regrouped in panels of 256: panel p = the 3K-1 parameter rows of features p*FP .. p*FP+FP-1, FP = 256 / (3K-1),
+ * zero rows behind (zuko_amd/nn.py:_Bf16Plan builds them); `tile_live_mask` as in zk_linear_bf16, one word per
+ * panel.  h[N, in] is the last hidden activation, x / y[N, features] the transform's input / output (bf16),
+ * `partial` a caller-owned fp32 workspace [panels, N], ladj[N] fp32 = sum over features of log|dy/dx|.
+ * K in {8, 16}. */
+int zk_linear_bf16_rqs(int64_t N, int in_features, int panels, const void* h, int64_t ldh, const void* weight_panels, const uint64_t* tile_live_mask,
+                       const void* bias_panels, int K, int features, double bound, double slope, const void* x, int64_t ldx, void* y, int64_t ldy,
+                       float* partial, float* ladj, void* stream);
+
 /* ---- fused masked-autoregressive layer (the dominant kernel of NSF / MAF log_prob) ----------------- *
  * Replaces, for one MaskedAutoregressiveTransform (zuko/flows/autoregressive.py:207-218 `meta` +
  * zuko/transforms.py:1005-1007 `call_and_ladj`):  phi = MaskedMLP(cat(x, c)) (zuko/nn.py:217-218 per

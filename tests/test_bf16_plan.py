@@ -58,3 +58,34 @@ def test_bf16_plan_skips_half_of_the_last_layer_at_cfg5_shape():
     plan = _Bf16Plan([L(m) for m in masks])
     frac = plan.live_fraction()
     assert 0.55 < frac[-1] < 0.65 and all(0.5 < f <= 0.7 for f in frac[:-1])
+
+
+@pytest.mark.parametrize("D,K,hidden", [(64, 16, [128, 128]), (70, 8, [64])])
+def test_spline_panels_regroup_the_last_layer(D, K, hidden):
+    """zk_linear_bf16_rqs wants the last layer's rows in panels of 256 = the 3K-1 parameters of 256 // (3K-1) whole
+    features: panel p, row (f % FP) * total + j == original row f * total + j; padding rows are zero and dead."""
+    from zuko_amd.nn import MaskedMLP, _Bf16Plan
+
+    torch.manual_seed(K)
+    total = 3 * K - 1
+    fp = 256 // total
+    order = torch.arange(D)
+    adjacency = (order[:, None] > order).repeat_interleave(total, dim=0)
+    mlp = MaskedMLP(adjacency, hidden_features=hidden).double()
+    lins = list(mlp)[0::2]
+    plan = _Bf16Plan(lins)
+    plan.refresh(lins)
+    wp, bp, live = plan.spline_panels(lins, K, D)
+    panels = -(-D // fp)
+    assert wp.shape == (panels * 256, hidden[-1]) and bp.shape == (panels * 256,) and live.shape == (panels,)
+    w, b = plan.weights[-1], plan.biases[-1]
+    used = torch.zeros(panels * 256, dtype=bool)
+    for f in range(D):
+        r0 = (f // fp) * 256 + (f % fp) * total
+        assert torch.equal(wp[r0 : r0 + total], w[f * total : (f + 1) * total]) and torch.equal(bp[r0 : r0 + total], b[f * total : (f + 1) * total])
+        used[r0 : r0 + total] = True
+    assert (wp[~used] == 0).all() and (bp[~used] == 0).all()
+    nz = (wp != 0).reshape(panels, 256, -1, 64).any(dim=3).any(dim=1)
+    bits = ((live.unsqueeze(-1) >> torch.arange(hidden[-1] // 64)) & 1).bool()
+    assert not (nz & ~bits).any()
+    assert plan.spline_panels(lins, K, D)[0] is wp  # cached per parameter version

@@ -325,6 +325,22 @@ def test_nsf_bf16_log_prob(dev):
     d = (lp.cpu() - emu).abs()
     assert d.max() < 0.5 and d.mean() < 0.05, f"vs bf16 emulation: max {d.max():.3f} mean {d.mean():.3f}"
 
+    # the spline-in-epilogue kernel (default) and the unfused path (phi through HBM) see bit-identical phi
+    import os
+
+    os.environ["ZUKO_AMD_BF16_UNFUSED"] = "1"
+    try:
+        with torch.no_grad():
+            t0 = flow_b.transform.transforms[0]()
+            y_u, l_u = t0.call_and_ladj(x.to(dev))
+    finally:
+        os.environ.pop("ZUKO_AMD_BF16_UNFUSED")
+    with torch.no_grad():
+        y_f, l_f = flow_b.transform.transforms[0]().call_and_ladj(x.to(dev))
+    assert y_f.dtype == torch.bfloat16 and l_f.dtype == torch.float32
+    assert torch.equal(y_f, y_u), f"{(y_f != y_u).sum().item()} of {y_f.numel()} outputs differ between the fused and the unfused bf16 layer"
+    assert torch.allclose(l_f, l_u, rtol=1e-5, atol=1e-4)
+
     # (b) the fp32 oracle on the same (bf16-valued) weights: bf16-level agreement
     flow32 = F.NSF(D, 0, transforms=T, bins=K, hidden_features=[128, 128])
     flow32.load_state_dict({k: (r(v) if v.is_floating_point() else v) for k, v in flow.state_dict().items()})

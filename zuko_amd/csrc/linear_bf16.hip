@@ -21,7 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "zk_common.h"
+#include "zk_univariate.h"
 
 namespace zk {
 
@@ -46,6 +46,12 @@ struct LinBf16Args {
   int nbx, nby, sr, sc, nsc;  // tile grid and super-tile shape (nsc super-tiles per row of super-tiles)
   int dbg;                    // ZUKO_AMD_BF16_DEBUG (ablations: 1 = no result stores, 2 = no epilogue at all)
   int ntiles;                 // raster length (super-tiles are padded: out-of-range tiles are filtered on the host)
+  // spline epilogue (SK > 0): the layer's outputs never leave the CU as phi
+  const __bf16* sx; int64_t ldsx;   // transform input  x[N, D]
+  __bf16* sy; int64_t ldsy;         // transform output y[N, D]
+  float* partial;                   // [panels][N]: per-panel sums of log|dy/dx|
+  int D;                            // features; panel p holds features [p * FP, p * FP + FP)
+  RqsLeanConst lc;
 };
 
 __device__ __forceinline__ float act_bf(float v, int act) {
@@ -66,6 +72,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lin_bf16_lds[];
 #define B_EPI_ROWB 144                       /* epilogue image: 64 cols of bf16 per row + 16 B pad */
 #define B_EPI_WAVE (64 * B_EPI_ROWB)         /* one wave's half sub-tile: 64 rows */
 #define B_LDS_BYTES (2 * B_STAGE_BYTES + 8 * B_EPI_WAVE - B_STAGE_BYTES)  /* stage 0 | stage 1 ∪ epilogue image */
+#define S_ROWB 520                           /* spline image: 256 bf16 per sample + 8 B pad (130 dwords: 2-way conflicts at most) */
+#define S_LDS_BYTES (B_STAGE_BYTES + 128 * S_ROWB + 11 * 128 * 4)  /* stage 0 | image of 128 samples | per-feature log-derivatives */
 
 typedef unsigned int u32x2_b __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_b __attribute__((ext_vector_type(4)));
@@ -84,7 +92,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 // first k-stage of the NEXT tile is already requested, so its DMA latency hides behind the stores.
 // GENERIC_ACT: activations other than none / ReLU are applied on the transposed bf16 image inside a rolled loop
 // (their inline expansions, unrolled over the 128 accumulators of a lane, made the epilogue instruction-cache bound)
-template <bool GENERIC_ACT> __global__ __launch_bounds__(512, 2) void linear_bf16_kernel(LinBf16Args a) {
+// SK > 0: spline epilogue.  The weight rows are laid out in PANELS of 256 that hold the 3 SK - 1 spline parameters
+// of FP = 256 / (3 SK - 1) whole features (rows past FP (3 SK - 1) are zero padding), so a tile owns every
+// parameter of FP features for 256 samples: bias-added outputs go to an LDS image as bf16 (the rounding the
+// unfused path applies when it writes phi), one thread per (sample, feature) evaluates rqs_lean on them, y
+// leaves as bf16 and the FP log-derivatives of a sample are summed into partial[panel][sample].
+template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void linear_bf16_kernel(LinBf16Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // wave tile: samples [wm*128, +128), outputs [wn*64, +64)
@@ -244,6 +257,59 @@ template <bool GENERIC_ACT> __global__ __launch_bounds__(512, 2) void linear_bf1
     const int col_w = by_c * BBN + wn * 64;
     const bool vec_ok = (a.ldy % 8 == 0) && ((((uintptr_t)a.y) & 15) == 0);
     const bool relu = a.act == 1;
+    if constexpr (SK > 0) {
+      constexpr int TOTAL = 3 * SK - 1, FP = 256 / TOTAL, ROUNDS = (FP + 3) / 4;
+      unsigned char* simg = lin_bf16_lds + B_STAGE_BYTES;                       // [128 samples][S_ROWB]
+      float* ljs = reinterpret_cast<float*>(lin_bf16_lds + B_STAGE_BYTES + 128 * S_ROWB);  // [FP][128]
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        if (wm == h) {  // the four waves that hold samples [128 h, 128 h + 128) of the tile
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const u32x2_b bv = bias4[j][q];
+                const float b0 = __builtin_bit_cast(float, bv.x << 16), b1 = __builtin_bit_cast(float, bv.x & 0xffff0000u);
+                const float b2 = __builtin_bit_cast(float, bv.y << 16), b3 = __builtin_bit_cast(float, bv.y & 0xffff0000u);
+                const u32x2_b pk = {pack_bf16x2(acc[i][j][4 * q + 0] + b0, acc[i][j][4 * q + 1] + b1),
+                                    pack_bf16x2(acc[i][j][4 * q + 2] + b2, acc[i][j][4 * q + 3] + b3)};
+                *reinterpret_cast<u32x2_b*>(simg + (i * 32 + fr) * S_ROWB + (wn * 64 + j * 32 + q * 8 + kg * 4) * 2) = pk;
+              }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+          const int id = tid + 512 * rd;
+          const int s_ = id & 127, fl = id >> 7;
+          const int feat = by_c * FP + fl;
+          const int64_t row = (int64_t)bx_c * BBM + h * 128 + s_;
+          if (fl < FP) {
+            float lj = 0.f;
+            if (feat < a.D && row < a.N) {
+              float p[TOTAL];
+              const unsigned short* src = reinterpret_cast<const unsigned short*>(simg + s_ * S_ROWB + fl * TOTAL * 2);
+#pragma unroll
+              for (int t = 0; t < TOTAL; ++t) p[t] = __builtin_bit_cast(float, (unsigned)src[t] << 16);
+              const float xv = (float)a.sx[row * a.ldsx + feat];
+              float yv;
+              rqs_lean<SK, false>([&](int t) { return p[t]; }, [&](int t) { return p[SK + t]; }, [&](int t) { return p[2 * SK + t]; }, a.lc, xv, yv, lj);
+              a.sy[row * a.ldsy + feat] = (__bf16)yv;
+            }
+            ljs[fl * 128 + s_] = lj;
+          }
+        }
+        __syncthreads();
+        if (tid < 128) {
+          const int64_t row = (int64_t)bx_c * BBM + h * 128 + tid;
+          float sum = 0.f;
+#pragma unroll
+          for (int fl = 0; fl < FP; ++fl) sum += ljs[fl * 128 + tid];
+          if (row < a.N) a.partial[(size_t)by_c * a.N + row] = sum;
+        }
+      }
+    } else
     if (!(a.dbg & 2))
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -312,6 +378,43 @@ static void bf16_supertile(int nbx, int nby, int& sr, int& sc) {
   if (sc > nby) sc = nby;
 }
 
+static int launch_linear_bf16(LinBf16Args a, int spline_k, hipStream_t stream) {
+  a.nbx = (int)((a.N + BBM - 1) / BBM);
+  a.nby = (a.OUT + BBN - 1) / BBN;
+  bf16_supertile(a.nbx, a.nby, a.sr, a.sc);
+  a.nsc = (a.nby + a.sc - 1) / a.sc;
+  const int64_t ntiles = (int64_t)a.nbx * a.nby;
+  if (ntiles > 0x7fffffff) return ZK_EINVAL;
+  a.ntiles = (int)ntiles;
+  { const char* e = getenv("ZUKO_AMD_BF16_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  const int act = a.act;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    n_cu = v;
+  }
+  const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);  // persistent: one 8-wave block per CU
+  if (spline_k == 8) hipLaunchKernelGGL((linear_bf16_kernel<false, 8>), dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, a);
+  else if (spline_k == 16) hipLaunchKernelGGL((linear_bf16_kernel<false, 16>), dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, a);
+  else if (act <= 1) hipLaunchKernelGGL((linear_bf16_kernel<false, 0>), dim3((unsigned)grid), dim3(512), B_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL((linear_bf16_kernel<true, 0>), dim3((unsigned)grid), dim3(512), B_LDS_BYTES, stream, a);
+  return ZK_LAUNCH_CHECK();
+}
+
+// out[n] = sum_p partial[p][n]
+__global__ __launch_bounds__(256) void panel_sum_kernel(int P, int64_t N, const float* __restrict__ partial, float* __restrict__ out) {
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partial[(size_t)p * N + n];
+    out[n] = s;
+  }
+}
+
 extern "C" int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* weight, const uint64_t* tile_live_mask,
                               const void* bias, int act, void* y, int64_t ldy, void* stream) {
   if (N <= 0 || out_features <= 0) return 0;
@@ -321,24 +424,25 @@ extern "C" int zk_linear_bf16(int64_t N, int in_features, int out_features, cons
   a.N = N; a.IN = in_features; a.OUT = out_features;
   a.x = (const __bf16*)x; a.ldx = ldx; a.w = (const __bf16*)weight; a.live = (const unsigned long long*)tile_live_mask; a.bias = (const __bf16*)bias; a.act = act;
   a.y = (__bf16*)y; a.ldy = ldy;
-  a.nbx = (int)((N + BBM - 1) / BBM);
-  a.nby = (out_features + BBN - 1) / BBN;
-  bf16_supertile(a.nbx, a.nby, a.sr, a.sc);
-  a.nsc = (a.nby + a.sc - 1) / a.sc;
-  const int64_t ntiles = (int64_t)a.nbx * a.nby;
-  if (ntiles > 0x7fffffff) return ZK_EINVAL;
-  a.ntiles = (int)ntiles;
-  { const char* e = getenv("ZUKO_AMD_BF16_DEBUG"); a.dbg = e ? atoi(e) : 0; }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)linear_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
-    n_cu = v;
-  }
-  const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);  // persistent: one 8-wave block per CU
-  if (act <= 1) hipLaunchKernelGGL(linear_bf16_kernel<false>, dim3((unsigned)grid), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(linear_bf16_kernel<true>, dim3((unsigned)grid), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
+  return launch_linear_bf16(a, 0, (hipStream_t)stream);
+}
+
+extern "C" int zk_linear_bf16_rqs(int64_t N, int in_features, int panels, const void* h, int64_t ldh, const void* weight_panels, const uint64_t* tile_live_mask,
+                                  const void* bias_panels, int K, int features, double bound, double slope, const void* x, int64_t ldx, void* y, int64_t ldy,
+                                  float* partial, float* ladj, void* stream) {
+  if (N <= 0 || features <= 0) return 0;
+  if (K != 8 && K != 16) return ZK_EINVAL;
+  const int FP = 256 / (3 * K - 1);
+  if (in_features <= 0 || in_features % BBK != 0 || panels != (features + FP - 1) / FP) return ZK_EINVAL;
+  if (ldh % 8 != 0 || (((uintptr_t)h | (uintptr_t)weight_panels) & 15) != 0) return ZK_EINVAL;
+  LinBf16Args a{};
+  a.N = N; a.IN = in_features; a.OUT = panels * 256;
+  a.x = (const __bf16*)h; a.ldx = ldh; a.w = (const __bf16*)weight_panels; a.live = (const unsigned long long*)tile_live_mask; a.bias = (const __bf16*)bias_panels; a.act = 0;
+  a.sx = (const __bf16*)x; a.ldsx = ldx; a.sy = (__bf16*)y; a.ldsy = ldy; a.partial = partial; a.D = features;
+  a.lc = rqs_lean_const(bound, log(slope));
+  const int rc = launch_linear_bf16(a, K, (hipStream_t)stream);
+  if (rc) return rc;
+  int64_t nb = (N + 255) / 256;
+  hipLaunchKernelGGL(panel_sum_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, panels, N, partial, ladj);
   return ZK_LAUNCH_CHECK();
 }

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 from functools import partial
 import math
+import os
 from math import ceil, prod
 from typing import Callable, Sequence
 
@@ -164,6 +165,18 @@ class MaskedAutoregressiveTransform(LazyTransform):
                 return lay, math.pi, slope
         return None
 
+    def _rqs_spec(self):
+        """(K, bound, slope) when the univariate map is a plain MonotonicRQSTransform over packed (K, K, K-1) parameters."""
+        u = self.univariate
+        f, kw = (u.func, dict(u.keywords)) if isinstance(u, partial) else (u, {})
+        if (isinstance(u, partial) and u.args) or f is not MonotonicRQSTransform:
+            return None
+        shapes = [tuple(s) for s in self.shapes]
+        if not (len(shapes) == 3 and len(shapes[0]) == 1 and shapes[0] == shapes[1] and shapes[2] == (shapes[0][0] - 1,)):
+            return None
+        slope, bound = kw.pop("slope", 1e-3), kw.pop("bound", 5.0)
+        return None if kw else (shapes[0][0], bound, slope)
+
     def fused_state(self, device: torch.device, inverse: bool = False):
         """Plan + device tables of the fused kernel (built once per device), or None.  `inverse=True`
         returns the group-aligned plan used by the partial (wavefront) inverse sweeps, when the layer
@@ -221,10 +234,34 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             return None
         return self.lazy.fused_state(x.device)
 
+    def _bf16_spline(self, x: Tensor):
+        """bf16 storage path (cfg5): conditioner on bf16 MFMA, the spline in the last layer's epilogue — phi stays on chip."""
+        lazy = self.lazy
+        if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() >= 1) or os.environ.get("ZUKO_AMD_BF16_UNFUSED", "0") == "1":
+            return None
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in lazy.hyper.parameters())):
+            return None
+        spec = lazy._rqs_spec()
+        if spec is None or spec[0] not in (8, 16) or not hasattr(lazy.hyper, "bf16_rqs"):
+            return None
+        c = self.c
+        if c is not None:
+            xb, cb = broadcast(x, c, ignore=1)
+            inp = torch.cat((xb, cb), dim=-1)
+        else:
+            xb, inp = x, x
+        D = lazy.features
+        batch = xb.shape[:-1]
+        out = lazy.hyper.bf16_rqs(inp.reshape(-1, inp.shape[-1]), xb.reshape(-1, D), *spec)
+        if out is None:
+            return None
+        return out[0].reshape(batch + (D,)), out[1].reshape(batch)
+
     def call_and_ladj(self, x: Tensor):
         st = self._fused(x)
         if st is None:
-            return super().call_and_ladj(x)
+            out = self._bf16_spline(x)
+            return out if out is not None else super().call_and_ladj(x)
         lazy, c = self.lazy, self.c
         D = lazy.features
         if c is not None:

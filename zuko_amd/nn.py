@@ -226,6 +226,31 @@ class _Bf16Plan:
             prev = perm
         self.version = version
 
+    def spline_panels(self, lins: Sequence["MaskedLinear"], K: int, features: int):
+        """(weight_panels, bias_panels, live) of the LAST layer for zk_linear_bf16_rqs: its rows (feature f, parameter j) ->
+        panel f // FP, row (f % FP) * (3K - 1) + j, FP = 256 // (3K - 1), zero rows behind.  Cached per parameter version
+        (call after `refresh`)."""
+        key = (self.version, K, features)
+        if self.__dict__.get("_sp_key") != key:
+            total = 3 * K - 1
+            fp = 256 // total
+            panels = -(-features // fp)
+            w, b, mp = self.weights[-1], self.biases[-1], self.masks_p[-1]
+            in_f = w.shape[1]
+            feat = torch.arange(features, device=w.device)
+            dst = ((feat // fp) * 256 + (feat % fp) * total).repeat_interleave(total) + torch.arange(total, device=w.device).repeat(features)
+            wp = torch.zeros((panels * 256, in_f), dtype=w.dtype, device=w.device)
+            wp[dst] = w
+            bp = None
+            if b is not None:
+                bp = torch.zeros(panels * 256, dtype=b.dtype, device=w.device)
+                bp[dst] = b
+            mpan = torch.zeros((panels * 256, in_f), dtype=torch.bool, device=w.device)
+            mpan[dst] = mp.bool()
+            live = live_tile_masks(mpan) if in_f // 64 <= 64 else None
+            self._sp_key, self._sp = key, (wp, bp, live)
+        return self._sp
+
     def live_fraction(self) -> list[float]:
         """Fraction of 256 x 64 weight tiles each layer actually multiplies."""
         out = []
@@ -288,6 +313,21 @@ class MaskedMLP(_FusedSequential):
     def _apply(self, fn, *args, **kwargs):  # device / dtype moves invalidate the bf16 tables
         self.__dict__.pop("_bf16_plan_cache", None)
         return super()._apply(fn, *args, **kwargs)
+
+    def bf16_rqs(self, inp: Tensor, x: Tensor, K: int, bound: float, slope: float):
+        """bf16 autoregressive spline layer with phi kept on chip: hidden layers through zk_linear_bf16, last layer +
+        spline + feature sum through zk_linear_bf16_rqs.  `inp` [N, in] conditioner input, x [N, D] transform input.
+        Returns (y, ladj) or None when the module has no bf16 plan."""
+        plan = self._bf16_plan()
+        if plan is None:
+            return None
+        lins = list(self)[0::2]
+        plan.refresh(lins)
+        h = inp
+        for w, b, live in zip(plan.weights[:-1], plan.biases[:-1], plan.live[:-1]):
+            h = ops.linear_bf16(h, w, b, live, plan.act)
+        wp, bp, lv = plan.spline_panels(lins, K, x.shape[-1])
+        return ops.linear_bf16_rqs(h, wp, bp, lv, x, K, bound, slope)
 
     def forward(self, x: Tensor) -> Tensor:
         if x.dtype == torch.bfloat16 and x.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):

@@ -357,6 +357,29 @@ def linear_bf16(x: Tensor, weight_masked: Tensor, bias: Tensor | None, tile_live
     return y.reshape(x.shape[:-1] + (out_f,))
 
 
+def linear_bf16_rqs(h: Tensor, weight_panels: Tensor, bias_panels: Tensor | None, tile_live: Tensor | None, x: Tensor, K: int, bound: float = 5.0,
+                    slope: float = 1e-3):
+    """(y bf16 [N, D], ladj fp32 [N]) of a bf16 autoregressive spline layer whose last conditioner layer and spline run
+    in one kernel (zk_linear_bf16_rqs): h [N, in] last hidden activation, x [N, D] transform input, weights in
+    feature panels (zuko_amd.nn._Bf16Plan.spline_panels)."""
+    _require_device(h, weight_panels, bias_panels, tile_live, x)
+    _no_grad_only(h, weight_panels, bias_panels, x)
+    rows, in_f = weight_panels.shape
+    panels = rows // 256
+    N, D = x.shape
+    if h.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or weight_panels.dtype != torch.bfloat16:
+        raise TypeError("zuko_amd.linear_bf16_rqs: bfloat16 tensors expected")
+    h2 = h if (h.stride(-1) == 1 and h.stride(0) % 8 == 0 and h.data_ptr() % 16 == 0) else h.contiguous()
+    x2 = x if x.stride(-1) == 1 else x.contiguous()
+    y = torch.empty((N, D), dtype=torch.bfloat16, device=x.device)
+    ladj = torch.empty(N, dtype=torch.float32, device=x.device)
+    partial = torch.empty((panels, N), dtype=torch.float32, device=x.device)
+    err = _C.lib().zk_linear_bf16_rqs(N, in_f, panels, _ptr(h2), h2.stride(0) if N > 1 else in_f, _ptr(weight_panels), _ptr(tile_live), _ptr(bias_panels), K, D,
+                                      bound, slope, _ptr(x2), x2.stride(0) if N > 1 else D, _ptr(y), D, _ptr(partial), _ptr(ladj), _stream())
+    _C.check(err, "zk_linear_bf16_rqs")
+    return y, ladj
+
+
 def diag_normal_log_prob(z: Tensor, loc: Tensor, scale: Tensor, ladj: Tensor | None = None) -> Tensor:
     _require_device(z, loc, scale, ladj)
     from . import autograd as AG
