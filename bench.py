@@ -196,7 +196,10 @@ def main() -> None:
         for name, recs in prof.items():
             groups = {}
             for a, b, cargs in recs:
-                sizes = cargs[0:3] if name == "zk_linear_bf16" else cargs[1:4]  # (dtype-less signature)
+                if name == "zk_linear_bf16_rqs":  # N, in, panels, K, features
+                    sizes = (cargs[0], cargs[1], cargs[2], cargs[8], cargs[9])
+                else:
+                    sizes = cargs[0:3] if name == "zk_linear_bf16" else cargs[1:4]  # (dtype-less signature)
                 key = (name,) + tuple(v for v in sizes if isinstance(v, int))
                 groups.setdefault(key, []).append(a.elapsed_time(b))
             for key, ts in groups.items():
@@ -284,7 +287,10 @@ def zuko_amd_roofline(kernels: dict, B: int):
     for name, rec in kernels.items():
         row = {"kernel": name, **rec}
         parts = name.split()
-        if parts[0] == "zk_linear_bf16":
+        if parts[0] == "zk_linear_bf16_rqs":  # last layer + spline in one kernel: useful (unpadded, dense-equivalent) FLOPs
+            n, fin, k, feats = int(parts[1]), int(parts[2]), int(parts[4]), int(parts[5])
+            row.update(bound="mfma", achieved=2.0 * n * fin * feats * (3 * k - 1) / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s")
+        elif parts[0] == "zk_linear_bf16":
             n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
             row.update(bound="mfma", achieved=2.0 * n * fin * fout / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s")
         elif parts[0] == "zk_linear":
