@@ -27,7 +27,6 @@ namespace zk {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16_b __attribute__((ext_vector_type(16)));
-typedef float f32x4_b __attribute__((ext_vector_type(4)));
 
 #define BBM 256
 #define BBN 256

@@ -133,32 +133,6 @@ template <typename T, int K, class M = MathIEEE<T>, typename Ld> __device__ __fo
   for (int j = 1; j < K; ++j) kd[j] = M::exp(softclip<T, M>(ld(j - 1), ls));
 }
 
-// k = #(knots < v) - 1 with a STRICT compare (transforms.py:521-526); NaN compares false -> k = -1
-template <typename T, int K> __device__ __forceinline__ int rqs_bin(const T (&knot)[K + 1], T v) {
-  int cnt = 0;
-#pragma unroll
-  for (int j = 0; j <= K; ++j) cnt += (knot[j] < v) ? 1 : 0;
-  return cnt - 1;
-}
-
-template <typename T, int K>
-__device__ __forceinline__ void rqs_select(const T (&kx)[K + 1], const T (&ky)[K + 1], const T (&kd)[K + 1], int k, bool& inside, T& x0, T& x1, T& y0,
-                                           T& y1, T& d0, T& d1) {
-  inside = (k >= 0) && (k < K);
-  int kw = k < 0 ? k + K : (k >= K ? k - K : k);  // python's k % K for k in [-1, K]  (transforms.py:502)
-  x0 = kx[0]; x1 = kx[1]; y0 = ky[0]; y1 = ky[1]; d0 = kd[0]; d1 = kd[1];
-#pragma unroll
-  for (int j = 1; j < K; ++j) {
-    bool s = (kw == j);
-    x0 = s ? kx[j] : x0;
-    x1 = s ? kx[j + 1] : x1;
-    y0 = s ? ky[j] : y0;
-    y1 = s ? ky[j + 1] : y1;
-    d0 = s ? kd[j] : d0;
-    d1 = s ? kd[j + 1] : d1;
-  }
-}
-
 // Bin search and corner gather in one sweep: k = #(search knots < v) - 1 (strict compare,
 // transforms.py:521-526) and the corners of the bin selected by the SAME compares — the knots are
 // increasing, so "knot j < v" is a prefix property and the last true j is the bin.  For v outside
