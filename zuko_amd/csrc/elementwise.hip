@@ -455,6 +455,9 @@ struct RqsStreamArgs {
   RqsLeanConst c;
 };
 
+#ifndef ZK_NT
+#define ZK_NT 1  /* phi is streamed once: non-temporal loads keep it from displacing x / y lines in L2 */
+#endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint32x4_t __attribute__((ext_vector_type(4)));
 // LM: 0 no ladj, 1 ladj[N, D], 2 ladj[N] with D == 64 (one row per tile), 3 ladj[N] for any other admissible D
@@ -485,7 +488,7 @@ template <int K, bool INV, int LM, bool BF> __global__ __launch_bounds__(256) vo
     const f32x4_t* src = phi4 + (t) * TILE_V;                                \
     _Pragma("unroll") for (int r = 0; r < NV; ++r) {                        \
       const int i = r * 64 + lane;                                          \
-      nxt[r] = src[((r + 1) * 64 <= TILE_V || i < TILE_V) ? i : TILE_V - 1]; \
+      nxt[r] = ZK_NT ? __builtin_nontemporal_load(&src[((r + 1) * 64 <= TILE_V || i < TILE_V) ? i : TILE_V - 1]) : src[((r + 1) * 64 <= TILE_V || i < TILE_V) ? i : TILE_V - 1]; \
     }                                                                       \
     xn = BF ? (float)((const __bf16*)a.x)[(t) * 64 + lane] : ((const float*)a.x)[(t) * 64 + lane]; \
   }
