@@ -100,3 +100,23 @@ def test_flow_state_dict_layout_and_pickle(tmp_path):
     for (k1, v1), (k2, v2) in zip(flow.state_dict().items(), again.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     assert "MaskedAutoregressiveTransform" in repr(flow)
+
+
+def test_product_code_never_touches_the_oracle_or_a_cpu_fallback():
+    """The oracle is test infrastructure: nothing under zuko_amd/ may import it, and the product path must fail
+    loudly (not fall back) on CPU tensors."""
+    import pathlib
+    import re
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|zuko_oracle", re.M)
+    for f in (root / "zuko_amd").rglob("*.py"):
+        assert not pat.search(f.read_text()), f"{f} references the oracle"
+    import torch
+
+    from zuko_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.rqs_forward(torch.zeros(4, 2), torch.zeros(4, 2, 8), torch.zeros(4, 2, 8), torch.zeros(4, 2, 7))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(3, 8))
