@@ -348,3 +348,33 @@ def test_nsf_bf16_log_prob(dev):
         lp32 = flow32.to(dev)().log_prob(x.float().to(dev)).cpu()
     rel = ((lp.cpu() - lp32).abs() / lp32.abs().clamp_min(1.0))
     assert rel.max() < 0.05 and rel.mean() < 0.01, f"vs fp32: max rel {rel.max():.3f} mean {rel.mean():.4f}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,K,ctx", [(300, 128, 8, 0), (77, 64, 16, 64), (1024, 192, 16, 0)])
+def test_bf16_layer_with_spline_epilogue_equals_unfused_layer(dev, N, D, K, ctx, monkeypatch):
+    """zk_linear_bf16_rqs (phi on chip) against zk_linear_bf16 + the bf16 stream kernel (phi through HBM) on ragged
+    batches, a last panel that is only partly filled, and a context: the same bf16 phi, so y is bit-identical."""
+    from zuko_amd.flows import MaskedAutoregressiveTransform
+    from zuko_amd.transforms import MonotonicRQSTransform
+
+    torch.manual_seed(N + D)
+    t = MaskedAutoregressiveTransform(D, ctx, univariate=MonotonicRQSTransform, shapes=[(K,), (K,), (K - 1,)], hidden_features=[128, 192])
+    t = t.to(dev).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(N, D, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    c = torch.randn(N, ctx, generator=g).to(torch.bfloat16).to(dev) if ctx else None
+    with torch.no_grad():
+        y_f, l_f = t(c).call_and_ladj(x)
+        monkeypatch.setenv("ZUKO_AMD_BF16_UNFUSED", "1")
+        if N * D % 64 == 0:  # (the unfused bf16 spline kernel needs whole 64-element tiles)
+            y_u, l_u = t(c).call_and_ladj(x)
+            assert torch.equal(y_f, y_u)
+            assert torch.allclose(l_f, l_u, rtol=1e-5, atol=1e-4)
+        # and against float32 arithmetic on the same bf16 values (fp32 layer-wise kernels)
+        t32 = MaskedAutoregressiveTransform(D, ctx, univariate=MonotonicRQSTransform, shapes=[(K,), (K,), (K - 1,)], hidden_features=[128, 192]).to(dev)
+        t32.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in t.state_dict().items()})
+        y32, l32 = t32(None if c is None else c.float()).call_and_ladj(x.float())
+    assert y_f.shape == (N, D) and l_f.shape == (N,) and torch.isfinite(l_f).all()
+    assert (y_f.float() - y32).abs().max() < 0.15 and (y_f.float() - y32).abs().mean() < 0.01
+    assert ((l_f - l32).abs() / l32.abs().clamp_min(1.0)).mean() < 0.05
