@@ -204,3 +204,28 @@ def test_univariate_transforms(dev, batched):
             J = torch.autograd.functional.jacobian(t, x)
             assert (torch.triu(J, diagonal=+1) == 0).all() and (torch.tril(J, diagonal=-1) == 0).all(), t
             assert torch.allclose(t.log_abs_det_jacobian(x, y), torch.diag(J).abs().log(), atol=1e-4), t
+
+
+def test_lazy_inverse_and_unconditional(dev):
+    """zuko/lazy.py:74-98, 242-330: `LazyTransform.inv` swaps the directions of the transforms it builds;
+    `UnconditionalTransform` / `UnconditionalDistribution` wrap parameter-free constructors."""
+    from zuko_amd.flows import MaskedAutoregressiveTransform
+    from zuko_amd.lazy import Flow, LazyInverse, UnconditionalDistribution, UnconditionalTransform
+    from zuko_amd.distributions import DiagNormal
+    from zuko_amd.transforms import SoftclipTransform
+
+    torch.manual_seed(6)
+    t = MaskedAutoregressiveTransform(5, 3).to(dev)
+    ti = t.inv
+    assert isinstance(ti, LazyInverse) and ti.inv is t
+    x, c = torch.randn(32, 5, device=dev), torch.randn(32, 3, device=dev)
+    with torch.no_grad():
+        y = t(c)(x)
+        assert torch.allclose(ti(c)(y), x, atol=1e-4)
+        assert torch.allclose(ti(c).inv(x), y, atol=1e-5)
+        # a flow whose generative direction is the conditioner's forward pass (fast sampling, slow density)
+        flow = Flow(ti, UnconditionalDistribution(DiagNormal, torch.zeros(5, device=dev), torch.ones(5, device=dev), buffer=True)).to(dev)
+        s = flow(c).sample()
+        assert s.shape == (32, 5) and torch.isfinite(flow(c).log_prob(s)).all()
+        u = UnconditionalTransform(SoftclipTransform, bound=6.0)
+        assert torch.allclose(u().inv(u()(x)), x, atol=1e-4)
