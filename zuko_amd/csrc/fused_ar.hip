@@ -119,6 +119,10 @@ template <int CH, int NR> struct RingT {
 // ---- univariate epilogues -------------------------------------------------------------------------
 struct UniAffine {
   static constexpr int TOTAL = 2, FPL = 2, NT = 1;
+  template <bool INV> static __device__ __forceinline__ void poison(float* p, int base, float nan_or_zero) {
+    p[base + 0] += nan_or_zero;
+    p[base + 1] += nan_or_zero;
+  }
   template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj) {
     affine_fwd<float, MathFast>(p(base + 0), p(base + 1), a.ls, x, y, lj);
   }
@@ -137,6 +141,14 @@ template <int K, bool CIRC> struct UniRqs {
     r = (r < 0.f) ? r + period : r;  // torch.remainder: result takes the sign of the divisor
     return r - bound;
   }
+  // All-NaN parameters (reference: zuko/nn.py:217-218 on a non-finite input) leave knot 0 = -B finite and every other
+  // knot NaN: values right of -B land in bin 0 with a NaN corner (y = NaN), values at or left of it, NaN and -inf keep
+  // y = v, and log|dy/dx| is NaN everywhere.  NaN widths (heights for the inverse, which searches the other axis) give
+  // exactly that: the remaining parameters never reach an output that is not already NaN.
+  template <bool INV> static __device__ __forceinline__ void poison(float* p, int base, float nan_or_zero) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) p[base + (INV ? K : 0) + j] += nan_or_zero;
+  }
   template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj) {
     rqs_lean<K, false>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, [&](int j) { return p(base + 2 * K + j); }, a.lc,
                        CIRC ? shift(x, a.bound) : x, y, lj);
@@ -154,13 +166,14 @@ typedef UniRqs<8, true> UniCircRqs8;
 
 extern __shared__ __attribute__((aligned(16))) float ar_lds[];
 
-// one masked layer with <= 256 inputs / outputs: out = W in, tiles skipped per (group of 4 out tiles, in tile)
-template <class Src> __device__ __forceinline__ void hidden_layer(Src& ring, const uint32_t* __restrict__ skip4, int olim, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T]) {
+// one masked layer with <= 256 inputs / outputs: out = W in + bias, tiles skipped per (group of 4 out tiles, in tile)
+template <class Src>
+__device__ __forceinline__ void hidden_layer(Src& ring, const uint32_t* __restrict__ skip4, int olim, const float* bias_q, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T]) {
 #pragma unroll
   for (int otg = 0; otg < 4; ++otg) {
     const uint32_t bits = otg <= olim ? skip4[otg] : 0u;  // partial sweeps evaluate a prefix of the out-groups
 #pragma unroll
-    for (int t = 0; t < 4; ++t) out[otg * 4 + t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) out[otg * 4 + t] = *reinterpret_cast<const f32x4*>(bias_q + (otg * 4 + t) * 16);  // accumulators start at the bias
 #pragma unroll
     for (int it = 0; it < AR_T; ++it) {
       if (bits & (1u << it)) {
@@ -270,11 +283,10 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
     const bool tprobe = ZK_AR_TIMING && (a.dbg & 8) && blockIdx.x == 0 && tile == (int64_t)gridDim.x && lane == 0 && (wave == 0 || wave == 4);
     if (ZK_AR_TIMING && (a.dbg & 8)) tstamp[0] = __builtin_amdgcn_s_memtime();
     for (int l = 0; l < a.L - 1; ++l) {
-      hidden_layer(ring, a.skip + l * 4, a.olim[l < 8 ? l : 7], in, out);
+      hidden_layer(ring, a.skip + l * 4, a.olim[l < 8 ? l : 7], bias_lds + l * 256 + 4 * q, in, out);
       if (ZK_AR_TIMING && (a.dbg & 8)) tstamp[1 + (l < 3 ? l : 3)] = __builtin_amdgcn_s_memtime();
-      const float* bl = bias_lds + l * 256 + 4 * q;
 #pragma unroll
-      for (int t = 0; t < AR_T; ++t) in[t] = out[t] + *reinterpret_cast<const f32x4*>(bl + t * 16);
+      for (int t = 0; t < AR_T; ++t) in[t] = out[t];
       // the activation id is wave-uniform: ONE switch around 64-element loops (not 64 switches)
       switch (a.act) {
         case 1:
@@ -314,15 +326,12 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
         if (XLDS) xin[fi] = xr[fc];
         else xin[fi] = INVERSE ? a.yin[nc * a.ldyin + fc] : xrow[fc];
       }
-      f32x4 bgrp[NT];
+      f32x4 acc[NT];  // the accumulators start at the bias
       {
         const float* bg = bias_last + (g * NT) * 16 + 4 * q;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bgrp[t] = *reinterpret_cast<const f32x4*>(bg + t * 16);
+        for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(bg + t * 16);
       }
-      f32x4 acc[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int it = 0; it < AR_T; ++it) {
         if (bits & (1u << it)) {
@@ -342,7 +351,11 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r] + bgrp[t][r] + poison;
+        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r];
+      // a sample with a non-finite input has NaN parameters throughout in the reference; making the parameters of
+      // the SEARCH axis NaN reproduces every output of that case (see Uni::poison) at a third of the additions
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) Uni::template poison<INVERSE>(p, fi * TOTAL, poison);
       auto ld = [&](int i) { return p[i]; };
 #pragma unroll
       for (int fi = 0; fi < FPL; ++fi) {
