@@ -51,6 +51,12 @@ def _require_device(*ts: Tensor) -> None:
             )
 
 
+def _no_bf16_grad(*ts: Tensor) -> None:
+    if any(t is not None and t.dtype == torch.bfloat16 for t in ts):
+        raise NotImplementedError("zuko_amd: the bfloat16 path is inference-only (gradients are built for float32 / float64); "
+                                  "evaluate under torch.no_grad() or train in float32")
+
+
 def _no_grad_only(*ts: Tensor) -> None:
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
         raise NotImplementedError(
@@ -149,6 +155,7 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
 
     if not want_bins and AG.needs_grad(x, widths, heights, derivatives):
         _require_device(x, widths, heights, derivatives)
+        _no_bf16_grad(x, widths)
         if K not in (4, 8, 16):
             raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
         return AG.UnivariateFn.apply(1, bound, slope, reduce, x, widths, heights, derivatives)
@@ -305,6 +312,7 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor |
     from . import autograd as AG
 
     if AG.needs_grad(x, weight, bias):
+        _no_bf16_grad(x, weight)
         if act not in AG.BACKWARD_ACTS:
             raise NotImplementedError("zuko_amd: this activation cannot be fused when gradients are required")
         return AG.LinearFn.apply(x, weight, bias, mask, act)
