@@ -97,3 +97,58 @@ void zoc_affine(int64_t n, double slope, const double* x, const double* shift, c
     x_of_y[i] = (y[i] - shift[i]) / exp(lsc);
   }
 }
+
+/* ---- whole-flow check: log p(x | c) of an autoregressive spline flow with explicit weights ----------------------
+ * Each transform: phi = MaskedMLP(cat(x, c)) with F.linear(h, mask * W, b) + ReLU between layers
+ * (nn.py:217-218, 300-313), spline over each feature from phi[f * (3K-1) ...] (flows/autoregressive.py:149,
+ * 212-215), ladj summed over features (transforms.py:210-214); the flow composes the transforms and adds the
+ * standard normal log-density of the result (transforms.py:141-150, distributions.py:115-119, 356).  The
+ * autoregressive structure lives entirely in the masks, which the caller passes (buffers of the modules).
+ * Layout: per transform t, layer l: W[t][l] is [out_l, in_l] row-major, mask likewise (bytes), b[t][l] [out_l];
+ * dims[l] for l = 0..L are the layer widths (dims[0] = D + C, dims[L] = D * (3K-1)), identical for all transforms. */
+void zoc_nsf_log_prob(int64_t n, int D, int C, int T, int L, const int* dims, int K, double bound, double slope, const double* x, const double* c,
+                      const double* const* W, const uint8_t* const* M, const double* const* B, double* z_out, double* ladj_out, double* logp) {
+  const int total = 3 * K - 1;
+  int wmax = 0;
+  for (int l = 0; l <= L; ++l) wmax = dims[l] > wmax ? dims[l] : wmax;
+  double hbuf[2][8192];
+  if (wmax > 8192) return;
+  for (int64_t i = 0; i < n; ++i) {
+    double cur[1024], ladj = 0.0;
+    for (int f = 0; f < D; ++f) cur[f] = x[i * D + f];
+    for (int t = 0; t < T; ++t) {
+      double* in = hbuf[0];
+      double* out = hbuf[1];
+      for (int f = 0; f < D; ++f) in[f] = cur[f];
+      for (int j = 0; j < C; ++j) in[D + j] = c[i * C + j];
+      for (int l = 0; l < L; ++l) {
+        const double* w = W[t * L + l];
+        const uint8_t* m = M[t * L + l];
+        const double* b = B[t * L + l];
+        const int ni = dims[l], no = dims[l + 1];
+        for (int o = 0; o < no; ++o) {
+          double acc = 0.0;
+          for (int k = 0; k < ni; ++k) acc += in[k] * (m[(int64_t)o * ni + k] ? w[(int64_t)o * ni + k] : 0.0);
+          acc += b[o];
+          out[o] = (l + 1 < L && acc < 0.0) ? 0.0 : acc;
+        }
+        double* tmp = in; in = out; out = tmp;
+      }
+      /* `in` now holds phi[D * total] */
+      for (int f = 0; f < D; ++f) {
+        double y, lj;
+        int64_t k;
+        zoc_rqs_forward(1, K, bound, slope, &cur[f], in + f * total, in + f * total + K, in + f * total + 2 * K, &y, &lj, &k);
+        cur[f] = y;
+        ladj += lj;
+      }
+    }
+    double lp = 0.0;
+    for (int f = 0; f < D; ++f) {
+      z_out[i * D + f] = cur[f];
+      lp += -0.5 * cur[f] * cur[f] - 0.91893853320467274178;
+    }
+    ladj_out[i] = ladj;
+    logp[i] = lp + ladj;
+  }
+}
