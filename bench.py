@@ -229,6 +229,16 @@ def main() -> None:
             if args.config == "cfg2":
                 kernels["zk_rqs_forward (standalone)"] = {"calls": 0, "avg_ms": float("nan"), "error": repr(exc)}
         roof, extra = zuko_amd_roofline(kernels, B)
+        # the fused kernel skips all-zero 16x16 weight tiles: also report the rate on the MFMAs it actually issues
+        try:
+            st = flow.transform.transforms[0].fused_state(dev) if roof and roof["kernel"].startswith("zk_ar_forward") else None
+            if st is not None:
+                executed = float(B) * st.plan.kept_tiles * 512.0  # 16 x 16 x 2 FLOP per kept tile per sample
+                roof["executed_flop_per_launch"] = executed
+                roof["achieved_executed"] = executed / (roof["avg_launch_ms"] * 1e-3) / 1e12
+                roof["frac_executed"] = roof["achieved_executed"] / roof["peak"]
+        except Exception:
+            pass
 
     if rank == 0:
         out = {
