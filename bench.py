@@ -229,6 +229,8 @@ def main() -> None:
             if args.config == "cfg2":
                 kernels["zk_rqs_forward (standalone)"] = {"calls": 0, "avg_ms": float("nan"), "error": repr(exc)}
         roof, extra = zuko_amd_roofline(kernels, B)
+        if roof and args.config != "cfg2":
+            roof["traffic"] = None  # the committed PMC passes were taken on the headline workload only
         # the fused kernel skips all-zero 16x16 weight tiles: also report the rate on the MFMAs it actually issues
         try:
             st = flow.transform.transforms[0].fused_state(dev) if roof and roof["kernel"].startswith("zk_ar_forward") else None
