@@ -115,3 +115,112 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Tile-level version on zuko's own masks: dependency classes aligned to MFMA k-steps
+# ------------------------------------------------------------------------------------------------------------------
+
+def class_aligned_layout(mask_in: np.ndarray):
+    """Hidden units of one layer grouped by dependency class (number of flow inputs they may see), every class padded
+    to whole k-steps of 4 rows.  Returns (perm with -1 padding, class of every k-step)."""
+    cls = mask_in.sum(axis=1)
+    perm, kclass = [], []
+    for c in np.unique(cls):
+        units = np.nonzero(cls == c)[0].tolist()
+        while len(units) % 4:
+            units.append(-1)
+        perm += units
+        kclass += [int(c)] * (len(units) // 4)
+    while len(perm) % 16:
+        perm += [-1] * 4
+        kclass.append(10**9)  # padding k-step: never needed
+    return np.array(perm), kclass
+
+
+def tile_level(D=64, H=256, layers=3, total=2, n=8, seed=1):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import torch
+
+    from zuko_amd.nn import masked_mlp_masks
+
+    order = torch.arange(D)
+    adjacency = (order[:, None] > order).repeat_interleave(total, dim=0)
+    masks = [m.numpy() for m in masked_mlp_masks(adjacency, [H] * layers)]
+    rng = np.random.default_rng(seed)
+    dims = [D] + [H] * layers + [D * total]
+    Ws = [rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i]) for i in range(len(dims) - 1)]
+    bs = [rng.standard_normal(dims[i + 1]) * 0.1 for i in range(len(dims) - 1)]
+    y = rng.standard_normal((n, D))
+    x_ref, _ = inverse_by_sweeps(masks, Ws, bs, y, total, D)
+
+    # dependency of every hidden unit on the flow inputs -> class; class-aligned row layout per hidden layer
+    dep = masks[0].astype(np.int64)
+    layouts = []
+    for l in range(layers):
+        layouts.append(class_aligned_layout(dep > 0))
+        if l + 1 < layers:
+            dep = (masks[l + 1].astype(np.int64) @ (dep > 0).astype(np.int64))
+    # padded, masked weights in the aligned layout
+    def padded(W, m, rows, cols):
+        Wm = W * m
+        out = np.zeros((len(rows), len(cols)))
+        r_ok, c_ok = rows >= 0, cols >= 0
+        out[np.ix_(r_ok, c_ok)] = Wm[np.ix_(rows[r_ok], cols[c_ok])]
+        return out
+    in_cols = np.arange(D)
+    Wp, bp = [], []
+    prev = in_cols
+    for l in range(layers):
+        rows = layouts[l][0]
+        Wp.append(padded(Ws[l], masks[l], rows, prev))
+        b = np.zeros(len(rows)); b[rows >= 0] = bs[l][rows[rows >= 0]]
+        bp.append(b)
+        prev = rows
+    Wp.append(padded(Ws[-1], masks[-1], np.arange(D * total), prev))
+    bp.append(bs[-1])
+
+    # incremental evaluation at k-step granularity: k-step (layer l, index s) is FINAL once class(s) - 1 <= last known order
+    ksteps = [len(kc) for _, kc in layouts]
+    pre = [np.tile(b, (n, 1)) for b in bp]
+    done = [np.zeros(k, dtype=bool) for k in ksteps]
+    x = np.zeros((n, D))
+    diag_mfma = bulk_mfma = 0
+
+    def push(layer, s):
+        """k-step s of hidden `layer` is final: activate its 4 rows and add their columns into the next layer (all
+        rows: in the kernel the rows of the current tile are the diagonal MFMA, the rest is pulled in bulk later)."""
+        nonlocal diag_mfma, bulk_mfma
+        rows = slice(4 * s, 4 * s + 4)
+        act = np.maximum(pre[layer][:, rows], 0.0)
+        nxt = Wp[layer + 1][:, rows]
+        pre[layer + 1] += act @ nxt.T
+        out_tiles = int(np.ceil(np.count_nonzero(np.abs(nxt).sum(axis=1)) / 16))  # 16-row tiles that hold non-zeros of this k-step
+        diag_mfma += 1
+        bulk_mfma += max(out_tiles - 1, 0)
+        done[layer][s] = True
+
+    for f in range(D):
+        phi = pre[-1].reshape(n, D, total)[:, f]
+        x[:, f] = (y[:, f] - phi[:, 0]) * np.exp(-phi[:, 1])
+        pre[0] += np.outer(x[:, f], Wp[0][:, f])
+        diag_mfma += 1
+        if f % 4 == 3:  # the group's k-step of inputs is complete: its bulk part into the later tiles
+            bulk_mfma += int(np.ceil(np.count_nonzero(np.abs(Wp[0][:, f - 3 : f + 1]).sum(axis=1)) / 16)) - 1
+        for l in range(layers):
+            for s, c in enumerate(layouts[l][1]):
+                if not done[l][s] and c - 1 <= f and (l == 0 or all(done[l - 1][t] for t, ct in enumerate(layouts[l - 1][1]) if ct <= c)):
+                    push(l, s)
+    assert np.allclose(x, x_ref, rtol=1e-9, atol=1e-9), np.abs(x - x_ref).max()
+    dense_fwd = sum((Wp[i].shape[0] // 16 if i < layers else -(-Wp[i].shape[0] // 16)) * (Wp[i].shape[1] // 4) for i in range(layers + 1))
+    print(f"tile level (zuko masks, D={D}, H={H}x{layers}): k-steps per hidden layer {ksteps} ({[k // 4 for k in ksteps]} tiles); "
+          f"x == sweeps (max diff {np.abs(x - x_ref).max():.1e}); dependent (diagonal) MFMAs {diag_mfma}, bulk MFMAs {bulk_mfma} "
+          f"(a dense forward over the padded layout: {dense_fwd})")
+    return diag_mfma, bulk_mfma
+
+
+if __name__ == "__main__":
+    tile_level()
