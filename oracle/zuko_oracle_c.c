@@ -152,3 +152,58 @@ void zoc_nsf_log_prob(int64_t n, int D, int C, int T, int L, const int* dims, in
     logp[i] = lp + ladj;
   }
 }
+
+/* ---- coupling flow (NICE / RealNVP) with affine univariate maps ---------------------------------------------------
+ * Each transform (flows/coupling.py:79-139, transforms.py:1010-1073): x_a = x[mask] passes through, phi =
+ * MLP(cat(x_a, c)) (dense Linear + ReLU, nn.py:13-22, 122-192), x_b = x[~mask] -> x_b * exp(softclip(scale)) + shift
+ * with (shift, scale) = phi[j * 2 + (0, 1)] for the j-th moved feature (transforms.py:436-446), ladj = sum of the
+ * soft-clipped log-scales.  masks[t] is the transform's boolean buffer (1 = pass-through). */
+void zoc_coupling_affine_log_prob(int64_t n, int D, int C, int T, int L, const int* dims, double slope, const double* x, const double* c,
+                                  const uint8_t* const* masks, const double* const* W, const double* const* B, double* z_out, double* ladj_out,
+                                  double* logp) {
+  const double ls = log(slope);
+  double hbuf[2][8192];
+  for (int l = 0; l < T * (L + 1); ++l)
+    if (dims[l] > 8192) return;  /* dims[t * (L + 1) + l]: the layer widths differ between transforms when D is odd */
+  for (int64_t i = 0; i < n; ++i) {
+    double cur[4096], ladj = 0.0;
+    for (int f = 0; f < D; ++f) cur[f] = x[i * D + f];
+    for (int t = 0; t < T; ++t) {
+      const uint8_t* mk = masks[t];
+      double* in = hbuf[0];
+      double* out = hbuf[1];
+      int na = 0;
+      for (int f = 0; f < D; ++f)
+        if (mk[f]) in[na++] = cur[f];
+      for (int j = 0; j < C; ++j) in[na + j] = c[i * C + j];
+      for (int l = 0; l < L; ++l) {
+        const double* w = W[t * L + l];
+        const double* b = B[t * L + l];
+        const int ni = dims[t * (L + 1) + l], no = dims[t * (L + 1) + l + 1];
+        for (int o = 0; o < no; ++o) {
+          double acc = 0.0;
+          for (int k = 0; k < ni; ++k) acc += in[k] * w[(int64_t)o * ni + k];
+          acc += b[o];
+          out[o] = (l + 1 < L && acc < 0.0) ? 0.0 : acc;
+        }
+        double* tmp = in; in = out; out = tmp;
+      }
+      int j = 0;
+      for (int f = 0; f < D; ++f) {
+        if (mk[f]) continue;
+        const double shift = in[2 * j], scale = in[2 * j + 1];
+        const double lsc = scale / (1.0 + fabs(scale / ls));
+        cur[f] = cur[f] * exp(lsc) + shift;
+        ladj += lsc;
+        ++j;
+      }
+    }
+    double lp = 0.0;
+    for (int f = 0; f < D; ++f) {
+      z_out[i * D + f] = cur[f];
+      lp += -0.5 * cur[f] * cur[f] - 0.91893853320467274178;
+    }
+    ladj_out[i] = ladj;
+    logp[i] = lp + ladj;
+  }
+}
