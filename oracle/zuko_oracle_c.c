@@ -106,9 +106,10 @@ void zoc_affine(int64_t n, double slope, const double* x, const double* shift, c
  * autoregressive structure lives entirely in the masks, which the caller passes (buffers of the modules).
  * Layout: per transform t, layer l: W[t][l] is [out_l, in_l] row-major, mask likewise (bytes), b[t][l] [out_l];
  * dims[l] for l = 0..L are the layer widths (dims[0] = D + C, dims[L] = D * (3K-1)), identical for all transforms. */
+/* K > 0: K-bin spline (NSF); K == 0: affine map with (shift, scale) = phi[f * 2 + (0, 1)] (MAF, transforms.py:436-446) */
 void zoc_nsf_log_prob(int64_t n, int D, int C, int T, int L, const int* dims, int K, double bound, double slope, const double* x, const double* c,
                       const double* const* W, const uint8_t* const* M, const double* const* B, double* z_out, double* ladj_out, double* logp) {
-  const int total = 3 * K - 1;
+  const int total = K > 0 ? 3 * K - 1 : 2;
   int wmax = 0;
   for (int l = 0; l <= L; ++l) wmax = dims[l] > wmax ? dims[l] : wmax;
   double hbuf[2][8192];
@@ -138,7 +139,13 @@ void zoc_nsf_log_prob(int64_t n, int D, int C, int T, int L, const int* dims, in
       for (int f = 0; f < D; ++f) {
         double y, lj;
         int64_t k;
-        zoc_rqs_forward(1, K, bound, slope, &cur[f], in + f * total, in + f * total + K, in + f * total + 2 * K, &y, &lj, &k);
+        if (K > 0) {
+          zoc_rqs_forward(1, K, bound, slope, &cur[f], in + f * total, in + f * total + K, in + f * total + 2 * K, &y, &lj, &k);
+        } else {
+          const double ls = log(slope), scale = in[f * 2 + 1];
+          lj = scale / (1.0 + fabs(scale / ls));
+          y = cur[f] * exp(lj) + in[f * 2];
+        }
         cur[f] = y;
         ladj += lj;
       }

@@ -60,16 +60,16 @@ def test_c_restatement_of_the_affine_map_matches_the_golden_vectors(clib):
     np.testing.assert_allclose(back[ok], x.reshape(-1)[ok], rtol=1e-9, atol=1e-9)
 
 
-def test_c_restatement_of_a_whole_flow_matches_the_flow_golden(clib):
-    """NSF cfg1 (3 features, 5 context, 3 transforms, 8 bins, [128]^3) in double-precision C from the module's weights
-    and mask buffers, against z / ladj / log_prob the reference produced in float32."""
+@pytest.mark.parametrize("name,D,C,K", [("nsf_cfg1", 3, 5, 8), ("nsf_cfg2", 64, 0, 8), ("maf_cfg3", 64, 0, 0), ("maf_doc", 3, 4, 0)])
+def test_c_restatement_of_a_whole_flow_matches_the_flow_golden(clib, name, D, C, K):
+    """Autoregressive flows (NSF: K-bin spline, MAF: affine map, K = 0) in double-precision C from the module's weights and
+    mask buffers, against z / ladj / log_prob the reference produced in float32."""
     import torch
 
     from conftest import build_flow
 
-    flow, entry = build_flow("nsf_cfg1")  # (seeded reconstruction, state_dict SHA-256 checked against the fixture)
-    g = golden("flow_nsf_cfg1.npz")
-    D, C, K = 3, 5, 8
+    flow, entry = build_flow(name)  # (seeded reconstruction, state_dict SHA-256 checked against the fixture)
+    g = golden(f"flow_{name}.npz")
     ts = list(flow.transform.transforms)
     lins = [[m for m in t.hyper if hasattr(m, "mask")] for t in ts]
     T_, L = len(ts), len(lins[0])
@@ -78,15 +78,16 @@ def test_c_restatement_of_a_whole_flow_matches_the_flow_golden(clib):
     M = [np.ascontiguousarray(l.mask.numpy().astype(np.uint8)) for tl in lins for l in tl]
     B = [np.ascontiguousarray(l.bias.detach().double().numpy()) for tl in lins for l in tl]
     arr = lambda xs: (ctypes.c_void_p * len(xs))(*[a.ctypes.data for a in xs])
-    x, c = np.ascontiguousarray(g["x"].astype(np.float64)), np.ascontiguousarray(g["c"].astype(np.float64))
-    n = x.shape[0]
+    n = min(128, g["x"].shape[0])
+    x = np.ascontiguousarray(g["x"][:n].astype(np.float64))
+    c = np.ascontiguousarray(g["c"][:n].astype(np.float64)) if C else np.zeros((n, 0))
     z, ladj, lp = np.empty((n, D)), np.empty(n), np.empty(n)
     clib.zoc_nsf_log_prob.restype = None
     clib.zoc_nsf_log_prob.argtypes = [ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 8
     clib.zoc_nsf_log_prob(n, D, C, T_, L, ptr(dims), K, 5.0, 1e-3, ptr(x), ptr(c), arr(W), arr(M), arr(B), ptr(z), ptr(ladj), ptr(lp))
-    np.testing.assert_allclose(z, g["z"], rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(ladj, g["ladj"], rtol=2e-5, atol=5e-5)
-    np.testing.assert_allclose(lp, g["log_prob"], rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(z, g["z"][:n], rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(ladj, g["ladj"][:n], rtol=5e-5, atol=2e-4)
+    np.testing.assert_allclose(lp, g["log_prob"][:n], rtol=2e-5, atol=2e-4)
 
 
 @pytest.mark.parametrize("name,D,C", [("nice_small", 5, 3), ("realnvp_cfg4", 256, 0)])
