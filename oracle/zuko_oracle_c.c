@@ -214,3 +214,37 @@ void zoc_coupling_affine_log_prob(int64_t n, int D, int C, int T, int L, const i
     logp[i] = lp + ladj;
   }
 }
+
+/* ---- sum-of-squares polynomial transform (transforms.py:927-963, 878-924; utils.py:349-363, 170-180) -------------
+ * g(x) = mean_k (1 + sum_j a[k][j] (x / 10)^j)^2 + slope;  f(x) = int_0^x g by Gauss-Legendre with the caller's nodes /
+ * weights on [0, 1] (n = L + 1 of them, numpy.leggauss in the reference);  ladj = log g(x);  inverse by `nbis` halvings of
+ * [-10, 10] followed by the midpoint.  a: [n, P, L1] row-major. */
+static double sos_g1(const double* a, int P, int L1, double slope, double x) {
+  const double u = x / 10.0;
+  double acc = 0.0;
+  for (int k = 0; k < P; ++k) {
+    double p = 1.0, pw = 1.0;
+    for (int j = 0; j < L1; ++j) { p += a[k * L1 + j] * pw; pw *= u; }
+    acc += p * p;
+  }
+  return acc / P + slope;
+}
+static double sos_f1(const double* a, int P, int L1, double slope, const double* nodes, const double* weights, int nn, double x) {
+  double s = 0.0;
+  for (int i = 0; i < nn; ++i) s += weights[i] * sos_g1(a, P, L1, slope, 0.0 + nodes[i] * (x - 0.0));
+  return (x - 0.0) * s;
+}
+void zoc_sos(int64_t n, int P, int L1, double slope, const double* nodes, const double* weights, int nn, int nbis, const double* x, const double* a,
+             const double* yin, double* y, double* ladj, double* x_inv) {
+  for (int64_t i = 0; i < n; ++i) {
+    const double* ai = a + i * P * L1;
+    y[i] = sos_f1(ai, P, L1, slope, nodes, weights, nn, x[i]);
+    ladj[i] = log(sos_g1(ai, P, L1, slope, x[i]));
+    double lo = -10.0, hi = 10.0;
+    for (int it = 0; it < nbis; ++it) {
+      const double c = (lo + hi) / 2;
+      if (sos_f1(ai, P, L1, slope, nodes, weights, nn, c) < yin[i]) lo = c; else hi = c;
+    }
+    x_inv[i] = (lo + hi) / 2;
+  }
+}

@@ -116,3 +116,23 @@ def test_c_restatement_of_a_coupling_flow_matches_the_flow_golden(clib, name, D,
     np.testing.assert_allclose(z, g["z"][:n], rtol=5e-5, atol=5e-5)
     np.testing.assert_allclose(ladj, g["ladj"][:n], rtol=5e-5, atol=2e-4)
     np.testing.assert_allclose(lp, g["log_prob"][:n], rtol=2e-5, atol=2e-4)
+
+
+def test_c_restatement_of_the_sos_transform_matches_the_golden_vectors(clib):
+    """Sum-of-squares polynomial: Gauss-Legendre integral with the reference's n = L + 1 nodes, log of the integrand,
+    25-step bisection inverse of y (x_inv = inverse(forward(x)) in the fixture)."""
+    import math
+
+    g = golden("sos_f64.npz")
+    a, x = np.ascontiguousarray(g["a"]), np.ascontiguousarray(g["x"])
+    nodes, weights = np.ascontiguousarray(g["gl_nodes01"]), np.ascontiguousarray(g["gl_weights01"])
+    n, P, L1 = x.size, a.shape[-2], a.shape[-1]
+    yin = np.ascontiguousarray(g["y"])
+    y, ladj, xinv = np.empty(n), np.empty(n), np.empty(n)
+    clib.zoc_sos.restype = None
+    clib.zoc_sos.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+    nbis = math.ceil(math.log2(2 * 10.0 / 1e-6))
+    clib.zoc_sos(n, P, L1, 1e-3, ptr(nodes), ptr(weights), len(nodes), nbis, ptr(x), ptr(a), ptr(yin), ptr(y), ptr(ladj), ptr(xinv))
+    np.testing.assert_allclose(y, g["y"].reshape(-1), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ladj, g["ladj"].reshape(-1), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(xinv, g["x_inv"].reshape(-1), rtol=0, atol=2e-6)  # bisection: interval width 20 / 2^25
