@@ -248,3 +248,64 @@ void zoc_sos(int64_t n, int P, int L1, double slope, const double* nodes, const 
     x_inv[i] = (lo + hi) / 2;
   }
 }
+
+/* ---- Bernstein polynomial transforms (transforms.py:640-777 unbounded, :780-831 bounded) --------------------------
+ * theta (constrained): unbounded = cumsum(cat(t_0, softplus(t_1), softplus(t_1..t_{M-1}), softplus(t_{M-1}))) - M ln2 / 2
+ * (:703-727); bounded = cumsum(cat(-B, d, d, softmax(t) (2B - 4d), d, d)), d = 2B / (M + 4) (:797-818).
+ * f(u) = sum_i C(n, i) u^i (1 - u)^(n - i) theta_i with u = (x + B) / 2B (:729-740; the reference's mean of Beta pdfs is
+ * this sum), linear extrapolation outside [eps, 1 - eps] (:742-760; bounded: offsets -+B, slopes 2B, :820-831);
+ * ladj = log f'(x) — the reference differentiates by autograd, here the closed form n sum C(n-1, i) (theta_{i+1} - theta_i)
+ * u^i (1-u)^(n-1-i) / 2B inside and slope / 2B outside. */
+static double binom(int n, int k) { double r = 1.0; for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i; return r; }
+static double bern_eval(const double* th, int n, double u) {  /* order n: n + 1 coefficients */
+  double s = 0.0;
+  for (int i = 0; i <= n; ++i) s += binom(n, i) * pow(u, i) * pow(1.0 - u, n - i) * th[i];
+  return s;
+}
+void zoc_bernstein(int64_t n, int M, int bounded, double bound, const double* x, const double* theta_unc, double* y, double* ladj, double* theta_out) {
+  const double eps = 1e-6;
+  for (int64_t e = 0; e < n; ++e) {
+    const double* t = theta_unc + e * M;
+    double th[80], dth[80];
+    int nc;
+    if (bounded) {
+      nc = M + 5;
+      const double d = 2.0 * bound / (M + 4);
+      double mx = t[0], s = 0.0, cum;
+      for (int i = 1; i < M; ++i) mx = t[i] > mx ? t[i] : mx;
+      for (int i = 0; i < M; ++i) s += exp(t[i] - mx);
+      cum = -bound; th[0] = cum;
+      cum += d; th[1] = cum;
+      cum += d; th[2] = cum;
+      for (int i = 0; i < M; ++i) { cum += exp(t[i] - mx) / s * (2.0 * bound - 4.0 * d); th[3 + i] = cum; }
+      cum += d; th[3 + M] = cum;
+      cum += d; th[4 + M] = cum;
+    } else {
+      nc = M + 2;
+      const double shift = log(2.0) * M / 2.0;
+      double diffs[80];
+      diffs[0] = t[0];
+      diffs[1] = log1p(exp(t[1]));
+      for (int i = 1; i < M; ++i) diffs[1 + i] = log1p(exp(t[i]));
+      diffs[M + 1] = log1p(exp(t[M - 1]));
+      double cum = 0.0;
+      for (int i = 0; i < nc; ++i) { cum += diffs[i]; th[i] = cum - shift; }
+    }
+    const int order = nc - 1;
+    for (int i = 0; i < order; ++i) dth[i] = order * (th[i + 1] - th[i]);
+    for (int i = 0; i < nc; ++i) theta_out[e * nc + i] = th[i];
+    double off_lo, off_hi, slp_lo, slp_hi;
+    if (bounded) { off_lo = -bound; off_hi = bound; slp_lo = slp_hi = 2.0 * bound; }
+    else {
+      off_lo = bern_eval(th, order, eps); off_hi = bern_eval(th, order, 1.0 - eps);
+      slp_lo = bern_eval(dth, order - 1, eps); slp_hi = bern_eval(dth, order - 1, 1.0 - eps);
+    }
+    const double u = (x[e] + bound) / (2.0 * bound);
+    double f, df;
+    if (u <= eps) { f = slp_lo * (u - eps) + off_lo; df = slp_lo; }
+    else if (u >= 1.0 - eps) { f = slp_hi * (u - 1.0 + eps) + off_hi; df = slp_hi; }
+    else { f = bern_eval(th, order, u); df = bern_eval(dth, order - 1, u); }
+    y[e] = f;
+    ladj[e] = log(df / (2.0 * bound));
+  }
+}

@@ -136,3 +136,20 @@ def test_c_restatement_of_the_sos_transform_matches_the_golden_vectors(clib):
     np.testing.assert_allclose(y, g["y"].reshape(-1), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(ladj, g["ladj"].reshape(-1), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(xinv, g["x_inv"].reshape(-1), rtol=0, atol=2e-6)  # bisection: interval width 20 / 2^25
+
+
+@pytest.mark.parametrize("name,bounded", [("bern", 0), ("bbern", 1)])
+def test_c_restatement_of_the_bernstein_transforms_matches_the_golden_vectors(clib, name, bounded):
+    """(Bounded) Bernstein polynomial: constrained coefficients, value with linear tails and the closed-form derivative
+    (the reference obtains it by autograd) against the fixture's theta / y / ladj."""
+    g = golden(f"{name}_f64.npz")
+    th, x = np.ascontiguousarray(g["theta"]), np.ascontiguousarray(g["x"])
+    n, M = x.size, th.shape[-1]
+    nc = g["theta_constrained"].shape[-1]
+    y, ladj, tc = np.empty(n), np.empty(n), np.empty((n, nc))
+    clib.zoc_bernstein.restype = None
+    clib.zoc_bernstein.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [ctypes.c_void_p] * 5
+    clib.zoc_bernstein(n, M, bounded, 5.0, ptr(x), ptr(th), ptr(y), ptr(ladj), ptr(tc))
+    np.testing.assert_allclose(tc, g["theta_constrained"].reshape(n, nc), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(y, g["y"].reshape(-1), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(ladj, g["ladj"].reshape(-1), rtol=1e-8, atol=1e-8)
