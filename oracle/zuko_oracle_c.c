@@ -1,8 +1,9 @@
-/* Plain-C restatement (double precision, one element at a time) of the two univariate maps that carry the
- * benchmark configurations: MonotonicRQSTransform and MonotonicAffineTransform of probabilists/zuko 1.6.0.
- * TEST INFRASTRUCTURE ONLY — an independent, torch-free cross-check of tests/golden/rqs_f64.npz and
- * affine_f64.npz (the PyTorch-ops oracle oracle/zuko_oracle.py is the one pinned bitwise against the live
- * reference; this file shares no code and no math library with it).  Built by oracle/build_c.py with gcc.
+/* Plain-C restatement (double precision, one element at a time) of the univariate maps and flows of the hot path of
+ * probabilists/zuko 1.6.0: MonotonicRQSTransform, MonotonicAffineTransform, SOSPolynomialTransform, (Bounded)BernsteinTransform,
+ * masked-autoregressive flows (NSF / MAF) and coupling flows (NICE / RealNVP).
+ * TEST INFRASTRUCTURE ONLY — an independent, torch-free cross-check of the golden vectors under tests/golden/ (the
+ * PyTorch-ops oracle oracle/zuko_oracle.py is the one pinned bitwise against the live reference; this file shares no code
+ * and no math library with it).  Built by oracle/build_c.py with gcc; exercised by tests/test_oracle_c.py.
  *
  * Reference lines (relative to /root/reference/zuko):
  *   softclip of widths / heights / derivatives      transforms.py:480-482
