@@ -54,3 +54,39 @@ def test_unsupported_shapes_fall_back():
     assert t._fusable_layout() is not None
     t = NSF(8, 0, transforms=1, bins=5).transform.transforms[0]
     assert t._fusable_layout() is None
+
+
+def test_plan_simulation_on_random_adjacencies():
+    """Free-form (DAG) adjacencies, random widths, context columns: whatever masks zuko's construction yields, the
+    plan's tile skipping and regrouping must leave the conditioner's output unchanged (property-style, seeded)."""
+    from zuko_amd import fused
+    from zuko_amd.flows import MaskedAutoregressiveTransform
+
+    rng = np.random.default_rng(7)
+    done = 0
+    for trial in range(40):
+        D = int(rng.integers(2, 33))
+        C = int(rng.integers(0, 4))
+        perm = rng.permutation(D)
+        adj = np.tril(rng.random((D, D)) < rng.uniform(0.1, 0.7), k=-1)
+        adj = adj[perm][:, perm] | np.eye(D, dtype=bool)  # a DAG under a random feature order, self loops as zuko expects
+        if C:
+            adj = np.concatenate((adj, rng.random((D, C)) < 0.6), axis=1)
+        hidden = [int(rng.choice([16, 40, 64, 100, 256])) for _ in range(int(rng.integers(1, 4)))]
+        torch.manual_seed(trial)
+        try:
+            t = MaskedAutoregressiveTransform(D, C, adjacency=torch.from_numpy(adj), hidden_features=hidden)
+        except ValueError:  # zuko refuses adjacencies that lead to a null Jacobian (nn.py:285-286)
+            continue
+        lins = [m for m in t.hyper if hasattr(m, "mask")]
+        masks = [m.mask for m in lins]
+        plan = fused.build_plan(masks, D, fused.uni_layout("affine", 2))
+        assert plan is not None
+        W = [m.weight.detach().double().numpy() for m in lins]
+        B = [m.bias.detach().double().numpy() for m in lins]
+        x = torch.randn(5, D + C, dtype=torch.float64)
+        ref = O.mlp_forward(x, [torch.tensor(w) for w in W], [torch.tensor(b) for b in B], masks).reshape(5, D, 2).numpy()
+        phi = fused.simulate(plan, W, B, [m.numpy() for m in masks], x.numpy(), lambda v: np.maximum(v, 0))
+        assert np.abs(phi - ref).max() < 1e-12, (trial, D, C, hidden)
+        done += 1
+    assert done >= 25
