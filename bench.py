@@ -9,9 +9,16 @@ One "step" = one pass of the hot path over the rank's batch: flow().log_prob(x) 
 the f64 reduction to the mean NLL, and (N > 1) ONE all-reduce of that scalar over RCCL.  Multi-GPU
 is weak scaling: every rank owns its own 2^20-row shard; nothing but the scalar crosses xGMI.
 
+`--gpus N` with N > 1 and no torchrun environment re-launches this script under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per
+GPU, rank -> device LOCAL_RANK, backend nccl = RCCL); under the driver's own torchrun launch the
+ranks are used as they come.  It refuses to run N ranks on fewer than N visible GPUs unless the dry-run
+environment ZUKO_BENCH_SINGLE_DEVICE=1 ZUKO_BENCH_BACKEND=gloo is set (code-path check on a 1-GPU box).
+
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured with events on the launch
-stream) and `cpu_baseline` (the CPU oracle = the reference's algorithm on PyTorch-CPU ops, timed on
-this host's cores on a bounded sample).
+stream; `achieved` counts the ALGORITHMIC = non-zero-weight FLOPs of SURVEY 8(d), so `frac` <= 1) and
+`cpu_baseline` (the CPU oracle = the reference's algorithm on PyTorch-CPU ops, bitwise-pinned to the
+reference in the build container, timed on this host's cores on a bounded sample).
 """
 
 from __future__ import annotations
@@ -19,42 +26,111 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FEATURES, TRANSFORMS, BINS, HIDDEN = 64, 8, 8, [256, 256, 256]
-# dense conditioner FLOPs per sample per transform = 2 * (64*256 + 256*256*2 + 256*1472)
-FLOP_PER_SAMPLE_TRANSFORM = 2 * (64 * 256 + 256 * 256 * 2 + 256 * 1472)
-NNZ_FLOP_PER_SAMPLE_TRANSFORM = 2 * 265784  # mask-aware (non-zero weights only), reported alongside
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA, same guide
-RQS_BYTES_PER_SAMPLE_TRANSFORM = 64 * (4 + 92 + 4) + 4  # x + phi + y per element, + ladj
+
+CONFIGS = {
+    # name: (constructor name, kwargs, workload string, bf16)
+    "cfg2": ("NSF", dict(features=64, context=0, transforms=8, bins=8, hidden_features=[256] * 3), "NSF(features=64, context=0, transforms=8, bins=8, hidden=[256]*3) log_prob", False),
+    "cfg3": ("MAF", dict(features=64, context=0, transforms=8, hidden_features=[256] * 3), "MAF(features=64, transforms=8, hidden=[256]*3) log_prob", False),
+    "cfg4": ("RealNVP", dict(features=256, context=0, transforms=16, hidden_features=[512] * 3), "RealNVP(features=256, transforms=16, hidden=[512]*3) log_prob", False),
+    "cfg5": ("NSF", dict(features=1024, context=0, transforms=12, bins=16, hidden_features=[1024] * 3), "NSF(features=1024, transforms=12, bins=16, hidden=[1024]*3) bf16 log_prob", True),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--no-bin-report", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
                     help="cfg2 = the headline NSF workload (default, the only graded line); cfg3 = MAF(64,T=8,H=256x3); "
                          "cfg4 = RealNVP(256,T=16,H=512x3); cfg5 = NSF(1024,T=12,K=16,H=1024x3) in bf16 (use --batch-log2 19) — "
                          "side measurements quoted in DESIGN.md")
     return ap.parse_args()
 
 
+# --------------------------------------------------------------------------------------------------
+# launching: `--gpus N` creates the N ranks itself when no torchrun environment is present
+# --------------------------------------------------------------------------------------------------
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(n: int) -> int:
+    """Re-exec this command line as N ranks (one per GPU) and return the launcher's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(args):
+    """(rank, world, local device index, dist module or None).  One process per GPU."""
+    import torch
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher created WORLD_SIZE={world} ranks")
+    selftest = os.environ.get("ZUKO_BENCH_LAUNCH_SELFTEST") == "1"  # CPU test of the launch path: no device work at all
+    if world == 1:
+        if not selftest:
+            torch.cuda.set_device(0)
+        return rank, world, 0, None
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("ZUKO_BENCH_BACKEND", "nccl")
+    single = os.environ.get("ZUKO_BENCH_SINGLE_DEVICE") == "1"
+    if selftest:
+        dist.init_process_group("gloo")
+        return rank, world, 0, dist
+    if single:
+        if backend == "nccl":
+            raise SystemExit("bench.py: ZUKO_BENCH_SINGLE_DEVICE=1 needs ZUKO_BENCH_BACKEND=gloo (RCCL cannot put two ranks on one GPU)")
+        local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s); "
+                         "set ZUKO_BENCH_SINGLE_DEVICE=1 ZUKO_BENCH_BACKEND=gloo for a single-GPU dry run of the multi-rank path")
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return rank, world, local, dist
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline
+# --------------------------------------------------------------------------------------------------
+
+
 def cpu_baseline(flow_cpu, seconds: float) -> dict:
     """The oracle (a restatement of the reference on PyTorch-CPU ops, bitwise equal to it in the
-    build container) timed on this host: chunks of 2^12 rows of the same workload, all cores."""
+    build container: tests/golden/make_golden.py) timed on this host: chunks of 2^12 rows of the same workload."""
+    import torch
+
     from oracle import zuko_oracle as O
 
     ncpu = os.cpu_count() or 1
@@ -72,12 +148,16 @@ def cpu_baseline(flow_cpu, seconds: float) -> dict:
     # host: 16 threads are fastest, all 256 are ~700x slower): pick the fastest of a bounded sweep up to 64 threads,
     # dropping a candidate as soon as its first pass is 3x off the best, then spend the rest of the budget there.
     best_t, best = None, float("inf")
+    sweep = {}
     with torch.no_grad():
         for threads in sorted({t for t in (4, 8, 16, 32, 64) if 1 <= t <= ncpu} or {1}):
             torch.set_num_threads(threads)
-            if once() > 3.0 * best:
+            first = once()
+            if first > 3.0 * best:
+                sweep[threads] = chunk / first
                 continue
             t = min(once(), once())
+            sweep[threads] = chunk / t
             if t < best:
                 best_t, best = threads, t
         threads = best_t
@@ -94,58 +174,128 @@ def cpu_baseline(flow_cpu, seconds: float) -> dict:
         "cores": threads,
         "host_cpus": ncpu,
         "kind": "port",
-        "sample": f"{len(times)} x chunk of 2^12 rows (median), same model; reference degrades at larger chunks (SURVEY 6)",
+        "pinned_bitwise": True,  # the port equals the live reference bit for bit (fixtures regenerated by tests/golden/make_golden.py)
+        "thread_sweep_samples_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
+        "sample": f"{len(times)} x chunk of 2^12 rows (median) at the fastest thread count of the sweep, same model; the reference degrades at larger chunks (SURVEY 6)",
         "cpu_model": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown"),
     }
 
 
+# --------------------------------------------------------------------------------------------------
+# bin-index report of the product kernel at the benchmark batch
+# --------------------------------------------------------------------------------------------------
+
+
+def bin_report(flow, flow_cpu, x, dev) -> dict:
+    """First transform of the headline flow at the FULL batch, through the diagnostic twin of the fused kernel
+    (same template / arithmetic, asserted bit-identical in tests/test_gpu_bins.py): the index the kernel used vs
+    #(its own knots < x) - 1 (must agree everywhere), vs a float64 evaluation of the layer-wise parameters on the
+    GPU (all rows), and vs the CPU oracle's index (first 4096 rows)."""
+    import torch
+
+    from zuko_amd import ops
+    from zuko_amd.nn import MaskedLinear
+    from zuko_amd.utils import unpack
+
+    lazy = flow.transform.transforms[0]
+    st = lazy.fused_state(dev)
+    if st is None:
+        return {"error": "first transform does not run on the fused kernel"}
+    K = BINS
+    N, D = x.shape
+    with torch.no_grad():
+        st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+        y, ladj = torch.empty_like(x), torch.empty(N, device=dev)
+        bins = torch.empty(N, D, dtype=torch.int32, device=dev)
+        knots = torch.empty(N, D, K + 1, device=dev)
+        st.run_diag(x, y, ladj, bins, knots)
+        own = ((knots < x.unsqueeze(-1)).sum(-1) - 1).to(torch.int32)
+        mism_own = int((own != bins).sum())
+        del own
+        # float64 evaluation (IEEE exp / division, max-subtracted softmax) of the layer-wise fp32 parameters
+        phi = lazy.hyper(x).unflatten(-1, (D, 3 * K - 1))
+        w, h, d = unpack(phi.double(), [(K,), (K,), (K - 1,)])
+        k64 = ops.rqs_forward(x.double(), w, h, d, want_bins=True)[2]
+        flips64 = int((k64 != bins).sum())
+        del phi, w, h, d, k64
+    out = {
+        "elements": N * D,
+        "mismatch_vs_own_knots": mism_own,
+        "flips_vs_f64_layerwise": flips64,
+        "flip_rate_vs_f64_layerwise": flips64 / float(N * D),
+    }
+    try:
+        from oracle import zuko_oracle as O
+
+        sd = {k: v for k, v in flow_cpu.state_dict().items() if v is not None}
+        spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(K), D)
+        n = min(N, 4096)
+        xc = x[:n].cpu()
+        with torch.no_grad():
+            phi = O._ar_phi(spec.layers[0], xc, None)
+            hor, _, _ = O.rqs_knots(*O.split_packed(phi, spec.layers[0].uni.shapes))
+            kref = O.rqs_bin_index(hor, xc)
+        kb = bins[:n].cpu().long()
+        fl = kb != kref
+        out["oracle_sample_elements"] = n * D
+        out["flips_vs_oracle_sample"] = int(fl.sum())
+        out["max_knot_dev_ulpB_vs_oracle_sample"] = float((knots[:n].cpu().double() - hor.double()).abs().max() / 2.0 ** -21)
+    except Exception as exc:  # the report must never break the headline line
+        out["oracle_sample_error"] = repr(exc)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+
+
+def model_flops(flow) -> dict:
+    """Per sample, whole flow: dense conditioner FLOPs (SURVEY 8d column 2) and FLOPs on non-zero (unmasked) weights."""
+    dense = nnz = 0
+    for t in flow.transform.transforms:
+        hyper = getattr(t, "hyper", None)
+        if hyper is None:
+            continue
+        for m in hyper.modules():
+            w = getattr(m, "weight", None)
+            if w is None or w.dim() != 2:
+                continue
+            dense += 2 * w.numel()
+            mask = getattr(m, "mask", None)
+            nnz += 2 * (int(mask.sum()) if mask is not None and mask.shape == w.shape else w.numel())
+    return {"dense": dense, "nnz": nnz}
+
+
 def main() -> None:
     args = parse()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1:
-        import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch_under_torchrun(args.gpus))
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # (dry-run aid: ZUKO_BENCH_SINGLE_DEVICE=1 ZUKO_BENCH_BACKEND=gloo lets several ranks share one GPU
-        #  so the multi-rank code path can be exercised on a 1-GPU box; never set by the driver)
-        if os.environ.get("ZUKO_BENCH_SINGLE_DEVICE") == "1":
-            local = 0
-        torch.cuda.set_device(local)
-        backend = os.environ.get("ZUKO_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    import torch
+
+    rank, world, local, dist = init_ranks(args)
+    if os.environ.get("ZUKO_BENCH_LAUNCH_SELFTEST") == "1":
+        got = 1
+        if dist is not None:
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            got = int(t.item())
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist else 1, "allreduce_of_ones": got}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    dev = torch.device("cuda", local)
 
     import zuko_amd
+    import zuko_amd.flows as ZF
     from zuko_amd import _C, ops
-    from zuko_amd.flows import MAF, NSF, RealNVP
 
-    global FEATURES, FLOP_PER_SAMPLE_TRANSFORM, TRANSFORMS
-    if args.config == "cfg3":
-        make = lambda: MAF(64, 0, transforms=8, hidden_features=HIDDEN)
-        FLOP_PER_SAMPLE_TRANSFORM, workload = 2 * (64 * 256 + 2 * 256 * 256 + 256 * 128), "MAF(features=64, transforms=8, hidden=[256]*3) log_prob"
-    elif args.config == "cfg4":
-        make = lambda: RealNVP(256, 0, transforms=16, hidden_features=[512] * 3)
-        FEATURES, TRANSFORMS = 256, 16
-        FLOP_PER_SAMPLE_TRANSFORM, workload = 2 * (128 * 512 + 2 * 512 * 512 + 512 * 256), "RealNVP(features=256, transforms=16, hidden=[512]*3) log_prob"
-    elif args.config == "cfg5":
-        make = lambda: NSF(1024, 0, transforms=12, bins=16, hidden_features=[1024] * 3)
-        FEATURES, TRANSFORMS = 1024, 12
-        FLOP_PER_SAMPLE_TRANSFORM, workload = 2 * (3 * 1024 * 1024 + 1024 * 48128), "NSF(features=1024, transforms=12, bins=16, hidden=[1024]*3) bf16 log_prob"
-    else:
-        make = lambda: NSF(FEATURES, 0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
-        workload = "NSF(features=64, context=0, transforms=8, bins=8, hidden=[256]*3) log_prob"
+    ctor, kw, workload, bf16 = CONFIGS[args.config]
+    make = lambda: getattr(ZF, ctor)(**kw)
+    features, transforms = kw["features"], kw["transforms"]
     torch.manual_seed(0)
-    bf16 = args.config == "cfg5"
     flow_cpu = make()
+    flops = model_flops(flow_cpu)
     if bf16:  # 629 M parameters: no second copy
         flow, flow_cpu = flow_cpu.to(dev).to(torch.bfloat16), None
     else:
@@ -153,7 +303,7 @@ def main() -> None:
         flow.load_state_dict(flow_cpu.state_dict())
         flow = flow.to(dev)
     B = 1 << args.batch_log2
-    x = torch.randn(B, FEATURES, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    x = torch.randn(B, features, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     if bf16:
         x = x.to(torch.bfloat16)
 
@@ -177,11 +327,15 @@ def main() -> None:
     for _ in range(args.steps):
         nll = step()
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    per_rank_ms = [dt_local / args.steps * 1e3]
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
+        mine = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        dt = max(float(t.item()) for t in every)  # MAX over ranks
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
     nll_value = float(nll.item())  # the all-reduced mean NLL of the last timed step
@@ -189,6 +343,7 @@ def main() -> None:
     # per-kernel durations over extra (profiled) steps: events on the launch stream
     roof = None
     kernels = {}
+    extra = []
     if rank == 0:
         _C.PROFILE = {}
         for _ in range(min(3, args.steps)):
@@ -208,39 +363,36 @@ def main() -> None:
                 kernels[" ".join(map(str, key))] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), **({"bf16": True} if bf16 else {})}
         # the standalone (phi-in-HBM) spline kernel is not on the fused path: time it on its own so its
         # HBM fraction (the bandwidth-bound roofline of north_star) is measured in the same run
-        try:
-            if args.config != "cfg2":
-                raise RuntimeError("side measurement only taken on the headline config")
-            gen = torch.Generator(device=dev).manual_seed(3)
-            phi = torch.randn(B, FEATURES, 3 * BINS - 1, generator=gen, device=dev)
-            w, h, d = phi[..., :BINS], phi[..., BINS : 2 * BINS], phi[..., 2 * BINS :]
-            with torch.no_grad():
-                ops.rqs_forward(x, w, h, d, reduce=True)
-                _C.PROFILE = {}
-                for _ in range(5):
+        if args.config == "cfg2":
+            try:
+                gen = torch.Generator(device=dev).manual_seed(3)
+                phi = torch.randn(B, features, 3 * BINS - 1, generator=gen, device=dev)
+                w, h, d = phi[..., :BINS], phi[..., BINS : 2 * BINS], phi[..., 2 * BINS :]
+                with torch.no_grad():
                     ops.rqs_forward(x, w, h, d, reduce=True)
-                torch.cuda.synchronize()
-            recs = _C.PROFILE.get("zk_rqs_forward", [])
-            _C.PROFILE = None
-            ts = [a.elapsed_time(b) for a, b, _ in recs]
-            kernels[f"zk_rqs_forward {B} {FEATURES} {BINS}"] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), "standalone": True}
-            del phi, w, h, d
-        except Exception as exc:  # never let the side measurement break the headline line
-            if args.config == "cfg2":
+                    _C.PROFILE = {}
+                    for _ in range(5):
+                        ops.rqs_forward(x, w, h, d, reduce=True)
+                    torch.cuda.synchronize()
+                recs = _C.PROFILE.get("zk_rqs_forward", [])
+                _C.PROFILE = None
+                ts = [a.elapsed_time(b) for a, b, _ in recs]
+                kernels[f"zk_rqs_forward {B} {features} {BINS}"] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), "standalone": True}
+                del phi, w, h, d
+            except Exception as exc:  # never let the side measurement break the headline line
+                _C.PROFILE = None
                 kernels["zk_rqs_forward (standalone)"] = {"calls": 0, "avg_ms": float("nan"), "error": repr(exc)}
-        roof, extra = zuko_amd_roofline(kernels, B)
-        if roof and args.config != "cfg2":
-            roof["traffic"] = None  # the committed PMC passes were taken on the headline workload only
-        # the fused kernel skips all-zero 16x16 weight tiles: also report the rate on the MFMAs it actually issues
+        per_transform = {k: v / transforms for k, v in flops.items()}
+        st = None
         try:
-            st = flow.transform.transforms[0].fused_state(dev) if roof and roof["kernel"].startswith("zk_ar_forward") else None
-            if st is not None:
-                executed = float(B) * st.plan.kept_tiles * 512.0  # 16 x 16 x 2 FLOP per kept tile per sample
-                roof["executed_flop_per_launch"] = executed
-                roof["achieved_executed"] = executed / (roof["avg_launch_ms"] * 1e-3) / 1e12
-                roof["frac_executed"] = roof["achieved_executed"] / roof["peak"]
+            st = flow.transform.transforms[0].fused_state(dev)
         except Exception:
-            pass
+            st = None
+        executed = None if st is None else st.plan.kept_tiles * 512.0  # 16 x 16 x 2 FLOP per kept tile per sample
+        last = [m for m in flow.transform.transforms[0].hyper.modules() if getattr(m, "weight", None) is not None][-1]
+        lmask = getattr(last, "mask", None)
+        per_transform["last_layer_nnz_frac"] = 1.0 if lmask is None else float(lmask.float().mean())
+        roof, extra = zuko_amd_roofline(kernels, B, per_transform, executed, args.config)
 
     if rank == 0:
         out = {
@@ -248,9 +400,11 @@ def main() -> None:
             "value": value,
             "unit": "samples/s",
             "n_gpus": world,
+            "rccl_world_size": dist.get_world_size() if dist is not None else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
+            "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -260,18 +414,25 @@ def main() -> None:
                 "workload": f"{workload}, batch=2^{args.batch_log2} per GPU, x~N(0,1), seed-0 init",
                 "batch_per_gpu": B,
                 "global_batch": B * world,
-                "parallelism": f"batch-sharded x{world}, one RCCL all-reduce of the scalar NLL",
+                "parallelism": f"batch-sharded x{world}, one {'RCCL' if os.environ.get('ZUKO_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ.get('ZUKO_BENCH_BACKEND')} all-reduce of the scalar NLL",
             },
             "roofline": roof,
             "end_to_end": {
-                "flop_per_sample": FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS,
-                "achieved_tflops_dense_equiv": value / world * FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12,
-                "frac_of_mfma_peak": value / world * FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS),
-                "mask_aware_tflops": value / world * NNZ_FLOP_PER_SAMPLE_TRANSFORM * TRANSFORMS / 1e12,
+                "flop_per_sample_dense": flops["dense"],
+                "flop_per_sample_nonzero_weights": flops["nnz"],
+                "tflops_on_nonzero_weights": value / world * flops["nnz"] / 1e12,
+                "frac_of_mfma_peak_on_nonzero_weights": value / world * flops["nnz"] / 1e12 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS),
+                "tflops_dense_equiv": value / world * flops["dense"] / 1e12,
+                "note": "dense_equiv counts masked-out (structurally zero) weights the kernels never multiply; it is NOT a hardware fraction",
             },
             "kernels": extra,
             "nll": nll_value,
         }
+        if world == 1 and args.config == "cfg2" and not args.no_bin_report:
+            try:
+                out["bin_index"] = bin_report(flow, flow_cpu, x, dev)
+            except Exception as exc:
+                out["bin_index"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             out["cpu_baseline"] = cpu_baseline(flow_cpu, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
@@ -280,60 +441,71 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def _pmc_traffic(B: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN/traffic.json; collected as MI355X_MICROARCH.md prescribes) — only valid for the
-    default 2^20 workload they were taken on."""
+def _pmc_traffic(B: int, config: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN/traffic.json;
+    FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 read-side correction as MI355X_MICROARCH.md prescribes) — valid
+    only for the default 2^20 headline workload they were taken on; counters cannot be read inside this process."""
     import glob
 
-    if B != 1 << 20:
-        return None
+    if B != 1 << 20 or config != "cfg2":
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
+        return json.load(f).get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
-def zuko_amd_roofline(kernels: dict, B: int):
-    """Roofline object for the dominant kernel + a per-kernel table (all measured in this run)."""
+def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_per_sample, config: str):
+    """Roofline object for the dominant kernel + a per-kernel table (all measured in this run).
+
+    MFMA-bound kernels: `achieved` = FLOPs on the non-zero (unmasked) weights the launch has to multiply / launch time
+    (SURVEY 8d's mask-aware figure; 531 568 per sample per transform at cfg2), so `frac` is a hardware fraction <= 1;
+    `frac_executed` additionally counts the zeros inside the 16x16 tiles the kernel keeps (what the matrix pipe issues).
+    HBM-bound kernels: algorithmic bytes / time."""
     table = []
     for name, rec in kernels.items():
         row = {"kernel": name, **rec}
         parts = name.split()
-        if parts[0] == "zk_linear_bf16_rqs":  # last layer + spline in one kernel: useful (unpadded, dense-equivalent) FLOPs
+        t = rec["avg_ms"] * 1e-3
+        if parts[0] == "zk_linear_bf16_rqs":  # last layer + spline in one kernel
             n, fin, k, feats = int(parts[1]), int(parts[2]), int(parts[4]), int(parts[5])
-            row.update(bound="mfma", achieved=2.0 * n * fin * feats * (3 * k - 1) / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s")
+            dense = 2.0 * n * fin * feats * (3 * k - 1)
+            row.update(bound="mfma", achieved=dense * flop_per_transform.get("last_layer_nnz_frac", 1.0) / t / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
+                       note=f"achieved counts the unmasked weights only ({flop_per_transform.get('last_layer_nnz_frac', 1.0):.4f} of the dense last layer)")
+            row["dense_equiv_tflops"] = dense / t / 1e12
         elif parts[0] == "zk_linear_bf16":
             n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
-            row.update(bound="mfma", achieved=2.0 * n * fin * fout / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s")
+            row.update(bound="mfma", achieved=2.0 * n * fin * fout / t / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", note="dense-equivalent (mask not accounted per layer)")
         elif parts[0] == "zk_linear":
             n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
-            flops = 2.0 * n * fin * fout
-            row.update(bound="mfma", achieved=flops / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
-        elif parts[0] == "zk_ar_forward":
-            flops = float(B) * FLOP_PER_SAMPLE_TRANSFORM
-            row.update(bound="mfma", achieved=flops / (rec["avg_ms"] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+            row.update(bound="mfma", achieved=2.0 * n * fin * fout / t / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+        elif parts[0] in ("zk_ar_forward", "zk_coupling_forward"):
+            row.update(bound="mfma", achieved=float(B) * flop_per_transform["nnz"] / t / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+            row["algorithmic_flop_per_launch"] = float(B) * flop_per_transform["nnz"]
+            row["dense_equiv_tflops"] = float(B) * flop_per_transform["dense"] / t / 1e12
+            if executed_per_sample and parts[0] == "zk_ar_forward":
+                row["executed_flop_per_launch"] = float(B) * executed_per_sample
+                row["achieved_executed"] = float(B) * executed_per_sample / t / 1e12
+                row["frac_executed"] = row["achieved_executed"] / PEAK_F32_MFMA_TFLOPS
         elif parts[0] == "zk_rqs_forward" and len(parts) == 4 and parts[1].isdigit():
             n, d, k = int(parts[1]), int(parts[2]), int(parts[3])
             esz = 2 if rec.get("bf16") else 4
             byts = float(n) * (d * (esz + esz * (3 * k - 1) + esz) + 4)  # x + phi + y per element, + ladj per row
-            row.update(bound="hbm", achieved=byts / (rec["avg_ms"] * 1e-3) / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
+            row.update(bound="hbm", achieved=byts / t / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
         if "achieved" in row:
             row["frac"] = row["achieved"] / row["peak"]
-        row["total_ms_per_step"] = rec["avg_ms"] * rec["calls"] / max(1, min(3, rec["calls"]))
         table.append(row)
-    # dominant = largest total time per step
-    per_step = {}
-    for row in table:
-        per_step[row["kernel"]] = row["avg_ms"] * row["calls"]
     dom = max((r for r in table if not r.get("standalone")), key=lambda r: r["avg_ms"] * r["calls"])
     roof = None
     if "achieved" in dom:
-        roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": _pmc_traffic(B),
+        traffic, src = _pmc_traffic(B, config)
+        roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                "traffic": traffic, "traffic_source": (f"{src}: rocprofv3 --pmc passes of this same command, not re-measured in this run" if src else None),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]}
-    for row in table:
-        row.pop("total_ms_per_step", None)
+        for k in ("algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
+            if k in dom:
+                roof[k] = dom[k]
     return roof, table
 
 

@@ -71,6 +71,15 @@ int zk_rqs_from_knots(int dtype, int inverse, int64_t N, int64_t D, int K, const
                       const void* vertical, const void* slopes, int64_t k_sN, int64_t k_sD, void* out, void* ladj,
                       int32_t* bin_out, void* stream);
 
+/* Diagnostic twin of zk_rqs_forward / zk_rqs_inverse (fp32, K in {4, 8, 16}): the SAME per-element arithmetic the product
+ * kernels run, additionally writing bin_out[N, D] (k = #(knots < v) - 1, zuko/transforms.py:521-523) and
+ * knots_out[N, D, K+1], the knots of the searched axis exactly as the bin search compared them.  With these the parity
+ * tests assert the product bin index on the kernel's OWN knots (exact) and bound every disagreement with the oracle's
+ * index by the distance between the two sets of knots.  ladj is [N, D] (NULL for the inverse). */
+int zk_rqs_diag(int inverse, int64_t N, int64_t D, int K, double bound, double slope, const void* in, const void* widths,
+                int64_t w_sN, int64_t w_sD, const void* heights, int64_t h_sN, int64_t h_sD, const void* derivs, int64_t d_sN,
+                int64_t d_sD, void* out, void* ladj, int32_t* bin_out, float* knots_out, void* stream);
+
 /* ---- MonotonicAffineTransform (zuko/transforms.py:412-446) -------------------------------------- */
 int zk_affine_forward(int dtype, int64_t N, int64_t D, double slope, const void* x, const void* shift, int64_t s_sN,
                       int64_t s_sD, const void* scale, int64_t c_sN, int64_t c_sD, void* y, void* ladj, int ladj_reduced,
@@ -90,8 +99,9 @@ int zk_sos_inverse(int dtype, int64_t N, int64_t D, int P, int L1, double slope,
                    int64_t a_sD, const void* constant, int64_t c_sN, int64_t c_sD, void* x, void* stream);
 
 /* ---- BernsteinTransform / BoundedBernsteinTransform (zuko/transforms.py:640-831) ---------------- *
- * theta is the UNCONSTRAINED [N, D, M]; M + 2 (unbounded) or M + 5 (bounded) must be one of
- * {6, 8, 10, 13, 14, 18, 21, 22, 34, 37} (register-resident de Casteljau instantiations). */
+ * theta is the UNCONSTRAINED [N, D, M]; NC = M + 2 (unbounded) or M + 5 (bounded) constrained coefficients.  NC in
+ * {6, 8, 10, 13, 14, 18, 21, 22, 34, 37} run register-resident de Casteljau instantiations, any other NC <= 72 a
+ * generic (slower) kernel with the same arithmetic; larger NC returns hipErrorInvalidValue. */
 int zk_bernstein_forward(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, const void* x,
                          const void* theta, int64_t t_sN, int64_t t_sD, void* y, void* ladj, int ladj_reduced, void* stream);
 int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, int n_bisect, const void* y,
@@ -143,12 +153,18 @@ int zk_linear_bf16_rqs(int64_t N, int in_features, int panels, const void* h, in
  *             (degree-sorted, tile-skipped weight stream of 1 KiB MFMA A-operand images, bias image,
  *             per-group skip bitmasks, feature regrouping of the last layer); wstream and bias are
  *             produced on the device by zk_gather_f32 from the module's weight / mask / bias tensors.
- *   variant   must be 0 (the LDS-ring weight feed; alternatives were measured and dropped)
+ *   variant   reserved, must be 0
  *   limits    DIN <= 256, every hidden width <= 256, >= 1 hidden layer.                             */
 int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
                   int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
                   const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
                   int variant, void* stream);
+/* Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3, LDS-staged tiles: D % 4 == 0): the same kernel
+ * template and arithmetic plus bin_out[N, D] (int32) and knots_out[N, D, K+1] (fp32), as zk_rqs_diag. */
+int zk_ar_forward_diag(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
+                       const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap,
+                       int n_layers, int n_groups, int n_chunks, int act, double bound, double slope, int32_t* bin_out,
+                       float* knots_out, void* stream);
 /* One sweep of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000, the body of its loop):
  *     x_out = univariate(*unpack(MaskedMLP(x_cond))).inv(y)
  * x_cond [N, DIN] as `x` of zk_ar_forward (features first, context after), y [N, D] the values to

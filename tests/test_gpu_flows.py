@@ -378,3 +378,53 @@ def test_bf16_layer_with_spline_epilogue_equals_unfused_layer(dev, N, D, K, ctx,
     assert y_f.shape == (N, D) and l_f.shape == (N,) and torch.isfinite(l_f).all()
     assert (y_f.float() - y32).abs().max() < 0.15 and (y_f.float() - y32).abs().mean() < 0.01
     assert ((l_f - l32).abs() / l32.abs().clamp_min(1.0)).mean() < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [256, 77])
+def test_cfg5_layer_shape_bf16(dev, N, monkeypatch):
+    """One autoregressive layer at cfg5's OWN shape (BASELINE.json configs[4]: D = 1024, 16 bins, hidden 1024^3, i.e.
+    a 1024 -> 48128 last layer in 205 feature panels), bf16, N = 256 and a ragged N:
+    (a) the spline-in-epilogue kernel and the unfused path (phi through HBM) give bit-identical y;
+    (b) SURVEY 9.1's bar: against the fp32 oracle, the HIP bf16 path is no worse than the REFERENCE'S OWN bf16 path
+        (the oracle evaluated in torch.bfloat16 on the CPU, as `flow.to(torch.bfloat16)` does in the reference)."""
+    from zuko_amd.flows import MaskedAutoregressiveTransform
+    from zuko_amd.transforms import MonotonicRQSTransform
+
+    D, K = 1024, 16
+    torch.manual_seed(5)
+    t = MaskedAutoregressiveTransform(D, 0, univariate=MonotonicRQSTransform, shapes=[(K,), (K,), (K - 1,)], hidden_features=[1024] * 3)
+    sd = {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in t.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, D, generator=g).to(torch.bfloat16)
+
+    # oracle on the bf16-VALUED weights: once in float32 (the yardstick), once in bfloat16 (the reference's bf16 path)
+    lins = [k[: -len(".weight")] for k in sd if k.endswith(".weight")]
+    def layer(dtype):
+        return O.ARLayer(O.uni_rqs(K), [sd[n + ".weight"].to(dtype) for n in lins], [sd[n + ".bias"].to(dtype) for n in lins],
+                         [sd[n + ".mask"] for n in lins], D, D)
+    with torch.no_grad():
+        y32, l32 = O.ar_forward(layer(torch.float32), x.float())
+        yb, lb = O.ar_forward(layer(torch.bfloat16), x)
+
+    tb = t.to(dev).to(torch.bfloat16)
+    xg = x.to(dev)
+    with torch.no_grad():
+        y_f, l_f = tb().call_and_ladj(xg)
+        assert tb.hyper._bf16_plan() is not None
+        monkeypatch.setenv("ZUKO_AMD_BF16_UNFUSED", "1")
+        y_u, l_u = tb().call_and_ladj(xg)
+        monkeypatch.delenv("ZUKO_AMD_BF16_UNFUSED")
+    assert y_f.dtype == torch.bfloat16 and l_f.dtype == torch.float32 and y_f.shape == (N, D) and l_f.shape == (N,)
+    assert torch.equal(y_f, y_u), f"{(y_f != y_u).sum().item()} of {y_f.numel()} outputs differ between the fused and the unfused bf16 layer"
+    assert torch.allclose(l_f, l_u, rtol=1e-5, atol=1e-3)
+
+    def stats(e):
+        e = e.double().flatten()
+        return float(e.mean()), float(e.median()), float(torch.quantile(e, 0.99)), float(e.max())
+
+    for what, hip, ref, gold in (("y", y_f.float().cpu(), yb.float(), y32), ("ladj", l_f.cpu(), lb.float(), l32)):
+        e_hip, e_ref = stats((hip - gold).abs()), stats((ref - gold).abs())
+        print(f"cfg5 layer N={N} {what}: |hip - fp32 oracle| mean/median/p99/max = {e_hip};  |bf16 oracle - fp32 oracle| = {e_ref}")
+        assert e_hip[0] <= e_ref[0] and e_hip[1] <= e_ref[1] + 1e-12 and e_hip[2] <= e_ref[2], f"{what}: HIP bf16 path is less accurate than the reference's own bf16 path"
+        assert e_hip[3] <= 2.0 * e_ref[3] + 1e-6

@@ -25,6 +25,7 @@ F = c_double
 SIGNATURES = {
     "zk_rqs_forward": [I, L, L, I, F, F, P, P, L, L, P, L, L, P, L, L, P, P, I, P, P],
     "zk_rqs_inverse": [I, L, L, I, F, F, P, P, L, L, P, L, L, P, L, L, P, P, P],
+    "zk_rqs_diag": [I, L, L, I, F, F, P, P, L, L, P, L, L, P, L, L, P, P, P, P, P],
     "zk_rqs_from_knots": [I, I, L, L, I, P, P, P, P, L, L, P, P, P, P],
     "zk_affine_forward": [I, L, L, F, P, P, L, L, P, L, L, P, P, I, P],
     "zk_affine_inverse": [I, L, L, F, P, P, L, L, P, L, L, P, P],
@@ -43,6 +44,7 @@ SIGNATURES = {
     "zk_act_backward": [L, P, P, I, P, P],
     "zk_ar_lds_bytes": [I, I],
     "zk_ar_forward": [I, L, I, I, P, L, P, L, P, I, P, P, I, P, P, I, I, I, I, F, F, I, P],
+    "zk_ar_forward_diag": [I, L, I, I, P, L, P, L, P, P, P, I, P, P, I, I, I, I, F, F, P, P, P],
     "zk_ar_inverse_sweep": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, I, P],
     "zk_ar_inverse_partial": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, P, I, POINTER(c_int), I, I, I, P],
 }

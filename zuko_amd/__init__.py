@@ -12,5 +12,17 @@ _C.lib()  # fail loudly at import time if libzuko_amd.so is missing or stale
 
 from . import distributions, flows, lazy, nn, ops, transforms, utils  # noqa: E402
 
-__version__ = "0.1.0"
-__all__ = ["distributions", "flows", "lazy", "nn", "ops", "transforms", "utils"]
+__version__ = "0.2.0"
+__all__ = ["distributions", "flows", "invalidate", "lazy", "nn", "ops", "transforms", "utils"]
+
+
+def invalidate(module) -> None:
+    """Drop every device-side table derived from `module`'s parameters / buffers (fused weight streams, bf16 `mask * W`
+    tables, sweep schedules).  The tables follow `Tensor._version`, which optimizers, `copy_` and `load_state_dict` bump;
+    call this after writing parameters through `.data` or raw pointers (EMA swaps, legacy initialisers), which do not."""
+    from .flows import autoregressive as _ar
+
+    for m in module.modules():
+        _ar._FUSED_CACHE.pop(m, None)
+        m.__dict__.pop("_bf16_plan_cache", None)
+        m.__dict__.pop("_coupling_cache", None)

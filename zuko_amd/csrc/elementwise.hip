@@ -34,6 +34,7 @@ struct UniArgs {
   void* ladj;      // may be null (inverse)
   int reduced;     // 1: ladj[N] summed over D, 0: ladj[N, D]
   int32_t* kout;   // optional bin index output [N, D] (RQS only)
+  float* knots_out;  // optional (fp32 lean spline only): the K+1 search-axis knots the bin search compared, [N, D, K+1]
   Seg seg[3];
   int total;       // packed values per element
   int64_t iters;   // wave-tile iterations per wave (uniform across the grid)
@@ -57,11 +58,11 @@ template <typename T> struct Ld {
 template <typename T, int K, bool INV> struct RqsOp {
   static constexpr int NSEG = 3;
   static __device__ __forceinline__ int off(int s, int) { return s * K; }  // packed offsets 0, K, 2K
-  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
+  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) {
     typedef typename MathStd<T>::type M;
     T kx[K + 1], ky[K + 1], kd[K + 1];
     if constexpr (sizeof(T) == 4) {  // fp32: the same arithmetic as the stream kernel and the fused epilogue
-      rqs_lean<K, INV>(ld[0], ld[1], ld[2], a.lc, in, out, ladj, k);
+      rqs_lean<K, INV>(ld[0], ld[1], ld[2], a.lc, in, out, ladj, k, a.knots_out ? a.knots_out + e * (K + 1) : nullptr);
     } else {
       rqs_axis_knots<T, K, M>(ld[0], T(a.bound), T(a.ls), kx);
       rqs_axis_knots<T, K, M>(ld[1], T(a.bound), T(a.ls), ky);
@@ -77,7 +78,7 @@ template <typename T, int K, bool INV> struct RqsOp {
 template <typename T, int K, bool INV> struct RqsKnotsOp {
   static constexpr int NSEG = 3;
   static __device__ __forceinline__ int off(int s, int) { return s * (K + 1); }
-  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
+  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) {
     T kx[K + 1], ky[K + 1], kd[K + 1];
 #pragma unroll
     for (int j = 0; j <= K; ++j) { kx[j] = ld[0](j); ky[j] = ld[1](j); kd[j] = ld[2](j); }
@@ -91,7 +92,7 @@ template <typename T, int K, bool INV> struct RqsKnotsOp {
 template <typename T, bool INV> struct RqsGenericOp {
   static constexpr int NSEG = 3;
   static __device__ __forceinline__ int off(int s, int K) { return s * K; }
-  template <typename A> static __device__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
+  template <typename A> static __device__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) {
     const int K = a.K;
     const T bound = T(a.bound), ls = T(a.ls);
     T kn[2][ZK_RQS_KMAX + 1], kd[ZK_RQS_KMAX + 1];
@@ -141,7 +142,7 @@ template <typename T, bool INV> struct RqsGenericOp {
 template <typename T, bool INV> struct AffineOp {
   static constexpr int NSEG = 2;
   static __device__ __forceinline__ int off(int s, int) { return s; }  // packed: [shift, scale]
-  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
+  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) {
     k = 0;
     typedef typename MathStd<T>::type M;
     if (INV) { out = affine_inv<T, M>(ld[0](0), ld[1](0), T(a.ls), in); ladj = T(0); }
@@ -159,7 +160,7 @@ template <typename T, bool INV> struct SosOp {
   SosConst<T> c;
   int has_const;
   __device__ __forceinline__ int offr(int s) const { return s * c.P * c.L1; }
-  template <typename A> __device__ __forceinline__ void runi(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) const {
+  template <typename A> __device__ __forceinline__ void runi(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) const {
     k = 0;
     T cst = has_const ? ld[1](0) : T(0);
     if (INV) {
@@ -175,7 +176,7 @@ template <typename T, bool INV> struct SosOp {
 template <typename T, int NC, bool INV> struct BernOp {
   static constexpr int NSEG = 1;
   static __device__ __forceinline__ int off(int, int) { return 0; }
-  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k) {
+  template <typename A> static __device__ __forceinline__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) {
     k = 0;
     T th[NC];
     const T bound = T(a.bound);
@@ -184,6 +185,98 @@ template <typename T, int NC, bool INV> struct BernOp {
     BernTails<T> t = bern_tails<T, NC>(th, a.bounded != 0, bound);
     if (INV) { out = bern_inv<T, NC>(th, t, bound, in, a.n_bisect); ladj = T(0); }
     else { T d; bern_fwd<T, NC>(th, t, bound, in, out, d); ladj = t_log(d); }
+  }
+};
+
+// any number of coefficients up to ZK_BERN_NCMAX: same expression trees as bern_* with run-time loops over local
+// arrays (slow path; the register-resident instantiations above cover BPF's default degree and the tested ones)
+#define ZK_BERN_NCMAX 72
+template <typename T, bool INV> struct BernGenericOp {
+  static constexpr int NSEG = 1;
+  static __device__ __forceinline__ int off(int, int) { return 0; }
+  static __device__ void eval(const T* th, int NC, T u, T& val, T& dval) {
+    T b[ZK_BERN_NCMAX];
+    for (int i = 0; i < NC; ++i) b[i] = th[i];
+    const T v = T(1) - u;
+    for (int r = 1; r < NC - 1; ++r)
+      for (int i = 0; i < NC - r; ++i) b[i] = v * b[i] + u * b[i + 1];
+    dval = T(NC - 1) * (b[1] - b[0]);
+    val = v * b[0] + u * b[1];
+  }
+  static __device__ void fwd(const T* th, int NC, const BernTails<T>& t, T bound, T x, T& y, T& dydx) {
+    const T eps = T(ZK_BERN_EPS);
+    T u = (x + bound) / (T(2) * bound);
+    bool lo = u <= eps;
+    bool hi = u >= T(1) - eps;
+    T safe = (lo || hi) ? T(0.5) : u;
+    T val, dval;
+    eval(th, NC, safe, val, dval);
+    T ylo = t.slp0 * (u - eps) + t.off0;
+    T yhi = t.slp1 * ((u - T(1)) + eps) + t.off1;
+    y = lo ? ylo : val;
+    y = hi ? yhi : y;
+    T du = lo ? t.slp0 : dval;
+    du = hi ? t.slp1 : du;
+    dydx = du / (T(2) * bound);
+  }
+  template <typename A> static __device__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) {
+    k = 0;
+    const int NC = a.K;  // constrained coefficients
+    const T bound = T(a.bound);
+    T th[ZK_BERN_NCMAX];
+    if (a.bounded) {  // bern_theta_bounded
+      const int n = NC - 5;
+      const T edge = (T(2) * bound) / T(n + 4);
+      const T span = T(2) * bound - T(4) * edge;
+      T m = ld[0](0);
+      for (int j = 1; j < n; ++j) { T v = ld[0](j); m = v > m ? v : m; }
+      T s = T(0);
+      for (int j = 0; j < n; ++j) { T ev = t_exp(ld[0](j) - m); th[3 + j] = ev; s += ev; }
+      T r = T(1) / s;
+      T cum = -bound;
+      th[0] = cum;
+      cum += edge; th[1] = cum;
+      cum += edge; th[2] = cum;
+      for (int j = 0; j < n; ++j) { cum += (th[3 + j] * r) * span; th[3 + j] = cum; }
+      cum += edge; th[n + 3] = cum;
+      cum += edge; th[n + 4] = cum;
+    } else {  // bern_theta_unbounded
+      const int n = NC - 2;
+      const T shift = T(0.69314718055994530942 * n / 2.0);
+      T cum = ld[0](0);
+      th[0] = cum - shift;
+      cum += softplus<T>(ld[0](1));
+      th[1] = cum - shift;
+      for (int j = 1; j < n; ++j) { cum += softplus<T>(ld[0](j)); th[j + 1] = cum - shift; }
+      cum += softplus<T>(ld[0](n - 1));
+      th[n + 1] = cum - shift;
+    }
+    BernTails<T> t;
+    if (a.bounded) { t.off0 = -bound; t.off1 = bound; t.slp0 = T(2) * bound; t.slp1 = T(2) * bound; }
+    else { eval(th, NC, T(ZK_BERN_EPS), t.off0, t.slp0); eval(th, NC, T(1) - T(ZK_BERN_EPS), t.off1, t.slp1); }
+    if (INV) {
+      const T eps = T(ZK_BERN_EPS);
+      T lo = -bound, hi = bound;
+      for (int it = 0; it < a.n_bisect; ++it) {
+        T mid = (lo + hi) / T(2);
+        T fy, d;
+        fwd(th, NC, t, bound, mid, fy, d);
+        bool below = fy < in;
+        lo = below ? mid : lo;
+        hi = below ? hi : mid;
+      }
+      T x = (lo + hi) / T(2);
+      T xlo = (((in - t.off0) / t.slp0 + eps) * T(2)) * bound - bound;
+      T xhi = ((((in - t.off1) / t.slp1 - eps) + T(1)) * T(2)) * bound - bound;
+      x = (in <= t.off0) ? xlo : x;
+      x = (in >= t.off1) ? xhi : x;
+      out = x;
+      ladj = T(0);
+    } else {
+      T d;
+      fwd(th, NC, t, bound, in, out, d);
+      ladj = t_log(d);
+    }
   }
 };
 
@@ -267,7 +360,7 @@ __device__ __forceinline__ void uni_driver(const UniArgs& a, T* sh, RunFn run) {
 #pragma unroll
           for (int s = 0; s < 3; ++s) ld[s].p = (const T*)a.seg[s].p + row * a.seg[s].sN + d * a.seg[s].sD;
         }
-        run(ld, xg[e], out, lj, k);
+        run(ld, xg[e], out, lj, k, e);
         yg[e] = out;
         if (lg && !a.reduced) lg[e] = lj;
         if (a.kout) a.kout[e] = k;
@@ -303,7 +396,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
 
 template <typename T, bool PACKED, typename Op> __global__ __launch_bounds__(256) void uni_kernel(UniArgs a) {
   T* sh = reinterpret_cast<T*>(zk_dyn_lds);
-  uni_driver<T, PACKED, Op>(a, sh, [&](const Ld<T>(&ld)[3], T in, T& out, T& lj, int& k) { Op::run(a, ld, in, out, lj, k); });
+  uni_driver<T, PACKED, Op>(a, sh, [&](const Ld<T>(&ld)[3], T in, T& out, T& lj, int& k, int64_t e) { Op::run(a, ld, in, out, lj, k, e); });
 }
 
 template <typename T, bool PACKED, bool INV> __global__ __launch_bounds__(256) void sos_kernel(UniArgs a, SosOp<T, INV> op) {
@@ -311,7 +404,7 @@ template <typename T, bool PACKED, bool INV> __global__ __launch_bounds__(256) v
   struct OffT {
     static __device__ __forceinline__ int off(int s, int K) { return s * K; }  // K carries P*L1 here
   };
-  uni_driver<T, PACKED, OffT>(a, sh, [&](const Ld<T>(&ld)[3], T in, T& out, T& lj, int& k) { op.runi(a, ld, in, out, lj, k); });
+  uni_driver<T, PACKED, OffT>(a, sh, [&](const Ld<T>(&ld)[3], T in, T& out, T& lj, int& k, int64_t e) { op.runi(a, ld, in, out, lj, k, e); });
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -409,7 +502,12 @@ template <typename T, bool INV> static int launch_bern(UniArgs a, int M, hipStre
     case 22: return launch_bern_nc<T, 22, INV>(a, st);
     case 34: return launch_bern_nc<T, 34, INV>(a, st);
     case 37: return launch_bern_nc<T, 37, INV>(a, st);
-    default: return ZK_EINVAL;
+    default: {
+      if (NC < 3 || NC > ZK_BERN_NCMAX || (a.bounded ? M < 1 : M < 2)) return ZK_EINVAL;
+      const int lens[1] = {M};
+      a.K = NC;
+      return launch_uni<T, BernGenericOp<T, INV>, BernGenericOp<T, INV>>(a, lens, 1, st);
+    }
   }
 }
 
@@ -737,6 +835,19 @@ int zk_rqs_inverse(int dtype, int64_t N, int64_t D, int K, double bound, double 
     if (rc >= 0) return rc;
   }
   return ZK_DISPATCH(dtype, (launch_rqs<float, true>(a, K, (hipStream_t)stream)), (launch_rqs<double, true>(a, K, (hipStream_t)stream)));
+}
+
+// Diagnostic twin of zk_rqs_forward / zk_rqs_inverse (fp32 only): the SAME per-element arithmetic the product kernels
+// run (rqs_lean) through the general kernel, additionally writing the bin index and the K+1 knots of the search axis.
+int zk_rqs_diag(int inverse, int64_t N, int64_t D, int K, double bound, double slope, const void* in, const void* widths, int64_t w_sN, int64_t w_sD,
+                const void* heights, int64_t h_sN, int64_t h_sD, const void* derivs, int64_t d_sN, int64_t d_sD, void* out, void* ladj, int32_t* bin_out,
+                float* knots_out, void* stream) {
+  if (K != 4 && K != 8 && K != 16) return ZK_EINVAL;
+  UniArgs a = base_args(N, D, in, out, inverse ? nullptr : ladj, 0, bin_out);
+  a.knots_out = knots_out;
+  a.seg[0] = {widths, w_sN, w_sD}; a.seg[1] = {heights, h_sN, h_sD}; a.seg[2] = {derivs, d_sN, d_sD};
+  a.bound = bound; a.ls = log(slope); a.lc = rqs_lean_const(bound, a.ls);
+  return inverse ? launch_rqs<float, true>(a, K, (hipStream_t)stream) : launch_rqs<float, false>(a, K, (hipStream_t)stream);
 }
 
 int zk_rqs_from_knots(int dtype, int inverse, int64_t N, int64_t D, int K, const void* in, const void* horizontal, const void* vertical, const void* slopes,

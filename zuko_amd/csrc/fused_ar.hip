@@ -25,7 +25,9 @@
 //
 // Host-side planning (permutations, stream order, skip masks): zuko_amd/fused.py.
 #include "zk_univariate.h"
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 // -DZK_AR_TIMING=1 compiles in the s_memtime/printf phase probes (dbg bits 3 and 4); off in the product build
 #ifndef ZK_AR_TIMING
@@ -61,6 +63,8 @@ struct ArArgs {
   float bound, ls;
   RqsLeanConst lc;   // spline epilogues: constants of rqs_lean
   int64_t n_tiles;
+  int32_t* bin_out;  // diagnostic instantiation only: bin index [N, D] and the K+1 search-axis knots [N, D, K+1]
+  float* knots_out;
 };
 
 __device__ __forceinline__ float act_f32(float v, int act) {
@@ -123,7 +127,8 @@ struct UniAffine {
     p[base + 0] += nan_or_zero;
     p[base + 1] += nan_or_zero;
   }
-  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj) {
+  static constexpr int NKNOT = 1;
+  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj, int* k = nullptr, float* ks = nullptr) {
     affine_fwd<float, MathFast>(p(base + 0), p(base + 1), a.ls, x, y, lj);
   }
   template <typename P, typename A> static __device__ __forceinline__ float inv(const P& p, int base, const A& a, float y) {
@@ -149,9 +154,13 @@ template <int K, bool CIRC> struct UniRqs {
 #pragma unroll
     for (int j = 0; j < K; ++j) p[base + (INV ? K : 0) + j] += nan_or_zero;
   }
-  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj) {
+  static constexpr int NKNOT = K + 1;
+  // k / ks (diagnostic instantiation): bin index and search-axis knots of THIS evaluation
+  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj, int* k = nullptr, float* ks = nullptr) {
+    int kk;
     rqs_lean<K, false>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, [&](int j) { return p(base + 2 * K + j); }, a.lc,
-                       CIRC ? shift(x, a.bound) : x, y, lj);
+                       CIRC ? shift(x, a.bound) : x, y, lj, kk, ks);
+    if (k) *k = kk;
   }
   template <typename P, typename A> static __device__ __forceinline__ float inv(const P& p, int base, const A& a, float y) {
     float x, lj;
@@ -192,7 +201,7 @@ __device__ __forceinline__ void hidden_layer(Src& ring, const uint32_t* __restri
   ring.end_layer();
 }
 
-template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
+template <typename Uni, bool INVERSE, class Src, bool XLDS, bool DIAG = false> __global__ __launch_bounds__(512, 2) void ar_kernel(ArArgs a) {
   constexpr bool DIRECT = false;
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   const int tid = threadIdx.x;
@@ -363,9 +372,18 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS> __global__ __launch_
         if (f >= 0) {
           const float xv = xin[fi];
           float yv, lj;
-          if (a.dbg & 1) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
+          if (ZK_AR_TIMING && (a.dbg & 1)) { yv = xv + p[fi * TOTAL]; lj = p[fi * TOTAL + 1]; }  // ablation: no univariate math
           else if (INVERSE) { yv = Uni::inv(ld, fi * TOTAL, a, xv); lj = 0.f; }
-          else Uni::fwd(ld, fi * TOTAL, a, xv, yv, lj);
+          else if (DIAG) {
+            int kb = 0;
+            float ks[Uni::NKNOT];
+            Uni::fwd(ld, fi * TOTAL, a, xv, yv, lj, &kb, ks);
+            if (live) {
+              a.bin_out[n * a.D + f] = kb;
+#pragma unroll
+              for (int jj = 0; jj < Uni::NKNOT; ++jj) a.knots_out[(n * a.D + f) * Uni::NKNOT + jj] = ks[jj];
+            }
+          } else Uni::fwd(ld, fi * TOTAL, a, xv, yv, lj);
           if (XLDS && !a.sched) xr[f] = yv;
           else if (live) a.y[n * a.ldy + f] = yv;  // (partial sweeps touch a few features only: direct stores)
           lacc += lj;
@@ -436,6 +454,8 @@ int zk_ar_lds_bytes(int variant, int bias_floats) { return (ar_base_lds_floats(b
 
 // uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23); contract in include/zuko_amd.h.
 struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and the prefix of the network they depend on
+  int32_t* bin_out = nullptr;  // diagnostic launch (forward, spline maps): bin index + search knots
+  float* knots_out = nullptr;
   const int* sched = nullptr;
   int n_sched = 0;
   const int* olim = nullptr;  // host array, one entry per hidden layer
@@ -461,12 +481,16 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   a.g0 = 0; a.g1 = n_groups;
   for (int l = 0; l < 8; ++l) a.olim[l] = 3;
   if (part.sched) {
-    if (part.n_sched < 2 || part.g0 < 0 || part.g1 > n_groups || part.g0 >= part.g1 || n_layers - 1 > 8) return ZK_EINVAL;
+    if (part.n_sched < 1 || part.g0 < 0 || part.g1 > n_groups || part.g0 >= part.g1 || n_layers - 1 > 8) return ZK_EINVAL;
     a.sched = part.sched; a.n_sched = part.n_sched; a.g0 = part.g0; a.g1 = part.g1;
     for (int l = 0; l < n_layers - 1; ++l) a.olim[l] = part.olim[l];
   }
-  a.dbg = (variant >> 8) & 0xff;  // undocumented profiling switches (bit0: skip univariate math, bit3: phase timestamps)
+#if ZK_AR_TIMING
+  a.dbg = (variant >> 8) & 0xff;  // probe build only (-DZK_AR_TIMING=1): bit0 skip univariate math, bit3 / bit4 phase timestamps
   if ((variant & 0xff) != 0) return ZK_EINVAL;
+#else
+  if (variant != 0) return ZK_EINVAL;  // `variant` is reserved: the product build has exactly one kernel per (map, direction)
+#endif
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
   a.xs = ((D + 3) / 4) * 4 + 4;  // +4 words: 16-byte aligned rows whose stride is not a multiple of 32 banks
   const bool vec_ok = (D % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)y % 16 == 0) && (!inverse || ((ldyin % 4 == 0) && ((uintptr_t)yin % 16 == 0)));
@@ -487,8 +511,26 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   else if (uni_kind == 3) fn = ZK_AR_PICK_X(UniRqs16);
   else if (uni_kind == 4) fn = ZK_AR_PICK_X(UniCircRqs8);
   else return ZK_EINVAL;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return (int)e;
+  if (part.bin_out || part.knots_out) {  // diagnostic twin: same template, same arithmetic, extra stores
+    if (inverse || part.sched || !a.xlds || !part.bin_out || !part.knots_out) return ZK_EINVAL;
+    a.bin_out = part.bin_out; a.knots_out = part.knots_out;
+    if (uni_kind == 1) fn = (const void*)ar_kernel<UniRqs8, false, Ring24x3, true, true>;
+    else if (uni_kind == 2) fn = (const void*)ar_kernel<UniRqs4, false, Ring24x3, true, true>;
+    else if (uni_kind == 3) fn = (const void*)ar_kernel<UniRqs16, false, Ring24x3, true, true>;
+    else return ZK_EINVAL;
+  }
+  hipError_t e = hipSuccess;
+  {  // the opt-in to > 64 KiB of dynamic LDS is per function: set it once (and again only if a larger size is asked for)
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    int& g = granted[fn];
+    if (g < lds) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      g = lds;
+    }
+  }
   void* kargs[] = {&a};
   e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
@@ -500,6 +542,18 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
                   double bound, double slope, int variant, void* stream) {
   return ar_launch(ArPartial{}, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
                    n_chunks, act, bound, slope, variant, stream);
+}
+
+// Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3): identical kernel template and arithmetic, plus
+// bin_out[N, D] (k = #(knots < x) - 1, zuko/transforms.py:521-523) and knots_out[N, D, K+1] (the horizontal knots the
+// search compared).  Lets the tests assert the bin index of the FUSED path on its own knots.
+int zk_ar_forward_diag(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj, const void* wstream,
+                       const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act,
+                       double bound, double slope, int32_t* bin_out, float* knots_out, void* stream) {
+  ArPartial part;
+  part.bin_out = bin_out; part.knots_out = knots_out;
+  return ar_launch(part, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
+                   n_chunks, act, bound, slope, 0, stream);
 }
 
 // One sweep of the autoregressive inverse (zuko/transforms.py:997-998): x_out = univariate(conditioner(x_cond)).inv(y).

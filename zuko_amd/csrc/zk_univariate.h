@@ -249,8 +249,11 @@ template <> struct RqsBisect<1> {
   }
 };
 
+// `ks_out` (optional, K+1 floats): the knots of the SEARCH axis exactly as the bisection compared them
+// (the diagnostic entry points zk_rqs_diag / zk_ar_forward_diag expose them, so that the bin index
+// can be asserted against the kernel's own knots: k == #(ks < v) - 1, zuko/transforms.py:521-523).
 template <int K, bool INV, typename LdW, typename LdH, typename LdD>
-__device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLeanConst& c, float v, float& out, float& ladj, int& k) {
+__device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLeanConst& c, float v, float& out, float& ladj, int& k, float* ks_out = nullptr) {
   static_assert((K & (K - 1)) == 0 && K >= 2, "bisection needs a power-of-two bin count");
   float kx[K + 1], ky[K + 1], kr[K + 1];
   f32x2_t acc = {0.f, 0.f};
@@ -275,6 +278,10 @@ __device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLea
 #pragma unroll
   for (int j = 1; j < K; ++j) kr[j] = ldd(j - 1);
 
+  if (ks_out) {
+#pragma unroll
+    for (int j = 0; j <= K; ++j) ks_out[j] = INV ? ky[j] : kx[j];
+  }
   float x0, x1, y0, y1, r0, r1;
   bool inside, above;
   int bin;

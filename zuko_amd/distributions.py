@@ -104,6 +104,8 @@ class NormalizingFlow(Distribution):
         z, ladj = self.transform.call_and_ladj(x)
         ladj = _sum_rightmost(ladj, self.reinterpreted)
         fused = self._fusable_base()
+        if fused is not None and torch.is_grad_enabled() and (fused[0].requires_grad or fused[1].requires_grad):
+            fused = None  # trainable base: its gradient flows through torch's Normal.log_prob, as in the reference
         if fused is not None and z.is_cuda and torch.is_tensor(ladj) and ladj.shape == z.shape[:-1]:
             return ops.diag_normal_log_prob(z, fused[0], fused[1], ladj)
         return self.base.log_prob(z) + ladj

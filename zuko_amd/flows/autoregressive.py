@@ -185,6 +185,12 @@ class MaskedAutoregressiveTransform(LazyTransform):
         key = str(device) + ("/inv" if inverse else "")
         if inverse and self.order is None:
             return None
+        # the plan is a function of the mask / order BUFFERS: load_state_dict() may overwrite them (randperm flows,
+        # custom adjacencies), so their versions are part of the cache entry
+        lins_all = [m for m in self.hyper if isinstance(m, MaskedLinear)]
+        structure = tuple((l.mask._version, l.mask.data_ptr()) for l in lins_all) + ((self.order._version, self.order.data_ptr()) if self.order is not None else ())
+        if key in cache and cache[key][0] != structure:
+            del cache[key]
         if key not in cache:
             state = None
             lay = self._fusable_layout()
@@ -200,8 +206,8 @@ class MaskedAutoregressiveTransform(LazyTransform):
                     state = fused.FusedAR(plan, device, codes.pop(), lay[1], lay[2], variant)
                     if inverse:
                         state.set_sweeps(self.order.cpu().numpy(), self.passes)
-            cache[key] = state
-        return cache[key]
+            cache[key] = (structure, state)
+        return cache[key][1]
 
 
 _FUSED_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()

@@ -349,32 +349,19 @@ def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], 
 # --------------------------------------------------------------------------------------------------
 
 
-VARIANT_RING = 0  # weight tiles shared through an LDS ring (global_load_lds DMA, workgroup barriers)
+def chunk_of(variant: int = 0) -> int:
+    """Tiles per chunk the stream is padded to (= AR_CH of csrc/fused_ar.hip: a 3 x 24-tile LDS ring)."""
+    return CHUNK
 
 
 def default_variant() -> int:
-    import os
-
-    return int(os.environ.get("ZUKO_AMD_AR_VARIANT", VARIANT_RING))  # ring measured faster than direct (profiles/)
-
-
-def _debug_flags() -> int:
-    import os
-
-    return int(os.environ.get("ZUKO_AMD_AR_DEBUG", 0))
-
-
-def chunk_of(variant: int) -> int:
-    """Tiles per chunk the stream is padded to (variant 0: 3 x 24-tile LDS ring)."""
-    import os
-
-    return int(os.environ.get("ZUKO_AMD_AR_CH", 24))  # must match the AR_CH the library was built with
+    return 0  # reserved argument of the C ABI
 
 
 class FusedAR:
     """Runs zk_ar_forward for one MaskedAutoregressiveTransform on one device."""
 
-    def __init__(self, plan: ArPlan, device: torch.device, act: int, bound: float, slope: float, variant: int = VARIANT_RING) -> None:
+    def __init__(self, plan: ArPlan, device: torch.device, act: int, bound: float, slope: float, variant: int = 0) -> None:
         self.plan = plan
         self.variant = variant
         self.device = device
@@ -395,7 +382,9 @@ class FusedAR:
         from . import _C
         from .ops import _ptr, _stream
 
-        stamp = tuple((m.weight._version, m.weight.data_ptr(), m.bias._version if m.bias is not None else -1) for m in linears)
+        from .nn import _param_stamp
+
+        stamp = _param_stamp(linears)
         if stamp == self._stamp:
             return
         lib = _C.lib()
@@ -425,9 +414,22 @@ class FusedAR:
         err = _C.lib().zk_ar_forward(
             p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
             _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, self.variant | (_debug_flags() << 8), _stream(),
+            self.act, self.bound, self.slope, 0, _stream(),
         )
         _C.check(err, "zk_ar_forward")
+
+    def run_diag(self, inp: Tensor, y: Tensor, ladj: Tensor, bins: Tensor, knots: Tensor) -> None:
+        """As run(), through the diagnostic twin of the kernel: also fills bins [N, D] int32 and knots [N, D, K+1]."""
+        from . import _C
+        from .ops import _ptr, _stream
+
+        p = self.plan
+        err = _C.lib().zk_ar_forward_diag(
+            p.layout.kind, inp.shape[0], p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj),
+            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
+            self.act, self.bound, self.slope, _ptr(bins), _ptr(knots), _stream(),
+        )
+        _C.check(err, "zk_ar_forward_diag")
 
     def run_inverse_sweep(self, buf: Tensor, y: Tensor) -> None:
         """One sweep x <- f^{-1}(y | x) in place: buf [N, DINP] holds cat(x, c, 0-pad), y [N, D]."""
@@ -438,7 +440,7 @@ class FusedAR:
         err = _C.lib().zk_ar_inverse_sweep(
             p.layout.kind, buf.shape[0], p.features, buf.shape[1], _ptr(buf), buf.stride(0), _ptr(y), y.stride(0), _ptr(buf), buf.stride(0),
             _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, self.variant | (_debug_flags() << 8), _stream(),
+            self.act, self.bound, self.slope, 0, _stream(),
         )
         _C.check(err, "zk_ar_inverse_sweep")
 
@@ -462,6 +464,10 @@ class FusedAR:
                 continue
             g0, g1 = int(slots.min() // per_group), int(slots.max() // per_group) + 1
             sched, olim = partial_schedule(p, g0, g1)
+            if not sched:
+                # root features (order 0, no context): every parameter is a bias, nothing is streamed.  The kernel still
+                # wants a valid ring schedule; chunk 0 is prefetched and never consumed (olim = -1, skip bits all clear).
+                sched = [0]
             self.sweeps.append((len(flat), len(sched), (ctypes.c_int * len(olim))(*olim), g0, g1))
             flat += sched
         self.sched_dev = torch.tensor(flat, dtype=torch.int32, device=self.device)
@@ -480,6 +486,6 @@ class FusedAR:
         err = _C.lib().zk_ar_inverse_partial(
             p.layout.kind, buf.shape[0], p.features, buf.shape[1], _ptr(buf), buf.stride(0), _ptr(y), y.stride(0), _ptr(buf), buf.stride(0),
             _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, sched_ptr, n_sched, olim, g0, g1, self.variant | (_debug_flags() << 8), _stream(),
+            self.act, self.bound, self.slope, sched_ptr, n_sched, olim, g0, g1, 0, _stream(),
         )
         _C.check(err, "zk_ar_inverse_partial")

@@ -159,6 +159,13 @@ def masked_mlp_masks(adjacency: BoolTensor, hidden_features: Sequence[int], resi
     return masks
 
 
+def _param_stamp(lins) -> tuple:
+    """Identity + version of every weight / bias of `lins`.  In-place updates made through autograd-visible ops
+    (optimizers, `copy_`, `load_state_dict`) bump `_version`; writes through `.data` / raw pointers do not — after those,
+    call `zuko_amd.invalidate(module)`."""
+    return tuple((l.weight._version, l.weight.data_ptr(), -1 if l.bias is None else l.bias._version, 0 if l.bias is None else l.bias.data_ptr()) for l in lins)
+
+
 def live_tile_masks(mask: Tensor) -> Tensor:
     """int64 [ceil(out / 256)]: bit k of word p is set iff rows [256 p, 256 p + 256) x columns [64 k, 64 k + 64) of
     `mask` (bool or numeric [out, in], in % 64 == 0, in <= 4096) hold a non-zero — the `tile_live_mask` argument of
@@ -211,7 +218,7 @@ class _Bf16Plan:
         self.biases: list[Tensor | None] = []
 
     def refresh(self, lins: Sequence["MaskedLinear"]) -> None:
-        version = tuple((l.weight._version, l.weight.data_ptr(), -1 if l.bias is None else l.bias._version) for l in lins)
+        version = _param_stamp(lins)
         if version == self.version:
             return
         self.weights, self.biases = [], []
@@ -298,6 +305,10 @@ class MaskedMLP(_FusedSequential):
 
     def _bf16_plan(self):
         """Plan of the bf16 fast path, or None when the module tree is not (linear, fusable activation)*."""
+        structure = tuple((m.mask._version, m.mask.data_ptr()) for m in self if isinstance(m, MaskedLinear))
+        if self.__dict__.get("_bf16_plan_structure") != structure:  # masks overwritten (load_state_dict): rebuild
+            self.__dict__.pop("_bf16_plan_cache", None)
+            self.__dict__["_bf16_plan_structure"] = structure
         plan = self.__dict__.get("_bf16_plan_cache")
         if plan is None:
             mods = list(self)

@@ -183,6 +183,24 @@ def rqs_inverse(y: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
     return (x, bins) if want_bins else x
 
 
+def rqs_diag(v: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor, bound: float = 5.0, slope: float = 1e-3, inverse: bool = False):
+    """Diagnostic twin of rqs_forward / rqs_inverse (fp32): (out, ladj or None, k int32, knots [..., K+1]) where `knots`
+    are the knots of the searched axis exactly as the product arithmetic compared them (zk_rqs_diag)."""
+    K = widths.shape[-1]
+    if v.dtype != torch.float32:
+        raise TypeError("zuko_amd.rqs_diag: float32 only (the fp64 path searches IEEE knots: use rqs_forward(want_bins=True))")
+    pr = _Prepared(v, [(widths, 1), (heights, 1), (derivatives, 1)])
+    out = pr.out()
+    ladj = None if inverse else pr.out_ladj(False)
+    bins = torch.empty(pr.shape, dtype=torch.int32, device=v.device)
+    knots = torch.empty(tuple(pr.shape) + (K + 1,), dtype=torch.float32, device=v.device)
+    (w, wn, wd), (h, hn, hd), (d, dn, dd) = pr.params
+    err = _C.lib().zk_rqs_diag(int(inverse), pr.N, pr.D, K, bound, slope, _ptr(pr.x), _ptr(w), wn, wd, _ptr(h), hn, hd, _ptr(d), dn, dd, _ptr(out), _ptr(ladj),
+                               _ptr(bins), _ptr(knots), _stream())
+    _C.check(err, "zk_rqs_diag")
+    return out, ladj, bins, knots
+
+
 def rqs_from_knots(v: Tensor, horizontal: Tensor, vertical: Tensor, slopes: Tensor, inverse: bool = False):
     """Test entry: evaluate from constrained knots; returns (out, ladj, k)."""
     K = horizontal.shape[-1] - 1
@@ -278,6 +296,7 @@ def sos_inverse(y: Tensor, a: Tensor, constant: Tensor | None = None, slope: flo
 # ------------------------------------------------------------------------------------------------
 
 BERN_EPS = 1e-6
+BERN_NC_MAX = 72  # ZK_BERN_NCMAX of csrc/elementwise.hip
 
 
 def bernstein_forward(x: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0, reduce: bool = False):

@@ -158,10 +158,15 @@ class BernsteinTransform(_Univariate):
     bounded = False
 
     def __init__(self, theta: Tensor, bound: float = 5.0, **kwargs) -> None:
-        kwargs.pop("eps", None)
+        eps = kwargs.pop("eps", ops.BERN_EPS)
+        if eps != ops.BERN_EPS:
+            raise NotImplementedError(f"zuko_amd: the Bernstein kernels are built for eps = {ops.BERN_EPS} (zuko/transforms.py:594 default), got {eps}")
         super().__init__(**kwargs)
         self.unconstrained_theta = theta
         self.bound = bound
+        nc = theta.shape[-1] + (5 if self.bounded else 2)
+        if nc > ops.BERN_NC_MAX:
+            raise NotImplementedError(f"zuko_amd: Bernstein polynomials are built for up to {ops.BERN_NC_MAX} constrained coefficients, got {nc}")
 
     def _forward(self, x, reduce):
         return ops.bernstein_forward(x, self.unconstrained_theta, self.bounded, self.bound, reduce)
