@@ -89,7 +89,7 @@ def test_standalone_bin_index(dev, K, inverse):
         _, _, k2, knots2 = ops.rqs_diag(v2, wg, hg, dg, inverse=inverse)
     assert torch.equal(knots2, knots)
     assert torch.equal(k2.cpu().long(), torch.full((N, D), K // 2 - 1)), "x == own knot j must give k = j - 1"
-    _check_bins(v, k.cpu().long(), knots.cpu(), k_ref, ref_knots, f"standalone K={K} {'inverse' if inverse else 'forward'}", max_knot_ulps=6)
+    _check_bins(v, k.cpu().long(), knots.cpu(), k_ref, ref_knots, f"standalone K={K} {'inverse' if inverse else 'forward'}", max_knot_ulps=16)
 
 
 @pytest.mark.parametrize("name,N", [("nsf_cfg2", 4096), ("nsf_ctx", 1000)])

@@ -428,3 +428,63 @@ def test_cfg5_layer_shape_bf16(dev, N, monkeypatch):
         print(f"cfg5 layer N={N} {what}: |hip - fp32 oracle| mean/median/p99/max = {e_hip};  |bf16 oracle - fp32 oracle| = {e_ref}")
         assert e_hip[0] <= e_ref[0] and e_hip[1] <= e_ref[1] + 1e-12 and e_hip[2] <= e_ref[2], f"{what}: HIP bf16 path is less accurate than the reference's own bf16 path"
         assert e_hip[3] <= 2.0 * e_ref[3] + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D", [("nsf", 8), ("maf", 16), ("nsf", 64)])
+def test_passes2_without_context_round_trip(dev, kind, D):
+    """`passes=2` (the documented "coupling" variant, zuko/flows/spline.py:25-26) with no context: the first half of
+    the features are roots (order 0: every parameter is a bias), so the first wavefront sweep streams no weights at all."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(D)
+    flow = (F.NSF(D, 0, transforms=3, passes=2, hidden_features=[64, 64]) if kind == "nsf" else F.MAF(D, 0, transforms=3, passes=2, hidden_features=[64, 64])).to(dev)
+    sd = {k: v.detach().cpu() for k, v in flow.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(8) if kind == "nsf" else O.UNI_AFFINE, D, passes=2)
+    x = torch.randn(333, D, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        z = flow().transform(x.to(dev))
+        xr = flow().transform.inv(z)
+        zo, _ = O.flow_forward(spec, x)
+        xo = O.flow_inverse(spec, zo)
+        s = flow().sample((64,))
+    assert torch.allclose(z.cpu(), zo, rtol=1e-5, atol=2e-5)
+    assert torch.allclose(xr.cpu(), xo, rtol=1e-4, atol=1e-4) and torch.allclose(xr.cpu(), x, rtol=1e-4, atol=1e-4)
+    assert s.shape == (64, D) and torch.isfinite(s).all()
+
+
+@pytest.mark.gpu
+def test_bf16_xcd_walk_equals_id_order_raster(dev, monkeypatch):
+    """The XCD-aware tile walk of zk_linear_bf16 / zk_linear_bf16_rqs (patches per XCD, ragged regions skipped) visits every
+    tile exactly once: bit-identical results to the id-order raster, for several patch shapes, with ragged row / column
+    regions and dead weight tiles."""
+    from zuko_amd import ops
+    from zuko_amd.flows import MaskedAutoregressiveTransform
+    from zuko_amd.transforms import MonotonicRQSTransform
+
+    N, D, K = 4096 + 300, 192, 16
+    torch.manual_seed(1)
+    t = MaskedAutoregressiveTransform(D, 0, univariate=MonotonicRQSTransform, shapes=[(K,), (K,), (K - 1,)], hidden_features=[256, 1024]).to(dev).to(torch.bfloat16)
+    x = (torch.randn(N, D, generator=torch.Generator().manual_seed(2)) * 1.2).to(torch.bfloat16).to(dev)
+    h = torch.randn(N, 1024, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(5000, 1024, generator=torch.Generator().manual_seed(4)) / 32).to(torch.bfloat16).to(dev)
+    w[:2000, 512:] = 0  # dead 256 x 64 tiles
+    from zuko_amd.nn import live_tile_masks
+
+    live = live_tile_masks(w)
+    outs = []
+    for env in ("0", None, "8,4,2,4", "2,16,8,1"):
+        if env is None:
+            monkeypatch.delenv("ZUKO_AMD_BF16_MAP", raising=False)
+        else:
+            monkeypatch.setenv("ZUKO_AMD_BF16_MAP", env)
+        with torch.no_grad():
+            y, l = t().call_and_ladj(x)
+            g = ops.linear_bf16(h, w, None, live, 1)
+        outs.append((y, l, g))
+    monkeypatch.delenv("ZUKO_AMD_BF16_MAP", raising=False)
+    for y, l, g in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(g, outs[0][2])
+        assert torch.equal(l, outs[0][1])
+    ref = (h.float() @ w.float().t()).relu()
+    assert (outs[0][2].float() - ref).abs().max() < 0.05 * ref.abs().max()
