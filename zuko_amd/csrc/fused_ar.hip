@@ -356,6 +356,11 @@ template <typename Uni, bool INVERSE, class Src, bool XLDS, bool DIAG = false> _
         }
       }
       if (ZK_AR_TIMING && (a.dbg & 16)) tg1 = __builtin_amdgcn_s_memtime();
+      // Pin the accumulators: without this use the register allocator is free to give the two sides of every skip
+      // branch above different VGPR tuples and reconcile them with ~28 v_mov per executed block (+6 % kernel time,
+      // measured: 5.80 vs 5.45 ms).  tests/test_codegen.py guards the instruction mix of this loop.
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
       float p[4 * NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t)
