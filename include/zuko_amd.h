@@ -199,11 +199,37 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
  * gl [N] if gl_reduced else [N, D] (may be NULL); outputs gx [N, D], gphi [N, D, total]. */
 int zk_univariate_backward(int kind, int64_t N, int64_t D, int K, double bound, double slope, const void* x, const void* phi,
                            const void* gy, const void* gl, int gl_reduced, void* gx, void* gphi, void* stream);
+/* Adjoint seeds of an INVERSE univariate map x = f^{-1}(y) (gradients through rsample; inverse function theorem):
+ * gy[e] = gx[e] * exp(-ladj[e]) with ladj = log f'(x), seed[e] = -gy[e] (zk_univariate_backward(x, phi, gy = seed) then
+ * yields dL/dphi). */
+int zk_inverse_seed(int64_t n, const void* gx, const void* ladj, void* gy, void* seed, void* stream);
 /* gz[n, d] = -g[n] * (z[n, d] - loc[d]) / scale[d]^2 */
 int zk_diag_normal_backward(int64_t N, int64_t D, const void* z, const void* loc, const void* scale, const void* g, void* gz,
                             void* stream);
 /* gin = gout * act'(.) written in terms of the activation OUTPUT y; act in {NONE, RELU, ELU, TANH, SIGMOID, LEAKY}. */
 int zk_act_backward(int64_t n, const void* y, const void* gout, int act, void* gin, void* stream);
+
+/* ---- conditioner GEMMs of the training path (fp32, v_mfma_f32_32x32x2_f32), mask-aware by tile skipping --------------- *
+ * They replace what autograd derives from `F.linear(x, mask * weight, bias)` + activation (zuko/nn.py:217-218): forward,
+ * dgrad and wgrad.  The caller (zuko_amd/train.py) works in a reparametrisation with degree-sorted hidden units, in which
+ * the masks are block lower-triangular, and passes skip maps / live-block lists derived from the permuted masks.
+ *
+ * zk_gemm_f32_skip:  y[N, OUT] = act(x[N, IN] w^T + bias) (* act'_{gate_act}(gate[N, OUT]) when gate != NULL).
+ *   w [OUT, IN] row-major, ALREADY masked.  kskip: NULL or one 64-bit word per block of 128 outputs, bit kt set = the
+ *   32-input k tile kt of that block holds non-zero weights (IN <= 2048).  act / gate_act in {NONE, RELU, ELU, TANH,
+ *   SIGMOID, LEAKY}; act' is evaluated on the activation OUTPUT stored in `gate` (dgrad: w = Ws^T, gate = saved h).
+ * zk_wgrad_f32:  dw[OUT, IN] (+)= mask .* (g[N, OUT]^T h[N, IN]) restricted to the 128 x 128 blocks listed in `pairs`
+ *   (device int32 [npairs][2] = (out block, in block)); other blocks are not written.  Split over
+ *   zk_wgrad_slices(N, npairs) sample slices whose partial blocks go to `partial` (>= slices * npairs * 16384 floats)
+ *   and are summed in slice order (deterministic).  mask: uint8 [OUT, IN] or NULL.
+ * zk_colsum_f32:  out[C] (+)= sum_n x[n, c] (bias gradients); workspace >= zk_colsum_slices(N) * C floats. */
+int zk_gemm_f32_skip(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* w, const uint64_t* kskip,
+                     const void* bias, int act, const void* gate, int64_t ldg, int gate_act, void* y, int64_t ldy, void* stream);
+int zk_wgrad_slices(int64_t N, int npairs);
+int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh,
+                 const int32_t* pairs, int npairs, float* partial, const uint8_t* mask, void* dw, int accumulate, void* stream);
+int zk_colsum_slices(int64_t N);
+int zk_colsum_f32(int64_t N, int C, const void* x, int64_t ld, float* workspace, void* out, int accumulate, void* stream);
 
 /* ---- base density + final reduction (zuko/distributions.py:115-119, 337-363) ---------------------- *
  * out[n] = sum_d Normal(loc[d], scale[d]).log_prob(z[n, d]) (+ ladj[n] if ladj != NULL). */

@@ -1,0 +1,112 @@
+"""GPU tests of the training GEMMs (csrc/train.hip: tile-skipping forward / dgrad, split-K wgrad, column sums) and of
+the sorted-domain conditioner (zuko_amd/train.py) against plain torch ops on the same device."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tri_mask(out_f, in_f, gen):
+    """A MADE-like mask: row r may see column c iff deg_in[c] <= deg_out[r] (random degrees)."""
+    dout = torch.randint(0, 64, (out_f,), generator=gen)
+    din = torch.randint(0, 64, (in_f,), generator=gen)
+    return dout[:, None] >= din[None, :]
+
+
+@pytest.mark.parametrize("N,IN,OUT", [(1000, 256, 256), (77, 64, 200), (4096, 256, 1472), (513, 1472, 256), (300, 37, 50)])
+def test_gemm_skip_wgrad_colsum(dev, N, IN, OUT):
+    from zuko_amd.train import SortedPlan
+
+    gen = torch.Generator().manual_seed(N + IN)
+    x = torch.randn(N, IN, generator=gen).to(dev)
+    w = (torch.randn(OUT, IN, generator=gen) / IN**0.5).to(dev)
+    b = torch.randn(OUT, generator=gen).to(dev)
+    mask = _tri_mask(OUT, IN, gen)
+    # sort rows / columns by degree so that whole tiles vanish, as the plan does
+    ro, co = torch.argsort(mask.sum(1), stable=True), torch.argsort(-mask.sum(0), stable=True)
+    mask = mask[ro][:, co].to(dev)
+    wm = (w * mask).contiguous()
+    ks = SortedPlan._kskip(mask.cpu())
+    ks = None if ks is None else ks.to(dev)
+
+    class P:  # just enough of a plan to call the wrappers
+        pass
+
+    plan = SortedPlan.__new__(SortedPlan)
+    ref = torch.relu(x @ wm.t() + b)
+    y = SortedPlan.gemm(plan, x, wm, ks, b, 1)
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * IN**0.5)
+    assert torch.equal(SortedPlan.gemm(plan, x, wm, None, b, 1), y), "skipping all-zero tiles must not change a single bit"
+    gate = torch.relu(torch.randn(N, OUT, generator=gen)).to(dev)
+    yg = SortedPlan.gemm(plan, x, wm, ks, None, 0, gate, 1)
+    assert torch.allclose(yg, (x @ wm.t()) * (gate > 0), rtol=1e-5, atol=1e-5 * IN**0.5)
+    # wgrad: dW = mask * g^T h over the live blocks
+    g = torch.randn(N, OUT, generator=gen).to(dev)
+    plan.shapes = [(OUT, IN)]
+    ob, ib = -(-OUT // 128), -(-IN // 128)
+    pad = torch.zeros((ob * 128, ib * 128), dtype=torch.bool)
+    pad[:OUT, :IN] = mask.cpu()
+    plan.pairs = [pad.reshape(ob, 128, ib, 128).any(3).any(1).nonzero().to(torch.int32).contiguous().to(dev)]
+    plan.mask_s = [mask.to(torch.uint8).contiguous()]
+    dw = plan.wgrad(0, g, x)
+    refw = (g.double().t() @ x.double()) * mask
+    assert torch.allclose(dw.double(), refw, rtol=1e-5, atol=2e-5 * refw.abs().max().item())
+    assert torch.equal(plan.wgrad(0, g, x), dw), "wgrad must be deterministic"
+    cs = plan.colsum(g)
+    assert torch.allclose(cs.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["nsf64", "maf_ctx", "coupling"])
+def test_conditioner_gradients_match_torch(dev, kind):
+    """hyper(x) through ConditionerFn (sorted domain, skipping) against autograd through plain torch ops on the module's own
+    (unsorted) parameters: phi, d phi / d x and every parameter gradient."""
+    import zuko_amd.flows as F
+    from zuko_amd.nn import MaskedLinear
+
+    torch.manual_seed(3)
+    if kind == "nsf64":
+        t = F.NSF(64, 0, transforms=1, bins=8, hidden_features=[256] * 3).transform.transforms[0]
+        din = 64
+    elif kind == "maf_ctx":
+        t = F.MAF(10, 3, transforms=1, hidden_features=[48, 40], activation=torch.nn.Tanh).transform.transforms[0]
+        din = 13
+    else:
+        t = F.RealNVP(12, 2, transforms=1, hidden_features=[64, 64]).transform.transforms[0]
+        din = t.hyper[0].weight.shape[1]
+    net = t.hyper.to(dev)
+    N = 700
+    x = torch.randn(N, din, generator=torch.Generator().manual_seed(5)).to(dev)
+    gphi = None
+
+    def run(use_hip):
+        nonlocal gphi
+        for p in net.parameters():
+            p.grad = None
+        xr = x.clone().requires_grad_()
+        if use_hip:
+            out = net(xr)
+        else:
+            h = xr
+            mods = list(net)
+            for m in mods:
+                if hasattr(m, "weight"):
+                    wgt = m.weight * m.mask if isinstance(m, MaskedLinear) else m.weight
+                    h = h @ wgt.t() + m.bias
+                else:
+                    h = m(h)
+            out = h
+        if gphi is None:
+            gphi = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).to(dev)
+        (out * gphi).sum().backward()
+        return out.detach(), xr.grad.clone(), [p.grad.clone() for p in net.parameters()]
+
+    o1, gx1, gp1 = run(True)
+    o0, gx0, gp0 = run(False)
+    assert torch.allclose(o1, o0, rtol=1e-5, atol=2e-5)
+    assert torch.allclose(gx1, gx0, rtol=1e-4, atol=1e-4 * gx0.abs().max().item())
+    for a, b in zip(gp1, gp0):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * b.abs().max().clamp_min(1e-6).item()), (a - b).abs().max().item()
+    for m in net.modules():
+        if isinstance(m, MaskedLinear):
+            assert (m.weight.grad[~m.mask] == 0).all()

@@ -42,6 +42,12 @@ SIGNATURES = {
     "zk_univariate_backward": [I, L, L, I, F, F, P, P, P, P, I, P, P, P],
     "zk_diag_normal_backward": [L, L, P, P, P, P, P, P],
     "zk_act_backward": [L, P, P, I, P, P],
+    "zk_inverse_seed": [L, P, P, P, P, P],
+    "zk_gemm_f32_skip": [L, I, I, P, L, P, P, P, I, P, L, I, P, L, P],
+    "zk_wgrad_slices": [L, I],
+    "zk_wgrad_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P],
+    "zk_colsum_slices": [L],
+    "zk_colsum_f32": [L, I, P, L, P, P, I, P],
     "zk_ar_lds_bytes": [I, I],
     "zk_ar_forward": [I, L, I, I, P, L, P, L, P, I, P, P, I, P, P, I, I, I, I, F, F, I, P],
     "zk_ar_forward_diag": [I, L, I, I, P, L, P, L, P, P, P, I, P, P, I, I, I, I, F, F, P, P, P],

@@ -29,6 +29,7 @@ SOURCES = {
     "linear_bf16.hip": ["-ffp-contract=off"],  # its spline epilogue must round like elementwise.hip's
     "fused_ar.hip": ["-ffp-contract=off"],
     "backward.hip": [],
+    "train.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 

@@ -112,6 +112,96 @@ class UnivariateFn(torch.autograd.Function):
         return (None, None, None, None, _sum_to(gx, ctx.xshape), *grads)
 
 
+def _kernel_fwd(kind, bound, slope, reduce, xe, phi, sizes):
+    from . import ops
+
+    pieces = phi.split(sizes, -1)
+    if kind == 0:
+        return ops.affine_forward(xe, pieces[0].squeeze(-1), pieces[1].squeeze(-1), slope, reduce)
+    return ops.rqs_forward(xe, pieces[0], pieces[1], pieces[2], bound, slope, reduce)
+
+
+class UnivariatePackedFn(torch.autograd.Function):
+    """As UnivariateFn, for parameters that ARE one packed phi[..., D, total] tensor (what the conditioner emits): phi
+    is the differentiable input itself, so autograd neither splits nor re-concatenates it (the cat of the three spline
+    pieces' gradients was a 386 MB copy per transform at batch 2^16)."""
+
+    @staticmethod
+    def forward(ctx, kind: int, bound: float, slope: float, reduce: bool, sizes, x: Tensor, phi: Tensor):
+        _require_f32(x, phi)
+        xe = x.expand(phi.shape[:-1]).contiguous()
+        ph = phi.detach()
+        if not ph.is_contiguous() or ph.data_ptr() % 16 != 0:
+            ph = ph.contiguous()
+        with torch.no_grad():
+            y, ladj = _kernel_fwd(kind, bound, slope, reduce, xe, ph, list(sizes))
+        ctx.kind, ctx.bound, ctx.slope, ctx.reduce, ctx.sizes, ctx.xshape = kind, bound, slope, reduce, list(sizes), x.shape
+        ctx.save_for_backward(xe, ph)
+        return y, ladj
+
+    @staticmethod
+    def backward(ctx, gy, gl):
+        xe, phi = ctx.saved_tensors
+        D = xe.shape[-1]
+        N = xe.numel() // max(D, 1)
+        gx, gphi = torch.empty_like(xe), torch.empty_like(phi)
+        gy_c = None if gy is None else gy.expand(xe.shape).contiguous()
+        gl_c = None if gl is None else (gl.expand(xe.shape[:-1]) if ctx.reduce else gl.expand(xe.shape)).contiguous()
+        K = ctx.sizes[0] if ctx.kind == 1 else 0
+        err = _C.lib().zk_univariate_backward(ctx.kind, N, D, K, ctx.bound, ctx.slope, _ptr(xe), _ptr(phi), _ptr(gy_c), _ptr(gl_c), int(ctx.reduce),
+                                              _ptr(gx), _ptr(gphi), _stream())
+        _C.check(err, "zk_univariate_backward")
+        return (None, None, None, None, None, _sum_to(gx, ctx.xshape), gphi)
+
+
+class UnivariateInverseFn(torch.autograd.Function):
+    """x = f^{-1}(y; phi) for the affine map / the spline, differentiable (gradients through `rsample`, which the
+    reference obtains by autograd through its inverse formulas, zuko/transforms.py:443, :534-548; asserted by its
+    tests/test_flows.py:46-54).  By the inverse function theorem, with f' = exp(ladj(x)):
+        dL/dy = g_x / f'(x),      dL/dphi = -(df/dphi)^T (g_x / f'(x)),
+    i.e. the forward map's own adjoint kernel evaluated at the solution x with the seed -g_x / f'(x)."""
+
+    @staticmethod
+    def forward(ctx, kind: int, bound: float, slope: float, y: Tensor, *params: Tensor):
+        from . import ops
+
+        _require_f32(y, *params)
+        parts = [p.unsqueeze(-1) for p in params] if kind == 0 else list(params)
+        batch = torch.broadcast_shapes(y.shape, *[p.shape[:-1] for p in parts])
+        ye = y.expand(batch).contiguous()
+        phi = _packed([p.detach() for p in parts], batch)
+        sizes = [p.shape[-1] for p in parts]
+        pieces = phi.split(sizes, -1)
+        with torch.no_grad():
+            if kind == 0:
+                x = ops.affine_inverse(ye, pieces[0].squeeze(-1), pieces[1].squeeze(-1), slope)
+            else:
+                x = ops.rqs_inverse(ye, pieces[0], pieces[1], pieces[2], bound, slope)
+        ctx.kind, ctx.bound, ctx.slope, ctx.sizes, ctx.yshape, ctx.pshapes = kind, bound, slope, sizes, y.shape, [p.shape for p in params]
+        ctx.save_for_backward(x, phi)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        x, phi = ctx.saved_tensors
+        D = x.shape[-1] if x.dim() else 1
+        N = x.numel() // max(D, 1)
+        with torch.no_grad():
+            _, ladj = _kernel_fwd(ctx.kind, ctx.bound, ctx.slope, False, x, phi, ctx.sizes)
+        gxc = gx.expand(x.shape).contiguous()
+        gy, seed = torch.empty_like(x), torch.empty_like(x)
+        _C.check(_C.lib().zk_inverse_seed(x.numel(), _ptr(gxc), _ptr(ladj.contiguous()), _ptr(gy), _ptr(seed), _stream()), "zk_inverse_seed")
+        scratch, gphi = torch.empty_like(x), torch.empty_like(phi)
+        K = ctx.sizes[0] if ctx.kind == 1 else 0
+        err = _C.lib().zk_univariate_backward(ctx.kind, N, D, K, ctx.bound, ctx.slope, _ptr(x), _ptr(phi), _ptr(seed), None, 0, _ptr(scratch), _ptr(gphi), _stream())
+        _C.check(err, "zk_univariate_backward")
+        pieces = gphi.split(ctx.sizes, -1)
+        if ctx.kind == 0:
+            pieces = [p.squeeze(-1) for p in pieces]
+        grads = [_sum_to(p, s) for p, s in zip(pieces, ctx.pshapes)]
+        return (None, None, None, _sum_to(gy, ctx.yshape), *grads)
+
+
 BACKWARD_ACTS = (0, 1, 2, 3, 6, 7)  # activations whose derivative is a function of their output
 
 

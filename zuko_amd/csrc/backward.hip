@@ -234,6 +234,15 @@ __global__ __launch_bounds__(256) void act_backward_kernel(int64_t n, const floa
   }
 }
 
+// seeds of the inverse map's adjoint: gy = gx * exp(-ladj) (= gx / f'(x)), seed = -gy
+__global__ __launch_bounds__(256) void inverse_seed_kernel(int64_t n, const float* gx, const float* ladj, float* gy, float* seed) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float v = gx[e] * expf(-ladj[e]);
+    gy[e] = v;
+    seed[e] = -v;
+  }
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -271,6 +280,13 @@ int zk_diag_normal_backward(int64_t N, int64_t D, const void* z, const void* loc
   const int64_t nb = (N * D + 255) / 256;
   hipLaunchKernelGGL(normal_backward_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, N, D, (const float*)z, (const float*)loc,
                      (const float*)scale, (const float*)g, (float*)gz);
+  return ZK_LAUNCH_CHECK();
+}
+
+int zk_inverse_seed(int64_t n, const void* gx, const void* ladj, void* gy, void* seed, void* stream) {
+  if (n <= 0) return 0;
+  const int64_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(inverse_seed_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, n, (const float*)gx, (const float*)ladj, (float*)gy, (float*)seed);
   return ZK_LAUNCH_CHECK();
 }
 

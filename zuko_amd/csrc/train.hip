@@ -1,0 +1,464 @@
+// zuko_amd — conditioner GEMMs of the TRAINING path: forward, dgrad and wgrad of the masked layers
+// F.linear(x, mask * W, b) (zuko/nn.py:217-218) in fp32 on v_mfma_f32_32x32x2_f32, mask-aware by TILE SKIPPING.
+//
+// The reference differentiates `x @ (mask * W).T + b` with autograd: two dense GEMMs per layer that multiply the
+// masked-out zeros (dgrad) or compute-and-discard them (wgrad).  Here the host (zuko_amd/train.py) works in a
+// reparametrised network whose hidden units are sorted by MADE degree — rows of W_l / b_l and columns of W_{l+1}
+// permuted together, an exact reparametrisation — where every mask is block lower-triangular.  Then
+//   * forward  Y = act(X Ws^T + bs)            skips the (128-row out block, 32-wide k tile) pairs the mask zeroes;
+//   * dgrad    Gin = (Gout Ws) . act'(H)        is the same kernel on Ws^T with ITS skip map and the activation
+//                                               derivative applied in the epilogue (no separate pass over [N, width]);
+//   * wgrad    dWs = Gout^T H                   is a split-K GEMM over sample slices that only visits the (128 x 128)
+//                                               output blocks the mask keeps; partials are reduced in a fixed order
+//                                               (deterministic) with the mask applied, bias gradients by column sums.
+// Operand layout notes are next to each kernel.  fp32 MFMA is bitwise an fmaf chain: results differ from any other fp32
+// GEMM by summation order only.
+#include "zk_common.h"
+
+namespace zk {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t4 __attribute__((ext_vector_type(4)));
+
+// derivative of the activation written in terms of its OUTPUT v (relu, elu, tanh, sigmoid, leaky relu; 0 = identity)
+__device__ __forceinline__ float act_grad_out(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? 1.f : 0.f;
+    case 2: return v > 0.f ? 1.f : v + 1.f;
+    case 3: return 1.f - v * v;
+    case 6: return v * (1.f - v);
+    case 7: return v > 0.f ? 1.f : 0.01f;
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  switch (act) {
+    case 1: return v < 0.f ? 0.f : v;
+    case 2: return v > 0.f ? v : expm1f(v);
+    case 3: return tanhf(v);
+    case 6: return 1.f / (1.f + expf(-v));
+    case 7: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+struct GemmArgs {
+  int64_t N;
+  int IN, OUT;
+  const float* x; int64_t ldx;   // [N, IN]
+  const float* w;                // [OUT, IN] row-major, ALREADY masked (zeros where the mask is false)
+  const uint64_t* kskip;         // [ceil(OUT / 128)]: bit kt set = k tile kt (32 inputs) of that out block has non-zero weights; null = all (IN <= 2048 with a map)
+  const float* bias;             // [OUT] or null
+  int act;                       // activation applied to x w^T + b (forward)
+  const float* gate; int64_t ldg;  // optional [N, OUT]: the result is multiplied by act'(gate) (dgrad: gate = the saved activation output)
+  int gate_act;
+  float* y; int64_t ldy;
+  int nbx, nby;
+};
+
+#define TBM 128
+#define TBN 128
+#define TBK 32
+#define TPAD 4
+
+// 128 x 128 x 32 LDS tile, 4 waves (2 x 2) x (2 x 2) v_mfma_f32_32x32x2_f32, transposed product (A operand = weight
+// rows) so a lane owns four consecutive outputs of one sample; register-staged prefetch of the next live k tile.
+template <bool VEC> __global__ __launch_bounds__(256) void gemm_f32_skip(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[TBM][TBK + TPAD];
+  __shared__ __attribute__((aligned(16))) float Bs[TBN][TBK + TPAD];
+  // blocks that share a row panel get consecutive logical ids, one contiguous range per XCD (block b runs on XCD b % 8)
+  int bx, by;
+  {
+    const int nwg = a.nbx * a.nby, orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    bx = logical / a.nby;
+    by = logical % a.nby;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t row0 = (int64_t)bx * TBM;
+  const int col0 = by * TBN;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (a.IN + TBK - 1) / TBK;
+  const uint64_t lv = a.kskip ? a.kskip[by] : ~0ull;
+  const uint64_t live = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(lv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lv);
+
+  float4 ga[4], gb[4];
+  const int lr = tid >> 3, lc = (tid & 7) * 4;  // 32 rows x 8 float4 per pass
+  constexpr bool vec = VEC;  // IN % 4 == 0, ldx % 4 == 0, x / w 16-byte aligned (checked by the launcher)
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = lr + 32 * p;
+      const int64_t gr = row0 + r;
+      const int k = k0 + lc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < a.N && k < a.IN) {
+        const float* src = a.x + gr * a.ldx + k;
+        if (vec) v = *reinterpret_cast<const float4*>(src);
+        else { v.x = src[0]; if (k + 1 < a.IN) v.y = src[1]; if (k + 2 < a.IN) v.z = src[2]; if (k + 3 < a.IN) v.w = src[3]; }
+      }
+      ga[p] = v;
+      const int gc = col0 + r;
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gc < a.OUT && k < a.IN) {
+        const float* src = a.w + (int64_t)gc * a.IN + k;
+        if (vec) u = *reinterpret_cast<const float4*>(src);
+        else { u.x = src[0]; if (k + 1 < a.IN) u.y = src[1]; if (k + 2 < a.IN) u.z = src[2]; if (k + 3 < a.IN) u.w = src[3]; }
+      }
+      gb[p] = u;
+    }
+  };
+
+  // next live k tile >= k (the map covers the first 64 tiles; beyond that — only without a map — every tile is live)
+  auto next_live = [&](int k) -> int {
+    if (k >= nk) return -1;
+    if (k >= 64) return k;
+    const uint64_t m = live >> k;
+    if (m) { const int t = k + (int)__builtin_ctzll(m); return t < nk ? t : -1; }
+    return nk > 64 ? 64 : -1;
+  };
+  int kt = next_live(0);
+  if (kt >= 0) gload(kt * TBK);
+  while (kt >= 0) {
+    const int ktn = next_live(kt + 1);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<float4*>(&As[lr + 32 * p][lc]) = ga[p];
+      *reinterpret_cast<float4*>(&Bs[lr + 32 * p][lc]) = gb[p];
+    }
+    __syncthreads();
+    if (ktn >= 0) gload(ktn * TBK);
+    const int fi = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < TBK / 8; ++kk) {
+      f32x4_t4 af[2], bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f32x4_t4*>(&As[wr * 64 + m * 32 + fi][kk * 8 + 4 * fh]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4_t4*>(&Bs[wc * 64 + n * 32 + fi][kk * 8 + 4 * fh]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[n][r], af[m][r], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+    kt = ktn;
+  }
+
+  // epilogue: acc[m][n][r] = Y[sample m*32 + (lane&31)][output n*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+  const bool vec_y = (a.ldy % 4 == 0) && ((((uintptr_t)a.y) & 15) == 0);
+  const bool vec_g = a.gate && (a.ldg % 4 == 0) && ((((uintptr_t)a.gate) & 15) == 0);
+  const bool relu = a.act == 1, relu_gate = a.gate_act == 1;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = col0 + wc * 64 + n * 32 + 8 * q + 4 * (lane >> 5);
+      float bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[t] = (a.bias && col + t < a.OUT) ? a.bias[col + t] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int64_t row = row0 + wr * 64 + m * 32 + (lane & 31);
+        if (row >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          v[t] = acc[m][n][4 * q + t] + bv[t];
+          if (relu) v[t] = v[t] < 0.f ? 0.f : v[t];  // NaN stays NaN, as torch.relu
+        }
+        if (a.gate) {
+          float gv[4] = {0.f, 0.f, 0.f, 0.f};
+          const float* gp = a.gate + row * a.ldg + col;
+          if (vec_g && col + 4 <= a.OUT) { const float4 t4 = *reinterpret_cast<const float4*>(gp); gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w; }
+          else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (col + t < a.OUT) gv[t] = gp[t];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] *= relu_gate ? (gv[t] > 0.f ? 1.f : 0.f) : act_grad_out(gv[t], a.gate_act);
+        }
+        float* dst = a.y + row * a.ldy + col;
+        if (vec_y && col + 4 <= a.OUT) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) if (col + t < a.OUT) dst[t] = v[t];
+        }
+      }
+    }
+  }
+  // (other activations: a ROLLED loop over the values this thread just stored — their inline expansions, unrolled 64
+  //  times, make the epilogue instruction-cache bound; forward only, a gate is never combined with them)
+  if (a.act > 1) {
+#pragma unroll 1
+    for (int e = 0; e < 64; ++e) {
+      const int n = e >> 5, m = (e >> 4) & 1, r = e & 15;
+      const int col = col0 + wc * 64 + n * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+      const int64_t row = row0 + wr * 64 + m * 32 + (lane & 31);
+      if (col < a.OUT && row < a.N) {
+        float* p = a.y + row * a.ldy + col;
+        *p = act_fwd(*p, a.act);
+      }
+    }
+  }
+}
+
+// ---- wgrad: dW[OUT, IN] = G^T H over the samples, split-K ------------------------------------------------------------
+// Block (pair p, slice s) accumulates the 128 x 128 output block pairs[p] = (ob, ib) over rows [s S, (s+1) S) of
+// G[N, OUT] and H[N, IN].  v_mfma_f32_32x32x2_f32 contracts two SAMPLES per instruction: its A operand wants
+// A[i = lane % 32][k = lane / 32] = G[n0 + k][o0 + i] and B[k][j = lane % 32] = H[n0 + k][i0 + j], i.e. 32 consecutive
+// floats of one row per half-wave — both operands load straight from global memory in MFMA layout, coalesced, with
+// no LDS staging; the four waves of a block (2 x 2, 64 x 64 each) share the rows through L1.
+struct WgradArgs {
+  int64_t N;
+  int OUT, IN;
+  const float* g; int64_t ldg;
+  const float* h; int64_t ldh;
+  const int32_t* pairs;   // [npairs][2] = (out block, in block)
+  int npairs;
+  int64_t S;              // rows per slice (even)
+  int nslices;
+  float* partial;         // [nslices][npairs][128 x 128]
+};
+
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
+  // k tile = 32 samples: G[32 x 128] and H[32 x 128] are staged through LDS in their natural [sample][unit] layout
+  // (register-staged float4 loads, next tile in flight during the MFMAs); the MFMA operands are then plain
+  // conflict-free ds_read_b32: A[i][k] = Gs[k][o], B[k][j] = Hs[k][c] with 32 consecutive units per half-wave.
+  __shared__ __attribute__((aligned(16))) float Gs[32][128 + 4];
+  __shared__ __attribute__((aligned(16))) float Hs[32][128 + 4];
+  const int p = blockIdx.x % a.npairs, s = blockIdx.x / a.npairs;
+  const int ob = a.pairs[2 * p], ib = a.pairs[2 * p + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, lk = lane >> 5;
+  const int64_t n_begin = (int64_t)s * a.S;
+  int64_t n_end = n_begin + a.S;
+  n_end = n_end < a.N ? n_end : a.N;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // loader: thread -> (row = tid / 32 + 8 pass, 4 consecutive units at (tid % 32) * 4)
+  const int lrow = tid >> 5, lcol = (tid & 31) * 4;
+  const int go = ob * 128 + lcol, hc = ib * 128 + lcol;
+  const bool vg = (a.ldg % 4 == 0) && ((((uintptr_t)a.g) & 15) == 0) && (go + 4 <= a.OUT);
+  const bool vh = (a.ldh % 4 == 0) && ((((uintptr_t)a.h) & 15) == 0) && (hc + 4 <= a.IN);
+  float4 rg[4], rh[4];
+  auto gload = [&](int64_t n0) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int64_t n = n0 + lrow + 8 * ps;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < n_end) {
+        const float* sg = a.g + n * a.ldg + go;
+        if (vg) v = *reinterpret_cast<const float4*>(sg);
+        else { if (go < a.OUT) v.x = sg[0]; if (go + 1 < a.OUT) v.y = sg[1]; if (go + 2 < a.OUT) v.z = sg[2]; if (go + 3 < a.OUT) v.w = sg[3]; }
+        const float* sh = a.h + n * a.ldh + hc;
+        if (vh) u = *reinterpret_cast<const float4*>(sh);
+        else { if (hc < a.IN) u.x = sh[0]; if (hc + 1 < a.IN) u.y = sh[1]; if (hc + 2 < a.IN) u.z = sh[2]; if (hc + 3 < a.IN) u.w = sh[3]; }
+      }
+      rg[ps] = v; rh[ps] = u;
+    }
+  };
+  gload(n_begin);
+  for (int64_t n0 = n_begin; n0 < n_end; n0 += 32) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      *reinterpret_cast<float4*>(&Gs[lrow + 8 * ps][lcol]) = rg[ps];
+      *reinterpret_cast<float4*>(&Hs[lrow + 8 * ps][lcol]) = rh[ps];
+    }
+    __syncthreads();
+    if (n0 + 32 < n_end) gload(n0 + 32);
+#pragma unroll 4
+    for (int kp = 0; kp < 16; ++kp) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) av[m] = Gs[2 * kp + lk][wr * 64 + m * 32 + li];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bv[n] = Hs[2 * kp + lk][wc * 64 + n * 32 + li];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // acc[m][n][r] = D[i = 8 (r >> 2) + 4 (lane >> 5) + (r & 3)][j = lane & 31] of the (m, n) 32 x 32 sub-block
+  float* dst = a.partial + ((size_t)s * a.npairs + p) * (128 * 128);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = wr * 64 + m * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        const int j = wc * 64 + n * 32 + (lane & 31);
+        dst[i * 128 + j] = acc[m][n][r];
+      }
+}
+
+// dW[o, i] (+)= mask[o, i] * sum_s partial[s][p][...] in slice order (deterministic); 64 blocks of 256 elements per pair
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int OUT, int IN, const int32_t* pairs, int npairs, int nslices, const float* partial,
+                                                           const uint8_t* mask, float* dw, int accumulate) {
+  const int p = blockIdx.x >> 6;
+  const int e = ((blockIdx.x & 63) << 8) + threadIdx.x;
+  const int ob = pairs[2 * p], ib = pairs[2 * p + 1];
+  const int i = e >> 7, j = e & 127;
+  const int o = ob * 128 + i, c = ib * 128 + j;
+  if (o >= OUT || c >= IN) return;
+  const float* src = partial + (size_t)p * (128 * 128) + e;
+  const size_t stride = (size_t)npairs * (128 * 128);
+  float sum = 0.f;
+  int s = 0;
+  for (; s + 8 <= nslices; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; s < nslices; ++s) sum += src[(size_t)s * stride];
+  const size_t idx = (size_t)o * IN + c;
+  if (mask && !mask[idx]) sum = 0.f;
+  dw[idx] = accumulate ? dw[idx] + sum : sum;
+}
+
+// column sums: out[c] = sum_n x[n, c] (bias gradients), two passes with a fixed reduction order
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t N, int C, const float* x, int64_t ld, int64_t S, float* partial) {
+  // block = 64 columns x one slice of S rows; thread = (column quad q = tid % 16, row phase = tid / 16): float4 loads,
+  // 8 rows in flight per thread
+  const int s = blockIdx.y;
+  const int q = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + q * 4;
+  __shared__ float sh[16][64];
+  const int64_t n0 = (int64_t)s * S;
+  int64_t n1 = n0 + S;
+  n1 = n1 < N ? n1 : N;
+  const bool vec = (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && (c0 + 4 <= C);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < C) {
+    int64_t n = n0 + ph;
+    for (; n + 16 * 7 < n1; n += 16 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* src = x + (n + 16 * u) * ld + c0;
+        if (vec) v[u] = *reinterpret_cast<const float4*>(src);
+        else v[u] = make_float4(src[0], c0 + 1 < C ? src[1] : 0.f, c0 + 2 < C ? src[2] : 0.f, c0 + 3 < C ? src[3] : 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+    }
+    for (; n < n1; n += 16) {
+      const float* src = x + n * ld + c0;
+      acc[0] += src[0];
+      if (c0 + 1 < C) acc[1] += src[1];
+      if (c0 + 2 < C) acc[2] += src[2];
+      if (c0 + 3 < C) acc[3] += src[3];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) sh[ph][q * 4 + t] = acc[t];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += sh[r][threadIdx.x];
+    if (c < C) partial[(size_t)s * C + c] = sum;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(int C, int nslices, const float* partial, float* out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float sum = 0.f;
+  for (int s = 0; s < nslices; ++s) sum += partial[(size_t)s * C + c];
+  out[c] = accumulate ? out[c] + sum : sum;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+// y = act(x w^T + bias) [ * act'_{gate_act}(gate) ],  w [OUT, IN] pre-masked, kskip: one 64-bit word per 128-row out block (or NULL)
+int zk_gemm_f32_skip(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* w, const uint64_t* kskip, const void* bias, int act,
+                     const void* gate, int64_t ldg, int gate_act, void* y, int64_t ldy, void* stream) {
+  if (N <= 0 || out_features <= 0) return 0;
+  if (in_features <= 0 || (kskip && in_features > 2048) || !(act == 0 || act == 1 || act == 2 || act == 3 || act == 6 || act == 7)) return ZK_EINVAL;
+  if (gate && !(gate_act == 0 || gate_act == 1 || gate_act == 2 || gate_act == 3 || gate_act == 6 || gate_act == 7)) return ZK_EINVAL;
+  GemmArgs a{};
+  a.N = N; a.IN = in_features; a.OUT = out_features; a.x = (const float*)x; a.ldx = ldx; a.w = (const float*)w; a.kskip = kskip; a.bias = (const float*)bias;
+  a.act = act; a.gate = (const float*)gate; a.ldg = ldg; a.gate_act = gate_act; a.y = (float*)y; a.ldy = ldy;
+  a.nbx = (int)((N + TBM - 1) / TBM);
+  a.nby = (out_features + TBN - 1) / TBN;
+  const bool vec = (in_features % 4 == 0) && (ldx % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)w)) % 16 == 0);
+  if (vec) hipLaunchKernelGGL(gemm_f32_skip<true>, dim3((unsigned)(a.nbx * a.nby)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gemm_f32_skip<false>, dim3((unsigned)(a.nbx * a.nby)), dim3(256), 0, (hipStream_t)stream, a);
+  return ZK_LAUNCH_CHECK();
+}
+
+// rows per slice / number of slices zk_wgrad_f32 will use for N rows and npairs live blocks (the caller sizes `partial`
+// as nslices * npairs * 128 * 128 floats)
+int zk_wgrad_slices(int64_t N, int npairs) {
+  if (N <= 0 || npairs <= 0) return 0;
+  int64_t want = (2 * 256 + npairs - 1) / npairs;  // ~2 blocks per CU
+  int64_t S = (N + want - 1) / want;
+  S = S < 512 ? 512 : S;
+  S = (S + 15) / 16 * 16;
+  return (int)((N + S - 1) / S);
+}
+
+// dw[OUT, IN] (+)= mask .* (g^T h): g [N, OUT], h [N, IN]; pairs = the (128 x 128) blocks of dw to compute (device, int32 [npairs][2]);
+// the blocks not listed are left untouched (the caller zero-fills dw once).  Deterministic.
+int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
+                 float* partial, const uint8_t* mask, void* dw, int accumulate, void* stream) {
+  if (N <= 0 || npairs <= 0) return 0;
+  WgradArgs a{};
+  a.N = N; a.OUT = out_features; a.IN = in_features; a.g = (const float*)g; a.ldg = ldg; a.h = (const float*)h; a.ldh = ldh; a.pairs = pairs; a.npairs = npairs;
+  a.nslices = zk_wgrad_slices(N, npairs);
+  a.S = ((N + a.nslices - 1) / a.nslices + 15) / 16 * 16;
+  a.nslices = (int)((N + a.S - 1) / a.S);
+  a.partial = partial;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)npairs * 64), dim3(256), 0, st, out_features, in_features, pairs, npairs, a.nslices, (const float*)partial, mask,
+                     (float*)dw, accumulate);
+  return ZK_LAUNCH_CHECK();
+}
+
+// out[c] (+)= sum_n x[n, c];  workspace: >= zk_colsum_slices(N) * C floats
+int zk_colsum_slices(int64_t N) {
+  int64_t s = (N + 2047) / 2048;
+  return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
+}
+int zk_colsum_f32(int64_t N, int C, const void* x, int64_t ld, float* workspace, void* out, int accumulate, void* stream) {
+  if (C <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = N > 0 ? zk_colsum_slices(N) : 1;
+  const int64_t S = N > 0 ? (N + ns - 1) / ns : 1;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)ns), dim3(256), 0, st, N, C, (const float*)x, ld, S, workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, C, ns, (const float*)workspace, (float*)out, accumulate);
+  return ZK_LAUNCH_CHECK();
+}
+
+}  // extern "C"

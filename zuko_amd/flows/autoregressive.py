@@ -134,7 +134,10 @@ class MaskedAutoregressiveTransform(LazyTransform):
         if c is not None:
             x = torch.cat(broadcast(x, c, ignore=1), dim=-1)
         phi = self.hyper(x).unflatten(-1, (-1, self.total))
-        return DependentTransform(self.univariate(*unpack(phi, self.shapes)), 1)
+        u = self.univariate(*unpack(phi, self.shapes))
+        if type(u) in (MonotonicAffineTransform, MonotonicRQSTransform):
+            u._packed = phi  # the views above were cut from this tensor: autograd can differentiate it directly
+        return DependentTransform(u, 1)
 
     def forward(self, c: Tensor | None = None) -> Transform:
         return FusedAutoregressiveTransform(self, c)

@@ -17,7 +17,7 @@ from torch.distributions import Transform
 from ..distributions import DiagNormal
 from ..lazy import Flow, LazyTransform, UnconditionalDistribution
 from ..nn import MLP
-from ..transforms import CouplingTransform, DependentTransform, MonotonicAffineTransform
+from ..transforms import CouplingTransform, DependentTransform, MonotonicAffineTransform, MonotonicRQSTransform
 from ..utils import broadcast, unpack
 from .autoregressive import _univariate_name
 from .elementwise import ElementWiseTransform
@@ -66,7 +66,10 @@ class GeneralCouplingTransform(LazyTransform):
         if c is not None:
             x = torch.cat(broadcast(x, c, ignore=1), dim=-1)
         phi = self.hyper(x).unflatten(-1, (-1, self.total))
-        return DependentTransform(self.univariate(*unpack(phi, self.shapes)), 1)
+        u = self.univariate(*unpack(phi, self.shapes))
+        if type(u) in (MonotonicAffineTransform, MonotonicRQSTransform):
+            u._packed = phi  # the views above were cut from this tensor: autograd can differentiate it directly
+        return DependentTransform(u, 1)
 
     def forward(self, c: Tensor | None = None) -> Transform:
         return CouplingTransform(partial(self.meta, c), self.mask)

@@ -78,6 +78,12 @@ class _FusedSequential(nn.Sequential):
     the GEMM epilogue knows; other modules are applied as-is."""
 
     def forward(self, x: Tensor) -> Tensor:
+        if torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from . import train
+
+            out = train.conditioner(self, x)  # HIP forward + mask-aware dgrad / wgrad (csrc/train.hip) for plain (linear, act)* stacks
+            if out is not None:
+                return out
         mods = list(self)
         i = 0
         while i < len(mods):

@@ -145,9 +145,14 @@ class _Prepared:
 # ------------------------------------------------------------------------------------------------
 
 
+def _packed_ok(x: Tensor, packed: Tensor | None, total: int) -> bool:
+    return packed is not None and packed.dim() >= 2 and packed.shape[-1] == total and x.dim() >= 1 and tuple(torch.broadcast_shapes(x.shape, packed.shape[:-1])) == tuple(packed.shape[:-1])
+
+
 def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor, bound: float = 5.0, slope: float = 1e-3,
-                reduce: bool = False, want_bins: bool = False):
-    """(y, ladj[, k]) — see include/zuko_amd.h:zk_rqs_forward."""
+                reduce: bool = False, want_bins: bool = False, packed: Tensor | None = None):
+    """(y, ladj[, k]) — see include/zuko_amd.h:zk_rqs_forward.  `packed`: the phi[..., D, 3K-1] tensor the three parameter
+    views were cut from, when the caller has it (lets autograd differentiate phi itself instead of the three views)."""
     K = widths.shape[-1]
     if heights.shape[-1] != K or derivatives.shape[-1] != K - 1:
         raise ValueError("zuko_amd: widths/heights must have K entries and derivatives K-1")
@@ -158,6 +163,8 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
         _no_bf16_grad(x, widths)
         if K not in (4, 8, 16):
             raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
+        if _packed_ok(x, packed, 3 * K - 1):
+            return AG.UnivariatePackedFn.apply(1, bound, slope, reduce, (K, K, K - 1), x, packed)
         return AG.UnivariateFn.apply(1, bound, slope, reduce, x, widths, heights, derivatives)
     pr = _Prepared(x, [(widths, 1), (heights, 1), (derivatives, 1)])
     if reduce and len(pr.shape) == 0:
@@ -173,6 +180,14 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
 
 def rqs_inverse(y: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor, bound: float = 5.0, slope: float = 1e-3, want_bins: bool = False):
     K = widths.shape[-1]
+    from . import autograd as AG
+
+    if not want_bins and AG.needs_grad(y, widths, heights, derivatives):
+        _require_device(y, widths, heights, derivatives)
+        _no_bf16_grad(y, widths)
+        if K not in (4, 8, 16):
+            raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
+        return AG.UnivariateInverseFn.apply(1, bound, slope, y, widths, heights, derivatives)
     pr = _Prepared(y, [(widths, 1), (heights, 1), (derivatives, 1)])
     x = pr.out()
     bins = torch.empty(pr.shape, dtype=torch.int32, device=y.device) if want_bins else None
@@ -221,11 +236,13 @@ def rqs_from_knots(v: Tensor, horizontal: Tensor, vertical: Tensor, slopes: Tens
 # ------------------------------------------------------------------------------------------------
 
 
-def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3, reduce: bool = False):
+def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3, reduce: bool = False, packed: Tensor | None = None):
     from . import autograd as AG
 
     if AG.needs_grad(x, shift, scale):
         _require_device(x, shift, scale)
+        if _packed_ok(x, packed, 2):
+            return AG.UnivariatePackedFn.apply(0, 5.0, slope, reduce, (1, 1), x, packed)
         return AG.UnivariateFn.apply(0, 5.0, slope, reduce, x, shift, scale)
     pr = _Prepared(x, [(shift.unsqueeze(-1), 1), (scale.unsqueeze(-1), 1)])
     y, ladj = pr.out(), pr.out_ladj(reduce)
@@ -236,6 +253,11 @@ def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3,
 
 
 def affine_inverse(y: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3) -> Tensor:
+    from . import autograd as AG
+
+    if AG.needs_grad(y, shift, scale):
+        _require_device(y, shift, scale)
+        return AG.UnivariateInverseFn.apply(0, 5.0, slope, y, shift, scale)
     pr = _Prepared(y, [(shift.unsqueeze(-1), 1), (scale.unsqueeze(-1), 1)])
     x = pr.out()
     (s, sn, sd), (c, cn, cd) = pr.params

@@ -1,0 +1,243 @@
+r"""Training path of the conditioner networks: `phi = hyper(x)` with HIP forward, dgrad and wgrad.
+
+The reference trains through `F.linear(x, mask * W, b)` (zuko/nn.py:217-218) with PyTorch autograd: per layer one dense
+GEMM forward and two dense GEMMs backward, all of which spend half their time on weights the mask holds at zero.  Here a
+plain (linear, activation)* network — `MaskedMLP` (autoregressive) or `MLP` (coupling) — is evaluated in a
+reparametrisation whose hidden units are sorted by the size of their dependency set (rows of W_l / b_l and columns of
+W_{l+1} permuted together: the function is unchanged), which makes the masks block lower-triangular; the three GEMMs of
+every layer then skip the blocks the mask zeroes (csrc/train.hip):
+
+    forward   h_{l+1} = act(h_l Ws_l^T + bs_l)              zk_gemm_f32_skip, (128 x 32) tile skipping
+    dgrad     g_l     = (g_{l+1} Ws_l) * act'(h_l)           the same kernel on Ws_l^T, derivative in the epilogue
+    wgrad     dWs_l   = mask * (g_{l+1}^T h_l), dbs_l = colsum(g_{l+1})   zk_wgrad_f32 (split-K, live 128 x 128 blocks), zk_colsum_f32
+
+Only integer bookkeeping (permutations, gather / scatter indices, skip maps) is done with torch ops, once per module.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch import Tensor
+
+from . import _C
+
+TRAIN_ACTS = (0, 1, 2, 3, 6, 7)  # activations whose derivative is a function of their output (as zk_act_backward)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class SortedPlan:
+    """Index tables of one (linear, activation)* network on one device."""
+
+    def __init__(self, lins, act_code: int, device: torch.device) -> None:
+        self.act = act_code
+        self.device = device
+        n = len(lins)
+        masks = [getattr(l, "mask", None) for l in lins]
+        shapes = [tuple(l.weight.shape) for l in lins]
+        # dependency-count sort of the hidden layers (identity for dense networks)
+        perms: list[Tensor | None] = []
+        if all(m is not None for m in masks):
+            dep = torch.eye(shapes[0][1], dtype=torch.float64)
+            for i, m in enumerate(masks):
+                dep = ((m.detach().cpu().double() @ dep) > 0).double()
+                if i + 1 < n:
+                    perm = torch.argsort(dep.sum(dim=1), stable=True)
+                    dep = dep[perm]
+                    perms.append(perm)
+                else:
+                    perms.append(None)
+        else:
+            perms = [None] * n
+        self.perms = perms
+        self.idx_w, self.idx_wt, self.idx_b, self.kskip_f, self.kskip_b, self.pairs, self.mask_s, self.shapes = [], [], [], [], [], [], [], shapes
+        self.mask_u8 = []
+        prev = None
+        for i, (out_f, in_f) in enumerate(shapes):
+            rows = perms[i] if perms[i] is not None else torch.arange(out_f)
+            cols = prev if prev is not None else torch.arange(in_f)
+            idx = (rows[:, None] * in_f + cols[None, :]).to(torch.int32)  # sorted [out, in] -> position in W.flatten()
+            m = masks[i]
+            ms = torch.ones((out_f, in_f), dtype=torch.bool) if m is None else m.detach().cpu().bool()[rows][:, cols]
+            self.idx_w.append(idx.reshape(-1).contiguous().to(device))
+            self.idx_wt.append(idx.t().reshape(-1).contiguous().to(device))
+            self.idx_b.append(rows.to(torch.int32).to(device))
+            kf, kb = (None, None) if m is None else (self._kskip(ms), self._kskip(ms.t().contiguous()))
+            self.kskip_f.append(None if kf is None else kf.to(device))
+            self.kskip_b.append(None if kb is None else kb.to(device))
+            ob, ib = -(-out_f // 128), -(-in_f // 128)
+            pad = torch.zeros((ob * 128, ib * 128), dtype=torch.bool)
+            pad[:out_f, :in_f] = ms
+            live = pad.reshape(ob, 128, ib, 128).any(dim=3).any(dim=1)
+            self.pairs.append(live.nonzero().to(torch.int32).contiguous().to(device))
+            self.mask_s.append(None if m is None else ms.to(torch.uint8).contiguous().to(device))
+            self.mask_u8.append(None if m is None else m.detach().contiguous().view(torch.uint8).to(device))
+            prev = perms[i]
+        self.idx_w64 = [t.long() for t in self.idx_w]
+        self.idx_b64 = [t.long() for t in self.idx_b]
+        self.kept = [float(k.shape[0]) / (-(-s[0] // 128) * -(-s[1] // 128)) for k, s in zip(self.pairs, shapes)]
+
+    @staticmethod
+    def _kskip(ms: Tensor):
+        """int64 word per 128-row block (raw bits of a uint64): bit kt set iff columns [32 kt, 32 kt + 32) of the block hold a
+        non-zero; None (no skipping) for layers with more than 2048 inputs."""
+        import numpy as np
+
+        out_f, in_f = ms.shape
+        if in_f > 2048:
+            return None
+        ob, kt = -(-out_f // 128), -(-in_f // 32)
+        pad = np.zeros((ob * 128, kt * 32), dtype=bool)
+        pad[:out_f, :in_f] = ms.numpy()
+        live = pad.reshape(ob, 128, kt, 32).any(axis=3).any(axis=1)  # [ob, kt]
+        words = (live.astype(np.uint64) << np.arange(kt, dtype=np.uint64)[None, :]).sum(axis=1, dtype=np.uint64)
+        return torch.from_numpy(words.view(np.int64).copy())
+
+    # ---- device work -------------------------------------------------------------------------------------------
+
+    def gather(self, lins):
+        """Sorted, masked weights Ws_l [out, in], their transposes [in, out] and sorted biases (fresh tensors)."""
+        lib = _C.lib()
+        ws, wts, bs = [], [], []
+        for l, lin in enumerate(lins):
+            out_f, in_f = self.shapes[l]
+            w = lin.weight.detach().contiguous()
+            ws_l = torch.empty((out_f, in_f), dtype=torch.float32, device=self.device)
+            wt_l = torch.empty((in_f, out_f), dtype=torch.float32, device=self.device)
+            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(self.mask_u8[l]), _ptr(self.idx_w[l]), out_f * in_f, _ptr(ws_l), _stream()), "zk_gather_f32")
+            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(self.mask_u8[l]), _ptr(self.idx_wt[l]), out_f * in_f, _ptr(wt_l), _stream()), "zk_gather_f32")
+            ws.append(ws_l)
+            wts.append(wt_l)
+            if lin.bias is None:
+                bs.append(None)
+            else:
+                b = torch.empty(out_f, dtype=torch.float32, device=self.device)
+                _C.check(lib.zk_gather_f32(_ptr(lin.bias.detach().contiguous()), None, _ptr(self.idx_b[l]), out_f, _ptr(b), _stream()), "zk_gather_f32")
+                bs.append(b)
+        return ws, wts, bs
+
+    def gemm(self, x: Tensor, w: Tensor, kskip, bias, act: int, gate: Tensor | None = None, gate_act: int = 0) -> Tensor:
+        out_f, in_f = w.shape
+        y = torch.empty((x.shape[0], out_f), dtype=torch.float32, device=x.device)
+        err = _C.lib().zk_gemm_f32_skip(x.shape[0], in_f, out_f, _ptr(x), x.stride(0), _ptr(w), _ptr(kskip), _ptr(bias), act,
+                                        _ptr(gate), 0 if gate is None else gate.stride(0), gate_act, _ptr(y), out_f, _stream())
+        _C.check(err, "zk_gemm_f32_skip")
+        return y
+
+    def wgrad(self, l: int, g: Tensor, h: Tensor) -> Tensor:
+        """Sorted-domain weight gradient dWs_l [out, in] (zeros where the mask is false)."""
+        lib = _C.lib()
+        out_f, in_f = self.shapes[l]
+        N = g.shape[0]
+        pairs = self.pairs[l]
+        npairs = pairs.shape[0]
+        dw = torch.zeros((out_f, in_f), dtype=torch.float32, device=g.device)
+        ns = lib.zk_wgrad_slices(N, npairs)
+        partial = torch.empty(max(1, ns) * npairs * 128 * 128, dtype=torch.float32, device=g.device)
+        err = lib.zk_wgrad_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(self.mask_s[l]), _ptr(dw), 0, _stream())
+        _C.check(err, "zk_wgrad_f32")
+        return dw
+
+    def colsum(self, g: Tensor) -> Tensor:
+        lib = _C.lib()
+        N, C = g.shape
+        ws = torch.empty(lib.zk_colsum_slices(max(N, 1)) * C, dtype=torch.float32, device=g.device)
+        out = torch.empty(C, dtype=torch.float32, device=g.device)
+        _C.check(lib.zk_colsum_f32(N, C, _ptr(g), g.stride(0), _ptr(ws), _ptr(out), 0, _stream()), "zk_colsum_f32")
+        return out
+
+
+class ConditionerFn(torch.autograd.Function):
+    """phi = net(x) for a plain (linear, activation)* network; x [N, in] contiguous fp32.  Inputs after `x`: weight_0,
+    bias_0 (or None), weight_1, ... in layer order."""
+
+    @staticmethod
+    def forward(ctx, plan: SortedPlan, lins, x: Tensor, *params):
+        n = len(lins)
+        ws, wts, bs = plan.gather(lins)
+        hs = [x]
+        h = x
+        for l in range(n):
+            h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l + 1 < n else 0)
+            hs.append(h)
+        ctx.plan, ctx.n = plan, n
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.save_for_backward(*hs[:-1], *wts)
+        return h
+
+    @staticmethod
+    def backward(ctx, g_phi: Tensor):
+        plan, n = ctx.plan, ctx.n
+        saved = ctx.saved_tensors
+        hs, wts = saved[:n], saved[n:]
+        g = g_phi.contiguous()
+        grads: list = [None] * (2 * n)
+        for l in range(n - 1, -1, -1):
+            out_f, in_f = plan.shapes[l]
+            if ctx.needs_input_grad[3 + 2 * l]:
+                dws = plan.wgrad(l, g, hs[l])
+                dw = torch.empty(out_f * in_f, dtype=torch.float32, device=g.device)
+                dw[plan.idx_w64[l]] = dws.reshape(-1)  # scatter back to the module's unit order (a bijection)
+                grads[2 * l] = dw.reshape(out_f, in_f)
+            if ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]:
+                dbs = plan.colsum(g)
+                db = torch.empty(out_f, dtype=torch.float32, device=g.device)
+                db[plan.idx_b64[l]] = dbs
+                grads[2 * l + 1] = db
+            if l > 0 or ctx.needs_input_grad[2]:
+                # g_l = (g_{l+1} Ws_l) * act'(h_l): Ws_l^T plays the weight, h_l (a saved activation OUTPUT) the gate
+                g = plan.gemm(g, wts[l], plan.kskip_b[l], None, 0, hs[l] if l > 0 else None, plan.act if l > 0 else 0)
+        gx = g if ctx.needs_input_grad[2] else None
+        return (None, None, gx, *grads)
+
+
+def plan_for(module, device: torch.device):
+    """SortedPlan of a `_FusedSequential` made of (linear, activation)* with a trainable activation, else None.  Cached on the
+    module per device and mask version."""
+    from .nn import Linear, MaskedLinear, _act_code
+
+    mods = list(module)
+    lins = mods[0::2]
+    acts = mods[1::2]
+    if not mods or not all(isinstance(m, (Linear, MaskedLinear)) for m in lins) or any(isinstance(m, (Linear, MaskedLinear)) for m in acts):
+        return None, None
+    if len(mods) != 2 * len(lins) - 1:
+        return None, None
+    codes = {_act_code(a) for a in acts}
+    if len(codes) > 1 or (codes and (None in codes or next(iter(codes)) not in TRAIN_ACTS)):
+        return None, None
+    if any(l.weight.dtype != torch.float32 for l in lins):
+        return None, None
+    key = (str(device),) + tuple((m.mask._version, m.mask.data_ptr()) for m in lins if hasattr(m, "mask"))
+    cache = module.__dict__.setdefault("_train_plan_cache", {})
+    if cache.get("key") != key:
+        cache.clear()
+        cache["key"] = key
+        cache["plan"] = SortedPlan(lins, codes.pop() if codes else 0, device)
+    return cache["plan"], lins
+
+
+def conditioner(module, x: Tensor):
+    """Differentiable `module(x)` through the HIP training kernels, or None when the module is not covered."""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return None
+    plan, lins = plan_for(module, x.device)
+    if plan is None:
+        return None
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) % 4 != 0) or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    params = []
+    for l in lins:
+        params += [l.weight, l.bias]
+    out = ConditionerFn.apply(plan, lins, x2, *params)
+    return out.reshape(lead + (out.shape[-1],))

@@ -88,7 +88,7 @@ class MonotonicAffineTransform(_Univariate):
         self.slope = slope
 
     def _forward(self, x, reduce):
-        return ops.affine_forward(x, self.shift, self.unconstrained_scale, self.slope, reduce)
+        return ops.affine_forward(x, self.shift, self.unconstrained_scale, self.slope, reduce, packed=getattr(self, "_packed", None))
 
     def _inverse(self, y: Tensor) -> Tensor:
         return ops.affine_inverse(y, self.shift, self.unconstrained_scale, self.slope)
@@ -114,7 +114,7 @@ class MonotonicRQSTransform(_Univariate):
         return self.widths.shape[-1]
 
     def _forward(self, x, reduce):
-        return ops.rqs_forward(x, self.widths, self.heights, self.unconstrained_derivatives, self.bound, self.slope, reduce)
+        return ops.rqs_forward(x, self.widths, self.heights, self.unconstrained_derivatives, self.bound, self.slope, reduce, packed=getattr(self, "_packed", None))
 
     def _inverse(self, y: Tensor) -> Tensor:
         return ops.rqs_inverse(y, self.widths, self.heights, self.unconstrained_derivatives, self.bound, self.slope)
