@@ -199,6 +199,15 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
  * gl [N] if gl_reduced else [N, D] (may be NULL); outputs gx [N, D], gphi [N, D, total]. */
 int zk_univariate_backward(int kind, int64_t N, int64_t D, int K, double bound, double slope, const void* x, const void* phi,
                            const void* gy, const void* gl, int gl_reduced, void* gx, void* gphi, void* stream);
+/* Adjoints of the polynomial maps (fp32; what autograd derives from zuko/transforms.py:927-963 + zuko/utils.py:297-326 and
+ * from :640-831).  SOS: params [N, D, P*L1 (+1)] = [a | constant?] packed, built for P * L1 == 15 (SOSPF default);
+ * Bernstein: theta [N, D, M] unconstrained, built for the BPF defaults (bounded M = 17, unbounded M = 16); other sizes
+ * return hipErrorInvalidValue.  gy [N, D] / gl ([N] if gl_reduced else [N, D]) may be NULL. */
+int zk_sos_backward(int64_t N, int64_t D, int P, int L1, double slope, const double* gl_nodes01, const double* gl_weights01,
+                    int has_const, const void* x, const void* params, const void* gy, const void* gl, int gl_reduced, void* gx,
+                    void* gparams, void* stream);
+int zk_bernstein_backward(int64_t N, int64_t D, int M, int bounded, double bound, const void* x, const void* theta, const void* gy,
+                          const void* gl, int gl_reduced, void* gx, void* gtheta, void* stream);
 /* Adjoint seeds of an INVERSE univariate map x = f^{-1}(y) (gradients through rsample; inverse function theorem):
  * gy[e] = gx[e] * exp(-ladj[e]) with ladj = log f'(x), seed[e] = -gy[e] (zk_univariate_backward(x, phi, gy = seed) then
  * yields dL/dphi). */

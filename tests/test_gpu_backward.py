@@ -115,3 +115,79 @@ def test_rsample_gradients_match_reference_autograd(dev, name):
     xs = flow(None if c is None else c.to(dev)).rsample((8,) if c is None else ())
     xs.square().sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in flow.parameters())
+
+
+def test_sos_backward_matches_autograd(dev):
+    """SOS polynomial adjoint kernel (forward-mode duals) against autograd through the oracle's quadrature (float64)."""
+    from zuko_amd import ops
+
+    gen = torch.Generator().manual_seed(4)
+    N, D = 300, 5
+    a = torch.randn(N, D, 3, 5, generator=gen) * 0.5
+    const = torch.randn(N, D, generator=gen)
+    x = torch.randn(N, D, generator=gen) * 3
+    gy, gl = torch.randn(N, D, generator=gen), torch.randn(N, D, generator=gen)
+    ad, cd, xd = a.double().requires_grad_(), const.double().requires_grad_(), x.double().requires_grad_()
+    y, l = O.sos_forward(ad, xd)
+    ((y + cd) * gy.double()).sum().add((l * gl.double()).sum()).backward()
+    ag, cg, xg = a.to(dev).requires_grad_(), const.to(dev).requires_grad_(), x.to(dev).requires_grad_()
+    yy, ll = ops.sos_forward(xg, ag, cg)
+    ((yy * gy.to(dev)).sum() + (ll * gl.to(dev)).sum()).backward()
+    for mine, ref, what in ((ag.grad, ad.grad, "a"), (cg.grad, cd.grad, "constant"), (xg.grad, xd.grad, "x")):
+        err = ((mine.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+        assert err < 1e-4, f"SOS grad {what}: {err:.2e}"
+    # gradient through the bisection inverse (inverse function theorem; zuko/utils.py:185-209)
+    yv = (yy.detach()).clone().requires_grad_()
+    a2 = a.to(dev).requires_grad_()
+    xi = ops.sos_inverse(yv, a2, const.to(dev))
+    (xi * gy.to(dev)).sum().backward()
+    # d x / d y = 1 / g(x)
+    g_at = O.sos_g(a.double(), xi.detach().cpu().double())
+    assert torch.allclose(yv.grad.cpu().double(), gy.double() / g_at, rtol=1e-3, atol=1e-5)
+    assert torch.isfinite(a2.grad).all() and a2.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("bounded,M", [(True, 17), (False, 16)])
+def test_bernstein_backward_matches_autograd(dev, bounded, M):
+    from zuko_amd import ops
+
+    gen = torch.Generator().manual_seed(6 + M)
+    N, D = 200, 4
+    th = torch.randn(N, D, M, generator=gen)
+    x = torch.randn(N, D, generator=gen) * 2.5
+    x[0, 0], x[0, 1] = 7.0, -7.0  # linear tails
+    gy, gl = torch.randn(N, D, generator=gen), torch.randn(N, D, generator=gen)
+    td, xd = th.double().requires_grad_(), x.double().requires_grad_()
+    theta = O.bern_constrain(td, bounded)
+    y = O.bern_f(theta, xd, bounded)
+    (jac,) = torch.autograd.grad(y, xd, torch.ones_like(y), create_graph=True)
+    ((y * gy.double()).sum() + (jac.log() * gl.double()).sum()).backward()
+    tg, xg = th.to(dev).requires_grad_(), x.to(dev).requires_grad_()
+    yy, ll = ops.bernstein_forward(xg, tg, bounded)
+    assert torch.allclose(yy.detach().cpu().double(), y.detach(), rtol=1e-4, atol=1e-4)
+    ((yy * gy.to(dev)).sum() + (ll * gl.to(dev)).sum()).backward()
+    for mine, ref, what in ((tg.grad, td.grad, "theta"), (xg.grad, xd.grad, "x")):
+        err = ((mine.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+        assert err < 2e-3, f"Bernstein grad {what}: {err:.2e}"
+
+
+@pytest.mark.parametrize("name", ["sospf_small", "bpf_small"])
+def test_polynomial_flows_train(dev, name):
+    """SOSPF / BPF: every parameter receives a finite gradient from log_prob and from rsample (zuko tests/test_flows.py:22-54)."""
+    flow, entry = build_flow(name)
+    flow = flow.to(dev)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(64, entry[1]["features"], generator=gen).to(dev)
+    c = torch.randn(64, entry[1]["context"], generator=gen).to(dev)
+    (-flow(c).log_prob(x).mean()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in flow.parameters())
+    if name == "sospf_small":  # value check against autograd through the oracle
+        flow2, entry2 = build_flow(name)
+        ref_loss, ref_grads, ref_gx = _oracle_grads(flow2, entry2, x.cpu(), c.cpu())
+        params = dict(flow.named_parameters())
+        for k, g in ref_grads.items():
+            err = ((params[k].grad.cpu() - g).abs().max() / g.abs().max().clamp_min(1e-6)).item()
+            assert err < 1e-3, f"{k}: {err:.2e}"
+    flow.zero_grad()
+    flow(c).rsample().square().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in flow.parameters())

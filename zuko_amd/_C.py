@@ -43,6 +43,8 @@ SIGNATURES = {
     "zk_diag_normal_backward": [L, L, P, P, P, P, P, P],
     "zk_act_backward": [L, P, P, I, P, P],
     "zk_inverse_seed": [L, P, P, P, P, P],
+    "zk_sos_backward": [L, L, I, I, F, POINTER(c_double), POINTER(c_double), I, P, P, P, P, I, P, P, P],
+    "zk_bernstein_backward": [L, L, I, I, F, P, P, P, P, I, P, P, P],
     "zk_gemm_f32_skip": [L, I, I, P, L, P, P, P, I, P, L, I, P, L, P],
     "zk_wgrad_slices": [L, I],
     "zk_wgrad_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P],

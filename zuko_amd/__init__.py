@@ -26,3 +26,6 @@ def invalidate(module) -> None:
         _ar._FUSED_CACHE.pop(m, None)
         m.__dict__.pop("_bf16_plan_cache", None)
         m.__dict__.pop("_coupling_cache", None)
+        from . import train as _train
+
+        _train._PLAN_CACHE.pop(m, None)

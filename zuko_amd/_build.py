@@ -30,6 +30,7 @@ SOURCES = {
     "fused_ar.hip": ["-ffp-contract=off"],
     "backward.hip": [],
     "train.hip": [],
+    "backward_poly.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 

@@ -3,15 +3,15 @@ r"""Autograd support: `loss = -flow(c).log_prob(x).mean(); l
 The reference relies on PyTorch autograd through every ATen op of the forward pass.  Here each
 HIP forward kernel that can sit on a differentiable path gets a `torch.autograd.Function` whose
 backward is a HIP kernel too (csrc/backward.hip: fused adjoint of softclip/softmax/cumsum/exp/bin
-gather/rational-quadratic; affine; base density; activations).  The dgrad / wgrad of a conditioner
-layer are plain GEMMs and go to the vendor library through `torch.mm` (the task rules reserve
-hand-written MFMA kernels for the fused hot ops and allow hipBLASLt/rocBLAS for plain library GEMMs);
-the mask is re-applied to the weight gradient.
+gather/rational-quadratic; affine; base density; activations; csrc/backward_poly.hip: SOS and Bernstein polynomials on
+forward-mode dual numbers).  The dgrad / wgrad of plain conditioner stacks run on the tile-skipping MFMA kernels of
+csrc/train.hip (zuko_amd/train.py); `LinearFn` below (library GEMMs through `torch.mm`) remains for module trees those
+do not cover (residual blocks, SiLU / GELU).
 
-Scope: fp32, forward direction (`log_prob`) of affine and RQS (4, 8 or 16 bins) transforms with
-MaskedMLP / MLP conditioners.  Gradients through the inverse (`rsample`), SOS and Bernstein are not
-provided yet and raise.  When gradients are required the layer-wise kernels are used (the fused
-inference kernel keeps no intermediates).
+Scope: fp32; affine, RQS (4, 8 or 16 bins), SOS polynomial (SOSPF default size) and (bounded) Bernstein polynomial
+(BPF default sizes), forward (`log_prob`) and inverse (`rsample`) directions, with MaskedMLP / MLP conditioners
+(zuko_amd/train.py).  When gradients are required the layer-wise kernels are used (the fused inference kernel keeps no
+intermediates).
 """
 
 from __future__ import annotations
@@ -63,143 +63,214 @@ def _packed(parts: list[Tensor], batch) -> Tensor:
     return torch.cat([p.expand(tuple(batch) + (p.shape[-1],)) for p in parts], dim=-1).contiguous()
 
 
+# ---- univariate maps: one description object, three autograd Functions ------------------------------------------------
+# meta = (kind, bound, slope, sizes, extra): kind 0 affine [shift | scale], 1 RQS [w(K) | h(K) | d(K-1)], 2 SOS
+# [a(P*L1) | constant?] with extra = (P, L1, has_const), 3 Bernstein [theta(M)] with extra = (bounded,).
+
+
+def _split(meta, phi):
+    kind, _, _, sizes, extra = meta
+    pieces = list(phi.split(list(sizes), -1))
+    if kind == 0:
+        return [pieces[0].squeeze(-1), pieces[1].squeeze(-1)]
+    if kind == 2:
+        P, L1, has_const = extra
+        return [pieces[0].unflatten(-1, (P, L1))] + ([pieces[1].squeeze(-1)] if has_const else [])
+    return pieces
+
+
+def _fwd_any(meta, xe, phi, reduce):
+    """(y, ladj) through the forward kernels (no autograd)."""
+    from . import ops
+
+    kind, bound, slope, _, extra = meta
+    pc = _split(meta, phi)
+    with torch.no_grad():
+        if kind == 0:
+            return ops.affine_forward(xe, pc[0], pc[1], slope, reduce)
+        if kind == 1:
+            return ops.rqs_forward(xe, pc[0], pc[1], pc[2], bound, slope, reduce)
+        if kind == 2:
+            return ops.sos_forward(xe, pc[0], pc[1] if extra[2] else None, slope, reduce)
+        return ops.bernstein_forward(xe, pc[0], extra[0], bound, reduce)
+
+
+def _inv_any(meta, ye, phi):
+    from . import ops
+
+    kind, bound, slope, _, extra = meta
+    pc = _split(meta, phi)
+    with torch.no_grad():
+        if kind == 0:
+            return ops.affine_inverse(ye, pc[0], pc[1], slope)
+        if kind == 1:
+            return ops.rqs_inverse(ye, pc[0], pc[1], pc[2], bound, slope)
+        if kind == 2:
+            return ops.sos_inverse(ye, pc[0], pc[1] if extra[2] else None, slope)
+        return ops.bernstein_inverse(ye, pc[0], extra[0], bound)
+
+
+def _adj_any(meta, xe, phi, gy, gl, reduce):
+    """(gx, gphi) = VJP of (y, ladj) w.r.t. (x, packed parameters): csrc/backward.hip, csrc/backward_poly.hip."""
+    kind, bound, slope, sizes, extra = meta
+    D = xe.shape[-1] if xe.dim() else 1
+    N = xe.numel() // max(D, 1)
+    gx, gphi = torch.empty_like(xe), torch.empty_like(phi)
+    lib = _C.lib()
+    if kind in (0, 1):
+        K = sizes[0] if kind == 1 else 0
+        err = lib.zk_univariate_backward(kind, N, D, K, bound, slope, _ptr(xe), _ptr(phi), _ptr(gy), _ptr(gl), int(reduce), _ptr(gx), _ptr(gphi), _stream())
+        _C.check(err, "zk_univariate_backward")
+    elif kind == 2:
+        from .ops import _leggauss01
+
+        P, L1, has_const = extra
+        nodes, weights = _leggauss01(L1)
+        err = lib.zk_sos_backward(N, D, P, L1, slope, nodes, weights, int(has_const), _ptr(xe), _ptr(phi), _ptr(gy), _ptr(gl), int(reduce), _ptr(gx), _ptr(gphi), _stream())
+        if err == 1:
+            raise NotImplementedError("zuko_amd: the SOS adjoint kernel is built for 15 coefficients per element (SOSPF default: 3 polynomials of degree 4)")
+        _C.check(err, "zk_sos_backward")
+    else:
+        M = sizes[0]
+        err = lib.zk_bernstein_backward(N, D, M, int(extra[0]), bound, _ptr(xe), _ptr(phi), _ptr(gy), _ptr(gl), int(reduce), _ptr(gx), _ptr(gphi), _stream())
+        if err == 1:
+            raise NotImplementedError("zuko_amd: the Bernstein adjoint kernel is built for the BPF defaults (bounded with 17 / unbounded with 16 unconstrained coefficients)")
+        _C.check(err, "zk_bernstein_backward")
+    return gx, gphi
+
+
+def _meta_of(kind, bound, slope, params, extra=()):
+    """(meta, parts): `parts` are the parameter tensors reshaped to [..., n_i] pieces of the packed layout."""
+    if kind == 0:
+        parts = [p.unsqueeze(-1) for p in params]
+    elif kind == 2:
+        parts = [params[0].flatten(-2)] + ([params[1].unsqueeze(-1)] if len(params) > 1 and params[1] is not None else [])
+        extra = (params[0].shape[-2], params[0].shape[-1], len(parts) > 1)
+    else:
+        parts = list(params)
+    return (kind, bound, slope, tuple(p.shape[-1] for p in parts), tuple(extra)), parts
+
+
+def _unparts(meta, pieces, pshapes):
+    kind = meta[0]
+    out = []
+    for g, shape in zip(pieces, pshapes):
+        if kind == 0 or (kind == 2 and len(shape) < g.dim()):
+            g = g.squeeze(-1)
+        if kind == 2 and len(out) == 0:
+            g = g.unflatten(-1, (meta[4][0], meta[4][1]))
+        out.append(_sum_to(g, shape))
+    return out
+
+
 class UnivariateFn(torch.autograd.Function):
-    """kind 0: affine(shift, scale); kind 1: RQS(widths, heights, derivatives).  Returns (y, ladj)."""
+    """(y, ladj) of a univariate map from separate parameter tensors (see _meta_of for the kinds)."""
 
     @staticmethod
     def forward(ctx, kind: int, bound: float, slope: float, reduce: bool, x: Tensor, *params: Tensor):
-        from . import ops
-
-        _require_f32(x, *params)
-        parts = [p.unsqueeze(-1) for p in params] if kind == 0 else list(params)
+        live = [p for p in params if p is not None]
+        _require_f32(x, *live)
+        meta, parts = _meta_of(kind, bound, slope, live)
         batch = torch.broadcast_shapes(x.shape, *[p.shape[:-1] for p in parts])
         xe = x.expand(batch).contiguous()
         phi = _packed([p.detach() for p in parts], batch)
-        sizes = [p.shape[-1] for p in parts]
-        pieces = phi.split(sizes, -1)
-        with torch.no_grad():
-            if kind == 0:
-                y, ladj = ops.affine_forward(xe, pieces[0].squeeze(-1), pieces[1].squeeze(-1), slope, reduce)
-            else:
-                y, ladj = ops.rqs_forward(xe, pieces[0], pieces[1], pieces[2], bound, slope, reduce)
-        ctx.kind, ctx.bound, ctx.slope, ctx.reduce = kind, bound, slope, reduce
-        ctx.sizes, ctx.xshape, ctx.pshapes = sizes, x.shape, [p.shape for p in params]
+        y, ladj = _fwd_any(meta, xe, phi, reduce)
+        ctx.meta, ctx.reduce, ctx.xshape, ctx.pshapes, ctx.nparams = meta, reduce, x.shape, [p.shape for p in live], len(params)
         ctx.save_for_backward(xe, phi)
         return y, ladj
 
     @staticmethod
     def backward(ctx, gy, gl):
         xe, phi = ctx.saved_tensors
-        D = xe.shape[-1] if xe.dim() else 1
-        N = xe.numel() // max(D, 1)
-        gx = torch.empty_like(xe)
-        gphi = torch.empty_like(phi)
         gy_c = None if gy is None else gy.expand(xe.shape).contiguous()
-        if gl is None:
-            gl_c = None
-        elif ctx.reduce:
-            gl_c = gl.expand(xe.shape[:-1]).contiguous()
-        else:
-            gl_c = gl.expand(xe.shape).contiguous()
-        K = ctx.sizes[0] if ctx.kind == 1 else 0
-        err = _C.lib().zk_univariate_backward(ctx.kind, N, D, K, ctx.bound, ctx.slope, _ptr(xe), _ptr(phi), _ptr(gy_c), _ptr(gl_c), int(ctx.reduce),
-                                              _ptr(gx), _ptr(gphi), _stream())
-        _C.check(err, "zk_univariate_backward")
-        pieces = gphi.split(ctx.sizes, -1)
-        if ctx.kind == 0:
-            pieces = [p.squeeze(-1) for p in pieces]
-        grads = [_sum_to(p, s) for p, s in zip(pieces, ctx.pshapes)]
+        gl_c = None if gl is None else (gl.expand(xe.shape[:-1]) if ctx.reduce else gl.expand(xe.shape)).contiguous()
+        gx, gphi = _adj_any(ctx.meta, xe, phi, gy_c, gl_c, ctx.reduce)
+        grads = _unparts(ctx.meta, gphi.split(list(ctx.meta[3]), -1), ctx.pshapes)
+        grads += [None] * (ctx.nparams - len(grads))
         return (None, None, None, None, _sum_to(gx, ctx.xshape), *grads)
 
 
-def _kernel_fwd(kind, bound, slope, reduce, xe, phi, sizes):
-    from . import ops
+class BernsteinFn(torch.autograd.Function):
+    """(y, ladj) of the (bounded) Bernstein polynomial (kind 3; `bounded` travels in meta.extra)."""
 
-    pieces = phi.split(sizes, -1)
-    if kind == 0:
-        return ops.affine_forward(xe, pieces[0].squeeze(-1), pieces[1].squeeze(-1), slope, reduce)
-    return ops.rqs_forward(xe, pieces[0], pieces[1], pieces[2], bound, slope, reduce)
+    @staticmethod
+    def forward(ctx, bounded: bool, bound: float, reduce: bool, x: Tensor, theta: Tensor):
+        _require_f32(x, theta)
+        meta, parts = _meta_of(3, bound, 0.0, [theta], (bounded,))
+        batch = torch.broadcast_shapes(x.shape, theta.shape[:-1])
+        xe = x.expand(batch).contiguous()
+        phi = _packed([theta.detach()], batch)
+        y, ladj = _fwd_any(meta, xe, phi, reduce)
+        ctx.meta, ctx.reduce, ctx.xshape, ctx.tshape = meta, reduce, x.shape, theta.shape
+        ctx.save_for_backward(xe, phi)
+        return y, ladj
+
+    @staticmethod
+    def backward(ctx, gy, gl):
+        xe, phi = ctx.saved_tensors
+        gy_c = None if gy is None else gy.expand(xe.shape).contiguous()
+        gl_c = None if gl is None else (gl.expand(xe.shape[:-1]) if ctx.reduce else gl.expand(xe.shape)).contiguous()
+        gx, gphi = _adj_any(ctx.meta, xe, phi, gy_c, gl_c, ctx.reduce)
+        return (None, None, None, _sum_to(gx, ctx.xshape), _sum_to(gphi, ctx.tshape))
 
 
 class UnivariatePackedFn(torch.autograd.Function):
     """As UnivariateFn, for parameters that ARE one packed phi[..., D, total] tensor (what the conditioner emits): phi
     is the differentiable input itself, so autograd neither splits nor re-concatenates it (the cat of the three spline
-    pieces' gradients was a 386 MB copy per transform at batch 2^16)."""
+    pieces' gradients was a 386 MB copy per transform at batch 2^16).  `meta` as built by _meta_of."""
 
     @staticmethod
-    def forward(ctx, kind: int, bound: float, slope: float, reduce: bool, sizes, x: Tensor, phi: Tensor):
+    def forward(ctx, meta, reduce: bool, x: Tensor, phi: Tensor):
         _require_f32(x, phi)
         xe = x.expand(phi.shape[:-1]).contiguous()
         ph = phi.detach()
         if not ph.is_contiguous() or ph.data_ptr() % 16 != 0:
             ph = ph.contiguous()
-        with torch.no_grad():
-            y, ladj = _kernel_fwd(kind, bound, slope, reduce, xe, ph, list(sizes))
-        ctx.kind, ctx.bound, ctx.slope, ctx.reduce, ctx.sizes, ctx.xshape = kind, bound, slope, reduce, list(sizes), x.shape
+        y, ladj = _fwd_any(meta, xe, ph, reduce)
+        ctx.meta, ctx.reduce, ctx.xshape = meta, reduce, x.shape
         ctx.save_for_backward(xe, ph)
         return y, ladj
 
     @staticmethod
     def backward(ctx, gy, gl):
         xe, phi = ctx.saved_tensors
-        D = xe.shape[-1]
-        N = xe.numel() // max(D, 1)
-        gx, gphi = torch.empty_like(xe), torch.empty_like(phi)
         gy_c = None if gy is None else gy.expand(xe.shape).contiguous()
         gl_c = None if gl is None else (gl.expand(xe.shape[:-1]) if ctx.reduce else gl.expand(xe.shape)).contiguous()
-        K = ctx.sizes[0] if ctx.kind == 1 else 0
-        err = _C.lib().zk_univariate_backward(ctx.kind, N, D, K, ctx.bound, ctx.slope, _ptr(xe), _ptr(phi), _ptr(gy_c), _ptr(gl_c), int(ctx.reduce),
-                                              _ptr(gx), _ptr(gphi), _stream())
-        _C.check(err, "zk_univariate_backward")
-        return (None, None, None, None, None, _sum_to(gx, ctx.xshape), gphi)
+        gx, gphi = _adj_any(ctx.meta, xe, phi, gy_c, gl_c, ctx.reduce)
+        return (None, None, _sum_to(gx, ctx.xshape), gphi)
 
 
 class UnivariateInverseFn(torch.autograd.Function):
-    """x = f^{-1}(y; phi) for the affine map / the spline, differentiable (gradients through `rsample`, which the
-    reference obtains by autograd through its inverse formulas, zuko/transforms.py:443, :534-548; asserted by its
-    tests/test_flows.py:46-54).  By the inverse function theorem, with f' = exp(ladj(x)):
+    """x = f^{-1}(y; phi), differentiable (gradients through `rsample`, which the reference obtains by autograd through its
+    inverse formulas, zuko/transforms.py:443, :534-548, and through Bisection.backward, zuko/utils.py:185-209; asserted by
+    its tests/test_flows.py:46-54).  By the inverse function theorem, with f' = exp(ladj(x)):
         dL/dy = g_x / f'(x),      dL/dphi = -(df/dphi)^T (g_x / f'(x)),
     i.e. the forward map's own adjoint kernel evaluated at the solution x with the seed -g_x / f'(x)."""
 
     @staticmethod
-    def forward(ctx, kind: int, bound: float, slope: float, y: Tensor, *params: Tensor):
-        from . import ops
-
-        _require_f32(y, *params)
-        parts = [p.unsqueeze(-1) for p in params] if kind == 0 else list(params)
+    def forward(ctx, kind: int, bound: float, slope: float, extra, y: Tensor, *params: Tensor):
+        live = [p for p in params if p is not None]
+        _require_f32(y, *live)
+        meta, parts = _meta_of(kind, bound, slope, live, extra)
         batch = torch.broadcast_shapes(y.shape, *[p.shape[:-1] for p in parts])
         ye = y.expand(batch).contiguous()
         phi = _packed([p.detach() for p in parts], batch)
-        sizes = [p.shape[-1] for p in parts]
-        pieces = phi.split(sizes, -1)
-        with torch.no_grad():
-            if kind == 0:
-                x = ops.affine_inverse(ye, pieces[0].squeeze(-1), pieces[1].squeeze(-1), slope)
-            else:
-                x = ops.rqs_inverse(ye, pieces[0], pieces[1], pieces[2], bound, slope)
-        ctx.kind, ctx.bound, ctx.slope, ctx.sizes, ctx.yshape, ctx.pshapes = kind, bound, slope, sizes, y.shape, [p.shape for p in params]
+        x = _inv_any(meta, ye, phi)
+        ctx.meta, ctx.yshape, ctx.pshapes, ctx.nparams = meta, y.shape, [p.shape for p in live], len(params)
         ctx.save_for_backward(x, phi)
         return x
 
     @staticmethod
     def backward(ctx, gx):
         x, phi = ctx.saved_tensors
-        D = x.shape[-1] if x.dim() else 1
-        N = x.numel() // max(D, 1)
-        with torch.no_grad():
-            _, ladj = _kernel_fwd(ctx.kind, ctx.bound, ctx.slope, False, x, phi, ctx.sizes)
+        _, ladj = _fwd_any(ctx.meta, x, phi, False)
         gxc = gx.expand(x.shape).contiguous()
         gy, seed = torch.empty_like(x), torch.empty_like(x)
         _C.check(_C.lib().zk_inverse_seed(x.numel(), _ptr(gxc), _ptr(ladj.contiguous()), _ptr(gy), _ptr(seed), _stream()), "zk_inverse_seed")
-        scratch, gphi = torch.empty_like(x), torch.empty_like(phi)
-        K = ctx.sizes[0] if ctx.kind == 1 else 0
-        err = _C.lib().zk_univariate_backward(ctx.kind, N, D, K, ctx.bound, ctx.slope, _ptr(x), _ptr(phi), _ptr(seed), None, 0, _ptr(scratch), _ptr(gphi), _stream())
-        _C.check(err, "zk_univariate_backward")
-        pieces = gphi.split(ctx.sizes, -1)
-        if ctx.kind == 0:
-            pieces = [p.squeeze(-1) for p in pieces]
-        grads = [_sum_to(p, s) for p, s in zip(pieces, ctx.pshapes)]
-        return (None, None, None, _sum_to(gy, ctx.yshape), *grads)
+        _, gphi = _adj_any(ctx.meta, x, phi, seed, None, False)
+        grads = _unparts(ctx.meta, gphi.split(list(ctx.meta[3]), -1), ctx.pshapes)
+        grads += [None] * (ctx.nparams - len(grads))
+        return (None, None, None, None, _sum_to(gy, ctx.yshape), *grads)
 
 
 BACKWARD_ACTS = (0, 1, 2, 3, 6, 7)  # activations whose derivative is a function of their output

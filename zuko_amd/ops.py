@@ -164,7 +164,7 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
         if K not in (4, 8, 16):
             raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
         if _packed_ok(x, packed, 3 * K - 1):
-            return AG.UnivariatePackedFn.apply(1, bound, slope, reduce, (K, K, K - 1), x, packed)
+            return AG.UnivariatePackedFn.apply((1, bound, slope, (K, K, K - 1), ()), reduce, x, packed)
         return AG.UnivariateFn.apply(1, bound, slope, reduce, x, widths, heights, derivatives)
     pr = _Prepared(x, [(widths, 1), (heights, 1), (derivatives, 1)])
     if reduce and len(pr.shape) == 0:
@@ -187,7 +187,7 @@ def rqs_inverse(y: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
         _no_bf16_grad(y, widths)
         if K not in (4, 8, 16):
             raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
-        return AG.UnivariateInverseFn.apply(1, bound, slope, y, widths, heights, derivatives)
+        return AG.UnivariateInverseFn.apply(1, bound, slope, (), y, widths, heights, derivatives)
     pr = _Prepared(y, [(widths, 1), (heights, 1), (derivatives, 1)])
     x = pr.out()
     bins = torch.empty(pr.shape, dtype=torch.int32, device=y.device) if want_bins else None
@@ -242,7 +242,7 @@ def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3,
     if AG.needs_grad(x, shift, scale):
         _require_device(x, shift, scale)
         if _packed_ok(x, packed, 2):
-            return AG.UnivariatePackedFn.apply(0, 5.0, slope, reduce, (1, 1), x, packed)
+            return AG.UnivariatePackedFn.apply((0, 5.0, slope, (1, 1), ()), reduce, x, packed)
         return AG.UnivariateFn.apply(0, 5.0, slope, reduce, x, shift, scale)
     pr = _Prepared(x, [(shift.unsqueeze(-1), 1), (scale.unsqueeze(-1), 1)])
     y, ladj = pr.out(), pr.out_ladj(reduce)
@@ -257,7 +257,7 @@ def affine_inverse(y: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3)
 
     if AG.needs_grad(y, shift, scale):
         _require_device(y, shift, scale)
-        return AG.UnivariateInverseFn.apply(0, 5.0, slope, y, shift, scale)
+        return AG.UnivariateInverseFn.apply(0, 5.0, slope, (), y, shift, scale)
     pr = _Prepared(y, [(shift.unsqueeze(-1), 1), (scale.unsqueeze(-1), 1)])
     x = pr.out()
     (s, sn, sd), (c, cn, cd) = pr.params
@@ -285,6 +285,11 @@ SOS_EPS = 1e-6
 
 
 def sos_forward(x: Tensor, a: Tensor, constant: Tensor | None = None, slope: float = 1e-3, reduce: bool = False):
+    from . import autograd as AG
+
+    if AG.needs_grad(x, a, constant):
+        _require_device(x, a, constant)
+        return AG.UnivariateFn.apply(2, SOS_BOUND, slope, reduce, x, a, constant)
     P, L1 = a.shape[-2:]
     plist = [(a, 2)] + ([(constant.unsqueeze(-1), 1)] if constant is not None else [])
     pr = _Prepared(x, plist)
@@ -299,6 +304,11 @@ def sos_forward(x: Tensor, a: Tensor, constant: Tensor | None = None, slope: flo
 
 
 def sos_inverse(y: Tensor, a: Tensor, constant: Tensor | None = None, slope: float = 1e-3) -> Tensor:
+    from . import autograd as AG
+
+    if AG.needs_grad(y, a, constant):
+        _require_device(y, a, constant)
+        return AG.UnivariateInverseFn.apply(2, SOS_BOUND, slope, (), y, a, constant)
     P, L1 = a.shape[-2:]
     plist = [(a, 2)] + ([(constant.unsqueeze(-1), 1)] if constant is not None else [])
     pr = _Prepared(y, plist)
@@ -322,6 +332,11 @@ BERN_NC_MAX = 72  # ZK_BERN_NCMAX of csrc/elementwise.hip
 
 
 def bernstein_forward(x: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0, reduce: bool = False):
+    from . import autograd as AG
+
+    if AG.needs_grad(x, theta):
+        _require_device(x, theta)
+        return AG.BernsteinFn.apply(bool(bounded), bound, reduce, x, theta)
     M = theta.shape[-1]
     pr = _Prepared(x, [(theta, 1)])
     y, ladj = pr.out(), pr.out_ladj(reduce)
@@ -332,6 +347,11 @@ def bernstein_forward(x: Tensor, theta: Tensor, bounded: bool, bound: float = 5.
 
 
 def bernstein_inverse(y: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0) -> Tensor:
+    from . import autograd as AG
+
+    if AG.needs_grad(y, theta):
+        _require_device(y, theta)
+        return AG.UnivariateInverseFn.apply(3, bound, 0.0, (bool(bounded),), y, theta)
     M = theta.shape[-1]
     pr = _Prepared(y, [(theta, 1)])
     x = pr.out()

@@ -23,6 +23,9 @@ from torch import Tensor
 
 from . import _C
 
+import weakref
+
+_PLAN_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 TRAIN_ACTS = (0, 1, 2, 3, 6, 7)  # activations whose derivative is a function of their output (as zk_act_backward)
 
 
@@ -79,7 +82,7 @@ class SortedPlan:
             live = pad.reshape(ob, 128, ib, 128).any(dim=3).any(dim=1)
             self.pairs.append(live.nonzero().to(torch.int32).contiguous().to(device))
             self.mask_s.append(None if m is None else ms.to(torch.uint8).contiguous().to(device))
-            self.mask_u8.append(None if m is None else m.detach().contiguous().view(torch.uint8).to(device))
+            self.mask_u8.append(None if m is None else m.detach().to(device=device, dtype=torch.uint8).contiguous())
             prev = perms[i]
         self.idx_w64 = [t.long() for t in self.idx_w]
         self.idx_b64 = [t.long() for t in self.idx_b]
@@ -217,7 +220,7 @@ def plan_for(module, device: torch.device):
     if any(l.weight.dtype != torch.float32 for l in lins):
         return None, None
     key = (str(device),) + tuple((m.mask._version, m.mask.data_ptr()) for m in lins if hasattr(m, "mask"))
-    cache = module.__dict__.setdefault("_train_plan_cache", {})
+    cache = _PLAN_CACHE.setdefault(module, {})  # (kept off the module: its __dict__ is pickled / deep-copied with it)
     if cache.get("key") != key:
         cache.clear()
         cache["key"] = key
