@@ -185,6 +185,20 @@ int zk_ar_inverse_partial(int uni_kind, int64_t N, int D, int DIN, const void* x
                           void* x_out, int64_t ldo, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
                           const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
                           const int32_t* sched, int n_sched, const int32_t* olim, int g0, int g1, int variant, void* stream);
+/* INCREMENTAL inverse: the whole loop of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000) in one launch whose
+ * multiply-add count is ~1.5x ONE density evaluation (every off-diagonal weight tile is multiplied once per sample; only the
+ * diagonal tiles of a 4-feature group are iterated).  Needs the aligned-tile plan of zuko_amd/incremental.py
+ * (build_inc_plan returns None for conditioners that do not fit: the caller then uses zk_ar_inverse_partial / _sweep).
+ *   y [N, D] values to invert, ctx [N, C] context (NULL when C = 0), x [N, D] result;
+ *   ladj [N] (optional) = sum over features of log|dy/dx| of the FORWARD map at x (what rsample_and_log_prob needs,
+ *   zuko/distributions.py:129-138);
+ *   uni_kind 0 affine, 1 / 2 / 3 spline with 8 / 4 / 16 bins; n_hidden 1..3; D <= 68, D + C <= 256;
+ *   bias_off: HOST array of n_hidden + 1 offsets into the bias image; featmap [4 n_groups], prog [n_groups][36]: device. */
+int zk_ar_inverse_incremental(int uni_kind, int n_hidden, int64_t N, int D, int C, const void* y, int64_t ldy, const void* ctx,
+                              int64_t ldc, void* x, int64_t ldx, void* ladj, const void* wstream, const void* bias, int bias_floats,
+                              const int32_t* bias_off, const int32_t* featmap, const int32_t* prog, int n_groups, int n_chunks, int act,
+                              double bound, double slope, void* stream);
+int zk_ar_inc_lds_bytes(int bias_floats, int nit);
 /* dynamic LDS bytes zk_ar_forward will request for `variant` and a bias image of `bias_floats` floats. */
 int zk_ar_lds_bytes(int variant, int bias_floats);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream

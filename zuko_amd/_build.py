@@ -30,9 +30,10 @@ SOURCES = {
     "fused_ar.hip": ["-ffp-contract=off"],
     "backward.hip": [],
     "train.hip": [],
+    "inc_inverse.hip": ["-ffp-contract=off"],
     "backward_poly.hip": ["-ffp-contract=off"],
 }
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"] + (["-DZK_INC_FAST_BUILD"] if os.environ.get("ZUKO_AMD_FAST_BUILD") == "1" else [])
 
 
 def _hipcc() -> str:

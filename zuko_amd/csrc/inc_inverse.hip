@@ -1,0 +1,404 @@
+// zuko_amd — INCREMENTAL autoregressive inverse: x = f^{-1}(y) of one MaskedAutoregressiveTransform in ONE launch whose
+// multiply-add count is ~1.5x that of a density evaluation.
+//
+// Replaces the loop of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000) — `passes` evaluations of the whole
+// conditioner (zuko/nn.py:217-218 x layers) + the inverse univariate map (zuko/transforms.py:534-548 / :443) — for masked
+// conditioners whose hidden units fit ALIGNED tiles (zuko_amd/incremental.py): tile j of every hidden layer depends only on
+// feature groups <= j, and group j's parameters only on tiles <= j.  Per 16 samples a wavefront then walks the groups once:
+//
+//   pull   pre-activations of tile j (all layers) and the parameters of group j receive, ONCE, the contributions of the
+//          final tiles t < j (v_mfma_f32_16x16x4_f32, weights streamed through the LDS ring in a fixed order);
+//   iterate the diagonal weight tiles stay in registers; pass r = 0..3 re-evaluates tile j of every layer and the group's
+//          parameters from them, inverts the univariate map for the group's r-th feature (the only one whose inputs just
+//          became final) and writes x back to the wave-private LDS tile the first layer reads its B operand from;
+//          a fifth pass finalises tile j.
+//
+// The final hidden activations of all tiles live in registers (3 x 17 tiles x 4 VGPRs): one wavefront per SIMD
+// (launch_bounds(256, 1)), four wavefronts = 64 samples per workgroup sharing the weight ring.
+// The kernel also accumulates log|dy/dx| of the forward map at the solution, so rsample_and_log_prob
+// (zuko/distributions.py:129-138) needs no second pass.
+#include "zk_univariate.h"
+#include <type_traits>
+
+namespace zk {
+
+typedef float f32x4i __attribute__((ext_vector_type(4)));
+
+#define IN_T 17      /* tiles per hidden layer = feature groups (static unroll depth) */
+#define IN_CH 24     /* tiles per ring chunk */
+#define IN_NR 3      /* ring slots */
+#define IN_WAVES 4
+#define IN_MAXD 4    /* dynamic first-layer input tiles kept in registers per group (= IN_L1D) */
+#define IN_PROG (2 + 2 * IN_T)
+
+struct IncArgs {
+  int64_t N;
+  int D, DIN, C, nit;
+  const float* yin; int64_t ldy;
+  const float* ctx; int64_t ldc;
+  float* x; int64_t ldx;
+  float* ladj;
+  const float* stream;
+  const float* bias;
+  const int32_t* featmap;
+  const int32_t* prog;
+  int G, n_chunks, act, bias_floats;
+  int bias_off[4];
+  int xs;
+  float bound, ls;
+  RqsLeanConst lc;
+  int64_t n_tiles;
+};
+
+// (not inlined: the group step below exists 17 times; inline expansions of expm1f / tanhf / erff at every activation
+//  site would make it instruction-cache bound — ReLU and identity, the common cases, are handled inline)
+__device__ __attribute__((noinline)) float inc_act(float v, int act) {
+  switch (act) {
+    case 1: return v < 0.f ? 0.f : v;
+    case 2: return v > 0.f ? v : expm1f(v);
+    case 3: return tanhf(v);
+    case 4: return v / (1.f + expf(-v));
+    case 5: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case 6: return 1.f / (1.f + expf(-v));
+    case 7: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+__device__ __forceinline__ f32x4i inc_act4(f32x4i v, int act) {
+  if (act == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+  } else if (act != 0) {
+#pragma unroll 1
+    for (int rep = 0; rep < 1; ++rep) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = inc_act(v[r], act);
+    }
+  }
+  return v;
+}
+
+// Stream layout of one pass (static, so that chunk boundaries fall at compile-time-known reads): per group j
+//   [IN_L1S first-layer tiles whose inputs are final (padded)] [(NH-1) j hidden pulls] [NT j last-layer pulls]
+//   [IN_L1D first-layer diagonal tiles (padded)] [(NH-1) hidden diagonal tiles] [NT last-layer diagonal tiles]
+#define IN_L1S 4
+#define IN_L1D 4
+__host__ __device__ constexpr int inc_group_tiles(int NH, int NT, int j) { return IN_L1S + (NH - 1) * j + NT * j + IN_L1D + (NH - 1) + NT; }
+__host__ __device__ constexpr int inc_group_start(int NH, int NT, int j) {
+  int s = 0;
+  for (int i = 0; i < j; ++i) s += inc_group_tiles(NH, NT, i);
+  return s;
+}
+
+// weight ring: 3 x 24 tile images of 1 KiB, filled by global_load_lds two chunks ahead, shared by the 4 wavefronts.
+// read(s) takes the position s of the tile inside the pass; every call site has a compile-time s after unrolling, so the
+// refill (barrier + DMA issue) is emitted only at the ~55 sites per pass where s is a multiple of the chunk size.
+struct IncRing {
+  float* lds;
+  const float* stream;
+  const float* cur;  // lds + slot * IN_CH * 256 + lane * 4
+  int n_chunks, slot, load_chunk, load_slot, wave, lane;
+  __device__ __forceinline__ void issue() {
+#pragma unroll
+    for (int i = 0; i < IN_CH / IN_WAVES; ++i) {
+      const int bi = i * IN_WAVES + wave;
+      const float* g = stream + ((size_t)load_chunk * IN_CH + bi) * 256 + lane * 4;
+      float* l = lds + (load_slot * IN_CH + bi) * 256;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
+    load_slot = (load_slot + 1 == IN_NR) ? 0 : load_slot + 1;
+  }
+  __device__ __forceinline__ void advance() {  // all wavefronts reach this at the same points of the (uniform) control flow
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue();
+    slot = (slot + 1 == IN_NR) ? 0 : slot + 1;
+    cur = lds + slot * IN_CH * 256 + lane * 4;
+  }
+  __device__ __forceinline__ f32x4i read(int s) {
+    if (s % IN_CH == 0) advance();
+    return *reinterpret_cast<const f32x4i*>(cur + (s % IN_CH) * 256);
+  }
+};
+
+#define IN_MFMA4(acc, a, b)                                                              \
+  {                                                                                      \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (acc) = __builtin_amdgcn_mfma_f32_16x16x4f32((a)[r_], (b)[r_], (acc), 0, 0, 0); \
+  }
+
+struct IncAffine {
+  static constexpr int TOTAL = 2, NT = 1;
+  template <typename A> static __device__ __forceinline__ void inv(const float* p, const A& a, float y, float& x, float& lj) {
+    const float lsc = softclip<float, MathFast>(p[1], a.ls);
+    x = MathFast::div_safe(y - p[0], MathFast::exp(lsc));
+    lj = lsc;
+  }
+};
+template <int K> struct IncRqs {
+  static constexpr int TOTAL = 3 * K - 1, NT = (TOTAL + 3) / 4;
+  template <typename A> static __device__ __forceinline__ void inv(const float* p, const A& a, float y, float& x, float& lj) {
+    int k;
+    rqs_lean<K, true, true>([&](int j) { return p[j]; }, [&](int j) { return p[K + j]; }, [&](int j) { return p[2 * K + j]; }, a.lc, y, x, lj, k);
+  }
+};
+
+extern __shared__ __attribute__((aligned(16))) float inc_lds[];
+
+template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_inverse_kernel(IncArgs a) {
+  constexpr int NT = Uni::NT, TOTAL = Uni::TOTAL;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & 15, q = lane >> 4;
+
+  float* ring_lds = inc_lds;
+  float* bias_lds = inc_lds + IN_NR * IN_CH * 256;
+  int* fmap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);
+  int* prog_lds = fmap_lds + IN_T * 4;
+  float* xw = reinterpret_cast<float*>(prog_lds + IN_T * IN_PROG) + (size_t)wave * 2 * 16 * a.xs;  // wave-private x tile, then y tile
+  float* yw = xw + 16 * a.xs;
+  for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+  for (int i = tid; i < a.G * 4; i += 256) fmap_lds[i] = a.featmap[i];
+  for (int i = tid; i < a.G * IN_PROG; i += 256) prog_lds[i] = a.prog[i];
+
+  IncRing ring;
+  ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < IN_NR - 1; ++i) ring.issue();
+  ring.slot = IN_NR - 1;
+  ring.cur = ring_lds;
+  __syncthreads();
+
+  const int xs = a.xs;
+  float* xrow = xw + jl * xs;
+  const float* yrow = yw + jl * xs;
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n = tile * 64 + wave * 16 + jl;
+    const bool live = n < a.N;
+    const int64_t nc = live ? n : a.N - 1;
+
+    // ---- stage the wave's 16 rows: x tile = [0 ... 0 | context | 0-pad], y tile = the values to invert ------------
+    int bad = 0;
+    for (int it = 0; it < a.nit; ++it) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = it * 16 + 4 * q + r;
+        float xv = 0.f, yv = 0.f;
+        if (col < a.D) yv = a.yin[nc * a.ldy + col];
+        else if (col < a.DIN) xv = a.ctx[nc * a.ldc + (col - a.D)];
+        bad |= !(fabsf(xv) < __builtin_inff()) | !(fabsf(yv) < __builtin_inff());
+        xrow[col] = xv;
+        xrow[col + 16 * xs] = yv;  // (the y tile sits 16 rows behind the x tile)
+      }
+    }
+    bad |= __shfl_xor(bad, 16, 64);
+    bad |= __shfl_xor(bad, 32, 64);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    f32x4i h1[IN_T], h2[NH > 1 ? IN_T : 1], h3[NH > 2 ? IN_T : 1];
+    float lacc = 0.f;
+
+    // one statically indexed copy of the group step per group (a generic lambda over integral constants: `#pragma unroll`
+    // does not unroll a loop of this size, and a run-time j would put the activation arrays in scratch memory)
+    auto group_step = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if (j < a.G) {
+        const int* pg = prog_lds + j * IN_PROG;
+        const int ns = __builtin_amdgcn_readfirstlane(pg[0]), nd = __builtin_amdgcn_readfirstlane(pg[1]);
+        constexpr int P_S = inc_group_start(NH, NT, j);            // first-layer tiles with final inputs
+        constexpr int P_H = P_S + IN_L1S;                          // hidden pulls
+        constexpr int P_L = P_H + (NH - 1) * j;                    // last-layer pulls
+        constexpr int P_D = P_L + NT * j;                          // diagonal tiles
+        // ---- pull: contributions of everything that is already final --------------------------------------------
+        f32x4i o1 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[0] + j * 16 + 4 * q);
+#pragma unroll
+        for (int s_ = 0; s_ < IN_L1S; ++s_) {
+          const f32x4i w = ring.read(P_S + s_);
+          if (s_ < ns) {
+            const int it = __builtin_amdgcn_readfirstlane(pg[2 + s_]);
+            const f32x4i b = *reinterpret_cast<const f32x4i*>(xrow + it * 16 + 4 * q);
+            IN_MFMA4(o1, w, b);
+          }
+        }
+        f32x4i o2 = {0.f, 0.f, 0.f, 0.f}, o3 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NH > 1) {
+          o2 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[1] + j * 16 + 4 * q);
+#pragma unroll
+          for (int t = 0; t < j; ++t) {
+            const f32x4i w = ring.read(P_H + t);
+            IN_MFMA4(o2, w, h1[t]);
+          }
+        }
+        if constexpr (NH > 2) {
+          o3 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[2] + j * 16 + 4 * q);
+#pragma unroll
+          for (int t = 0; t < j; ++t) {
+            const f32x4i w = ring.read(P_H + j + t);
+            IN_MFMA4(o3, w, h2[t]);
+          }
+        }
+        f32x4i po[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) po[tt] = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[NH] + (j * NT + tt) * 16 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < j; ++t) {
+          f32x4i hb;
+          if constexpr (NH == 1) hb = h1[t];
+          else if constexpr (NH == 2) hb = h2[t];
+          else hb = h3[t];
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) {
+            const f32x4i w = ring.read(P_L + t * NT + tt);
+            IN_MFMA4(po[tt], w, hb);
+          }
+        }
+        // ---- the diagonal tiles stay in registers over the five passes -------------------------------------------
+        f32x4i wd[IN_MAXD];
+        int itd[IN_MAXD];
+#pragma unroll
+        for (int i = 0; i < IN_MAXD; ++i) {
+          itd[i] = i < nd ? __builtin_amdgcn_readfirstlane(pg[2 + IN_T + i]) : 0;
+          wd[i] = ring.read(P_D + i);
+        }
+        f32x4i wh2 = {0.f, 0.f, 0.f, 0.f}, wh3 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NH > 1) wh2 = ring.read(P_D + IN_L1D);
+        if constexpr (NH > 2) wh3 = ring.read(P_D + IN_L1D + 1);
+        f32x4i wl[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) wl[tt] = ring.read(P_D + IN_L1D + (NH - 1) + tt);
+
+        const int f = fmap_lds[j * 4 + q];
+        const float yv = yrow[f < 0 ? 0 : f];
+        f32x4i h1j, h2j, h3j;
+#pragma unroll 1
+        for (int r = 0; r < 5; ++r) {
+          f32x4i c1 = o1;
+#pragma unroll
+          for (int i = 0; i < IN_MAXD; ++i) {
+            if (i < nd) {
+              const f32x4i b = *reinterpret_cast<const f32x4i*>(xrow + itd[i] * 16 + 4 * q);
+              IN_MFMA4(c1, wd[i], b);
+            }
+          }
+          h1j = inc_act4(c1, a.act);
+          if constexpr (NH > 1) {
+            f32x4i c2 = o2;
+            IN_MFMA4(c2, wh2, h1j);
+            h2j = inc_act4(c2, a.act);
+          }
+          if constexpr (NH > 2) {
+            f32x4i c3 = o3;
+            IN_MFMA4(c3, wh3, h2j);
+            h3j = inc_act4(c3, a.act);
+          }
+          if (r == 4) break;
+          f32x4i hl;
+          if constexpr (NH == 1) hl = h1j;
+          else if constexpr (NH == 2) hl = h2j;
+          else hl = h3j;
+          float p[4 * NT];
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) {
+            f32x4i c = po[tt];
+            IN_MFMA4(c, wl[tt], hl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[4 * tt + e] = c[e];
+          }
+          float xv, lj;
+          Uni::inv(p, a, yv, xv, lj);
+          if (q == r && f >= 0) {
+            xrow[f] = xv;
+            lacc += lj;
+          }
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        }
+        h1[j] = h1j;
+        if constexpr (NH > 1) h2[j] = h2j;
+        if constexpr (NH > 2) h3[j] = h3j;
+      }
+    };
+#define ZK_INC_STEP(J) group_step(std::integral_constant<int, J>{});
+    ZK_INC_STEP(0) ZK_INC_STEP(1) ZK_INC_STEP(2) ZK_INC_STEP(3) ZK_INC_STEP(4) ZK_INC_STEP(5) ZK_INC_STEP(6) ZK_INC_STEP(7) ZK_INC_STEP(8)
+    ZK_INC_STEP(9) ZK_INC_STEP(10) ZK_INC_STEP(11) ZK_INC_STEP(12) ZK_INC_STEP(13) ZK_INC_STEP(14) ZK_INC_STEP(15) ZK_INC_STEP(16)
+#undef ZK_INC_STEP
+    static_assert(IN_T == 17, "one ZK_INC_STEP per group");
+
+    // ---- results: x rows (16-byte stores where possible), ladj reduced over the four lanes of a sample -------------
+    const float nanv = __builtin_nanf("");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+      for (int c0 = 4 * q; c0 < a.D; c0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e < a.D) a.x[n * a.ldx + c0 + e] = bad ? nanv : xrow[c0 + e];
+      }
+    }
+    if (a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = bad ? nanv : lacc;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must land before the LDS is released
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+static int inc_lds_floats(int bias_floats, int G, int xs) { return IN_NR * IN_CH * 256 + bias_floats + IN_T * 4 + IN_T * IN_PROG + IN_WAVES * 2 * 16 * xs; }
+
+extern "C" {
+
+int zk_ar_inc_lds_bytes(int bias_floats, int nit) { return inc_lds_floats(bias_floats, IN_T, nit * 16 + 4) * (int)sizeof(float); }
+
+// x[N, D] = f^{-1}(y[N, D] | ctx[N, C]) of one masked autoregressive transform, and (optionally) ladj[N] = sum over features
+// of log|dy/dx| of the forward map at x.  uni_kind: 0 affine, 1 / 2 / 3 RQS with 8 / 4 / 16 bins.  wstream / bias / featmap
+// / prog / bias_off (host, n_hidden + 1 ints) / n_groups / n_chunks: the plan of zuko_amd/incremental.py.
+int zk_ar_inverse_incremental(int uni_kind, int n_hidden, int64_t N, int D, int C, const void* y, int64_t ldy, const void* ctx, int64_t ldc, void* x, int64_t ldx,
+                              void* ladj, const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* featmap,
+                              const int32_t* prog, int n_groups, int n_chunks, int act, double bound, double slope, void* stream) {
+  if (N <= 0) return 0;
+  if (n_hidden < 1 || n_hidden > 3 || n_groups < 1 || n_groups > IN_T || D < 1 || D > 4 * IN_T || C < 0 || D + C > 256 || n_chunks < 1 || (C > 0 && !ctx)) return ZK_EINVAL;
+  IncArgs a{};
+  a.N = N; a.D = D; a.C = C; a.DIN = D + C; a.nit = (D + C + 15) / 16;
+  a.yin = (const float*)y; a.ldy = ldy; a.ctx = (const float*)ctx; a.ldc = ldc; a.x = (float*)x; a.ldx = ldx; a.ladj = (float*)ladj;
+  a.stream = (const float*)wstream; a.bias = (const float*)bias; a.featmap = featmap; a.prog = prog;
+  a.G = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
+  for (int l = 0; l <= n_hidden; ++l) a.bias_off[l] = bias_off[l];
+  a.xs = a.nit * 16 + 4;
+  a.bound = (float)bound; a.ls = (float)log(slope); a.lc = rqs_lean_const(bound, log(slope));
+  a.n_tiles = (N + 63) / 64;
+  const int lds = inc_lds_floats(bias_floats, n_groups, a.xs) * (int)sizeof(float);
+  if (lds > 160 * 1024) return ZK_EINVAL;
+  const void* fn = nullptr;
+#ifdef ZK_INC_FAST_BUILD  /* development: the two benchmark instantiations only */
+  if (n_hidden != 3) return ZK_EINVAL;
+  if (uni_kind == 0) fn = (const void*)inc_inverse_kernel<IncAffine, 3>;
+  else if (uni_kind == 1) fn = (const void*)inc_inverse_kernel<IncRqs<8>, 3>;
+  else return ZK_EINVAL;
+#else
+#define ZK_INC_PICK(UNI) (n_hidden == 1 ? (const void*)inc_inverse_kernel<UNI, 1> : (n_hidden == 2 ? (const void*)inc_inverse_kernel<UNI, 2> : (const void*)inc_inverse_kernel<UNI, 3>))
+  if (uni_kind == 0) fn = ZK_INC_PICK(IncAffine);
+  else if (uni_kind == 1) fn = ZK_INC_PICK(IncRqs<8>);
+  else if (uni_kind == 2) fn = ZK_INC_PICK(IncRqs<4>);
+  else if (uni_kind == 3) fn = ZK_INC_PICK(IncRqs<16>);
+  else return ZK_EINVAL;
+#endif
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  void* kargs[] = {&a};
+  e = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  return ZK_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -252,7 +252,9 @@ template <> struct RqsBisect<1> {
 // `ks_out` (optional, K+1 floats): the knots of the SEARCH axis exactly as the bisection compared them
 // (the diagnostic entry points zk_rqs_diag / zk_ar_forward_diag expose them, so that the bin index
 // can be asserted against the kernel's own knots: k == #(ks < v) - 1, zuko/transforms.py:521-523).
-template <int K, bool INV, typename LdW, typename LdH, typename LdD>
+// INV_LADJ (inverse only): also return log|dy/dx| of the FORWARD map at the solution (the incremental inverse kernel
+// accumulates it, so that rsample_and_log_prob needs no second pass; zuko/distributions.py:129-138).
+template <int K, bool INV, bool INV_LADJ = false, typename LdW, typename LdH, typename LdD>
 __device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLeanConst& c, float v, float& out, float& ladj, int& k, float* ks_out = nullptr) {
   static_assert((K & (K - 1)) == 0 && K >= 2, "bisection needs a power-of-two bin count");
   float kx[K + 1], ky[K + 1], kr[K + 1];
@@ -317,7 +319,16 @@ __device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLea
     float z = (2.f * qc) * rq;
     z = fmaf(fmaf(-qd, z, 2.f * qc), rq, z);
     out = inside ? fmaf(z, dx, x0) : v;
-    ladj = 0.f;
+    if constexpr (INV_LADJ) {
+      const float omz = 1.f - z;
+      const float zz = z * omz;
+      const float rden = __builtin_amdgcn_rcpf(fmaf(t, zz, s));
+      const float jn = fmaf(d1 * z, z, fmaf(d0 * omz, omz, (2.f * s) * zz));
+      const float sr = s * rden;
+      ladj = m * (__builtin_amdgcn_logf((sr * sr) * jn) * c.il2e);
+    } else {
+      ladj = 0.f;
+    }
   } else {
     const float z = (m * (v - x0)) * rdx;
     const float omz = 1.f - z;
@@ -336,7 +347,7 @@ __device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLea
 template <int K, bool INV, typename LdW, typename LdH, typename LdD>
 __device__ __forceinline__ void rqs_lean(LdW ldw, LdH ldh, LdD ldd, const RqsLeanConst& c, float v, float& out, float& ladj) {
   int k;
-  rqs_lean<K, INV>(ldw, ldh, ldd, c, v, out, ladj, k);
+  rqs_lean<K, INV, false>(ldw, ldh, ldd, c, v, out, ladj, k);
 }
 
 // ---------------------------------------------------------------------------------------------

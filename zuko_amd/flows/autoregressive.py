@@ -180,6 +180,33 @@ class MaskedAutoregressiveTransform(LazyTransform):
         slope, bound = kw.pop("slope", 1e-3), kw.pop("bound", 5.0)
         return None if kw else (shapes[0][0], bound, slope)
 
+    def incremental_state(self, device: torch.device):
+        """Plan + device tables of the incremental inverse kernel (csrc/inc_inverse.hip), or None when the conditioner does
+        not fit its aligned-tile layout (zuko_amd/incremental.py) — the partial sweeps are used then."""
+        from .. import incremental as inc
+
+        if self.order is None:
+            return None
+        cache = _FUSED_CACHE.setdefault(self, {})
+        lins = [m for m in self.hyper if isinstance(m, MaskedLinear)]
+        structure = tuple((l.mask._version, l.mask.data_ptr()) for l in lins) + (self.order._version, self.order.data_ptr())
+        key = str(device) + "/inc"
+        if key in cache and cache[key][0] != structure:
+            del cache[key]
+        if key not in cache:
+            state = None
+            lay = self._fusable_layout()
+            mods = list(self.hyper)
+            simple = all(isinstance(a, MaskedLinear) != (i % 2 == 1) for i, a in enumerate(mods))
+            codes = {_act_code(a) for a in mods if not isinstance(a, MaskedLinear)}
+            if lay is not None and lay[0].kind in (0, 1, 2, 3) and simple and len(codes) == 1 and None not in codes and all(l.weight.dtype == torch.float32 for l in lins):
+                layout = fused.UniLayout(lay[0].kind, lay[0].total, 1, (lay[0].total + 3) // 4, lay[0].bins)
+                plan = inc.build_inc_plan([l.mask for l in lins], self.features, self.order.cpu().numpy(), layout)
+                if plan is not None:
+                    state = inc.IncAR(plan, lins, device, codes.pop(), lay[1], lay[2])
+            cache[key] = (structure, state)
+        return cache[key][1]
+
     def fused_state(self, device: torch.device, inverse: bool = False):
         """Plan + device tables of the fused kernel (built once per device), or None.  `inverse=True`
         returns the group-aligned plan used by the partial (wavefront) inverse sweeps, when the layer
@@ -214,6 +241,10 @@ class MaskedAutoregressiveTransform(LazyTransform):
 
 
 _FUSED_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _incremental_enabled() -> bool:
+    return os.environ.get("ZUKO_AMD_NO_INCREMENTAL", "0") != "1"
 
 
 def _partial_inverse_enabled() -> bool:
@@ -314,6 +345,13 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             yb, cb = y, None
         batch = yb.shape[:-1]
         y2 = yb.reshape(-1, D).contiguous()
+        inc_state = lazy.incremental_state(y.device) if _incremental_enabled() and _partial_inverse_enabled() else None
+        if inc_state is not None:
+            # incremental form: one launch, every off-diagonal weight tile multiplied once per sample
+            inc_state.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+            c2 = None if cb is None else cb.reshape(-1, cb.shape[-1]).contiguous()
+            x2, _ = inc_state.run(y2, c2, False)
+            return x2.reshape(batch + (D,))
         din = D + (0 if cb is None else cb.shape[-1])
         buf = y2.new_zeros((y2.shape[0], -(-din // 4) * 4))
         if cb is not None:
