@@ -90,3 +90,56 @@ def test_plan_simulation_on_random_adjacencies():
         assert np.abs(phi - ref).max() < 1e-12, (trial, D, C, hidden)
         done += 1
     assert done >= 25
+
+
+@pytest.mark.parametrize("kind,D,hidden,bins", [("rqs", 64, [256] * 3, 8), ("affine", 64, [256] * 3, 0), ("rqs", 32, [128], 16), ("affine", 5, [24, 32], 0),
+                                                 ("rqs", 40, [160, 160], 4), ("affine", 64, [256, 256], 0)])
+def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bins):
+    """The aligned-tile plan of the incremental inverse kernel, walked in numpy over the very tables / stream the kernel
+    consumes, reproduces the oracle's `passes`-sweep inverse and the forward log-determinant at the solution (float64)."""
+    import numpy as np
+
+    import zuko_amd.flows as F
+    from oracle import zuko_oracle as O
+    from zuko_amd import fused, incremental as inc
+
+    torch.manual_seed(D + len(hidden))
+    ctx = 2 if D == 5 else 0
+    flow = F.MAF(D, ctx, transforms=2, hidden_features=hidden) if kind == "affine" else F.NSF(D, ctx, transforms=2, bins=bins, hidden_features=hidden)
+    lazy = flow.transform.transforms[1]  # descending order
+    lins = [m for m in lazy.hyper if hasattr(m, "mask")]
+    lay = fused.UniLayout(0, 2, 1, 1) if kind == "affine" else fused.UniLayout({8: 1, 4: 2, 16: 3}[bins], 3 * bins - 1, 1, (3 * bins - 1 + 3) // 4, bins)
+    plan = inc.build_inc_plan([l.mask for l in lins], D, lazy.order.numpy(), lay)
+    assert plan is not None and plan.n_groups <= inc.MAX_TILES and plan.n_blocks % inc.CHUNK == 0
+    # stream length = the static layout the kernel assumes
+    NH, NT = plan.n_hidden, plan.nt
+    assert plan.n_blocks == -(-sum(inc.L1S + (NH - 1) * j + NT * j + inc.L1D + (NH - 1) + NT for j in range(plan.n_groups)) // inc.CHUNK) * inc.CHUNK
+    W = [l.weight.detach().double().numpy() for l in lins]
+    B = [l.bias.detach().double().numpy() for l in lins]
+    Mk = [l.mask.numpy() for l in lins]
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(30, D, generator=g, dtype=torch.float64)
+    c = torch.randn(30, ctx, generator=g, dtype=torch.float64) if ctx else None
+    uni = O.UNI_AFFINE if kind == "affine" else O.uni_rqs(bins)
+    layer = O.ARLayer(uni, [torch.from_numpy(w) for w in W], [torch.from_numpy(b) for b in B], [torch.from_numpy(m) for m in Mk], lazy.passes, D)
+    xo = O.ar_inverse(layer, y, c)
+    _, lo = O.ar_forward(layer, xo, c)
+
+    def inv_fn(phi, yv):
+        ph, yy = torch.from_numpy(phi)[:, None, :], torch.from_numpy(yv)[:, None]
+        x = O.univariate_inverse(uni, ph, yy)
+        _, l = O.univariate_forward(uni, ph, x)
+        return x[:, 0].numpy(), l[:, 0].numpy()
+
+    xs, ls = inc.simulate(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn)
+    assert np.abs(xs - xo.numpy()).max() < 1e-12 and np.abs(ls - lo.numpy()).max() < 1e-11
+
+
+def test_incremental_plan_rejects_layouts_that_do_not_fit():
+    import zuko_amd.flows as F
+    from zuko_amd import fused, incremental as inc
+
+    torch.manual_seed(0)
+    lazy = F.NSF(3, 5, transforms=1, hidden_features=[128] * 3).transform.transforms[0]  # 64 units per degree: no 16-unit aligned tiles
+    lins = [m for m in lazy.hyper if hasattr(m, "mask")]
+    assert inc.build_inc_plan([l.mask for l in lins], 3, lazy.order.numpy(), fused.UniLayout(1, 23, 1, 6, 8)) is None

@@ -331,9 +331,24 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
     def log_abs_det_jacobian(self, x: Tensor, y: Tensor) -> Tensor:
         return self.call_and_ladj(x)[1]
 
+    @property
+    def inv(self) -> Transform:
+        return _FusedInverse(self)
+
+    def inverse_and_ladj(self, y: Tensor):
+        """(x, log|det dy/dx| of the FORWARD map at x).  With the incremental kernel both come out of the one launch that
+        inverts (what `rsample_and_log_prob` needs, zuko/distributions.py:129-138); otherwise inverse + one forward."""
+        out = self._inverse_impl(y, True)
+        if isinstance(out, tuple):
+            return out
+        return out, self.log_abs_det_jacobian(out, y)
+
     def _inverse(self, y: Tensor) -> Tensor:
-        """`passes` sweeps x <- meta(x).inv(y) from x = 0 (zuko/transforms.py:994-1000); each sweep is
-        one fused launch (conditioner + univariate inverse), updating the buffer in place."""
+        return self._inverse_impl(y, False)
+
+    def _inverse_impl(self, y: Tensor, want_ladj: bool):
+        """`passes` sweeps x <- meta(x).inv(y) from x = 0 (zuko/transforms.py:994-1000): one incremental launch when the
+        conditioner fits the aligned-tile plan, else one fused launch per (partial) sweep, updating the buffer in place."""
         st = self._fused(y)
         if st is None:
             return super()._inverse(y)
@@ -350,8 +365,8 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             # incremental form: one launch, every off-diagonal weight tile multiplied once per sample
             inc_state.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
             c2 = None if cb is None else cb.reshape(-1, cb.shape[-1]).contiguous()
-            x2, _ = inc_state.run(y2, c2, False)
-            return x2.reshape(batch + (D,))
+            x2, l2 = inc_state.run(y2, c2, want_ladj)
+            return (x2.reshape(batch + (D,)), l2.reshape(batch)) if want_ladj else x2.reshape(batch + (D,))
         din = D + (0 if cb is None else cb.shape[-1])
         buf = y2.new_zeros((y2.shape[0], -(-din // 4) * 4))
         if cb is not None:
@@ -369,6 +384,36 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             for _ in range(self.passes):
                 st.run_inverse_sweep(buf, y2)
         return buf[:, :D].reshape(batch + (D,)).contiguous() if buf.shape[1] != D else buf.reshape(batch + (D,))
+
+
+class _FusedInverse(Transform):
+    """`FusedAutoregressiveTransform.inv`: the inverse as a Transform of its own (as torch's _InverseTransform), whose
+    `call_and_ladj` takes x AND the log-determinant from the single incremental launch."""
+
+    domain = AutoregressiveTransform.codomain
+    codomain = AutoregressiveTransform.domain
+    bijective = True
+
+    def __init__(self, fwd: FusedAutoregressiveTransform) -> None:
+        super().__init__()
+        self._fwd = fwd
+
+    @property
+    def inv(self) -> Transform:
+        return self._fwd
+
+    def _call(self, y: Tensor) -> Tensor:
+        return self._fwd._inverse(y)
+
+    def _inverse(self, x: Tensor) -> Tensor:
+        return self._fwd._call(x)
+
+    def log_abs_det_jacobian(self, y: Tensor, x: Tensor) -> Tensor:
+        return -self._fwd.log_abs_det_jacobian(x, y)
+
+    def call_and_ladj(self, y: Tensor):
+        x, ladj = self._fwd.inverse_and_ladj(y)
+        return x, -ladj
 
 
 class MAF(Flow):
