@@ -388,7 +388,7 @@ def main() -> None:
             st = flow.transform.transforms[0].fused_state(dev)
         except Exception:
             st = None
-        executed = None if st is None else st.plan.kept_tiles * 512.0  # 16 x 16 x 2 FLOP per kept tile per sample
+        executed = None if st is None or not hasattr(st.plan, "kept_tiles") else st.plan.kept_tiles * 512.0  # 16 x 16 x 2 FLOP per kept tile per sample
         last = [m for m in flow.transform.transforms[0].hyper.modules() if getattr(m, "weight", None) is not None][-1]
         lmask = getattr(last, "mask", None)
         per_transform["last_layer_nnz_frac"] = 1.0 if lmask is None else float(lmask.float().mean())

@@ -185,6 +185,21 @@ int zk_ar_inverse_partial(int uni_kind, int64_t N, int D, int DIN, const void* x
                           void* x_out, int64_t ldo, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
                           const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
                           const int32_t* sched, int n_sched, const int32_t* olim, int g0, int g1, int variant, void* stream);
+/* ---- fused coupling transform (NICE / RealNVP) ------------------------------------------------------------------------ *
+ * Replaces GeneralCouplingTransform.meta + CouplingTransform.call_and_ladj (zuko/flows/coupling.py:128-136,
+ * zuko/transforms.py:1040-1048, :1068-1073) with the affine univariate (zuko/transforms.py:436-446): split by index maps,
+ * dense MLP (zuko/nn.py:13-15 per layer + activation) with activations register-resident (widths <= 512), affine map of the
+ * moved half, merge — one launch, nothing but x / y / ladj touches HBM.
+ *   x [N, D] (row stride ldx), ctx [N, C] or NULL, y [N, D], ladj [N] (accumulate != 0 adds)
+ *   amap [nit * 16] (device): conditioner input i = column amap[i] of x (>= 0), context column -(2 + amap[i]), or padding (-1)
+ *   fmap [n_groups * 8] (device): column of x of every transformed slot, -1 = padding
+ *   tiles / widths (host, n_layers - 1 ints): 16-row output tiles and true width of every hidden layer;
+ *   bias_off (host, n_layers ints); wstream / bias: zuko_amd/coupling_plan.py (zk_gather_f32 from the module's parameters);
+ *   static_ok != 0 allows the shape-specialised instantiation (ReLU, 128 inputs, hidden 512s) when the shapes match. */
+int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy,
+                        void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off,
+                        const int32_t* amap, int nit, const int32_t* fmap, int n_groups, int n_layers, const int32_t* tiles,
+                        const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream);
 /* INCREMENTAL inverse: the whole loop of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000) in one launch whose
  * multiply-add count is ~1.5x ONE density evaluation (every off-diagonal weight tile is multiplied once per sample; only the
  * diagonal tiles of a 4-feature group are iterated).  Needs the aligned-tile plan of zuko_amd/incremental.py

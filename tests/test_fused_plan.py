@@ -143,3 +143,30 @@ def test_incremental_plan_rejects_layouts_that_do_not_fit():
     lazy = F.NSF(3, 5, transforms=1, hidden_features=[128] * 3).transform.transforms[0]  # 64 units per degree: no 16-unit aligned tiles
     lins = [m for m in lazy.hyper if hasattr(m, "mask")]
     assert inc.build_inc_plan([l.mask for l in lins], 3, lazy.order.numpy(), fused.UniLayout(1, 23, 1, 6, 8)) is None
+
+
+@pytest.mark.parametrize("D,ctx,hidden", [(256, 0, [512] * 3), (5, 3, [32, 32]), (12, 2, [40, 70, 24])])
+def test_coupling_plan_simulation_matches_oracle(D, ctx, hidden):
+    """The fused coupling kernel's stream / index maps, walked in numpy, reproduce the oracle's coupling layer (float64)."""
+    import numpy as np
+
+    import zuko_amd.flows as F
+    from oracle import zuko_oracle as O
+    from zuko_amd import coupling_plan as cp
+
+    torch.manual_seed(D)
+    t = F.RealNVP(D, ctx, transforms=2, hidden_features=hidden).transform.transforms[1]
+    lins = list(t.hyper)[0::2]
+    idx_a, idx_b = t.mask.nonzero().squeeze(-1).numpy(), (~t.mask).nonzero().squeeze(-1).numpy()
+    plan = cp.build_coupling_plan([tuple(l.weight.shape) for l in lins], idx_a, idx_b, D, ctx)
+    assert plan is not None and plan.n_blocks % cp.CHUNK == 0
+    W = [l.weight.detach().double().numpy() for l in lins]
+    B = [l.bias.detach().double().numpy() for l in lins]
+    g = torch.Generator().manual_seed(2)
+    n = 8 if D > 64 else 40
+    x = torch.randn(n, D, generator=g, dtype=torch.float64)
+    c = torch.randn(n, ctx, generator=g, dtype=torch.float64) if ctx else None
+    layer = O.CouplingLayer(O.UNI_AFFINE, [torch.from_numpy(w) for w in W], [torch.from_numpy(b) for b in B], t.mask)
+    yo, lo = O.coupling_forward(layer, x, c)
+    ys, ls = cp.simulate(plan, W, B, x.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), float(np.log(1e-3)))
+    assert np.abs(ys - yo.numpy()).max() < 1e-12 and np.abs(ls - lo.numpy()).max() < 1e-12

@@ -524,3 +524,42 @@ def test_incremental_inverse_kernel(dev, name, monkeypatch):
         torch.manual_seed(0)
         xs, lp = flow().rsample_and_log_prob((513,))
         assert torch.allclose(lp, flow().log_prob(xs), rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,ctx,hidden,N", [(256, 0, [512] * 3, 300), (5, 3, [32, 32], 1000), (12, 2, [40, 70, 24], 77), (64, 0, [256], 4096 + 5)])
+def test_fused_coupling_kernel(dev, D, ctx, hidden, N, monkeypatch):
+    """zk_coupling_forward (conditioner + affine map + split / merge in one launch) against the layer-wise HIP path and the
+    oracle; ragged batches, context, widths that are not multiples of 16, non-finite inputs."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(D + N)
+    flow = F.RealNVP(D, ctx, transforms=3, hidden_features=hidden)
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "coupling", O.UNI_AFFINE, D)
+    flow = flow.to(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, D, generator=g)
+    c = torch.randn(N, ctx, generator=g) if ctx else None
+    cg = None if c is None else c.to(dev)
+    with torch.no_grad():
+        assert all(t.fused_state(dev) is not None for t in flow.transform.transforms)
+        z, ladj = flow(cg).transform.call_and_ladj(x.to(dev))
+        lp = flow(cg).log_prob(x.to(dev))
+        monkeypatch.setenv("ZUKO_AMD_NO_FUSED_COUPLING", "1")
+        z_l, ladj_l = flow(cg).transform.call_and_ladj(x.to(dev))
+        monkeypatch.delenv("ZUKO_AMD_NO_FUSED_COUPLING")
+        zo, lo = O.flow_forward(spec, x, c)
+        lpo = O.flow_log_prob(spec, x, c)
+    assert torch.allclose(z, z_l, rtol=1e-5, atol=2e-5) and torch.allclose(ladj, ladj_l, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(z.cpu(), zo, rtol=1e-5, atol=2e-5) and torch.allclose(ladj.cpu(), lo, rtol=1e-5, atol=1e-4)
+    assert ((lp.cpu() - lpo).abs() / lpo.abs().clamp_min(1.0)).max() < 1e-5
+    # a non-finite input poisons the transformed half of its own row only; pass-through columns stay as they are
+    xb = x[:4].clone()
+    t0 = flow.transform.transforms[0]
+    xb[1, int(t0.mask.nonzero()[0])] = float("nan")  # a pass-through (conditioning) column
+    with torch.no_grad():
+        yb, lb = t0(None if cg is None else cg[:4]).call_and_ladj(xb.to(dev))
+    a_cols = t0.mask.cpu()
+    assert torch.equal(yb.cpu()[:, a_cols][[0, 2, 3]], xb[:, a_cols][[0, 2, 3]]) and torch.isfinite(yb.cpu()[[0, 2, 3]]).all()
+    assert torch.isnan(lb[1]) and torch.isnan(yb.cpu()[1, ~a_cols]).all()

@@ -27,5 +27,8 @@ def invalidate(module) -> None:
         m.__dict__.pop("_bf16_plan_cache", None)
         m.__dict__.pop("_coupling_cache", None)
         from . import train as _train
+        from .flows import coupling as _cp
+
+        _cp._COUPLING_CACHE.pop(m, None)
 
         _train._PLAN_CACHE.pop(m, None)

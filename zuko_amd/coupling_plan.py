@@ -1,0 +1,246 @@
+r"""Host-side plan of the fused coupling kernel (csrc/fused_coupling.hip).
+
+One `GeneralCouplingTransform` (zuko/flows/coupling.py:25-139) = dense MLP on the pass-through half (+ context) followed by
+the affine map of the other half.  The kernel streams the MLP's weights as 1 KiB MFMA A-operand images in consumption
+order; this module builds that order (gather indices into the concatenated layer weights), the bias image and the two
+index maps that implement `CouplingTransform`'s split / merge (zuko/transforms.py:1037-1048) inside the kernel.
+`simulate` walks the same tables in numpy (CPU tests).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+TILE = 16
+CHUNK = 24
+RING = 3     # CP_NR: ring slots
+MAX_T = 32    # CP_T: activation tiles (hidden width <= 512)
+MAX_IT = 16   # CP_IT: input tiles (conditioner inputs <= 256)
+
+
+@dataclass
+class CouplingPlan:
+    n_layers: int
+    din: int
+    nit: int
+    widths: list
+    tiles: list
+    moved: int
+    n_groups: int
+    gather: np.ndarray       # int32 [n_blocks * 256] into the concatenated weights (-1 -> 0)
+    n_blocks: int
+    n_chunks: int
+    bias_gather: np.ndarray  # int32 into the concatenated biases (-1 -> 0)
+    bias_off: list
+    amap: np.ndarray         # int32 [nit * 16]
+    fmap: np.ndarray         # int32 [n_groups * 8]
+    features: int
+    context: int
+
+
+def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk: int = CHUNK):
+    """shapes: [(out, in)] of the MLP's linear layers; idx_a / idx_b: columns of x that pass through / are transformed.
+    Returns None when the network does not fit the kernel (widths > 512, inputs > 256, fewer than two layers)."""
+    L = len(shapes)
+    idx_a, idx_b = np.asarray(idx_a, dtype=np.int64), np.asarray(idx_b, dtype=np.int64)
+    if L < 2 or L > 8:
+        return None
+    din = shapes[0][1]
+    moved = len(idx_b)
+    if din != len(idx_a) + context or shapes[-1][0] != 2 * moved:
+        return None
+    widths = [s[0] for s in shapes[:-1]]
+    if din > MAX_IT * TILE or any(w > MAX_T * TILE for w in widths) or any(shapes[l + 1][1] != widths[l] for l in range(L - 1)):
+        return None
+    if (CHUNK * RING * 256 + 4 * 16 * (features + context + 8)) * 4 > 150 * 1024:
+        return None
+    nit = -(-din // TILE)
+    tiles = [-(-w // TILE) for w in widths]
+    n_groups = -(-moved // 8)
+    w_off, b_off = [], []
+    acc = 0
+    for o, i in shapes:
+        w_off.append(acc)
+        acc += o * i
+    acc = 0
+    for o, _ in shapes:
+        b_off.append(acc)
+        acc += o
+    lane = np.arange(64)
+    li, lq = lane % 16, lane // 16
+
+    def image(l, rows, cols):
+        r = rows[li][:, None]
+        c = cols[(4 * lq)[:, None] + np.arange(4)[None, :]]
+        idx = w_off[l] + r * shapes[l][1] + c
+        idx[(r < 0) | (c < 0)] = -1
+        return idx.reshape(-1)
+
+    def span(t, limit):
+        v = np.arange(t * TILE, (t + 1) * TILE)
+        v[v >= limit] = -1
+        return v
+
+    def last_rows(g):
+        rows = -np.ones(TILE, dtype=np.int64)
+        for i in range(TILE):
+            fi, p = divmod(i & 3, 2)
+            slot = g * 8 + (i >> 2) * 2 + fi
+            if slot < moved:
+                rows[i] = slot * 2 + p
+        return rows
+
+    blocks = []
+
+    def pad():
+        n = len(blocks)
+        blocks.extend([-np.ones(256, dtype=np.int64)] * (-(-n // chunk) * chunk - n))
+
+    for l in range(L - 1):
+        n_in, in_w = (nit, din) if l == 0 else (tiles[l - 1], widths[l - 1])
+        for otg in range(-(-tiles[l] // 4)):
+            for it in range(n_in):
+                for t in range(4):
+                    blocks.append(image(l, span(otg * 4 + t, widths[l]), span(it, in_w)))
+        pad()
+    for g in range(n_groups):
+        for it in range(tiles[-1]):
+            blocks.append(image(L - 1, last_rows(g), span(it, widths[-1])))
+    pad()
+    gather = np.concatenate(blocks).astype(np.int32)
+
+    bias_gather, bias_off = [], []
+    cur = 0
+    for l in range(L - 1):
+        units = np.arange(MAX_T * TILE)
+        bias_gather.append(np.where(units < widths[l], b_off[l] + units, -1))
+        bias_off.append(cur)
+        cur += MAX_T * TILE
+    bias_off.append(cur)
+    lastb = []
+    for g in range(n_groups):
+        rows = last_rows(g)
+        lastb.append(np.where(rows >= 0, b_off[L - 1] + np.maximum(rows, 0), -1))
+    bias_gather.append(np.concatenate(lastb))
+
+    amap = -np.ones(nit * TILE, dtype=np.int64)
+    amap[: len(idx_a)] = idx_a
+    for c in range(context):
+        amap[len(idx_a) + c] = -(2 + c)
+    fmap = -np.ones(n_groups * 8, dtype=np.int64)
+    fmap[:moved] = idx_b
+    return CouplingPlan(
+        n_layers=L, din=din, nit=nit, widths=widths, tiles=tiles, moved=moved, n_groups=n_groups, gather=gather, n_blocks=len(blocks),
+        n_chunks=len(blocks) // chunk, bias_gather=np.concatenate(bias_gather).astype(np.int32), bias_off=bias_off, amap=amap.astype(np.int32),
+        fmap=fmap.astype(np.int32), features=features, context=context,
+    )
+
+
+def simulate(plan: CouplingPlan, weights, biases, x: np.ndarray, ctx: np.ndarray | None, act, ls: float):
+    """Numpy walk through the kernel's tables: returns (y [n, D], ladj [n])."""
+    n = x.shape[0]
+    wcat = np.concatenate([np.asarray(w).reshape(-1) for w in weights])
+    bcat = np.concatenate([np.asarray(b).reshape(-1) for b in biases])
+    stream = np.where(plan.gather >= 0, wcat[np.maximum(plan.gather, 0)], 0.0).reshape(-1, 64, 4)
+    bias = np.where(plan.bias_gather >= 0, bcat[np.maximum(plan.bias_gather, 0)], 0.0)
+
+    def tile_mat(blk):
+        return blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)
+
+    cur = np.zeros((n, plan.nit * TILE))
+    for i, src in enumerate(plan.amap):
+        if src >= 0:
+            cur[:, i] = x[:, src]
+        elif src <= -2:
+            cur[:, i] = ctx[:, -2 - src]
+    pos = 0
+    L = plan.n_layers
+    for l in range(L - 1):
+        n_in = plan.nit if l == 0 else plan.tiles[l - 1]
+        out = np.zeros((n, MAX_T * TILE))
+        for otg in range(-(-plan.tiles[l] // 4)):
+            for t in range(4):
+                out[:, (otg * 4 + t) * TILE : (otg * 4 + t + 1) * TILE] = bias[plan.bias_off[l] + (otg * 4 + t) * TILE : plan.bias_off[l] + (otg * 4 + t + 1) * TILE]
+            for it in range(n_in):
+                for t in range(4):
+                    out[:, (otg * 4 + t) * TILE : (otg * 4 + t + 1) * TILE] += cur[:, it * TILE : (it + 1) * TILE] @ tile_mat(stream[pos]).T
+                    pos += 1
+        pos = -(-pos // CHUNK) * CHUNK
+        cur = act(out)
+        cur[:, plan.widths[l] :] = 0.0
+    y = x.copy()
+    ladj = np.zeros(n)
+    for g in range(plan.n_groups):
+        acc = np.zeros((n, TILE)) + bias[plan.bias_off[L - 1] + g * TILE : plan.bias_off[L - 1] + (g + 1) * TILE]
+        for it in range(plan.tiles[-1]):
+            acc += cur[:, it * TILE : (it + 1) * TILE] @ tile_mat(stream[pos]).T
+            pos += 1
+        for qq in range(4):
+            for fi in range(2):
+                f = plan.fmap[g * 8 + qq * 2 + fi]
+                if f >= 0:
+                    shift, scale = acc[:, 4 * qq + 2 * fi], acc[:, 4 * qq + 2 * fi + 1]
+                    lsc = scale / (1 + np.abs(scale / ls))
+                    y[:, f] = x[:, f] * np.exp(lsc) + shift
+                    ladj += lsc
+    return y, ladj
+
+
+class FusedCoupling:
+    """Runs zk_coupling_forward for one GeneralCouplingTransform on one device."""
+
+    def __init__(self, plan: CouplingPlan, device, act: int, slope: float) -> None:
+        import ctypes
+
+        import torch
+
+        self.plan, self.device, self.act, self.slope = plan, device, act, slope
+        self.gather = torch.from_numpy(plan.gather).to(device)
+        self.bias_gather = torch.from_numpy(plan.bias_gather).to(device)
+        self.amap = torch.from_numpy(plan.amap).to(device)
+        self.fmap = torch.from_numpy(plan.fmap).to(device)
+        self.stream = torch.empty(plan.n_blocks * 256, dtype=torch.float32, device=device)
+        self.bias = torch.empty(len(plan.bias_gather), dtype=torch.float32, device=device)
+        nl = plan.n_layers
+        self.bias_off = (ctypes.c_int * nl)(*[int(v) for v in plan.bias_off])
+        self.tiles = (ctypes.c_int * (nl - 1))(*[int(v) for v in plan.tiles])
+        self.widths = (ctypes.c_int * (nl - 1))(*[int(v) for v in plan.widths])
+        self._stamp = None
+
+    def refresh(self, lins) -> None:
+        import torch
+
+        from . import _C
+        from .nn import _param_stamp
+        from .ops import _ptr, _stream
+
+        stamp = _param_stamp(lins)
+        if stamp == self._stamp:
+            return
+        lib = _C.lib()
+        wcat = torch.cat([l.weight.detach().reshape(-1) for l in lins])
+        bcat = torch.cat([(l.bias.detach() if l.bias is not None else torch.zeros(l.weight.shape[0], device=self.device)).reshape(-1) for l in lins])
+        _C.check(lib.zk_gather_f32(_ptr(wcat), None, _ptr(self.gather), self.gather.numel(), _ptr(self.stream), _stream()), "zk_gather_f32")
+        _C.check(lib.zk_gather_f32(_ptr(bcat), None, _ptr(self.bias_gather), self.bias_gather.numel(), _ptr(self.bias), _stream()), "zk_gather_f32")
+        self._stamp = stamp
+
+    def run(self, x, ctx):
+        """x [N, D] fp32 (row stride arbitrary), ctx [N, C] or None -> (y [N, D], ladj [N])."""
+        import torch
+
+        from . import _C
+        from .ops import _ptr, _stream
+
+        p = self.plan
+        N = x.shape[0]
+        y = torch.empty((N, p.features), dtype=torch.float32, device=x.device)
+        ladj = torch.empty(N, dtype=torch.float32, device=x.device)
+        err = _C.lib().zk_coupling_forward(
+            N, p.features, p.context, _ptr(x), x.stride(0), _ptr(ctx), 0 if ctx is None else ctx.stride(0), _ptr(y), p.features, _ptr(ladj), 0,
+            _ptr(self.stream), _ptr(self.bias), self.bias.numel(), self.bias_off, _ptr(self.amap), p.nit, _ptr(self.fmap), p.n_groups, p.n_layers,
+            self.tiles, self.widths, p.n_chunks, self.act, self.slope, 1, _stream(),
+        )
+        _C.check(err, "zk_coupling_forward")
+        return y, ladj

@@ -87,22 +87,33 @@ template <int CH, int NR> struct RingT {
   int n_chunks, pos, slot, load_chunk, load_slot, wave, lane, dbg;
   const int* sched;  // when set, load_chunk indexes this list (length n_chunks) instead of the stream
 
-  __device__ __forceinline__ void issue() {
-#pragma unroll
-    for (int i = 0; i < CH / AR_WAVES; ++i) {
-      const int bi = i * AR_WAVES + wave;
-      const int chunk_id = sched ? sched[load_chunk] : load_chunk;
-      const float* g = stream + ((size_t)chunk_id * CH + bi) * AR_TF + lane * 4;
-      float* l = lds + (load_slot * CH + bi) * AR_TF;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  // Each wave copies CH / AR_WAVES CONSECUTIVE tiles: one LDS base (M0) and one address per chunk, the tiles selected by
+  // the instruction's immediate offset (it moves the global and the LDS address alike).  A vector-memory instruction costs
+  // the issuing wave ~40 cycles of its instruction stream and every M0 write ~20 more (scripts/probes/dma_issue_probe.hip).
+  template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
+    if constexpr (I < CH / AR_WAVES) {
+#ifndef ZK_AR_NO_RING_DMA  // probe builds only (wrong results): what the ring DMAs cost the instruction stream
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, I * AR_TF * 4, 0);
+#endif
+      dma<I + 1>(g, l);
     }
+  }
+  __device__ __forceinline__ void issue() {
+    static_assert((CH / AR_WAVES - 1) * AR_TF * 4 < 4096, "immediate offset range");
+    const int b0 = wave * (CH / AR_WAVES);
+    const int chunk_id = sched ? sched[load_chunk] : load_chunk;
+    const float* g = stream + ((size_t)chunk_id * CH + b0) * AR_TF + lane * 4;
+    float* l = lds + (load_slot * CH + b0) * AR_TF;
+    dma<0>(g, l);
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
     load_slot = (load_slot + 1 == NR) ? 0 : load_slot + 1;
   }
   // all 8 waves call this at the same point of the (uniform) control flow
   __device__ __forceinline__ void advance() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my own tile DMAs have landed
-    __syncthreads();                                   // everyone's have; previous chunk fully consumed
+    // my DMAs of the chunk about to be read have landed (younger chunks stay in flight); my reads of the chunk being released returned
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NR - 2) * (CH / AR_WAVES)) : "memory");
+    __builtin_amdgcn_s_barrier();  // bare barrier: __syncthreads() would prepend s_waitcnt vmcnt(0) and drain the look-ahead DMAs
+    asm volatile("" ::: "memory");
     issue();                                           // refill the slot that was just released
     slot = (slot + 1 == NR) ? 0 : slot + 1;
     pos = 0;

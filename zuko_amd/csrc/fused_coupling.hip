@@ -1,0 +1,666 @@
+// zuko_amd — fused COUPLING transform: dense conditioner MLP + affine map + log|det J| in one launch.
+//
+// Replaces, for one GeneralCouplingTransform of NICE / RealNVP (zuko/flows/coupling.py:128-136 `meta`,
+// zuko/transforms.py:1040-1048 / :1068-1073 `CouplingTransform`):
+//     x_a, x_b = split(x);  phi = MLP(cat(x_a, c))  (zuko/nn.py:13-15 per layer + activations);
+//     y_b, ladj = MonotonicAffineTransform(*unpack(phi)).call_and_ladj(x_b)  (zuko/transforms.py:436-446);  y = merge(x_a, y_b)
+// Layer by layer this moves every hidden activation through HBM ([N, 512] fp32 = 1 GiB per layer at cfg4's 2^19 rows per
+// GPU); here a wavefront carries 16 samples through all layers with the activations in registers, exactly as the
+// autoregressive kernel (fused_ar.hip) does, but for hidden widths up to 512:
+//   * every layer is computed transposed, H^T = W X^T, on v_mfma_f32_16x16x4_f32 (exact fp32); the D fragment of a layer
+//     is the B operand of the next one, so nothing is shuffled or staged between layers;
+//   * 32 + 32 activation tiles = 256 VGPRs/AGPRs: one wavefront per SIMD (launch_bounds(256, 1)), four wavefronts = 64
+//     samples per workgroup share the weight stream (2.9 MB per transform at cfg4, L2-resident) through a 3 x 24 KiB LDS
+//     ring filled by global_load_lds two chunks ahead;
+//   * the split / merge of CouplingTransform is index arithmetic on a wave-private LDS image of the 16 input rows: the
+//     conditioner's B operands are gathered from it (idx_a), the affine map overwrites the moved columns (idx_b) in
+//     place, and the image leaves as whole rows.
+// Host-side planning (stream order, bias image, index maps): zuko_amd/coupling_plan.py.
+#include "zk_univariate.h"
+
+namespace zk {
+
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+
+#define CP_T 32      /* activation tiles (hidden width <= 512) */
+#define CP_IT 16     /* input tiles (conditioner inputs <= 256) */
+#define CP_CH 24
+#define CP_NR 3
+#define CP_WAVES 4
+#define CP_MAXL 8
+
+struct CpArgs {
+  int64_t N;
+  int D, C;                     // features of x, context width
+  const float* x; int64_t ldx;
+  const float* ctx; int64_t ldc;
+  float* y; int64_t ldy;
+  float* ladj; int accumulate;
+  const float* stream;
+  const float* bias;
+  const int32_t* amap;          // [nit * 16]: column of x (>= 0), -(2 + c) for context column c, -1 for padding
+  const int32_t* fmap;          // [NG * 8]: column of x the slot's feature lives in, -1 = padding
+  int L;                        // linear layers (>= 2)
+  int nit;                      // input tiles of the first layer
+  int wt[CP_MAXL];              // output tiles of every hidden layer
+  int width[CP_MAXL];           // hidden widths (units beyond are padding)
+  int NG;                       // groups of 8 moved features
+  int n_chunks, act, bias_floats;
+  int bias_off[CP_MAXL];
+  int xs;                       // LDS row stride (floats) of the wave-private row image
+  int vec4;                     // rows of y can be written 16 bytes per lane
+  int vec4_in;                  // rows of x / context can be fetched 16 bytes per lane
+  float ls;
+  int64_t n_tiles;
+};
+
+__device__ __attribute__((noinline)) float cp_act_slow(float v, int act) {
+  switch (act) {
+    case 2: return v > 0.f ? v : expm1f(v);
+    case 3: return tanhf(v);
+    case 4: return v / (1.f + expf(-v));
+    case 5: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case 6: return 1.f / (1.f + expf(-v));
+    case 7: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+struct CpRing {
+  float* lds;
+  const float* stream;
+  int n_chunks, pos, slot, load_chunk, load_slot, wave, lane;
+  // each wave copies CP_CH / CP_WAVES consecutive tiles: one address and one M0 value per four of them, the tile selected by
+  // the instruction's immediate offset (scripts/probes/dma_issue_probe.hip: ~40 cycles of issue per vector-memory
+  // instruction, ~20 more per M0 write)
+  template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
+    if constexpr (I < CP_CH / CP_WAVES) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (I / 4) * 1024), (__attribute__((address_space(3))) void*)(l + (I / 4) * 1024), 16, (I % 4) * 1024, 0);
+      dma<I + 1>(g, l);
+    }
+  }
+  __device__ __forceinline__ void issue() {
+    const int b0 = wave * (CP_CH / CP_WAVES);
+    dma<0>(stream + ((size_t)load_chunk * CP_CH + b0) * 256 + lane * 4, lds + (load_slot * CP_CH + b0) * 256);
+    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
+    load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
+  }
+  __device__ __forceinline__ void advance() {  // all wavefronts reach this at the same points of the (uniform) control flow
+    // the oldest chunk in flight is the one about to be read: the younger (CP_NR - 2) chunks' DMAs may stay outstanding
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CP_NR - 2) * (CP_CH / CP_WAVES)) : "memory");
+    __builtin_amdgcn_s_barrier();  // bare barrier: __syncthreads() would prepend s_waitcnt vmcnt(0) and drain the look-ahead DMAs
+    asm volatile("" ::: "memory");
+    issue();
+    slot = (slot + 1 == CP_NR) ? 0 : slot + 1;
+    pos = 0;
+  }
+  template <int G> __device__ __forceinline__ void begin() {
+    if (pos == CP_CH) advance();
+  }
+  __device__ __forceinline__ f32x4c tile(int t) const { return *reinterpret_cast<const f32x4c*>(lds + (slot * CP_CH + pos + t) * 256 + lane * 4); }
+  template <int G> __device__ __forceinline__ void commit() { pos += G; }
+  __device__ __forceinline__ void end_layer() {
+    if (pos != 0) pos = CP_CH;
+  }
+};
+
+// The wave's 16 rows [x | context] -> its LDS image, by LDS-DMA (4 bytes per lane, consecutive lanes = consecutive columns of
+// one row): all row pieces are in flight together and are waited for once.  (A load-to-register / ds_write loop pays one
+// memory round trip per piece, each queued behind the ring DMAs in flight: measured ~20 % of the pass at D = 256.)
+__device__ __forceinline__ void cp_stage_rows(const CpArgs& a, float* xw, int xs, int64_t n0, int lane) {
+  const int DC = a.D + a.C;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous pass's reads of the image have returned
+  if (a.vec4_in) {  // 16 bytes per lane: a row of 256 columns is one DMA
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) {
+      const int64_t nr = (n0 + r < a.N) ? n0 + r : a.N - 1;
+      const float* xg = a.x + nr * a.ldx;
+      const float* cg = a.C ? a.ctx + nr * a.ldc - a.D : xg;
+#pragma unroll 1
+      for (int c0 = 0; c0 < DC; c0 += 256) {
+        const int c = c0 + lane * 4;
+        if (c < DC) {
+          const float* g = (c < a.D ? xg : cg) + c;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(xw + r * xs + c0), 16, 0, 0);
+        }
+      }
+    }
+  } else
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) {
+    const int64_t nr = (n0 + r < a.N) ? n0 + r : a.N - 1;
+    const float* xg = a.x + nr * a.ldx;
+    const float* cg = a.C ? a.ctx + nr * a.ldc - a.D : xg;
+#pragma unroll 1
+    for (int c0 = 0; c0 < DC; c0 += 64) {
+      const int c = c0 + lane;
+      if (c < DC) {
+        const float* g = (c < a.D ? xg : cg) + c;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(xw + r * xs + c0), 4, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Results: whole rows out of the image (16 bytes per lane when the row layout allows it).
+__device__ __forceinline__ void cp_store_rows(const CpArgs& a, const float* xw, int xs, int64_t n0, int lane) {
+  if (a.vec4) {
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) {
+      if (n0 + r < a.N)
+#pragma unroll 1
+        for (int c = lane * 4; c < a.D; c += 256) *reinterpret_cast<f32x4c*>(a.y + (n0 + r) * a.ldy + c) = *reinterpret_cast<const f32x4c*>(xw + r * xs + c);
+    }
+  } else {
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) {
+      if (n0 + r < a.N)
+#pragma unroll 1
+        for (int c = lane; c < a.D; c += 64) a.y[(n0 + r) * a.ldy + c] = xw[r * xs + c];
+    }
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) float cp_lds[];
+
+// 32 activation tiles as TWO arrays of 16: a single 512-byte array is not promoted to registers by the compiler (it stays in
+// scratch memory — measured 4x slower), two 256-byte ones are.  `t` is a compile-time constant at every use after unrolling.
+struct CpAct {
+  f32x4c (&lo)[16];
+  f32x4c (&hi)[16];
+  __device__ __forceinline__ f32x4c& operator[](int t) const { return t < 16 ? lo[t & 15] : hi[t & 15]; }
+};
+
+// one dense layer: out[ot] = bias + sum_it W[ot, it] in[it]; NIN = static bound of the input tiles
+template <int NIN> __device__ __forceinline__ void cp_layer(CpRing& ring, int n_in, int n_out, const float* bias_q, const CpAct& in, const CpAct& out) {
+#pragma unroll
+  for (int otg = 0; otg < CP_T / 4; ++otg) {
+    if (otg * 4 < n_out) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out[otg * 4 + t] = *reinterpret_cast<const f32x4c*>(bias_q + (otg * 4 + t) * 16);
+#pragma unroll
+      for (int it = 0; it < NIN; ++it) {
+        if (it < n_in) {
+          ring.template begin<4>();
+          f32x4c a[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a[t] = ring.tile(t);
+          ring.template commit<4>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][r], in[it][r], out[otg * 4 + t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  ring.end_layer();
+}
+
+__device__ __forceinline__ void cp_activate(const CpAct& h, int n_out, int width, int act, int q) {
+#pragma unroll
+  for (int t = 0; t < CP_T; ++t) {
+    if (t < n_out) {
+      if (act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = h[t][r] < 0.f ? 0.f : h[t][r];  // NaN stays NaN, as torch.relu
+      } else if (act != 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = cp_act_slow(h[t][r], act);
+      }
+      // units beyond the layer's width are padding: keep them at exactly 0 (0 * non-finite would poison the next layer)
+      if ((t + 1) * 16 > width) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t * 16 + 4 * q + r >= width) h[t][r] = 0.f;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void coupling_kernel(CpArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & 15, q = lane >> 4;
+
+  float* bias_lds = cp_lds + CP_NR * CP_CH * 256;
+  int* amap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);
+  int* fmap_lds = amap_lds + CP_IT * 16;
+  float* xw = reinterpret_cast<float*>(fmap_lds + a.NG * 8 + 3 * CP_MAXL) + (size_t)wave * 16 * a.xs;
+  // per-layer scalars are read through LDS: indexing the by-value kernel argument arrays with a run-time layer index
+  // would make the compiler spill the whole argument block to scratch memory
+  int* lay_lds = fmap_lds + a.NG * 8;  // [3 * CP_MAXL]: tiles, widths, bias offsets
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < CP_MAXL; ++l) { lay_lds[l] = a.wt[l]; lay_lds[CP_MAXL + l] = a.width[l]; lay_lds[2 * CP_MAXL + l] = a.bias_off[l]; }
+  }
+  for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+  for (int i = tid; i < a.nit * 16; i += 256) amap_lds[i] = a.amap[i];
+  for (int i = tid; i < a.NG * 8; i += 256) fmap_lds[i] = a.fmap[i];
+
+  CpRing ring;
+  ring.lds = cp_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < CP_NR - 1; ++i) ring.issue();
+  ring.slot = CP_NR - 1;
+  ring.pos = CP_CH;
+  __syncthreads();
+
+  const int xs = a.xs;
+  float* xrow = xw + jl * xs;
+  const int DC = a.D + a.C;
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * 64 + wave * 16;
+    const int64_t n = n0 + jl;
+    const bool live = n < a.N;
+
+    // ---- the wave's 16 rows [x | context] -> LDS image (coalesced: a row is read by consecutive lanes) ------------
+    cp_stage_rows(a, xw, xs, n0, lane);
+
+    // ---- first layer: B operands gathered from the image through idx_a ---------------------------------------------
+    f32x4c out_lo[16], out_hi[16], in_lo[16], in_hi[16];
+    const CpAct out{out_lo, out_hi}, in{in_lo, in_hi};
+#pragma unroll
+    for (int it = 0; it < CP_T; ++it) in[it] = f32x4c{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < CP_IT; ++it) {
+      f32x4c v = {0.f, 0.f, 0.f, 0.f};
+      if (it < a.nit) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int src = amap_lds[it * 16 + 4 * q + r];
+          v[r] = src >= 0 ? xrow[src] : (src <= -2 ? xrow[a.D + (-2 - src)] : 0.f);
+        }
+      }
+      in[it] = v;
+    }
+    int n_prev = __builtin_amdgcn_readfirstlane(lay_lds[0]);
+    cp_layer<CP_IT>(ring, a.nit, n_prev, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL]) + 4 * q, in, out);
+    cp_activate(out, n_prev, __builtin_amdgcn_readfirstlane(lay_lds[CP_MAXL]), a.act, q);
+    // ---- further hidden layers --------------------------------------------------------------------------------------
+    for (int l = 1; l < a.L - 1; ++l) {
+#pragma unroll
+      for (int t = 0; t < CP_T; ++t) in[t] = out[t];
+      const int n_out = __builtin_amdgcn_readfirstlane(lay_lds[l]);
+      cp_layer<CP_T>(ring, n_prev, n_out, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + l]) + 4 * q, in, out);
+      cp_activate(out, n_out, __builtin_amdgcn_readfirstlane(lay_lds[CP_MAXL + l]), a.act, q);
+      n_prev = n_out;
+    }
+    // ---- last layer + affine map, one group of 8 moved features at a time (lane (j, q): slots 2 q, 2 q + 1) -------
+    const int n_last_in = n_prev;
+    const float* bias_last = bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + a.L - 1]) + 4 * q;
+    float lacc = 0.f;
+    for (int g = 0; g < a.NG; ++g) {
+      const int f0 = fmap_lds[g * 8 + 2 * q], f1 = fmap_lds[g * 8 + 2 * q + 1];
+      const float x0 = xrow[f0 < 0 ? 0 : f0], x1 = xrow[f1 < 0 ? 0 : f1];
+      f32x4c acc0 = *reinterpret_cast<const f32x4c*>(bias_last + g * 16), acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: a dependent one would wait 40 cycles per MFMA
+#pragma unroll
+      for (int it = 0; it < CP_T; it += 2) {
+        if (it < n_last_in) {
+          ring.template begin<1>();
+          const f32x4c w0 = ring.tile(0);
+          ring.template commit<1>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[r], out[it][r], acc0, 0, 0, 0);
+        }
+        if (it + 1 < n_last_in) {
+          ring.template begin<1>();
+          const f32x4c w1 = ring.tile(0);
+          ring.template commit<1>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], out[it + 1][r], acc1, 0, 0, 0);
+        }
+      }
+      const f32x4c p = acc0 + acc1;  // (shift, scale) of slot 2 q, then of slot 2 q + 1
+      float y0, y1, l0, l1;
+      affine_fwd<float, MathFast>(p[0], p[1], a.ls, x0, y0, l0);
+      affine_fwd<float, MathFast>(p[2], p[3], a.ls, x1, y1, l1);
+      if (f0 >= 0) { xrow[f0] = y0; lacc += l0; }
+      if (f1 >= 0) { xrow[f1] = y1; lacc += l1; }
+    }
+    ring.end_layer();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- results: whole rows out of the image -------------------------------------------------------------------------
+    cp_store_rows(a, xw, xs, n0, lane);
+    if (a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must land before the LDS is released
+}
+
+
+// ---- static-shape fast path ----------------------------------------------------------------------------------------------
+// Same data flow, with the layer shapes as template parameters (NIT input tiles, every hidden layer HT tiles wide, NG
+// groups): no per-tile guards, and the position of every weight tile inside the pass is a compile-time constant, so the ring
+// refill (barrier + DMA issue) is emitted only where that position is a multiple of the chunk size and the code between
+// two refills is one basic block the scheduler can software-pipeline (ds_read of the next tiles above the current MFMAs).
+#ifndef ZK_CP_ABLATE
+#define ZK_CP_ABLATE 0  // probe builds only (wrong results): 1 = no ring DMAs in the steady state, 2 = no chunk barriers, 4 = no row staging / stores
+#endif
+#ifndef ZK_CP_TIMING
+#define ZK_CP_TIMING 0  // -DZK_CP_TIMING=1: s_memtime phase probes printed by wave 0 of block 0 (probe build only)
+#endif
+struct CpRingS {
+  unsigned long long t_wait = 0, t_bar = 0, t_iss = 0;
+  float* lds;
+  const float* stream;
+  const float* cur;
+  int n_chunks, slot, load_chunk, load_slot, wave, lane;
+  // The refill of a released slot is spread over the consumption of the next chunk, one 1 KiB DMA per four tiles: issued
+  // back to back at the barrier, the six DMAs of a wave stall its instruction stream for ~1100 cycles per chunk (the vector
+  // memory path accepts ~22 B/clk per CU while four waves push 24 KiB at once; measured with the ZK_CP_TIMING probes:
+  // 12.7 % of the pass) — with no second wave on the SIMD that is matrix time lost.
+  int fill_chunk, fill_slot, fill_done;
+  static constexpr int kPerWave = CP_CH / CP_WAVES;
+  static_assert(kPerWave == 6, "issue_one() enumerates six tiles");
+  // each wave copies kPerWave consecutive tiles of the chunk; tile i = address / M0 value of its group of four + the
+  // instruction's immediate offset (one M0 write serves four DMAs: ~20 cycles of issue each, scripts/probes/dma_issue_probe.hip)
+  const float* fill_g;
+  float* fill_l;
+  __device__ __forceinline__ void fill_begin() {
+    const int b0 = wave * kPerWave;
+    fill_g = stream + ((size_t)fill_chunk * CP_CH + b0) * 256 + lane * 4;
+    fill_l = lds + (fill_slot * CP_CH + b0) * 256;
+  }
+  template <int I> __device__ __forceinline__ void issue_static() {
+    if (!(ZK_CP_ABLATE & 32))
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fill_g + (I / 4) * 1024), (__attribute__((address_space(3))) void*)(fill_l + (I / 4) * 1024), 16, (I % 4) * 1024, 0);
+  }
+  __device__ __forceinline__ void issue_one(int i) {
+    switch (i) {
+      case 0: issue_static<0>(); break;
+      case 1: issue_static<1>(); break;
+      case 2: issue_static<2>(); break;
+      case 3: issue_static<3>(); break;
+      case 4: issue_static<4>(); break;
+      default: issue_static<5>(); break;
+    }
+  }
+  __device__ __forceinline__ void issue() {  // whole chunk at once (prologue)
+    fill_chunk = load_chunk; fill_slot = load_slot;
+    fill_begin();
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) issue_one(i);
+    fill_done = kPerWave;
+    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
+    load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
+  }
+  __device__ __forceinline__ void advance() {
+    unsigned long long p0 = 0, p1 = 0, p2 = 0;
+    if (ZK_CP_TIMING) p0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (; fill_done < kPerWave; ++fill_done) issue_one(fill_done);  // a layer that ended inside its last chunk left DMAs unissued
+    // my DMAs of the chunk about to be read have landed (the CP_NR - 2 younger chunks stay in flight: a DMA takes ~5 k cycles,
+    // one chunk is consumed in ~3 k); my (prefetching) reads of the slot to be refilled have returned
+    if (!(ZK_CP_ABLATE & 16)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CP_NR - 2) * (CP_CH / CP_WAVES)) : "memory");
+    if (ZK_CP_TIMING) p1 = __builtin_amdgcn_s_memtime();
+    if (!(ZK_CP_ABLATE & 8)) __builtin_amdgcn_s_barrier();  // bare barrier: __syncthreads() would prepend s_waitcnt vmcnt(0) and drain the look-ahead DMAs
+    asm volatile("" ::: "memory");
+    if (ZK_CP_TIMING) {
+      p2 = __builtin_amdgcn_s_memtime();
+      t_wait += p1 - p0; t_bar += p2 - p1;
+    }
+    fill_chunk = load_chunk; fill_slot = load_slot; fill_done = 0;  // the slot just released, refilled while the next chunk is read
+    fill_begin();
+    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
+    load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
+    slot = (slot + 1 == CP_NR) ? 0 : slot + 1;
+    cur = lds + slot * CP_CH * 256 + lane * 4;
+  }
+  __device__ __forceinline__ f32x4c read(int s) {  // s: position inside the layer (layers start on chunk boundaries)
+    if (s % CP_CH == 0 && !(ZK_CP_ABLATE & 2)) advance();
+    return *reinterpret_cast<const f32x4c*>(cur + (s % CP_CH) * 256);
+  }
+  // one refill DMA per step of four tiles; called where the wave has no LDS read outstanding (s = first tile of the step
+  // being multiplied, whose chunk was entered by an earlier read())
+  __device__ __forceinline__ void fill(int s) {
+    if (s % 4 == 0 && (s % CP_CH) / 4 < kPerWave && !(ZK_CP_ABLATE & 1)) {
+      issue_one((s % CP_CH) / 4);
+      fill_done = (s % CP_CH) / 4 + 1;
+    }
+  }
+};
+
+template <int NIN, int HT> __device__ __forceinline__ void cp_layer_static(CpRingS& ring, const float* bias_q, const CpAct& in, const CpAct& out) {
+  // software pipeline: the four A tiles of step s + 1 are requested (into the other register set) before the 16 MFMAs of
+  // step s are issued, so the LDS round trip hides behind 512 cycles of matrix work (one wavefront per SIMD: there is no
+  // partner wave to hide it)
+  constexpr int STEPS = (HT / 4) * NIN;
+  f32x4c a[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a[0][t] = ring.read(t);
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int otg = st / NIN, it = st % NIN;
+    if (it == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out[otg * 4 + t] = *reinterpret_cast<const f32x4c*>(bias_q + (otg * 4 + t) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][t][r], in[it][r], out[otg * 4 + t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    ring.fill(st * 4);
+    if (st + 1 < STEPS) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[(st + 1) & 1][t] = ring.read((st + 1) * 4 + t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 2; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][t][r], in[it][r], out[otg * 4 + t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_kernel_static(CpArgs a) {
+  static_assert(HT % 4 == 0 && HT <= CP_T && NIT <= CP_IT, "shape");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & 15, q = lane >> 4;
+  float* bias_lds = cp_lds + CP_NR * CP_CH * 256;
+  int* amap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);
+  int* fmap_lds = amap_lds + CP_IT * 16;
+  int* lay_lds = fmap_lds + a.NG * 8;
+  float* xw = reinterpret_cast<float*>(lay_lds + 3 * CP_MAXL) + (size_t)wave * 16 * a.xs;
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < CP_MAXL; ++l) lay_lds[2 * CP_MAXL + l] = a.bias_off[l];
+  }
+  for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+  for (int i = tid; i < NIT * 16; i += 256) amap_lds[i] = a.amap[i];
+  for (int i = tid; i < a.NG * 8; i += 256) fmap_lds[i] = a.fmap[i];
+  CpRingS ring;
+  ring.lds = cp_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < CP_NR - 1; ++i) ring.issue();
+  ring.slot = CP_NR - 1;
+  ring.cur = cp_lds;
+  __syncthreads();
+
+  const int xs = a.xs;
+  float* xrow = xw + jl * xs;
+  const int DC = a.D + a.C;
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tacc[5] = {0, 0, 0, 0, 0};
+  int n_pass = 0;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * 64 + wave * 16;
+    const int64_t n = n0 + jl;
+    const bool live = n < a.N;
+    if (ZK_CP_TIMING) ts[0] = __builtin_amdgcn_s_memtime();
+    if (!(ZK_CP_ABLATE & 4)) cp_stage_rows(a, xw, xs, n0, lane);
+    if (ZK_CP_TIMING) ts[1] = __builtin_amdgcn_s_memtime();
+
+    f32x4c out_lo[16], out_hi[16], in_lo[16], in_hi[16];
+    const CpAct out{out_lo, out_hi}, in{in_lo, in_hi};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      f32x4c v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int src = amap_lds[it * 16 + 4 * q + r];
+        v[r] = src >= 0 ? xrow[src] : (src <= -2 ? xrow[a.D + (-2 - src)] : 0.f);
+      }
+      in[it] = v;
+    }
+    cp_layer_static<NIT, HT>(ring, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL]) + 4 * q, in, out);
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];
+    if (ZK_CP_TIMING) ts[2] = __builtin_amdgcn_s_memtime();
+    for (int l = 1; l < a.L - 1; ++l) {
+#pragma unroll
+      for (int t = 0; t < HT; ++t) in[t] = out[t];
+      cp_layer_static<HT, HT>(ring, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + l]) + 4 * q, in, out);
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];
+    }
+    if (ZK_CP_TIMING) ts[3] = __builtin_amdgcn_s_memtime();
+    const float* bias_last = bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + a.L - 1]) + 4 * q;
+    float lacc = 0.f;
+    // groups are walked in pairs so that the tile positions are static: 2 * HT tiles per pair (HT = 32: 64 tiles, not a
+    // multiple of the chunk — the position is carried in a run-time base that only changes by multiples of the chunk)
+    static_assert((3 * HT) % CP_CH == 0, "three groups of the last layer must fill whole chunks");
+    for (int g3 = 0; g3 < a.NG; g3 += 3) {
+#pragma unroll
+      for (int gg = 0; gg < 3; ++gg) {
+        const int g = g3 + gg;
+        if (g < a.NG) {
+          const int f0 = fmap_lds[g * 8 + 2 * q], f1 = fmap_lds[g * 8 + 2 * q + 1];
+          const float x0 = xrow[f0 < 0 ? 0 : f0], x1 = xrow[f1 < 0 ? 0 : f1];
+          // four accumulators (one per tile of the step): a dependent MFMA every fourth issue, as in the hidden layers
+          f32x4c acc[4] = {*reinterpret_cast<const f32x4c*>(bias_last + g * 16), {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          f32x4c w[2][4];  // four tiles per step, the next step requested in the middle of this step's MFMAs
+#pragma unroll
+          for (int t = 0; t < 4; ++t) w[0][t] = ring.read(gg * HT + t);
+#pragma unroll
+          for (int it = 0; it < HT; it += 4) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(it >> 2) & 1][t][r], out[it + t][r], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ring.fill(gg * HT + it);
+            if (it + 4 < HT) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) w[((it >> 2) + 1) & 1][t] = ring.read(gg * HT + it + 4 + t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 2; r < 4; ++r)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(it >> 2) & 1][t][r], out[it + t][r], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const f32x4c p = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+          float y0, y1, l0, l1;
+          affine_fwd<float, MathFast>(p[0], p[1], a.ls, x0, y0, l0);
+          affine_fwd<float, MathFast>(p[2], p[3], a.ls, x1, y1, l1);
+          if (f0 >= 0) { xrow[f0] = y0; lacc += l0; }
+          if (f1 >= 0) { xrow[f1] = y1; lacc += l1; }
+        }
+      }
+    }
+    if (ZK_CP_TIMING) ts[4] = __builtin_amdgcn_s_memtime();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (!(ZK_CP_ABLATE & 4)) cp_store_rows(a, xw, xs, n0, lane);
+    if (a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (ZK_CP_TIMING) {
+      ts[5] = __builtin_amdgcn_s_memtime();
+      for (int i = 0; i < 5; ++i) tacc[i] += ts[i + 1] - ts[i];
+      ++n_pass;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if ZK_CP_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("cp timing (memtime ticks, %d passes): stage %llu layer0 %llu hidden %llu last %llu store %llu | advance: wait %llu barrier %llu issue %llu\n", n_pass,
+           tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], ring.t_wait, ring.t_bar, ring.t_iss);
+#endif
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+// y[N, D] = merge(x_a, affine(x_b | MLP(cat(x_a, ctx)))), ladj[N] (+)= sum log|dy_b/dx_b| for one coupling transform.
+// n_layers linear layers; tiles / widths: HOST arrays with the output tiles and widths of the n_layers - 1 hidden layers;
+// bias_off: HOST array of n_layers offsets into the bias image; amap [nit * 16], fmap [n_groups * 8]: DEVICE index maps;
+// wstream / bias: the plan of zuko_amd/coupling_plan.py.  Limits: D + C <= 1024 columns in the row image with
+// 4 * 16 * (D + C + 4) * 4 bytes of LDS beside the 72 KiB ring, conditioner inputs <= 256, hidden widths <= 512.
+int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy, void* ladj, int accumulate,
+                        const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* amap, int nit, const int32_t* fmap,
+                        int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream) {
+  if (N <= 0) return 0;
+  if (n_layers < 2 || n_layers > CP_MAXL || nit < 1 || nit > CP_IT || n_groups < 1 || n_chunks < 1 || D < 2 || C < 0 || (C > 0 && !ctx)) return ZK_EINVAL;
+  CpArgs a{};
+  a.N = N; a.D = D; a.C = C; a.x = (const float*)x; a.ldx = ldx; a.ctx = (const float*)ctx; a.ldc = ldc; a.y = (float*)y; a.ldy = ldy;
+  a.ladj = (float*)ladj; a.accumulate = accumulate; a.stream = (const float*)wstream; a.bias = (const float*)bias; a.amap = amap; a.fmap = fmap;
+  a.L = n_layers; a.nit = nit; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
+  for (int l = 0; l < n_layers - 1; ++l) {
+    if (tiles[l] < 1 || tiles[l] > CP_T) return ZK_EINVAL;
+    a.wt[l] = tiles[l]; a.width[l] = widths[l];
+  }
+  for (int l = 0; l < n_layers; ++l) a.bias_off[l] = bias_off[l];
+  a.xs = ((D + C + 3) / 4) * 4 + 4;
+  a.vec4 = (D % 4 == 0) && (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  a.vec4_in = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+              (C == 0 || ((C % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(ctx) & 15) == 0)));
+  a.ls = (float)log(slope);
+  a.n_tiles = (N + 63) / 64;
+  const int lds = (CP_NR * CP_CH * 256 + bias_floats + CP_IT * 16 + n_groups * 8 + 3 * CP_MAXL + CP_WAVES * 16 * a.xs) * (int)sizeof(float);
+  if (lds > 160 * 1024) return ZK_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)coupling_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  // static-shape instantiation: ReLU, every hidden layer 512 wide (32 tiles), 128 conditioner inputs (8 tiles), groups in
+  // whole triples padded by the plan (cfg4 of BASELINE.json: RealNVP(256, hidden [512] * 3)); `static_ok` is the plan's word
+  // that its stream has the matching layout (every layer and every triple of groups starts on a chunk boundary)
+  bool same = act == 1 && nit == 8;
+  for (int l = 0; l < n_layers - 1; ++l) same = same && tiles[l] == 32 && widths[l] == 512;
+  if (same && static_ok) {
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute((const void*)coupling_kernel_static<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((coupling_kernel_static<8, 32>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    return ZK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(coupling_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  return ZK_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -98,20 +98,26 @@ struct IncRing {
   const float* stream;
   const float* cur;  // lds + slot * IN_CH * 256 + lane * 4
   int n_chunks, slot, load_chunk, load_slot, wave, lane;
-  __device__ __forceinline__ void issue() {
-#pragma unroll
-    for (int i = 0; i < IN_CH / IN_WAVES; ++i) {
-      const int bi = i * IN_WAVES + wave;
-      const float* g = stream + ((size_t)load_chunk * IN_CH + bi) * 256 + lane * 4;
-      float* l = lds + (load_slot * IN_CH + bi) * 256;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  // each wave copies IN_CH / IN_WAVES consecutive tiles: one address and one M0 value per four of them, the tile selected by
+  // the instruction's immediate offset (a vector-memory instruction costs the wave ~40 cycles of issue, an M0 write ~20 more:
+  // scripts/probes/dma_issue_probe.hip)
+  template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
+    if constexpr (I < IN_CH / IN_WAVES) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (I / 4) * 1024), (__attribute__((address_space(3))) void*)(l + (I / 4) * 1024), 16, (I % 4) * 1024, 0);
+      dma<I + 1>(g, l);
     }
+  }
+  __device__ __forceinline__ void issue() {
+    const int b0 = wave * (IN_CH / IN_WAVES);
+    dma<0>(stream + ((size_t)load_chunk * IN_CH + b0) * 256 + lane * 4, lds + (load_slot * IN_CH + b0) * 256);
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
     load_slot = (load_slot + 1 == IN_NR) ? 0 : load_slot + 1;
   }
   __device__ __forceinline__ void advance() {  // all wavefronts reach this at the same points of the (uniform) control flow
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // only the chunk about to be read has to have landed; the (IN_NR - 2) younger ones stay in flight
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((IN_NR - 2) * (IN_CH / IN_WAVES)) : "memory");
+    __builtin_amdgcn_s_barrier();  // bare barrier: __syncthreads() would prepend s_waitcnt vmcnt(0) and drain the look-ahead DMAs
+    asm volatile("" ::: "memory");
     issue();
     slot = (slot + 1 == IN_NR) ? 0 : slot + 1;
     cur = lds + slot * IN_CH * 256 + lane * 4;

@@ -6,6 +6,7 @@ API / module-tree mirror of zuko/flows/coupling.py:25-200: dense `zuko_amd.nn.ML
 
 from __future__ import annotations
 
+import os
 from functools import partial
 from math import prod
 from typing import Callable, Sequence
@@ -72,7 +73,85 @@ class GeneralCouplingTransform(LazyTransform):
         return DependentTransform(u, 1)
 
     def forward(self, c: Tensor | None = None) -> Transform:
-        return CouplingTransform(partial(self.meta, c), self.mask)
+        return FusedCouplingTransform(self, c)
+
+    def fused_state(self, device: torch.device):
+        """Plan + device tables of the fused coupling kernel (csrc/fused_coupling.hip), or None when the layer does not fit it
+        (affine univariate with default shapes, plain (Linear, activation)* conditioner, widths <= 512, inputs <= 256)."""
+        from .. import coupling_plan as cp
+        from ..nn import Linear, _act_code
+
+        cache = _COUPLING_CACHE.setdefault(self, {})
+        key = (str(device), self.mask._version, self.mask.data_ptr())
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+            state = None
+            u = self.univariate
+            f, kw = (u.func, dict(u.keywords)) if isinstance(u, partial) else (u, {})
+            slope = kw.pop("slope", 1e-3)
+            mods = list(self.hyper)
+            lins, acts = mods[0::2], mods[1::2]
+            simple = len(mods) == 2 * len(lins) - 1 and all(isinstance(m, Linear) for m in lins) and not any(isinstance(m, Linear) for m in acts)
+            codes = {_act_code(m) for m in acts}
+            if (f is MonotonicAffineTransform and not kw and not (isinstance(u, partial) and u.args) and [tuple(s_) for s_ in self.shapes] == [(), ()]
+                    and simple and len(codes) == 1 and None not in codes and all(l.weight.dtype == torch.float32 for l in lins)):
+                idx_a = self.mask.nonzero().squeeze(-1).cpu().numpy()
+                idx_b = (~self.mask).nonzero().squeeze(-1).cpu().numpy()
+                context = lins[0].weight.shape[1] - len(idx_a)
+                plan = cp.build_coupling_plan([tuple(l.weight.shape) for l in lins], idx_a, idx_b, int(self.mask.numel()), context)
+                if plan is not None:
+                    state = cp.FusedCoupling(plan, device, codes.pop(), slope)
+            cache["state"] = state
+        return cache["state"]
+
+
+import weakref
+
+_COUPLING_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+class FusedCouplingTransform(CouplingTransform):
+    r"""The Transform `GeneralCouplingTransform.forward(c)` returns: zuko's CouplingTransform(partial(meta, c), mask)
+    (zuko/transforms.py:1010-1073) whose `call_and_ladj` runs conditioner + affine map + merge in ONE kernel
+    (zk_coupling_forward) when no gradient is required and the layer fits; otherwise the layer-wise kernels through `meta`."""
+
+    def __init__(self, lazy: GeneralCouplingTransform, c: Tensor | None) -> None:
+        super().__init__(partial(lazy.meta, c), lazy.mask)
+        self.lazy = lazy
+        self.c = c
+
+    def call_and_ladj(self, x: Tensor):
+        lazy, c = self.lazy, self.c
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1) or os.environ.get("ZUKO_AMD_NO_FUSED_COUPLING", "0") == "1":
+            return super().call_and_ladj(x)
+        if torch.is_grad_enabled() and (x.requires_grad or (c is not None and c.requires_grad) or any(p.requires_grad for p in lazy.hyper.parameters())):
+            return super().call_and_ladj(x)
+        st = lazy.fused_state(x.device)
+        if st is None:
+            return super().call_and_ladj(x)
+        D = x.shape[-1]
+        if c is not None:
+            xb, cb = broadcast(x, c, ignore=1)
+        else:
+            xb, cb = x, None
+        batch = xb.shape[:-1]
+        x2 = xb.reshape(-1, D)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        c2 = None
+        if cb is not None:
+            c2 = cb.reshape(-1, cb.shape[-1])
+            c2 = c2 if c2.stride(-1) == 1 else c2.contiguous()
+        st.refresh(list(lazy.hyper)[0::2])
+        y, ladj = st.run(x2, c2)
+        return y.reshape(batch + (D,)), ladj.reshape(batch)
+
+    def _call(self, x: Tensor) -> Tensor:
+        return self.call_and_ladj(x)[0]
+
+    def log_abs_det_jacobian(self, x: Tensor, y: Tensor) -> Tensor:
+        return self.call_and_ladj(x)[1]
 
 
 class NICE(Flow):
