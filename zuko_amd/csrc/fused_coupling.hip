@@ -75,13 +75,14 @@ struct CpRing {
   // instruction, ~20 more per M0 write)
   template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
     if constexpr (I < CP_CH / CP_WAVES) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (I / 4) * 1024), (__attribute__((address_space(3))) void*)(l + (I / 4) * 1024), 16, (I % 4) * 1024, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, (I - 4) * 1024, 0);
       dma<I + 1>(g, l);
     }
   }
   __device__ __forceinline__ void issue() {
-    const int b0 = wave * (CP_CH / CP_WAVES);
-    dma<0>(stream + ((size_t)load_chunk * CP_CH + b0) * 256 + lane * 4, lds + (load_slot * CP_CH + b0) * 256);
+    static_assert(CP_CH / CP_WAVES == 6, "immediates -4096 .. +1024 around the wave's fifth tile reach six tiles");
+    const int b4 = wave * (CP_CH / CP_WAVES) + 4;
+    dma<0>(stream + ((size_t)load_chunk * CP_CH + b4) * 256 + lane * 4, lds + (load_slot * CP_CH + b4) * 256);
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
     load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
   }
@@ -344,6 +345,9 @@ __global__ __launch_bounds__(256, 1) void coupling_kernel(CpArgs a) {
 // groups): no per-tile guards, and the position of every weight tile inside the pass is a compile-time constant, so the ring
 // refill (barrier + DMA issue) is emitted only where that position is a multiple of the chunk size and the code between
 // two refills is one basic block the scheduler can software-pipeline (ds_read of the next tiles above the current MFMAs).
+#ifndef CP_FILL_SPREAD
+#define CP_FILL_SPREAD 0  // 1: one refill DMA per step of four tiles instead of six back to back after the chunk barrier
+#endif
 #ifndef ZK_CP_ABLATE
 #define ZK_CP_ABLATE 0  // probe builds only (wrong results): 1 = no ring DMAs in the steady state, 2 = no chunk barriers, 4 = no row staging / stores
 #endif
@@ -367,14 +371,14 @@ struct CpRingS {
   // instruction's immediate offset (one M0 write serves four DMAs: ~20 cycles of issue each, scripts/probes/dma_issue_probe.hip)
   const float* fill_g;
   float* fill_l;
-  __device__ __forceinline__ void fill_begin() {
-    const int b0 = wave * kPerWave;
-    fill_g = stream + ((size_t)fill_chunk * CP_CH + b0) * 256 + lane * 4;
-    fill_l = lds + (fill_slot * CP_CH + b0) * 256;
+  __device__ __forceinline__ void fill_begin() {  // address / LDS base of the wave's FIFTH tile: immediates -4096 .. +1024 reach all six
+    const int b4 = wave * kPerWave + 4;
+    fill_g = stream + ((size_t)fill_chunk * CP_CH + b4) * 256 + lane * 4;
+    fill_l = lds + (fill_slot * CP_CH + b4) * 256;
   }
   template <int I> __device__ __forceinline__ void issue_static() {
     if (!(ZK_CP_ABLATE & 32))
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fill_g + (I / 4) * 1024), (__attribute__((address_space(3))) void*)(fill_l + (I / 4) * 1024), 16, (I % 4) * 1024, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)fill_g, (__attribute__((address_space(3))) void*)fill_l, 16, (I - 4) * 1024, 0);
   }
   __device__ __forceinline__ void issue_one(int i) {
     switch (i) {
@@ -410,8 +414,13 @@ struct CpRingS {
       p2 = __builtin_amdgcn_s_memtime();
       t_wait += p1 - p0; t_bar += p2 - p1;
     }
-    fill_chunk = load_chunk; fill_slot = load_slot; fill_done = 0;  // the slot just released, refilled while the next chunk is read
+    fill_chunk = load_chunk; fill_slot = load_slot; fill_done = 0;  // the slot just released
     fill_begin();
+    if (!CP_FILL_SPREAD) {  // six DMAs back to back on one M0 value: ~40 cycles of issue for the first, ~15 for each further one
+#pragma unroll
+      for (int i = 0; i < kPerWave; ++i) issue_one(i);
+      fill_done = kPerWave;
+    }
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
     load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
     slot = (slot + 1 == CP_NR) ? 0 : slot + 1;
@@ -424,7 +433,7 @@ struct CpRingS {
   // one refill DMA per step of four tiles; called where the wave has no LDS read outstanding (s = first tile of the step
   // being multiplied, whose chunk was entered by an earlier read())
   __device__ __forceinline__ void fill(int s) {
-    if (s % 4 == 0 && (s % CP_CH) / 4 < kPerWave && !(ZK_CP_ABLATE & 1)) {
+    if (CP_FILL_SPREAD && s % 4 == 0 && (s % CP_CH) / 4 < kPerWave && !(ZK_CP_ABLATE & 1)) {
       issue_one((s % CP_CH) / 4);
       fill_done = (s % CP_CH) / 4 + 1;
     }

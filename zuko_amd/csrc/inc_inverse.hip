@@ -98,18 +98,19 @@ struct IncRing {
   const float* stream;
   const float* cur;  // lds + slot * IN_CH * 256 + lane * 4
   int n_chunks, slot, load_chunk, load_slot, wave, lane;
-  // each wave copies IN_CH / IN_WAVES consecutive tiles: one address and one M0 value per four of them, the tile selected by
-  // the instruction's immediate offset (a vector-memory instruction costs the wave ~40 cycles of issue, an M0 write ~20 more:
+  // each wave copies IN_CH / IN_WAVES consecutive tiles: one address and one M0 value for all of them, the tile selected by
+  // the instruction's (signed) immediate offset (a vector-memory instruction costs the wave ~40 cycles of issue, an M0 write ~20 more:
   // scripts/probes/dma_issue_probe.hip)
   template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
     if constexpr (I < IN_CH / IN_WAVES) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (I / 4) * 1024), (__attribute__((address_space(3))) void*)(l + (I / 4) * 1024), 16, (I % 4) * 1024, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, (I - 4) * 1024, 0);
       dma<I + 1>(g, l);
     }
   }
   __device__ __forceinline__ void issue() {
-    const int b0 = wave * (IN_CH / IN_WAVES);
-    dma<0>(stream + ((size_t)load_chunk * IN_CH + b0) * 256 + lane * 4, lds + (load_slot * IN_CH + b0) * 256);
+    static_assert(IN_CH / IN_WAVES == 6, "immediates -4096 .. +1024 around the wave's fifth tile reach six tiles");
+    const int b4 = wave * (IN_CH / IN_WAVES) + 4;
+    dma<0>(stream + ((size_t)load_chunk * IN_CH + b4) * 256 + lane * 4, lds + (load_slot * IN_CH + b4) * 256);
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
     load_slot = (load_slot + 1 == IN_NR) ? 0 : load_slot + 1;
   }
