@@ -1,5 +1,5 @@
 """One fused coupling launch of the cfg4 shape (RealNVP d=256, hidden 512 x 3), for the -DZK_CP_TIMING probe build:
-    bash scripts/build_cp_probe.sh && ZUKO_AMD_LIB=scripts/probes/ab/lib_cpt.so python scripts/cp_probe.py"""
+    bash scripts/build_tu_variant.sh fused_coupling cp_t -DZK_CP_TIMING=1 && ZUKO_AMD_LIB=scripts/probes/ab/lib_cp_t.so python scripts/cp_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
