@@ -216,6 +216,14 @@ int zk_ar_inverse_incremental(int uni_kind, int n_hidden, int64_t N, int D, int 
 int zk_ar_inc_lds_bytes(int bias_floats, int nit);
 /* dynamic LDS bytes zk_ar_forward will request for `variant` and a bias image of `bias_floats` floats. */
 int zk_ar_lds_bytes(int variant, int bias_floats);
+/* Static-shape instantiation of zk_ar_forward (`variant` = 1 or 2; csrc/fused_ar_static.hip): the conditioner of
+ * MaskedAutoregressiveTransform(features = 64, hidden_features = [256] * 3), no context, ReLU, uni_kind 0 or 1 — the block
+ * pattern of its masks (zuko/nn.py:270-295 with the hidden units sorted by dependency count) is fixed, so the kernel is
+ * straight-line code.  zk_ar_static_skip writes the skip words (same layout as zk_ar_forward's `skip`: 4 per hidden layer,
+ * then one per feature group; at most 28) a plan MUST have for that variant and returns their count (0: no such kernel):
+ * variant 1 = first-layer pattern of an ascending feature order, 2 = of a descending one.  The caller compares its plan
+ * against them once; zk_ar_forward itself only checks the shape arguments.  Results are bit-identical to variant 0. */
+int zk_ar_static_skip(int uni_kind, int variant, uint32_t* out_words);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
 int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);

@@ -23,7 +23,7 @@ def _isa() -> str:
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     h = hashlib.sha256()
-    for name in ("fused_ar.hip", "zk_univariate.h", "zk_common.h"):
+    for name in ("fused_ar.hip", "zk_ar_common.h", "zk_univariate.h", "zk_common.h"):
         h.update(open(os.path.join(CSRC, name), "rb").read())
     out = os.path.join(ROOT, "zuko_amd", "lib", f"fused_ar.{h.hexdigest()[:16]}.s")
     if not os.path.exists(out):
@@ -48,3 +48,70 @@ def test_headline_kernel_instruction_mix():
     k = s.index(".amdhsa_kernel " + HEADLINE)
     desc = s[k : s.index(".end_amdhsa_kernel", k)]
     assert ".amdhsa_private_segment_fixed_size 0" in desc, "scratch (VGPR spill) in the headline kernel"
+
+
+def _isa_of(tu: str) -> str:
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    h = hashlib.sha256()
+    for name in (tu, "zk_ar_common.h", "zk_univariate.h", "zk_common.h"):
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+    out = os.path.join(ROOT, "zuko_amd", "lib", f"{tu.split('.')[0]}.{h.hexdigest()[:16]}.s")
+    if not os.path.exists(out):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-ffp-contract=off", "--cuda-device-only", "-S",
+                        os.path.join(CSRC, tu), "-o", out], check=True, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
+    """fused_ar_static.hip issues its weight-tile reads from inline assembly and makes them usable through an
+    `s_waitcnt lgkmcnt(n)` it places itself.  Between the read and a wait that covers it no instruction may mention the
+    destination registers (a register copy inserted there by the allocator would read data that has not arrived).  LDS
+    operations of a wave complete in order, so a wait lgkmcnt(n) covers every asm read except the youngest n."""
+    import re
+
+    s = _isa_of("fused_ar_static.hip")
+    kernels = [m.start() for m in re.finditer(r"^_ZN2zk16ar_static_kernel[^\n]*:", s, flags=re.M)]
+    assert len(kernels) == 2
+
+    def regs(t):
+        out = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", t):
+            if m.group(1):
+                out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+            else:
+                out.add(int(m.group(3)))
+        return out
+
+    for k in kernels:
+        body = s[k : s.index("s_endpgm", k)].split("\n")
+        pending, in_asm, n_reads, mfma = [], False, 0, 0
+        for line in body:
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t[0] in ";.":
+                continue
+            mfma += "v_mfma" in t
+            m = re.match(r"ds_read_b128 (v\[\d+:\d+\]), ", t)
+            if m and in_asm:
+                pending.append(regs(m.group(1)))
+                n_reads += 1
+                continue
+            w = re.match(r"s_waitcnt .*lgkmcnt\((\d+)\)", t)
+            if w:
+                n = int(w.group(1))
+                pending = pending[len(pending) - n :] if 0 < n < len(pending) else ([] if n == 0 else pending)
+                continue
+            used = regs(t)
+            assert not any(used & r for r in pending), f"'{t}' touches a weight tile whose LDS read has not been waited for"
+        assert n_reads * 4 == mfma and n_reads in (1176, 432)  # every tile is read once and multiplied by four k-steps
+    for name in re.findall(r"\.amdhsa_kernel (_ZN2zk16ar_static_kernel\S+)", s):
+        k = s.index(".amdhsa_kernel " + name)
+        assert ".amdhsa_private_segment_fixed_size 0" in s[k : s.index(".end_amdhsa_kernel", k)]

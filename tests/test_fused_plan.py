@@ -170,3 +170,29 @@ def test_coupling_plan_simulation_matches_oracle(D, ctx, hidden):
     yo, lo = O.coupling_forward(layer, x, c)
     ys, ls = cp.simulate(plan, W, B, x.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), float(np.log(1e-3)))
     assert np.abs(ys - yo.numpy()).max() < 1e-12 and np.abs(ls - lo.numpy()).max() < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["nsf", "maf"])
+def test_static_kernel_pattern_is_the_plan_of_cfg2_and_cfg3(kind):
+    """zk_ar_static_skip() (csrc/fused_ar_static.hip) must describe exactly the plan fused.py builds for the conditioner of
+    cfg2 / cfg3 — for both feature orders zuko alternates between (zuko/flows/autoregressive.py:121-125) — and nothing else."""
+    import ctypes
+
+    from zuko_amd import _C, fused
+    from zuko_amd.flows import MAF, NSF
+    from zuko_amd.nn import MaskedLinear
+
+    torch.manual_seed(0)
+    flow = NSF(64, 0, transforms=2, bins=8, hidden_features=[256] * 3) if kind == "nsf" else MAF(64, 0, transforms=2, hidden_features=[256] * 3)
+    layout = fused.uni_layout("rqs", 23, 8) if kind == "nsf" else fused.uni_layout("affine", 2)
+    words = (ctypes.c_uint32 * 28)()
+    for i, lazy in enumerate(flow.transform.transforms):
+        plan = fused.build_plan([m.mask for m in lazy.hyper if isinstance(m, MaskedLinear)], 64, layout)
+        assert plan.n_chunks == (50 if kind == "nsf" else 19)
+        n = _C.lib().zk_ar_static_skip(layout.kind, 1 + i, words)
+        assert n == len(plan.skip) and [int(words[j]) for j in range(n)] == [int(v) for v in plan.skip]
+    other = NSF(48, 0, transforms=1, bins=8, hidden_features=[256] * 3).transform.transforms[0]
+    plan = fused.build_plan([m.mask for m in other.hyper if isinstance(m, MaskedLinear)], 48, fused.uni_layout("rqs", 23, 8))
+    n = _C.lib().zk_ar_static_skip(1, 1, words)
+    assert [int(words[j]) for j in range(n)] != [int(v) for v in plan.skip][:n] or n != len(plan.skip)
+    assert _C.lib().zk_ar_static_skip(2, 1, words) == 0 and _C.lib().zk_ar_static_skip(1, 3, words) == 0

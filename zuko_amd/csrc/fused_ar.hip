@@ -24,7 +24,7 @@
 //     registers; y is stored, ladj reduced over q with two shuffles and over groups in a register.
 //
 // Host-side planning (permutations, stream order, skip masks): zuko_amd/fused.py.
-#include "zk_univariate.h"
+#include "zk_ar_common.h"
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -36,49 +36,6 @@
 
 namespace zk {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define AR_TF 256 /* floats per tile image */
-#define AR_WAVES 8
-#define AR_T 16   /* activation tiles (256 units) */
-
-struct ArArgs {
-  int64_t N;
-  int D, DIN;               // features, conditioner inputs (features + context), DIN % 4 == 0
-  const float* x; int64_t ldx;  // [N, DIN] = cat(x, c) zero-padded to a multiple of 4; rows 16-byte aligned
-  float* y; int64_t ldy;
-  const float* yin; int64_t ldyin;  // INVERSE only: the values to invert (y of the forward map)
-  float* ladj; int accumulate;
-  const float* stream;
-  const float* bias;
-  const uint32_t* skip;
-  const int32_t* featmap;
-  int L, NG, n_chunks, act, bias_floats, dbg;
-  const int* sched;  // optional chunk schedule (partial inverse sweeps): stream chunk ids in consumption order
-  int n_sched;
-  int olim[8];       // per hidden layer: last out-group (of 4 tiles) to evaluate; 3 = all
-  int g0, g1;        // last-layer groups [g0, g1) to evaluate
-  int xlds;  // x (or y_in) and the result tile are staged in a wave-private LDS region (stride xs words)
-  int xs;
-  float bound, ls;
-  RqsLeanConst lc;   // spline epilogues: constants of rqs_lean
-  int64_t n_tiles;
-  int32_t* bin_out;  // diagnostic instantiation only: bin index [N, D] and the K+1 search-axis knots [N, D, K+1]
-  float* knots_out;
-};
-
-__device__ __forceinline__ float act_f32(float v, int act) {
-  switch (act) {
-    case 1: return v < 0.f ? 0.f : v;
-    case 2: return v > 0.f ? v : expm1f(v);
-    case 3: return tanhf(v);
-    case 4: return v / (1.f + expf(-v));
-    case 5: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    case 6: return 1.f / (1.f + expf(-v));
-    case 7: return v > 0.f ? v : 0.01f * v;
-    default: return v;
-  }
-}
 
 template <int CH, int NR> struct RingT {
   static constexpr int kChunk = CH, kSlots = NR;
@@ -131,60 +88,9 @@ template <int CH, int NR> struct RingT {
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-// ---- univariate epilogues -------------------------------------------------------------------------
-struct UniAffine {
-  static constexpr int TOTAL = 2, FPL = 2, NT = 1;
-  template <bool INV> static __device__ __forceinline__ void poison(float* p, int base, float nan_or_zero) {
-    p[base + 0] += nan_or_zero;
-    p[base + 1] += nan_or_zero;
-  }
-  static constexpr int NKNOT = 1;
-  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj, int* k = nullptr, float* ks = nullptr) {
-    affine_fwd<float, MathFast>(p(base + 0), p(base + 1), a.ls, x, y, lj);
-  }
-  template <typename P, typename A> static __device__ __forceinline__ float inv(const P& p, int base, const A& a, float y) {
-    return affine_inv<float, MathFast>(p(base + 0), p(base + 1), a.ls, y);
-  }
-};
-
-// K-bin rational-quadratic spline; CIRC: preceded by the circular shift of NCSF (zuko/flows/spline.py:65-72,
-// zuko/transforms.py:344-348: x -> remainder(x, 2B) - B with B = pi passed as `bound`).
-template <int K, bool CIRC> struct UniRqs {
-  static constexpr int TOTAL = 3 * K - 1, FPL = 1, NT = (TOTAL + 3) / 4;
-  static __device__ __forceinline__ float shift(float v, float bound) {
-    const float period = 2.f * bound;
-    float r = fmodf(v, period);
-    r = (r < 0.f) ? r + period : r;  // torch.remainder: result takes the sign of the divisor
-    return r - bound;
-  }
-  // All-NaN parameters (reference: zuko/nn.py:217-218 on a non-finite input) leave knot 0 = -B finite and every other
-  // knot NaN: values right of -B land in bin 0 with a NaN corner (y = NaN), values at or left of it, NaN and -inf keep
-  // y = v, and log|dy/dx| is NaN everywhere.  NaN widths (heights for the inverse, which searches the other axis) give
-  // exactly that: the remaining parameters never reach an output that is not already NaN.
-  template <bool INV> static __device__ __forceinline__ void poison(float* p, int base, float nan_or_zero) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) p[base + (INV ? K : 0) + j] += nan_or_zero;
-  }
-  static constexpr int NKNOT = K + 1;
-  // k / ks (diagnostic instantiation): bin index and search-axis knots of THIS evaluation
-  template <typename P, typename A> static __device__ __forceinline__ void fwd(const P& p, int base, const A& a, float x, float& y, float& lj, int* k = nullptr, float* ks = nullptr) {
-    int kk;
-    rqs_lean<K, false>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, [&](int j) { return p(base + 2 * K + j); }, a.lc,
-                       CIRC ? shift(x, a.bound) : x, y, lj, kk, ks);
-    if (k) *k = kk;
-  }
-  template <typename P, typename A> static __device__ __forceinline__ float inv(const P& p, int base, const A& a, float y) {
-    float x, lj;
-    rqs_lean<K, true>([&](int j) { return p(base + j); }, [&](int j) { return p(base + K + j); }, [&](int j) { return p(base + 2 * K + j); }, a.lc, y, x, lj);
-    return CIRC ? shift(x, a.bound) : x;
-  }
-};
-typedef UniRqs<8, false> UniRqs8;
-typedef UniRqs<4, false> UniRqs4;
-typedef UniRqs<16, false> UniRqs16;
-typedef UniRqs<8, true> UniCircRqs8;
-
 extern __shared__ __attribute__((aligned(16))) float ar_lds[];
+
+int ar_static_launch(ArArgs& a, int uni_kind, int variant, int lds, unsigned grid, hipStream_t stream);  // fused_ar_static.hip
 
 // one masked layer with <= 256 inputs / outputs: out = W in + bias, tiles skipped per (group of 4 out tiles, in tile)
 template <class Src>
@@ -505,7 +411,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   a.dbg = (variant >> 8) & 0xff;  // probe build only (-DZK_AR_TIMING=1): bit0 skip univariate math, bit3 / bit4 phase timestamps
   if ((variant & 0xff) != 0) return ZK_EINVAL;
 #else
-  if (variant != 0) return ZK_EINVAL;  // `variant` is reserved: the product build has exactly one kernel per (map, direction)
+  if (variant < 0 || variant > 2) return ZK_EINVAL;  // 0 = generic kernel, 1 / 2 = static-shape kernel (fused_ar_static.hip)
 #endif
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
   a.xs = ((D + 3) / 4) * 4 + 4;  // +4 words: 16-byte aligned rows whose stride is not a multiple of 32 banks
@@ -514,6 +420,13 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   const int lds = (ar_base_lds_floats(bias_floats) + (a.xlds ? 8 * 16 * a.xs : 0)) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+#if !ZK_AR_TIMING
+  if (variant != 0) {  // the caller has compared its plan's skip words with zk_ar_static_skip()
+    if (inverse || part.sched || part.bin_out || part.knots_out) return ZK_EINVAL;
+    if (a.xlds) return ar_static_launch(a, uni_kind, variant, lds, grid, (hipStream_t)stream);
+    // (rows that are not 16-byte addressable: the generic kernel's unstaged instantiation below; same results)
+  }
+#endif
   const void* fn = nullptr;
 #define ZK_AR_PICK(UNI)                                                                                                                     \
   (inverse ? (a.xlds ? (const void*)ar_kernel<UNI, true, Ring24x3, true> : (const void*)ar_kernel<UNI, true, Ring24x3, false>)            \

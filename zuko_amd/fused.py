@@ -376,6 +376,24 @@ class FusedAR:
         self.bias_floats = plan.bias_off[-1] + len(plan.bias_gather[-1])
         self.bias = torch.empty(self.bias_floats, dtype=torch.float32, device=device)
         self._stamp = None
+        self.static_variant = self._static_variant()
+
+    def _static_variant(self) -> int:
+        """1 / 2 when the plan is exactly the block pattern the static-shape kernel (csrc/fused_ar_static.hip) is compiled for."""
+        import ctypes
+        import os
+
+        from . import _C
+
+        p = self.plan
+        if os.environ.get("ZUKO_AMD_NO_STATIC_AR", "0") == "1" or self.act != 1 or p.n_layers != 4 or p.features != 64 or p.din != 64 or p.layout.kind not in (0, 1):
+            return 0
+        words = (ctypes.c_uint32 * 28)()
+        for variant in (1, 2):
+            n = _C.lib().zk_ar_static_skip(p.layout.kind, variant, words)
+            if n == len(p.skip) and all(int(words[i]) == int(p.skip[i]) for i in range(n)):
+                return variant
+        return 0
 
     def refresh(self, linears) -> None:
         """(Re)build the weight stream / bias image if any parameter changed since the last call."""
@@ -414,7 +432,7 @@ class FusedAR:
         err = _C.lib().zk_ar_forward(
             p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
             _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, 0, _stream(),
+            self.act, self.bound, self.slope, self.static_variant if inp.shape[1] == 64 else 0, _stream(),
         )
         _C.check(err, "zk_ar_forward")
 
