@@ -351,7 +351,7 @@ def main() -> None:
         torch.cuda.synchronize()
         prof, _C.PROFILE = _C.PROFILE, None
         for name, recs in prof.items():
-            groups = {}
+            groups, variants = {}, {}
             for a, b, cargs in recs:
                 if name == "zk_linear_bf16_rqs":  # N, in, panels, K, features
                     sizes = (cargs[0], cargs[1], cargs[2], cargs[8], cargs[9])
@@ -359,8 +359,11 @@ def main() -> None:
                     sizes = cargs[0:3] if name == "zk_linear_bf16" else cargs[1:4]  # (dtype-less signature)
                 key = (name,) + tuple(v for v in sizes if isinstance(v, int))
                 groups.setdefault(key, []).append(a.elapsed_time(b))
+                if name == "zk_ar_forward":  # variant argument: 0 = generic tile-skipping kernel, 1 / 2 = static-shape kernel (csrc/fused_ar_static.hip)
+                    variants.setdefault(key, set()).add("static-shape" if cargs[21] else "generic")
             for key, ts in groups.items():
-                kernels[" ".join(map(str, key))] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), **({"bf16": True} if bf16 else {})}
+                kernels[" ".join(map(str, key))] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), **({"bf16": True} if bf16 else {}),
+                                                    **({"instantiation": "+".join(sorted(variants[key]))} if key in variants else {})}
         # the standalone (phi-in-HBM) spline kernel is not on the fused path: time it on its own so its
         # HBM fraction (the bandwidth-bound roofline of north_star) is measured in the same run
         if args.config == "cfg2":
@@ -503,7 +506,7 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
         roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                 "traffic": traffic, "traffic_source": (f"{src}: rocprofv3 --pmc passes of this same command, not re-measured in this run" if src else None),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]}
-        for k in ("algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
+        for k in ("instantiation", "algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
             if k in dom:
                 roof[k] = dom[k]
     return roof, table

@@ -18,6 +18,9 @@
 // Host-side planning (stream order, bias image, index maps): zuko_amd/coupling_plan.py.
 #include "zk_univariate.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace zk {
 
 typedef float f32x4c __attribute__((ext_vector_type(4)));
@@ -345,68 +348,46 @@ __global__ __launch_bounds__(256, 1) void coupling_kernel(CpArgs a) {
 // groups): no per-tile guards, and the position of every weight tile inside the pass is a compile-time constant, so the ring
 // refill (barrier + DMA issue) is emitted only where that position is a multiple of the chunk size and the code between
 // two refills is one basic block the scheduler can software-pipeline (ds_read of the next tiles above the current MFMAs).
-#ifndef CP_FILL_SPREAD
-#define CP_FILL_SPREAD 0  // 1: one refill DMA per step of four tiles instead of six back to back after the chunk barrier
-#endif
 #ifndef ZK_CP_ABLATE
-#define ZK_CP_ABLATE 0  // probe builds only (wrong results): 1 = no ring DMAs in the steady state, 2 = no chunk barriers, 4 = no row staging / stores
+#define ZK_CP_ABLATE 0  // probe builds only (wrong results): 2 = no chunk barriers / refills, 4 = no row staging / stores, 8 = no s_barrier, 32 = no ring DMAs
 #endif
 #ifndef ZK_CP_TIMING
 #define ZK_CP_TIMING 0  // -DZK_CP_TIMING=1: s_memtime phase probes printed by wave 0 of block 0 (probe build only)
 #endif
+#define CP_ALWAYS_INLINE __attribute__((always_inline))
+template <class F, int... I> __device__ __forceinline__ void cp_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void cp_for(F&& f) { cp_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 struct CpRingS {
   unsigned long long t_wait = 0, t_bar = 0, t_iss = 0;
   float* lds;
   const float* stream;
-  const float* cur;
+  unsigned cur_off;  // LDS byte address of the slot being read + lane * 16
+  unsigned lds_off;  // LDS byte address of the ring
   int n_chunks, slot, load_chunk, load_slot, wave, lane;
-  // The refill of a released slot is spread over the consumption of the next chunk, one 1 KiB DMA per four tiles: issued
-  // back to back at the barrier, the six DMAs of a wave stall its instruction stream for ~1100 cycles per chunk (the vector
-  // memory path accepts ~22 B/clk per CU while four waves push 24 KiB at once; measured with the ZK_CP_TIMING probes:
-  // 12.7 % of the pass) — with no second wave on the SIMD that is matrix time lost.
-  int fill_chunk, fill_slot, fill_done;
   static constexpr int kPerWave = CP_CH / CP_WAVES;
-  static_assert(kPerWave == 6, "issue_one() enumerates six tiles");
-  // each wave copies kPerWave consecutive tiles of the chunk; tile i = address / M0 value of its group of four + the
-  // instruction's immediate offset (one M0 write serves four DMAs: ~20 cycles of issue each, scripts/probes/dma_issue_probe.hip)
-  const float* fill_g;
-  float* fill_l;
-  __device__ __forceinline__ void fill_begin() {  // address / LDS base of the wave's FIFTH tile: immediates -4096 .. +1024 reach all six
-    const int b4 = wave * kPerWave + 4;
-    fill_g = stream + ((size_t)fill_chunk * CP_CH + b4) * 256 + lane * 4;
-    fill_l = lds + (fill_slot * CP_CH + b4) * 256;
-  }
-  template <int I> __device__ __forceinline__ void issue_static() {
-    if (!(ZK_CP_ABLATE & 32))
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)fill_g, (__attribute__((address_space(3))) void*)fill_l, 16, (I - 4) * 1024, 0);
-  }
-  __device__ __forceinline__ void issue_one(int i) {
-    switch (i) {
-      case 0: issue_static<0>(); break;
-      case 1: issue_static<1>(); break;
-      case 2: issue_static<2>(); break;
-      case 3: issue_static<3>(); break;
-      case 4: issue_static<4>(); break;
-      default: issue_static<5>(); break;
+  static_assert(kPerWave == 6, "immediates -4096 .. +1024 around the wave's fifth tile reach six tiles");
+  // Each wave copies kPerWave consecutive tiles of a chunk, six DMAs back to back on ONE address / M0 value (that of its fifth
+  // tile) with the instruction's signed immediate offset: ~40 cycles of issue for the first, ~15 for each further one
+  // (scripts/probes/dma_issue_probe.hip).  Spreading them over the chunk (one per step) was measured: no better.
+  template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
+    if constexpr (I < kPerWave) {
+      if (!(ZK_CP_ABLATE & 32)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, (I - 4) * 1024, 0);
+      dma<I + 1>(g, l);
     }
   }
-  __device__ __forceinline__ void issue() {  // whole chunk at once (prologue)
-    fill_chunk = load_chunk; fill_slot = load_slot;
-    fill_begin();
-#pragma unroll
-    for (int i = 0; i < kPerWave; ++i) issue_one(i);
-    fill_done = kPerWave;
+  __device__ __forceinline__ void issue() {
+    const int b4 = wave * kPerWave + 4;
+    dma<0>(stream + ((size_t)load_chunk * CP_CH + b4) * 256 + lane * 4, lds + (load_slot * CP_CH + b4) * 256);
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
     load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
   }
   __device__ __forceinline__ void advance() {
     unsigned long long p0 = 0, p1 = 0, p2 = 0;
     if (ZK_CP_TIMING) p0 = __builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (; fill_done < kPerWave; ++fill_done) issue_one(fill_done);  // a layer that ended inside its last chunk left DMAs unissued
     // my DMAs of the chunk about to be read have landed (the CP_NR - 2 younger chunks stay in flight: a DMA takes ~5 k cycles,
     // one chunk is consumed in ~3 k); my (prefetching) reads of the slot to be refilled have returned
-    if (!(ZK_CP_ABLATE & 16)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CP_NR - 2) * (CP_CH / CP_WAVES)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CP_NR - 2) * (CP_CH / CP_WAVES)) : "memory");
     if (ZK_CP_TIMING) p1 = __builtin_amdgcn_s_memtime();
     if (!(ZK_CP_ABLATE & 8)) __builtin_amdgcn_s_barrier();  // bare barrier: __syncthreads() would prepend s_waitcnt vmcnt(0) and drain the look-ahead DMAs
     asm volatile("" ::: "memory");
@@ -414,31 +395,27 @@ struct CpRingS {
       p2 = __builtin_amdgcn_s_memtime();
       t_wait += p1 - p0; t_bar += p2 - p1;
     }
-    fill_chunk = load_chunk; fill_slot = load_slot; fill_done = 0;  // the slot just released
-    fill_begin();
-    if (!CP_FILL_SPREAD) {  // six DMAs back to back on one M0 value: ~40 cycles of issue for the first, ~15 for each further one
-#pragma unroll
-      for (int i = 0; i < kPerWave; ++i) issue_one(i);
-      fill_done = kPerWave;
-    }
-    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
-    load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
+    issue();  // the slot just released
     slot = (slot + 1 == CP_NR) ? 0 : slot + 1;
-    cur = lds + slot * CP_CH * 256 + lane * 4;
+    cur_off = lds_off + (unsigned)(slot * CP_CH * 1024 + lane * 16);
   }
-  __device__ __forceinline__ f32x4c read(int s) {  // s: position inside the layer (layers start on chunk boundaries)
-    if (s % CP_CH == 0 && !(ZK_CP_ABLATE & 2)) advance();
-    return *reinterpret_cast<const f32x4c*>(cur + (s % CP_CH) * 256);
-  }
-  // one refill DMA per step of four tiles; called where the wave has no LDS read outstanding (s = first tile of the step
-  // being multiplied, whose chunk was entered by an earlier read())
-  __device__ __forceinline__ void fill(int s) {
-    if (CP_FILL_SPREAD && s % 4 == 0 && (s % CP_CH) / 4 < kPerWave && !(ZK_CP_ABLATE & 1)) {
-      issue_one((s % CP_CH) / 4);
-      fill_done = (s % CP_CH) / 4 + 1;
+  // Position S inside the layer (layers start on chunk boundaries; static).  The read is issued from inline assembly and returns
+  // a RAW value: the compiler does not know it is an LDS operation and inserts no wait for it — with a global_load_lds in flight
+  // hipcc turns every LDS wait into lgkmcnt(0), which would make a step wait for the tiles it has just requested for the NEXT
+  // step.  cp_settle<N>() makes the value usable: it waits until at most N younger LDS operations are outstanding (LDS
+  // operations of a wave complete in order) and is the only consumer of the raw registers (tests/test_codegen.py checks the ISA).
+  template <int S> __device__ __forceinline__ f32x4c read() {
+    if constexpr (S % CP_CH == 0) {
+      if (!(ZK_CP_ABLATE & 2)) advance();
     }
+    f32x4c v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(cur_off), "n"((S % CP_CH) * 1024));
+    return v;
   }
 };
+template <int N> __device__ __forceinline__ void cp_settle(f32x4c& a0, f32x4c& a1, f32x4c& a2, f32x4c& a3) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N));
+}
 
 template <int NIN, int HT> __device__ __forceinline__ void cp_layer_static(CpRingS& ring, const float* bias_q, const CpAct& in, const CpAct& out) {
   // software pipeline: the four A tiles of step s + 1 are requested (into the other register set) before the 16 MFMAs of
@@ -446,33 +423,24 @@ template <int NIN, int HT> __device__ __forceinline__ void cp_layer_static(CpRin
   // partner wave to hide it)
   constexpr int STEPS = (HT / 4) * NIN;
   f32x4c a[2][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) a[0][t] = ring.read(t);
-#pragma unroll
-  for (int st = 0; st < STEPS; ++st) {
-    const int otg = st / NIN, it = st % NIN;
-    if (it == 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) out[otg * 4 + t] = *reinterpret_cast<const f32x4c*>(bias_q + (otg * 4 + t) * 16);
+  cp_for<4>([&](auto t) CP_ALWAYS_INLINE { a[0][t] = ring.template read<decltype(t)::value>(); });
+  cp_for<STEPS>([&](auto st_) CP_ALWAYS_INLINE {
+    constexpr int st = st_, otg = st / NIN, it = st % NIN;
+    if constexpr (it == 0) {
+      cp_for<4>([&](auto t) CP_ALWAYS_INLINE { out[otg * 4 + t] = *reinterpret_cast<const f32x4c*>(bias_q + (otg * 4 + t) * 16); });
+    }
+    if constexpr (st + 1 < STEPS) {
+      cp_for<4>([&](auto t) CP_ALWAYS_INLINE { a[(st + 1) & 1][t] = ring.template read<(st + 1) * 4 + decltype(t)::value>(); });
+      cp_settle<4>(a[st & 1][0], a[st & 1][1], a[st & 1][2], a[st & 1][3]);
+    } else {
+      cp_settle<0>(a[st & 1][0], a[st & 1][1], a[st & 1][2], a[st & 1][3]);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][t][r], in[it][r], out[otg * 4 + t], 0, 0, 0);
+    cp_for<4>([&](auto r) CP_ALWAYS_INLINE {
+      cp_for<4>([&](auto t) CP_ALWAYS_INLINE { out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][t][(int)r], in[it][(int)r], out[otg * 4 + t], 0, 0, 0); });
+    });
     __builtin_amdgcn_sched_barrier(0);
-    ring.fill(st * 4);
-    if (st + 1 < STEPS) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[(st + 1) & 1][t] = ring.read((st + 1) * 4 + t);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 2; r < 4; ++r)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1][t][r], in[it][r], out[otg * 4 + t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  });
 }
 
 template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_kernel_static(CpArgs a) {
@@ -498,7 +466,8 @@ template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_ke
 #pragma unroll
   for (int i = 0; i < CP_NR - 1; ++i) ring.issue();
   ring.slot = CP_NR - 1;
-  ring.cur = cp_lds;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)cp_lds);
+  ring.cur_off = ring.lds_off;
   __syncthreads();
 
   const int xs = a.xs;
@@ -548,37 +517,30 @@ template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_ke
     // multiple of the chunk — the position is carried in a run-time base that only changes by multiples of the chunk)
     static_assert((3 * HT) % CP_CH == 0, "three groups of the last layer must fill whole chunks");
     for (int g3 = 0; g3 < a.NG; g3 += 3) {
-#pragma unroll
-      for (int gg = 0; gg < 3; ++gg) {
+      cp_for<3>([&](auto gg_) CP_ALWAYS_INLINE {
+        constexpr int gg = gg_;
         const int g = g3 + gg;
         if (g < a.NG) {
           const int f0 = fmap_lds[g * 8 + 2 * q], f1 = fmap_lds[g * 8 + 2 * q + 1];
           const float x0 = xrow[f0 < 0 ? 0 : f0], x1 = xrow[f1 < 0 ? 0 : f1];
           // four accumulators (one per tile of the step): a dependent MFMA every fourth issue, as in the hidden layers
           f32x4c acc[4] = {*reinterpret_cast<const f32x4c*>(bias_last + g * 16), {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-          f32x4c w[2][4];  // four tiles per step, the next step requested in the middle of this step's MFMAs
-#pragma unroll
-          for (int t = 0; t < 4; ++t) w[0][t] = ring.read(gg * HT + t);
-#pragma unroll
-          for (int it = 0; it < HT; it += 4) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(it >> 2) & 1][t][r], out[it + t][r], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            ring.fill(gg * HT + it);
-            if (it + 4 < HT) {
-#pragma unroll
-              for (int t = 0; t < 4; ++t) w[((it >> 2) + 1) & 1][t] = ring.read(gg * HT + it + 4 + t);
+          f32x4c w[2][4];  // four tiles per step, the next step requested before this step's MFMAs
+          cp_for<4>([&](auto t) CP_ALWAYS_INLINE { w[0][t] = ring.template read<gg * HT + decltype(t)::value>(); });
+          cp_for<HT / 4>([&](auto k_) CP_ALWAYS_INLINE {
+            constexpr int k = k_, it = 4 * k;
+            if constexpr (it + 4 < HT) {
+              cp_for<4>([&](auto t) CP_ALWAYS_INLINE { w[(k + 1) & 1][t] = ring.template read<gg * HT + it + 4 + decltype(t)::value>(); });
+              cp_settle<4>(w[k & 1][0], w[k & 1][1], w[k & 1][2], w[k & 1][3]);
+            } else {
+              cp_settle<0>(w[k & 1][0], w[k & 1][1], w[k & 1][2], w[k & 1][3]);
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 2; r < 4; ++r)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(it >> 2) & 1][t][r], out[it + t][r], acc[t], 0, 0, 0);
+            cp_for<4>([&](auto r) CP_ALWAYS_INLINE {
+              cp_for<4>([&](auto t) CP_ALWAYS_INLINE { acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k & 1][t][(int)r], out[it + t][(int)r], acc[t], 0, 0, 0); });
+            });
             __builtin_amdgcn_sched_barrier(0);
-          }
+          });
           const f32x4c p = (acc[0] + acc[1]) + (acc[2] + acc[3]);
           float y0, y1, l0, l1;
           affine_fwd<float, MathFast>(p[0], p[1], a.ls, x0, y0, l0);
@@ -586,7 +548,7 @@ template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_ke
           if (f0 >= 0) { xrow[f0] = y0; lacc += l0; }
           if (f1 >= 0) { xrow[f1] = y1; lacc += l1; }
         }
-      }
+      });
     }
     if (ZK_CP_TIMING) ts[4] = __builtin_amdgcn_s_memtime();
     asm volatile("" ::: "memory");
