@@ -391,7 +391,8 @@ def main() -> None:
             st = flow.transform.transforms[0].fused_state(dev)
         except Exception:
             st = None
-        executed = None if st is None or not hasattr(st.plan, "kept_tiles") else st.plan.kept_tiles * 512.0  # 16 x 16 x 2 FLOP per kept tile per sample
+        # 16 x 16 x 2 FLOP per streamed tile per sample (the static-shape kernel streams fewer tiles than the generic one)
+        executed = None if st is None or not hasattr(st.plan, "kept_tiles") else (st.plan.fine_kept_tiles if getattr(st, "static_variant", 0) else st.plan.kept_tiles) * 512.0
         last = [m for m in flow.transform.transforms[0].hyper.modules() if getattr(m, "weight", None) is not None][-1]
         lmask = getattr(last, "mask", None)
         per_transform["last_layer_nnz_frac"] = 1.0 if lmask is None else float(lmask.float().mean())

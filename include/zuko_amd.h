@@ -222,8 +222,15 @@ int zk_ar_lds_bytes(int variant, int bias_floats);
  * straight-line code.  zk_ar_static_skip writes the skip words (same layout as zk_ar_forward's `skip`: 4 per hidden layer,
  * then one per feature group; at most 28) a plan MUST have for that variant and returns their count (0: no such kernel):
  * variant 1 = first-layer pattern of an ascending feature order, 2 = of a descending one.  The caller compares its plan
- * against them once; zk_ar_forward itself only checks the shape arguments.  Results are bit-identical to variant 0. */
+ * against them once; zk_ar_forward itself only checks the shape arguments.  Results are bit-identical to variant 0 (the
+ * tiles the static stream drops hold zeros only). */
 int zk_ar_static_skip(int uni_kind, int variant, uint32_t* out_words);
+/* The static kernel consumes a PER-TILE stream: inside a kept (out-group, input tile) block of hidden layers 2 and 3 only the
+ * 16x16 tiles that hold non-zero weights are streamed (ArPlan.fine_gather of zuko_amd/fused.py; 48 chunks for uni_kind 1, 17
+ * for uni_kind 0 — pass THAT stream and chunk count with variant 1 / 2).  zk_ar_static_tiles writes the pattern it is compiled
+ * for: out[(l * 4 + otg) * 16 + it] = 4-bit mask of the out tiles of group otg multiplied by input tile it of hidden layer l
+ * (192 bytes; returns 192, or 0 if there is no such kernel).  Rows of x and y must be 16-byte addressable (EINVAL otherwise). */
+int zk_ar_static_tiles(int uni_kind, int variant, uint8_t* out_masks);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
 int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);

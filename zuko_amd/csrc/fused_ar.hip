@@ -423,8 +423,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
 #if !ZK_AR_TIMING
   if (variant != 0) {  // the caller has compared its plan's skip words with zk_ar_static_skip()
     if (inverse || part.sched || part.bin_out || part.knots_out) return ZK_EINVAL;
-    if (a.xlds) return ar_static_launch(a, uni_kind, variant, lds, grid, (hipStream_t)stream);
-    // (rows that are not 16-byte addressable: the generic kernel's unstaged instantiation below; same results)
+    return ar_static_launch(a, uni_kind, variant, lds, grid, (hipStream_t)stream);  // (needs 16-byte addressable rows: EINVAL otherwise)
   }
 #endif
   const void* fn = nullptr;

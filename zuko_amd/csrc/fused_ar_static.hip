@@ -11,7 +11,7 @@
 //     layers 2, 3 (256^2):   out-group o multiplies input tiles 0 .. 4 (o + 1) - 1
 //     last layer:            feature group g (4 lanes x FPL features) multiplies hidden tiles 0 .. FPL (g + 1) - 1
 //
-// so the weight stream of fused.py has a fixed length (50 chunks of 24 tiles for the spline, 19 for the affine map) and
+// so the (per-tile) weight stream of fused.py has a fixed length (48 chunks of 24 tiles for the spline, 17 for the affine map) and
 // every tile's position in it is a compile-time constant.  The generic kernel finds that structure at run time (a
 // wave-uniform bit test and branch per tile block, `s_waitcnt lgkmcnt(0)` at every join, ring position in a register);
 // here the pass over a 16-sample wave tile is straight-line code: ring refills only where a position is a multiple of the
@@ -35,12 +35,30 @@ template <class F, int... I> __device__ __forceinline__ void ars_for_impl(F&& f,
 template <int N, class F> __device__ __forceinline__ void ars_for(F&& f) { ars_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // ---- the block pattern -------------------------------------------------------------------------------------------
+// Hidden layers: step s of a layer = (out-group otg of 4 tiles, j-th input tile of that group); layer 1 multiplies whole
+// 4-tile blocks, layers 2 and 3 only the 16x16 tiles that hold non-zero weights: inside the diagonal 64x64 block of out-group o
+// its k-th input tile (it = 4 o + k) reaches out tiles t >= k (the units are sorted by dependency count), except that zuko
+// gives the first degrees five units each, which makes tile (0, 1) non-empty as well (zuko_amd/fused.py: ArPlan.fine_tilemask
+// is compared with zk_ar_static_tiles() before this kernel is selected).
 __host__ __device__ constexpr int ars_hid_steps(int l) { return l == 0 ? 10 : 40; }
 __host__ __device__ constexpr int ars_hid_first(int l, int otg) { return l == 0 ? otg * (otg + 1) / 2 : 2 * otg * (otg + 1); }
 __host__ __device__ constexpr int ars_hid_otg(int l, int s) { return s < ars_hid_first(l, 1) ? 0 : s < ars_hid_first(l, 2) ? 1 : s < ars_hid_first(l, 3) ? 2 : 3; }
-__host__ __device__ constexpr int ars_hid_base(int l) { return l == 0 ? 0 : l == 1 ? 48 : 216; }  // 40 -> 48 and 160 -> 168 tiles: layers are padded to whole chunks
-__host__ __device__ constexpr int ars_last_base() { return 384; }
+__host__ __device__ constexpr unsigned ars_tmask(int l, int otg, int j) {  // bit t: out tile 4 otg + t is multiplied in step (otg, j)
+  if (l == 0) return 0xFu;
+  const int k = j - 4 * otg;
+  return k < 0 ? 0xFu : (otg == 0 && k == 1) ? 0xFu : (0xFu << k) & 0xFu;
+}
+__host__ __device__ constexpr int ars_popc(unsigned m) { return (int)((m & 1u) + ((m >> 1) & 1u) + ((m >> 2) & 1u) + ((m >> 3) & 1u)); }
+__host__ __device__ constexpr unsigned ars_step_mask(int l, int s) { return ars_tmask(l, ars_hid_otg(l, s), s - ars_hid_first(l, ars_hid_otg(l, s))); }
+__host__ __device__ constexpr int ars_hid_pos(int l, int s) {  // tiles of layer l streamed before step s
+  int n = 0;
+  for (int i = 0; i < s; ++i) n += ars_popc(ars_step_mask(l, i));
+  return n;
+}
+__host__ __device__ constexpr int ars_hid_base(int l) { return l == 0 ? 0 : l == 1 ? 48 : 192; }  // 40 -> 48 and 137 -> 144 tiles: layers are padded to whole chunks
+__host__ __device__ constexpr int ars_last_base() { return 336; }
 __host__ __device__ constexpr int ars_last_first(int fpl, int g) { return fpl * g * (g + 1) / 2; }  // steps before group g
+static_assert(ars_hid_pos(0, 10) == 40 && ars_hid_pos(1, 40) == 137 && ars_hid_pos(2, 40) == 137, "tiles per hidden layer");
 
 struct ArRingS {
   float* lds;
@@ -99,15 +117,22 @@ extern __shared__ __attribute__((aligned(16))) float ars_lds[];
 template <int L> __device__ __forceinline__ void ars_hidden(ArRingS& ring, const float* bias_q, const f32x4 (&in)[AR_T], f32x4 (&out)[AR_T], bool rev) {
   constexpr int NS = ars_hid_steps(L), BASE = ars_hid_base(L);
   f32x4 a[2][4];
-  ars_for<4>([&](auto t) ARS_ALWAYS_INLINE { a[0][t] = ring.template read<BASE + decltype(t)::value>(); });
+  ars_for<4>([&](auto t) ARS_ALWAYS_INLINE { a[0][t] = ring.template read<BASE + decltype(t)::value>(); });  // (step 0 multiplies all four tiles)
+  static_assert(ars_step_mask(L, 0) == 0xFu, "first step");
   ars_for<NS>([&](auto s_) ARS_ALWAYS_INLINE {
     constexpr int s = s_, otg = ars_hid_otg(L, s), j = s - ars_hid_first(L, otg);
+    constexpr unsigned M = ars_step_mask(L, s);
     if constexpr (j == 0) {
       ars_for<4>([&](auto t) ARS_ALWAYS_INLINE { out[otg * 4 + t] = *reinterpret_cast<const f32x4*>(bias_q + (otg * 4 + t) * 16); });  // accumulators start at the bias
     }
     if constexpr (s + 1 < NS) {
-      ars_for<4>([&](auto t) ARS_ALWAYS_INLINE { a[(s + 1) & 1][t] = ring.template read<BASE + (s + 1) * 4 + decltype(t)::value>(); });
-      ars_settle<4>(a[s & 1][0], a[s & 1][1], a[s & 1][2], a[s & 1][3]);  // this step's tiles are in; the next step's four may be outstanding
+      constexpr unsigned MN = ars_step_mask(L, s + 1);
+      constexpr int PN = BASE + ars_hid_pos(L, s + 1);
+      ars_for<4>([&](auto t) ARS_ALWAYS_INLINE {
+        constexpr int tt = decltype(t)::value;
+        if constexpr ((MN >> tt) & 1u) a[(s + 1) & 1][tt] = ring.template read<PN + ars_popc(MN & ((1u << tt) - 1u))>();
+      });
+      ars_settle<ars_popc(MN)>(a[s & 1][0], a[s & 1][1], a[s & 1][2], a[s & 1][3]);  // this step's tiles are in; only the next step's may be outstanding
     } else {
       ars_settle<0>(a[s & 1][0], a[s & 1][1], a[s & 1][2], a[s & 1][3]);
     }
@@ -122,7 +147,9 @@ template <int L> __device__ __forceinline__ void ars_hidden(ArRingS& ring, const
       b = in[j];
     }
     ars_for<4>([&](auto r) ARS_ALWAYS_INLINE {
-      ars_for<4>([&](auto t) ARS_ALWAYS_INLINE { out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][t][(int)r], b[(int)r], out[otg * 4 + t], 0, 0, 0); });
+      ars_for<4>([&](auto t) ARS_ALWAYS_INLINE {
+        if constexpr ((M >> decltype(t)::value) & 1u) out[otg * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][t][(int)r], b[(int)r], out[otg * 4 + t], 0, 0, 0);
+      });
     });
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -270,8 +297,8 @@ template <typename Uni> __global__ __launch_bounds__(512, 2) void ar_static_kern
 int ar_static_launch(ArArgs& a, int uni_kind, int variant, int lds, unsigned grid, hipStream_t stream) {
   if (a.D != 64 || a.DIN != 64 || a.L != 4 || a.act != 1 || !a.xlds || a.sched || (variant != 1 && variant != 2)) return ZK_EINVAL;
   const void* fn = nullptr;
-  if (uni_kind == 1 && a.NG == 16 && a.n_chunks == 50) fn = (const void*)ar_static_kernel<UniRqs8>;
-  else if (uni_kind == 0 && a.NG == 8 && a.n_chunks == 19) fn = (const void*)ar_static_kernel<UniAffine>;
+  if (uni_kind == 1 && a.NG == 16 && a.n_chunks == 48) fn = (const void*)ar_static_kernel<UniRqs8>;
+  else if (uni_kind == 0 && a.NG == 8 && a.n_chunks == 17) fn = (const void*)ar_static_kernel<UniAffine>;
   else return ZK_EINVAL;
   a.l1rev = variant == 2;
   hipError_t e = hipSuccess;
@@ -308,6 +335,20 @@ int zk_ar_static_skip(int uni_kind, int variant, uint32_t* out) {
     for (int o = 0; o < 4; ++o) out[n++] = (1u << (4 * (o + 1))) - 1u;
   for (int g = 0; g < ng; ++g) out[n++] = (1u << (fpl * (g + 1))) - 1u;
   return n;
+}
+
+// The per-tile pattern of the stream the static kernel consumes (ArPlan.fine_tilemask of zuko_amd/fused.py): out[(l * 4 + otg) * 16 + it]
+// = 4-bit mask of the out tiles of group otg that input tile it of hidden layer l is multiplied into (0: block skipped).
+// Returns 192 (3 layers x 4 out-groups x 16 input tiles), or 0 if (uni_kind, variant) has no static kernel.
+int zk_ar_static_tiles(int uni_kind, int variant, uint8_t* out) {
+  if ((uni_kind != 0 && uni_kind != 1) || (variant != 1 && variant != 2)) return 0;
+  for (int i = 0; i < 192; ++i) out[i] = 0;
+  for (int o = 0; o < 4; ++o)
+    for (int j = 0; j <= o; ++j) out[(0 * 4 + o) * 16 + (variant == 1 ? j : 3 - o + j)] = 0xF;
+  for (int l = 1; l < 3; ++l)
+    for (int o = 0; o < 4; ++o)
+      for (int it = 0; it < 4 * (o + 1); ++it) out[(l * 4 + o) * 16 + it] = (uint8_t)zk::ars_tmask(l, o, it);
+  return 192;
 }
 
 }  // extern "C"

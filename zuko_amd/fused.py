@@ -84,6 +84,14 @@ class ArPlan:
     otg_blocks_end: list = None
     group_chunk0: list = None  # (align_groups plans) first chunk / chunk count of every last-layer group
     group_nchunks: list = None
+    # second stream for the static-shape kernel (csrc/fused_ar_static.hip): inside a kept (out-group, in-tile) block only the
+    # 16x16 tiles that hold non-zero weights (the strictly upper tiles of the diagonal 64x64 blocks are dropped)
+    fine_gather: list = None       # per layer, like `gather`
+    fine_layer_block0: list = None
+    fine_n_blocks: int = 0
+    fine_n_chunks: int = 0
+    fine_tilemask: np.ndarray = None  # uint8 [n_layers - 1, 4, 16]: bit t = out tile 4 otg + t multiplies in tile it
+    fine_kept_tiles: int = 0       # tiles of the per-tile stream (without chunk padding)
 
 
 def _deps(masks: list[np.ndarray]) -> list[np.ndarray]:
@@ -131,7 +139,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
     gather, layer_block0, bias_gather, bias_off, skip = [], [], [], [], []
     block_cursor = 0
     bias_cursor = 0
-    dense_tiles = kept_tiles = 0
+    dense_tiles = kept_tiles = fine_kept = 0
 
     lane = np.arange(64)
     li, lq = lane % 16, lane // 16
@@ -163,6 +171,18 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         layer_block0.append(block_cursor)
         block_cursor += len(blocks)
 
+    fine_gather, fine_layer_block0 = [], []
+    fine_cursor = 0
+    tilemask = np.zeros((L - 1, MAX_WIDTH // TILE // GROUP_HIDDEN, MAX_WIDTH // TILE), dtype=np.uint8)
+
+    def finish_fine_layer(blocks: list[np.ndarray]) -> None:
+        nonlocal fine_cursor
+        n = len(blocks)
+        blocks = blocks + [-np.ones(256, dtype=np.int64)] * (-(-n // chunk) * chunk - n)
+        fine_gather.append(np.concatenate(blocks).astype(np.int32) if blocks else np.zeros(0, np.int32))
+        fine_layer_block0.append(fine_cursor)
+        fine_cursor += len(blocks)
+
     otg_blocks_end: list[list[int]] = []  # [layer][otg] blocks of the layer consumed once out-group otg is done
     group_chunk0: list[int] = []
     group_nchunks: list[int] = []
@@ -173,6 +193,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         n_ot = len(rows_all) // TILE
         n_it = len(in_cols) // TILE
         blocks = []
+        fblocks = []
         for otg in range(MAX_WIDTH // TILE // GROUP_HIDDEN):
             bits = 0
             ots = [otg * GROUP_HIDDEN + t for t in range(GROUP_HIDDEN)]
@@ -187,13 +208,19 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
                                 nz = True
                     if nz:
                         bits |= 1 << it
-                        for ot in ots:
+                        for t, ot in enumerate(ots):
                             rr = rows_all[ot * TILE : (ot + 1) * TILE] if ot < n_ot else -np.ones(TILE, dtype=np.int64)
-                            blocks.append(block_index(rr, cc, M[l].shape[1]))
+                            blk = block_index(rr, cc, M[l].shape[1])
+                            blocks.append(blk)
                             kept_tiles += 1
+                            if l == 0 or (ot < n_ot and tile_nonzero(M[l], rr, cc)):  # (layer 1 keeps whole blocks: its columns are features, not sorted units)
+                                fblocks.append(blk)
+                                fine_kept += 1
+                                tilemask[l, otg, it] |= 1 << t
             skip.append(bits)
             otg_blocks_end[l].append(len(blocks))
         finish_layer(blocks)
+        finish_fine_layer(fblocks)
         b = -np.ones(MAX_WIDTH, dtype=np.int64)
         b[: len(rows_all)] = rows_all
         bias_gather.append(b.astype(np.int32))
@@ -228,6 +255,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
                 for rows in tiles_rows:
                     blocks.append(block_index(rows, cc, M[-1].shape[1]))
                     kept_tiles += 1
+                    fine_kept += 1
         skip.append(bits)
         if align_groups:
             n = len(blocks) - g_start
@@ -235,6 +263,8 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
             group_chunk0.append((block_cursor + g_start) // chunk)
             group_nchunks.append((len(blocks) - g_start) // chunk)
     finish_layer(blocks)
+    if not align_groups:
+        finish_fine_layer(blocks)
     bias_gather.append(np.concatenate(bias_last).astype(np.int32))
     bias_off.append(bias_cursor)
 
@@ -258,6 +288,12 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         otg_blocks_end=otg_blocks_end,
         group_chunk0=group_chunk0,
         group_nchunks=group_nchunks,
+        fine_gather=None if align_groups else fine_gather,
+        fine_layer_block0=None if align_groups else fine_layer_block0,
+        fine_n_blocks=0 if align_groups else fine_cursor,
+        fine_n_chunks=0 if align_groups else fine_cursor // chunk,
+        fine_tilemask=tilemask,
+        fine_kept_tiles=0 if align_groups else fine_kept,
     )
 
 
@@ -377,6 +413,9 @@ class FusedAR:
         self.bias = torch.empty(self.bias_floats, dtype=torch.float32, device=device)
         self._stamp = None
         self.static_variant = self._static_variant()
+        if self.static_variant:  # the static-shape kernel reads its own (per-tile) stream
+            self.fine_gather = [torch.from_numpy(g).to(device) for g in plan.fine_gather]
+            self.fine_stream = torch.empty(plan.fine_n_blocks * 256, dtype=torch.float32, device=device)
 
     def _static_variant(self) -> int:
         """1 / 2 when the plan is exactly the block pattern the static-shape kernel (csrc/fused_ar_static.hip) is compiled for."""
@@ -388,11 +427,17 @@ class FusedAR:
         p = self.plan
         if os.environ.get("ZUKO_AMD_NO_STATIC_AR", "0") == "1" or self.act != 1 or p.n_layers != 4 or p.features != 64 or p.din != 64 or p.layout.kind not in (0, 1):
             return 0
+        if p.fine_gather is None:
+            return 0
         words = (ctypes.c_uint32 * 28)()
+        tiles = (ctypes.c_uint8 * 192)()
         for variant in (1, 2):
             n = _C.lib().zk_ar_static_skip(p.layout.kind, variant, words)
-            if n == len(p.skip) and all(int(words[i]) == int(p.skip[i]) for i in range(n)):
-                return variant
+            if n != len(p.skip) or any(int(words[i]) != int(p.skip[i]) for i in range(n)):
+                continue
+            if _C.lib().zk_ar_static_tiles(p.layout.kind, variant, tiles) != 192 or not np.array_equal(np.frombuffer(tiles, dtype=np.uint8), p.fine_tilemask.reshape(-1)):
+                continue
+            return variant
         return 0
 
     def refresh(self, linears) -> None:
@@ -414,6 +459,9 @@ class FusedAR:
             n = self.gather[l].numel()
             dst = self.stream[self.plan.layer_block0[l] * 256 :]
             _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), n, _ptr(dst), _stream()), "zk_gather_f32")
+            if self.static_variant:
+                fdst = self.fine_stream[self.plan.fine_layer_block0[l] * 256 :]
+                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel(), _ptr(fdst), _stream()), "zk_gather_f32")
             nb = self.bias_gather[l].numel()
             bdst = self.bias[self.plan.bias_off[l] :]
             if m.bias is None:
@@ -429,10 +477,13 @@ class FusedAR:
 
         p = self.plan
         N = inp.shape[0]
+        # static-shape kernel: rows of x and y 16-byte addressable (the generic kernel has an instantiation for the other case)
+        variant = self.static_variant if (inp.shape[1] == 64 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0) else 0
+        stream, n_chunks = (self.fine_stream, p.fine_n_chunks) if variant else (self.stream, p.n_chunks)
         err = _C.lib().zk_ar_forward(
             p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
-            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, self.static_variant if inp.shape[1] == 64 else 0, _stream(),
+            _ptr(stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, n_chunks,
+            self.act, self.bound, self.slope, variant, _stream(),
         )
         _C.check(err, "zk_ar_forward")
 
