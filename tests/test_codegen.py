@@ -50,31 +50,26 @@ def test_headline_kernel_instruction_mix():
     assert ".amdhsa_private_segment_fixed_size 0" in desc, "scratch (VGPR spill) in the headline kernel"
 
 
-def _isa_of(tu: str) -> str:
+def _isa_of(tu: str, extra=()) -> str:
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    h = hashlib.sha256()
+    h = hashlib.sha256(" ".join(extra).encode())
     for name in (tu, "zk_ar_common.h", "zk_univariate.h", "zk_common.h"):
         h.update(open(os.path.join(CSRC, name), "rb").read())
     out = os.path.join(ROOT, "zuko_amd", "lib", f"{tu.split('.')[0]}.{h.hexdigest()[:16]}.s")
     if not os.path.exists(out):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-ffp-contract=off", "--cuda-device-only", "-S",
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-ffp-contract=off", *extra, "--cuda-device-only", "-S",
                         os.path.join(CSRC, tu), "-o", out], check=True, stderr=subprocess.DEVNULL)
     return open(out).read()
 
 
-def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
-    """fused_ar_static.hip issues its weight-tile reads from inline assembly and makes them usable through an
-    `s_waitcnt lgkmcnt(n)` it places itself.  Between the read and a wait that covers it no instruction may mention the
-    destination registers (a register copy inserted there by the allocator would read data that has not arrived).  LDS
-    operations of a wave complete in order, so a wait lgkmcnt(n) covers every asm read except the youngest n."""
+def _check_raw_reads(s: str, prefix: str):
+    """For every kernel whose mangled name starts with `prefix`: between an inline-assembly `ds_read_b128` and an
+    `s_waitcnt lgkmcnt(n)` that covers it (LDS operations of a wave complete in order: a wait lgkmcnt(n) covers every read
+    except the youngest n) no instruction may mention the destination registers.  Returns [(asm reads, MFMAs)] per kernel."""
     import re
-
-    s = _isa_of("fused_ar_static.hip")
-    kernels = [m.start() for m in re.finditer(r"^_ZN2zk16ar_static_kernel[^\n]*:", s, flags=re.M)]
-    assert len(kernels) == 2
 
     def regs(t):
         out = set()
@@ -85,7 +80,8 @@ def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
                 out.add(int(m.group(3)))
         return out
 
-    for k in kernels:
+    stats = []
+    for k in [m.start() for m in re.finditer(r"^" + prefix + r"[^\n]*:", s, flags=re.M)]:
         body = s[k : s.index("s_endpgm", k)].split("\n")
         pending, in_asm, n_reads, mfma = [], False, 0, 0
         for line in body:
@@ -111,7 +107,29 @@ def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
                 continue
             used = regs(t)
             assert not any(used & r for r in pending), f"'{t}' touches a weight tile whose LDS read has not been waited for"
-        assert n_reads * 4 == mfma and n_reads in (1130, 386)  # every streamed tile is read once and multiplied by four k-steps (1176 - 46 / 432 - 46 all-zero tiles)
+        stats.append((n_reads, mfma))
+    return stats
+
+
+def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
+    """fused_ar_static.hip issues its weight-tile reads from inline assembly and makes them usable through an
+    `s_waitcnt lgkmcnt(n)` it places itself: a register copy inserted between the two by the allocator would read data
+    that has not arrived."""
+    import re
+
+    s = _isa_of("fused_ar_static.hip")
+    stats = _check_raw_reads(s, "_ZN2zk16ar_static_kernel")
+    assert sorted(stats) == [(386, 1544), (1130, 4520)]  # every streamed tile is read once and multiplied by four k-steps (1176 - 46 / 432 - 46 all-zero tiles)
     for name in re.findall(r"\.amdhsa_kernel (_ZN2zk16ar_static_kernel\S+)", s):
         k = s.index(".amdhsa_kernel " + name)
         assert ".amdhsa_private_segment_fixed_size 0" in s[k : s.index(".end_amdhsa_kernel", k)]
+
+
+@pytest.mark.parametrize("tu,prefix,extra,n_kernels", [
+    ("inc_inverse.hip", "_ZN2zk18inc_inverse_kernel", ("-DZK_INC_FAST_BUILD",), 2),
+    ("fused_coupling.hip", "_ZN2zk22coupling_kernel_static", ("-mllvm", "-pragma-unroll-threshold=1000000"), 1),
+])
+def test_raw_lds_reads_of_the_other_ring_kernels(tu, prefix, extra, n_kernels):
+    """Same guard for the incremental inverse (the two benchmark instantiations) and the static coupling kernel."""
+    stats = _check_raw_reads(_isa_of(tu, extra), prefix)
+    assert len(stats) == n_kernels and all(r > 0 and m >= 4 * r for r, m in stats)

@@ -19,6 +19,7 @@
 // (zuko/distributions.py:129-138) needs no second pass.
 #include "zk_univariate.h"
 #include <type_traits>
+#include <utility>
 
 namespace zk {
 
@@ -96,7 +97,8 @@ __host__ __device__ constexpr int inc_group_start(int NH, int NT, int j) {
 struct IncRing {
   float* lds;
   const float* stream;
-  const float* cur;  // lds + slot * IN_CH * 256 + lane * 4
+  unsigned cur_off;  // LDS byte address of the slot being read + lane * 16
+  unsigned lds_off;  // LDS byte address of the ring
   int n_chunks, slot, load_chunk, load_slot, wave, lane;
   // each wave copies IN_CH / IN_WAVES consecutive tiles: one address and one M0 value for all of them, the tile selected by
   // the instruction's (signed) immediate offset (a vector-memory instruction costs the wave ~40 cycles of issue, an M0 write ~20 more:
@@ -121,13 +123,23 @@ struct IncRing {
     asm volatile("" ::: "memory");
     issue();
     slot = (slot + 1 == IN_NR) ? 0 : slot + 1;
-    cur = lds + slot * IN_CH * 256 + lane * 4;
+    cur_off = lds_off + (unsigned)(slot * IN_CH * 1024 + lane * 16);
   }
-  __device__ __forceinline__ f32x4i read(int s) {
-    if (s % IN_CH == 0) advance();
-    return *reinterpret_cast<const f32x4i*>(cur + (s % IN_CH) * 256);
+  // Position S of the tile inside the pass (static).  The read is issued from inline assembly and returns a RAW value: the
+  // compiler does not know it is an LDS operation and inserts no wait — with a global_load_lds in flight hipcc turns every LDS wait
+  // into lgkmcnt(0), so the compiler-visible form of this loop was `ds_read; s_waitcnt lgkmcnt(0); 4 MFMAs` per tile, the full LDS
+  // round trip exposed every 128 cycles of matrix work (one wavefront per SIMD).  inc_settle<N>() makes a raw value usable: it waits
+  // until at most N younger LDS operations are outstanding (they complete in order) and is the only consumer of the raw registers.
+  template <int S> __device__ __forceinline__ f32x4i read() {
+    if constexpr (S % IN_CH == 0) advance();
+    f32x4i v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(cur_off), "n"((S % IN_CH) * 1024));
+    return v;
   }
 };
+template <int N> __device__ __forceinline__ void inc_settle(f32x4i& w) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N)); }
+template <class F, int... I> __device__ __forceinline__ void inc_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void inc_for(F&& f) { inc_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #define IN_MFMA4(acc, a, b)                                                              \
   {                                                                                      \
@@ -174,7 +186,8 @@ template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_in
 #pragma unroll
   for (int i = 0; i < IN_NR - 1; ++i) ring.issue();
   ring.slot = IN_NR - 1;
-  ring.cur = ring_lds;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)ring_lds);
+  ring.cur_off = ring.lds_off;
   __syncthreads();
 
   const int xs = a.xs;
@@ -219,63 +232,57 @@ template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_in
         constexpr int P_H = P_S + IN_L1S;                          // hidden pulls
         constexpr int P_L = P_H + (NH - 1) * j;                    // last-layer pulls
         constexpr int P_D = P_L + NT * j;                          // diagonal tiles
-        // ---- pull: contributions of everything that is already final --------------------------------------------
+        // ---- pull: contributions of everything that is already final, then the diagonal tiles into registers -----------
+        // One static sequence of NTOT consecutive stream tiles, three raw reads in flight: tile i + 2 is requested before tile i
+        // is multiplied (or stored away, for the diagonal tiles that stay in registers over the five passes).
         f32x4i o1 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[0] + j * 16 + 4 * q);
-#pragma unroll
-        for (int s_ = 0; s_ < IN_L1S; ++s_) {
-          const f32x4i w = ring.read(P_S + s_);
-          if (s_ < ns) {
-            const int it = __builtin_amdgcn_readfirstlane(pg[2 + s_]);
-            const f32x4i b = *reinterpret_cast<const f32x4i*>(xrow + it * 16 + 4 * q);
-            IN_MFMA4(o1, w, b);
-          }
-        }
         f32x4i o2 = {0.f, 0.f, 0.f, 0.f}, o3 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (NH > 1) {
-          o2 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[1] + j * 16 + 4 * q);
-#pragma unroll
-          for (int t = 0; t < j; ++t) {
-            const f32x4i w = ring.read(P_H + t);
-            IN_MFMA4(o2, w, h1[t]);
-          }
-        }
-        if constexpr (NH > 2) {
-          o3 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[2] + j * 16 + 4 * q);
-#pragma unroll
-          for (int t = 0; t < j; ++t) {
-            const f32x4i w = ring.read(P_H + j + t);
-            IN_MFMA4(o3, w, h2[t]);
-          }
-        }
+        if constexpr (NH > 1) o2 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[1] + j * 16 + 4 * q);
+        if constexpr (NH > 2) o3 = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[2] + j * 16 + 4 * q);
         f32x4i po[NT];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) po[tt] = *reinterpret_cast<const f32x4i*>(bias_lds + a.bias_off[NH] + (j * NT + tt) * 16 + 4 * q);
+        f32x4i l1b[IN_L1S];  // B operands of the first-layer pulls (final input tiles), fetched up front
 #pragma unroll
-        for (int t = 0; t < j; ++t) {
-          f32x4i hb;
-          if constexpr (NH == 1) hb = h1[t];
-          else if constexpr (NH == 2) hb = h2[t];
-          else hb = h3[t];
-#pragma unroll
-          for (int tt = 0; tt < NT; ++tt) {
-            const f32x4i w = ring.read(P_L + t * NT + tt);
-            IN_MFMA4(po[tt], w, hb);
-          }
+        for (int s_ = 0; s_ < IN_L1S; ++s_) {
+          const int it = s_ < ns ? __builtin_amdgcn_readfirstlane(pg[2 + s_]) : 0;
+          l1b[s_] = *reinterpret_cast<const f32x4i*>(xrow + it * 16 + 4 * q);
         }
-        // ---- the diagonal tiles stay in registers over the five passes -------------------------------------------
         f32x4i wd[IN_MAXD];
         int itd[IN_MAXD];
 #pragma unroll
-        for (int i = 0; i < IN_MAXD; ++i) {
-          itd[i] = i < nd ? __builtin_amdgcn_readfirstlane(pg[2 + IN_T + i]) : 0;
-          wd[i] = ring.read(P_D + i);
-        }
+        for (int i = 0; i < IN_MAXD; ++i) itd[i] = i < nd ? __builtin_amdgcn_readfirstlane(pg[2 + IN_T + i]) : 0;
         f32x4i wh2 = {0.f, 0.f, 0.f, 0.f}, wh3 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (NH > 1) wh2 = ring.read(P_D + IN_L1D);
-        if constexpr (NH > 2) wh3 = ring.read(P_D + IN_L1D + 1);
         f32x4i wl[NT];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) wl[tt] = ring.read(P_D + IN_L1D + (NH - 1) + tt);
+        constexpr int N_H = (NH - 1) * j, N_L = NT * j, NPULL = IN_L1S + N_H + N_L, NTOT = NPULL + IN_L1D + (NH - 1) + NT;
+        static_assert(P_D == P_S + NPULL, "pull tiles are consecutive in the stream");
+        f32x4i buf[3];
+        buf[0] = ring.template read<P_S>();
+        buf[1] = ring.template read<P_S + 1>();
+        inc_for<NTOT>([&](auto i_) __attribute__((always_inline)) {
+          constexpr int i = decltype(i_)::value;
+          if constexpr (i + 2 < NTOT) buf[(i + 2) % 3] = ring.template read<P_S + i + 2>();
+          inc_settle<(NTOT - 1 - i) < 2 ? (NTOT - 1 - i) : 2>(buf[i % 3]);
+          const f32x4i w = buf[i % 3];
+          if constexpr (i < IN_L1S) {  // first-layer tiles whose inputs are final
+            if (i < ns) IN_MFMA4(o1, w, l1b[i]);
+          } else if constexpr (i < IN_L1S + N_H) {  // hidden pulls: layer 2 from h1, then layer 3 from h2
+            constexpr int k = i - IN_L1S;
+            if constexpr (k < j) { IN_MFMA4(o2, w, h1[k]); }
+            else { IN_MFMA4(o3, w, h2[k - j]); }
+          } else if constexpr (i < NPULL) {  // last-layer pulls
+            constexpr int k = i - IN_L1S - N_H, t = k / NT, tt = k % NT;
+            if constexpr (NH == 1) { IN_MFMA4(po[tt], w, h1[t]); }
+            else if constexpr (NH == 2) { IN_MFMA4(po[tt], w, h2[t]); }
+            else { IN_MFMA4(po[tt], w, h3[t]); }
+          } else {  // the diagonal tiles stay in registers over the five passes
+            constexpr int d = i - NPULL;
+            if constexpr (d < IN_L1D) wd[d] = w;
+            else if constexpr (NH > 1 && d == IN_L1D) wh2 = w;
+            else if constexpr (NH > 2 && d == IN_L1D + 1) wh3 = w;
+            else wl[d - IN_L1D - (NH - 1)] = w;
+          }
+        });
 
         const int f = fmap_lds[j * 4 + q];
         const float yv = yrow[f < 0 ? 0 : f];
