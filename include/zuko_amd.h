@@ -200,6 +200,14 @@ int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, con
                         void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off,
                         const int32_t* amap, int nit, const int32_t* fmap, int n_groups, int n_layers, const int32_t* tiles,
                         const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream);
+/* The inverse of the same coupling transform (CouplingTransform._inverse, zuko/transforms.py:1050-1056), same plan and arguments:
+ * y_in [N, D] -> x [N, D]; the conditioner sees the pass-through half, which both directions share, the moved half is mapped back
+ * by x_b = (y_b - shift) exp(-softclip(scale)).  ladj (optional) = log|det dy/dx| of the FORWARD map at the solution (negate it for
+ * the inverse transform), the convention of zk_ar_inverse_incremental. */
+int zk_coupling_inverse(int64_t N, int D, int C, const void* y_in, int64_t ldy, const void* ctx, int64_t ldc, void* x, int64_t ldx,
+                        void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off,
+                        const int32_t* amap, int nit, const int32_t* fmap, int n_groups, int n_layers, const int32_t* tiles,
+                        const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream);
 /* INCREMENTAL inverse: the whole loop of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000) in one launch whose
  * multiply-add count is ~1.5x ONE density evaluation (every off-diagonal weight tile is multiplied once per sample; only the
  * diagonal tiles of a 4-feature group are iterated).  Needs the aligned-tile plan of zuko_amd/incremental.py

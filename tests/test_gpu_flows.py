@@ -599,3 +599,39 @@ def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, kind, N):
         st.run(x, torch.empty_like(x), l2, True)
         ref = out[0][1] + out[0][1]
         assert same(l2[~torch.isnan(ref)], ref[~torch.isnan(ref)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,ctx,hidden,N", [(256, 0, [512] * 3, 300), (5, 3, [32, 32], 1000), (12, 2, [40, 70, 24], 77)])
+def test_fused_coupling_inverse(dev, D, ctx, hidden, N, monkeypatch):
+    """zk_coupling_inverse (CouplingTransform._inverse, zuko/transforms.py:1050-1056, in one launch) against the layer-wise
+    HIP inverse, the oracle's inverse and the round trip through the fused forward; `.inv.call_and_ladj` and
+    `rsample_and_log_prob` take x and the log-determinant from the same launch."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(D + N + 1)
+    flow = F.RealNVP(D, ctx, transforms=3, hidden_features=hidden)
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "coupling", O.UNI_AFFINE, D)
+    flow = flow.to(dev)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(N, D, generator=g)
+    c = torch.randn(N, ctx, generator=g) if ctx else None
+    cg = None if c is None else c.to(dev)
+    with torch.no_grad():
+        t = flow(cg).transform
+        x = t.inv(z.to(dev))
+        x2, ladj_inv = t.inv.call_and_ladj(z.to(dev))
+        monkeypatch.setenv("ZUKO_AMD_NO_FUSED_COUPLING", "1")
+        x_l = flow(cg).transform.inv(z.to(dev))
+        monkeypatch.delenv("ZUKO_AMD_NO_FUSED_COUPLING")
+        z_back, ladj_fwd = t.call_and_ladj(x)
+        xo = O.flow_inverse(spec, z, c)
+    assert torch.equal(x, x2)
+    assert torch.allclose(x, x_l, rtol=1e-5, atol=2e-5), (x - x_l).abs().max()
+    assert torch.allclose(x.cpu(), xo, rtol=1e-5, atol=5e-5), (x.cpu() - xo).abs().max()
+    assert torch.allclose(z_back.cpu(), z, rtol=1e-5, atol=5e-5)
+    assert torch.allclose(ladj_inv, -ladj_fwd, rtol=1e-5, atol=1e-4)
+    with torch.no_grad():
+        xs, lp = flow(cg).rsample_and_log_prob(() if ctx else (257,))
+        assert torch.allclose(lp, flow(cg).log_prob(xs), rtol=1e-4, atol=5e-4)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "zk_ar_forward_diag": [I, L, I, I, P, L, P, L, P, P, P, I, P, P, I, I, I, I, F, F, P, P, P],
     "zk_ar_inverse_sweep": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, I, P],
     "zk_coupling_forward": [L, I, I, P, L, P, L, P, L, P, I, P, P, I, POINTER(c_int), P, I, P, I, I, POINTER(c_int), POINTER(c_int), I, I, F, I, P],
+    "zk_coupling_inverse": [L, I, I, P, L, P, L, P, L, P, I, P, P, I, POINTER(c_int), P, I, P, I, I, POINTER(c_int), POINTER(c_int), I, I, F, I, P],
     "zk_ar_inverse_incremental": [I, I, L, I, I, P, L, P, L, P, L, P, P, P, I, POINTER(c_int), P, P, I, I, I, F, F, P],
     "zk_ar_inc_lds_bytes": [I, I],
     "zk_ar_inverse_partial": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, P, I, POINTER(c_int), I, I, I, P],

@@ -226,8 +226,9 @@ class FusedCoupling:
         _C.check(lib.zk_gather_f32(_ptr(bcat), None, _ptr(self.bias_gather), self.bias_gather.numel(), _ptr(self.bias), _stream()), "zk_gather_f32")
         self._stamp = stamp
 
-    def run(self, x, ctx):
-        """x [N, D] fp32 (row stride arbitrary), ctx [N, C] or None -> (y [N, D], ladj [N])."""
+    def run(self, x, ctx, inverse: bool = False):
+        """x [N, D] fp32 (row stride arbitrary), ctx [N, C] or None -> (y [N, D], ladj [N]).  inverse=True: x holds the transform's
+        output and the result is its preimage; ladj is log|det dy/dx| of the FORWARD map at that preimage either way."""
         import torch
 
         from . import _C
@@ -237,10 +238,11 @@ class FusedCoupling:
         N = x.shape[0]
         y = torch.empty((N, p.features), dtype=torch.float32, device=x.device)
         ladj = torch.empty(N, dtype=torch.float32, device=x.device)
-        err = _C.lib().zk_coupling_forward(
+        fn = _C.lib().zk_coupling_inverse if inverse else _C.lib().zk_coupling_forward
+        err = fn(
             N, p.features, p.context, _ptr(x), x.stride(0), _ptr(ctx), 0 if ctx is None else ctx.stride(0), _ptr(y), p.features, _ptr(ladj), 0,
             _ptr(self.stream), _ptr(self.bias), self.bias.numel(), self.bias_off, _ptr(self.amap), p.nit, _ptr(self.fmap), p.n_groups, p.n_layers,
             self.tiles, self.widths, p.n_chunks, self.act, self.slope, 1, _stream(),
         )
-        _C.check(err, "zk_coupling_forward")
+        _C.check(err, "zk_coupling_inverse" if inverse else "zk_coupling_forward")
         return y, ladj

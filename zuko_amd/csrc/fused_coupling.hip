@@ -53,6 +53,7 @@ struct CpArgs {
   int xs;                       // LDS row stride (floats) of the wave-private row image
   int vec4;                     // rows of y can be written 16 bytes per lane
   int vec4_in;                  // rows of x / context can be fetched 16 bytes per lane
+  int inverse;                  // x holds y: the moved half is mapped back (x_b = (y_b - shift) exp(-scale)); ladj stays that of the forward map
   float ls;
   int64_t n_tiles;
 };
@@ -107,6 +108,13 @@ struct CpRing {
     if (pos != 0) pos = CP_CH;
   }
 };
+
+// the affine map of one moved feature (zuko/transforms.py:412-446), forward or inverse; l = log|dy/dx| of the FORWARD map either way
+__device__ __forceinline__ void cp_affine(const CpArgs& a, float shift, float scale, float v, float& out, float& l) {
+  const float lsc = softclip<float, MathFast>(scale, a.ls);
+  out = a.inverse ? MathFast::div_safe(v - shift, MathFast::exp(lsc)) : v * MathFast::exp(lsc) + shift;
+  l = lsc;
+}
 
 // The wave's 16 rows [x | context] -> its LDS image, by LDS-DMA (4 bytes per lane, consecutive lanes = consecutive columns of
 // one row): all row pieces are in flight together and are waited for once.  (A load-to-register / ds_write loop pays one
@@ -321,8 +329,8 @@ __global__ __launch_bounds__(256, 1) void coupling_kernel(CpArgs a) {
       }
       const f32x4c p = acc0 + acc1;  // (shift, scale) of slot 2 q, then of slot 2 q + 1
       float y0, y1, l0, l1;
-      affine_fwd<float, MathFast>(p[0], p[1], a.ls, x0, y0, l0);
-      affine_fwd<float, MathFast>(p[2], p[3], a.ls, x1, y1, l1);
+      cp_affine(a, p[0], p[1], x0, y0, l0);
+      cp_affine(a, p[2], p[3], x1, y1, l1);
       if (f0 >= 0) { xrow[f0] = y0; lacc += l0; }
       if (f1 >= 0) { xrow[f1] = y1; lacc += l1; }
     }
@@ -543,8 +551,8 @@ template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_ke
           });
           const f32x4c p = (acc[0] + acc[1]) + (acc[2] + acc[3]);
           float y0, y1, l0, l1;
-          affine_fwd<float, MathFast>(p[0], p[1], a.ls, x0, y0, l0);
-          affine_fwd<float, MathFast>(p[2], p[3], a.ls, x1, y1, l1);
+          cp_affine(a, p[0], p[1], x0, y0, l0);
+          cp_affine(a, p[2], p[3], x1, y1, l1);
           if (f0 >= 0) { xrow[f0] = y0; lacc += l0; }
           if (f1 >= 0) { xrow[f1] = y1; lacc += l1; }
         }
@@ -586,12 +594,13 @@ extern "C" {
 // bias_off: HOST array of n_layers offsets into the bias image; amap [nit * 16], fmap [n_groups * 8]: DEVICE index maps;
 // wstream / bias: the plan of zuko_amd/coupling_plan.py.  Limits: D + C <= 1024 columns in the row image with
 // 4 * 16 * (D + C + 4) * 4 bytes of LDS beside the 72 KiB ring, conditioner inputs <= 256, hidden widths <= 512.
-int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy, void* ladj, int accumulate,
+static int cp_launch(int inverse, int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy, void* ladj, int accumulate,
                         const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* amap, int nit, const int32_t* fmap,
                         int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream) {
   if (N <= 0) return 0;
   if (n_layers < 2 || n_layers > CP_MAXL || nit < 1 || nit > CP_IT || n_groups < 1 || n_chunks < 1 || D < 2 || C < 0 || (C > 0 && !ctx)) return ZK_EINVAL;
   CpArgs a{};
+  a.inverse = inverse;
   a.N = N; a.D = D; a.C = C; a.x = (const float*)x; a.ldx = ldx; a.ctx = (const float*)ctx; a.ldc = ldc; a.y = (float*)y; a.ldy = ldy;
   a.ladj = (float*)ladj; a.accumulate = accumulate; a.stream = (const float*)wstream; a.bias = (const float*)bias; a.amap = amap; a.fmap = fmap;
   a.L = n_layers; a.nit = nit; a.NG = n_groups; a.n_chunks = n_chunks; a.act = act; a.bias_floats = bias_floats;
@@ -632,6 +641,24 @@ int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, con
   }
   hipLaunchKernelGGL(coupling_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   return ZK_LAUNCH_CHECK();
+}
+
+
+int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy, void* ladj, int accumulate,
+                        const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* amap, int nit, const int32_t* fmap,
+                        int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream) {
+  return cp_launch(0, N, D, C, x, ldx, ctx, ldc, y, ldy, ladj, accumulate, wstream, bias, bias_floats, bias_off, amap, nit, fmap, n_groups, n_layers, tiles, widths,
+                   n_chunks, act, slope, static_ok, stream);
+}
+
+// The inverse of the same transform (CouplingTransform._inverse, zuko/transforms.py:1050-1056): `y_in` [N, D] in, x [N, D] out —
+// the conditioner sees the pass-through half, which both directions share; ladj (optional) = log|det dy/dx| of the FORWARD map at the
+// solution (the caller negates it for the inverse transform), as zk_ar_inverse_incremental returns it.
+int zk_coupling_inverse(int64_t N, int D, int C, const void* y_in, int64_t ldy, const void* ctx, int64_t ldc, void* x, int64_t ldx, void* ladj, int accumulate,
+                        const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* amap, int nit, const int32_t* fmap,
+                        int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream) {
+  return cp_launch(1, N, D, C, y_in, ldy, ctx, ldc, x, ldx, ladj, accumulate, wstream, bias, bias_floats, bias_off, amap, nit, fmap, n_groups, n_layers, tiles, widths,
+                   n_chunks, act, slope, static_ok, stream);
 }
 
 }  // extern "C"

@@ -121,15 +121,16 @@ class FusedCouplingTransform(CouplingTransform):
         self.lazy = lazy
         self.c = c
 
-    def call_and_ladj(self, x: Tensor):
+    def _fused(self, x: Tensor, inverse: bool):
+        """(result, ladj of the forward map) from the fused kernel, or None when the layer-wise path has to be taken."""
         lazy, c = self.lazy, self.c
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1) or os.environ.get("ZUKO_AMD_NO_FUSED_COUPLING", "0") == "1":
-            return super().call_and_ladj(x)
+            return None
         if torch.is_grad_enabled() and (x.requires_grad or (c is not None and c.requires_grad) or any(p.requires_grad for p in lazy.hyper.parameters())):
-            return super().call_and_ladj(x)
+            return None
         st = lazy.fused_state(x.device)
         if st is None:
-            return super().call_and_ladj(x)
+            return None
         D = x.shape[-1]
         if c is not None:
             xb, cb = broadcast(x, c, ignore=1)
@@ -144,14 +145,37 @@ class FusedCouplingTransform(CouplingTransform):
             c2 = cb.reshape(-1, cb.shape[-1])
             c2 = c2 if c2.stride(-1) == 1 else c2.contiguous()
         st.refresh(list(lazy.hyper)[0::2])
-        y, ladj = st.run(x2, c2)
+        y, ladj = st.run(x2, c2, inverse)
         return y.reshape(batch + (D,)), ladj.reshape(batch)
+
+    def call_and_ladj(self, x: Tensor):
+        out = self._fused(x, False)
+        return super().call_and_ladj(x) if out is None else out
 
     def _call(self, x: Tensor) -> Tensor:
         return self.call_and_ladj(x)[0]
 
     def log_abs_det_jacobian(self, x: Tensor, y: Tensor) -> Tensor:
         return self.call_and_ladj(x)[1]
+
+    def inverse_and_ladj(self, y: Tensor):
+        """(x, log|det dy/dx| of the FORWARD map at x): one launch of zk_coupling_inverse (CouplingTransform._inverse,
+        zuko/transforms.py:1050-1056, plus what rsample_and_log_prob needs, zuko/distributions.py:129-138)."""
+        out = self._fused(y, True)
+        if out is not None:
+            return out
+        x = super()._inverse(y)
+        return x, super().log_abs_det_jacobian(x, y)
+
+    def _inverse(self, y: Tensor) -> Tensor:
+        out = self._fused(y, True)
+        return super()._inverse(y) if out is None else out[0]
+
+    @property
+    def inv(self):
+        from .autoregressive import _FusedInverse
+
+        return _FusedInverse(self)
 
 
 class NICE(Flow):
