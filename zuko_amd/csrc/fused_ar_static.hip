@@ -181,6 +181,13 @@ template <typename Uni> __global__ __launch_bounds__(512, 2) void ar_static_kern
   for (int i = tid; i < NG * 4 * FPL; i += 512) fmap_lds[i] = a.featmap[i];
   __syncthreads();
   const float* bias_last = bias_lds + 3 * 256;
+  // feature ids of this lane's slots in every group: constant over the launch, kept in registers (a per-group LDS read would put
+  // one exposed LDS round trip in front of the read of x that depends on it)
+  int fids[NG * FPL];
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+#pragma unroll
+    for (int fi = 0; fi < FPL; ++fi) fids[i * FPL + fi] = fmap_lds[(i * 4 + q) * FPL + fi];
 
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n = tile * 128 + wave * 16 + j;
@@ -236,7 +243,7 @@ template <typename Uni> __global__ __launch_bounds__(512, 2) void ar_static_kern
       float xin[FPL];
 #pragma unroll
       for (int fi = 0; fi < FPL; ++fi) {
-        fid[fi] = fmap_lds[(g * 4 + q) * FPL + fi];
+        fid[fi] = fids[g * FPL + fi];
         xin[fi] = xr[fid[fi] < 0 ? 0 : fid[fi]];
       }
       f32x4 acc[NT];  // the accumulators start at the bias
