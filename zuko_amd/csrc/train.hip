@@ -14,6 +14,7 @@
 // Operand layout notes are next to each kernel.  fp32 MFMA is bitwise an fmaf chain: results differ from any other fp32
 // GEMM by summation order only.
 #include "zk_common.h"
+#include <stdlib.h>
 
 namespace zk {
 
@@ -421,7 +422,11 @@ int zk_gemm_f32_skip(int64_t N, int in_features, int out_features, const void* x
 // as nslices * npairs * 128 * 128 floats)
 int zk_wgrad_slices(int64_t N, int npairs) {
   if (N <= 0 || npairs <= 0) return 0;
-  int64_t want = (2 * 256 + npairs - 1) / npairs;  // ~2 blocks per CU
+  // at most BPC (default 4: the kernel's LDS allows four blocks per CU; measured 0.72 -> 0.52 ms for 1472 x 256 at N = 2^16) blocks per CU, rounded DOWN: with a few blocks more than a whole number per CU (e.g. 520 on 256 CUs) the CUs that
+  // receive an extra block finish 1.5x later and the launch waits for them
+  static const int bpc = [] { const char* e = getenv("ZUKO_AMD_WGRAD_BPC"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 4; }();
+  int64_t want = (bpc * 256) / npairs;
+  want = want < 1 ? 1 : want;
   int64_t S = (N + want - 1) / want;
   S = S < 512 ? 512 : S;
   S = (S + 15) / 16 * 16;
@@ -448,7 +453,7 @@ int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, in
 
 // out[c] (+)= sum_n x[n, c];  workspace: >= zk_colsum_slices(N) * C floats
 int zk_colsum_slices(int64_t N) {
-  int64_t s = (N + 2047) / 2048;
+  int64_t s = (N + 511) / 512;  // (2048 rows per slice left a 256-column sum with 128 blocks on 256 CUs)
   return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
 }
 int zk_colsum_f32(int64_t N, int C, const void* x, int64_t ld, float* workspace, void* out, int accumulate, void* stream) {
