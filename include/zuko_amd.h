@@ -239,6 +239,13 @@ int zk_ar_static_skip(int uni_kind, int variant, uint32_t* out_words);
  * for: out[(l * 4 + otg) * 16 + it] = 4-bit mask of the out tiles of group otg multiplied by input tile it of hidden layer l
  * (192 bytes; returns 192, or 0 if there is no such kernel).  Rows of x and y must be 16-byte addressable (EINVAL otherwise). */
 int zk_ar_static_tiles(int uni_kind, int variant, uint8_t* out_masks);
+/* Conditioner-only launch of the static kernel for the training forward (zuko_amd/train.py): phi [N, 64 * total] = net(x) in
+ * module order (what the last MaskedLinear of zuko/nn.py:221-318 returns) and the hidden activations h1, h2, h3 [N, 256] with the
+ * units in the stream's dependency-sorted order, which the mask-aware dgrad / wgrad kernels consume.  Same per-tile stream, bias
+ * image, feature map, chunk count and variant as zk_ar_forward(variant = 1 | 2); the univariate map is not evaluated. */
+int zk_ar_forward_train(int uni_kind, int64_t N, const void* x, int64_t ldx, void* h1, void* h2, void* h3, void* phi, int64_t ldphi,
+                        const void* wstream, const void* bias, int bias_floats, const int32_t* featmap, int n_chunks, int variant,
+                        void* stream);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
 int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);

@@ -202,3 +202,24 @@ def test_static_kernel_pattern_is_the_plan_of_cfg2_and_cfg3(kind):
     n = _C.lib().zk_ar_static_skip(1, 1, words)
     assert [int(words[j]) for j in range(n)] != [int(v) for v in plan.skip][:n] or n != len(plan.skip)
     assert _C.lib().zk_ar_static_skip(2, 1, words) == 0 and _C.lib().zk_ar_static_skip(1, 3, words) == 0
+
+
+def test_training_plan_sorts_units_by_their_true_dependency_count():
+    """zuko_amd/train.py:SortedPlan must sort every hidden layer by the dependency count computed in the MODULE's unit order
+    (a regression here keeps the reparametrisation exact but leaves the sorted masks dense: no k-tile or block is skipped)."""
+    import zuko_amd.flows as F
+    from zuko_amd import fused, train
+    from zuko_amd.nn import MaskedLinear
+
+    torch.manual_seed(4)
+    flow = F.NSF(64, 0, transforms=2, bins=8, hidden_features=[256] * 3)
+    for lazy in flow.transform.transforms:
+        lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+        plan = train.SortedPlan(lins, 1, torch.device("cpu"))
+        assert plan.kept[1] == 0.75 and plan.kept[2] == 0.75 and plan.kept[3] < 0.8  # block lower-triangular at 128 x 128
+        live = [[bin(int(np.uint64(v))).count("1") for v in k.numpy().view(np.uint64)] for k in plan.kskip_f]
+        assert live[1] == [4, 8] and live[2] == [4, 8] and live[3] in (sorted(live[3]), sorted(live[3], reverse=True)) and min(live[3]) == 1
+        # the same permutations as the fused kernels' plan (stable sort on the same keys): their activations are interchangeable
+        deps = fused._deps([m.mask.numpy().astype(bool) for m in lins])
+        for l in range(3):
+            assert np.array_equal(plan.perms[l].numpy(), np.argsort(deps[l].sum(axis=1), kind="stable"))

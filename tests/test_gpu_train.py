@@ -110,3 +110,52 @@ def test_conditioner_gradients_match_torch(dev, kind):
     for m in net.modules():
         if isinstance(m, MaskedLinear):
             assert (m.weight.grad[~m.mask] == 0).all()
+
+
+@pytest.mark.parametrize("kind", ["nsf", "maf"])
+def test_fused_training_forward(dev, kind, monkeypatch):
+    """zk_ar_forward_train (the static-shape kernel as the conditioner's forward under autograd) must be selected for the cfg2 / cfg3
+    conditioner and give the layer-wise kernels' phi, hidden activations and gradients (ragged batch, a poisoned row)."""
+    import zuko_amd.flows as F
+    from zuko_amd import train
+    from zuko_amd.nn import MaskedLinear
+
+    torch.manual_seed(4)
+    flow = (F.NSF(64, 0, transforms=1, bins=8, hidden_features=[256] * 3) if kind == "nsf" else F.MAF(64, 0, transforms=1, hidden_features=[256] * 3)).to(dev)
+    net = flow.transform.transforms[0].hyper
+    plan, lins = train.plan_for(net, dev)
+    st = train._fused_forward_state(plan, lins, dev)
+    assert st is not None, "the fused training forward must be available for this conditioner"
+    N = 1000 + 37
+    x = torch.randn(N, 64, generator=torch.Generator().manual_seed(6)).to(dev)
+    x[11, 3] = float("nan")
+    hs_f, phi_f = train._fused_forward(st, x, lins[-1].weight.shape[0])
+    ws, _, bs = plan.gather(lins)
+    h = x
+    for l in range(4):
+        h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], 1 if l < 3 else 0)
+        ref = hs_f[l] if l < 3 else phi_f
+        ok = torch.ones(N, dtype=torch.bool, device=dev)
+        ok[11] = False
+        assert torch.allclose(ref[ok], h[ok], rtol=1e-5, atol=2e-5), (l, (ref[ok] - h[ok]).abs().max().item())
+    assert torch.isnan(phi_f[11]).all(), "a non-finite input makes every parameter of its sample NaN (zuko/nn.py:217-218)"
+
+    xg = x.clone()
+    xg[11, 3] = 0.5
+    gphi = torch.randn(N, lins[-1].weight.shape[0], generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        xr = xg.clone().requires_grad_()
+        out = net(xr)
+        (out * gphi).sum().backward()
+        return out.detach(), xr.grad.clone(), [p.grad.clone() for p in net.parameters()]
+
+    o1, gx1, gp1 = run()
+    monkeypatch.setenv("ZUKO_AMD_NO_FUSED_TRAIN", "1")
+    o0, gx0, gp0 = run()
+    assert torch.allclose(o1, o0, rtol=1e-5, atol=2e-5)
+    assert torch.allclose(gx1, gx0, rtol=1e-4, atol=1e-4 * gx0.abs().max().item())
+    for a, b in zip(gp1, gp0):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * b.abs().max().clamp_min(1e-6).item()), (a - b).abs().max().item()

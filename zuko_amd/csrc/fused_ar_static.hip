@@ -155,7 +155,9 @@ template <int L> __device__ __forceinline__ void ars_hidden(ArRingS& ring, const
   });
 }
 
-template <typename Uni> __global__ __launch_bounds__(512, 2) void ar_static_kernel(ArArgs a) {
+// TRAIN: conditioner only — the three hidden activations and phi are stored for the backward pass (zuko_amd/train.py), the
+// univariate map is not evaluated (the autograd graph applies it to phi itself).
+template <typename Uni, bool TRAIN = false> __global__ __launch_bounds__(512, 2) void ar_static_kernel(ArArgs a) {
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   constexpr int NG = 64 / (4 * FPL);                         // feature groups
   constexpr int NSTEP = ars_last_first(FPL, NG);             // steps of the last layer
@@ -221,16 +223,34 @@ template <typename Uni> __global__ __launch_bounds__(512, 2) void ar_static_kern
     for (int t = 0; t < AR_T; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) in[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
+    if constexpr (TRAIN) {
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < AR_T; ++t) *reinterpret_cast<f32x4*>(a.act_out[0] + n * 256 + t * 16 + 4 * q) = in[t];
+      }
+    }
     ars_hidden<1>(ring, bias_lds + 1 * 256 + 4 * q, in, out, rev);
 #pragma unroll
     for (int t = 0; t < AR_T; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) in[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];
+    if constexpr (TRAIN) {
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < AR_T; ++t) *reinterpret_cast<f32x4*>(a.act_out[1] + n * 256 + t * 16 + 4 * q) = in[t];
+      }
+    }
     ars_hidden<2>(ring, bias_lds + 2 * 256 + 4 * q, in, out, rev);
 #pragma unroll
     for (int t = 0; t < AR_T; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) in[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];
+    if constexpr (TRAIN) {
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < AR_T; ++t) *reinterpret_cast<f32x4*>(a.act_out[2] + n * 256 + t * 16 + 4 * q) = in[t];
+      }
+    }
 
     // ---- last layer + univariate transform, one group of 4 * FPL features at a time --------------------------------
     float lacc = 0.f;
@@ -270,27 +290,40 @@ template <typename Uni> __global__ __launch_bounds__(512, 2) void ar_static_kern
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r];
       });
+      if constexpr (TRAIN) {
+        // the reference multiplies every input by mask * W: a non-finite input makes ALL parameters of its sample NaN
 #pragma unroll
-      for (int fi = 0; fi < FPL; ++fi) Uni::template poison<false>(p, fi * TOTAL, poison);
-      auto ld = [&](int i) { return p[i]; };
+        for (int fi = 0; fi < FPL; ++fi) {
+          const int f = fid[fi];
+          if (f >= 0 && live) {
+            float* dst = a.phi_out + n * a.ldphi + f * TOTAL;
 #pragma unroll
-      for (int fi = 0; fi < FPL; ++fi) {
-        const int f = fid[fi];
-        if (f >= 0) {
-          float yv, lj;
-          Uni::fwd(ld, fi * TOTAL, a, xin[fi], yv, lj);
-          xr[f] = yv;
-          lacc += lj;
+            for (int i = 0; i < TOTAL; ++i) dst[i] = p[fi * TOTAL + i] + poison;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int fi = 0; fi < FPL; ++fi) Uni::template poison<false>(p, fi * TOTAL, poison);
+        auto ld = [&](int i) { return p[i]; };
+#pragma unroll
+        for (int fi = 0; fi < FPL; ++fi) {
+          const int f = fid[fi];
+          if (f >= 0) {
+            float yv, lj;
+            Uni::fwd(ld, fi * TOTAL, a, xin[fi], yv, lj);
+            xr[f] = yv;
+            lacc += lj;
+          }
         }
       }
     });
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (live) {
+    if (!TRAIN && live) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.y + n * a.ldy + it * 16 + 4 * q) = *reinterpret_cast<const f32x4*>(xr + it * 16 + 4 * q);
     }
-    if (a.ladj) {
+    if (!TRAIN && a.ladj) {
       lacc += __shfl_xor(lacc, 16, 64);
       lacc += __shfl_xor(lacc, 32, 64);
       if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
@@ -303,9 +336,10 @@ template <typename Uni> __global__ __launch_bounds__(512, 2) void ar_static_kern
 // pattern of an ascending feature order, 2 = of a descending one.
 int ar_static_launch(ArArgs& a, int uni_kind, int variant, int lds, unsigned grid, hipStream_t stream) {
   if (a.D != 64 || a.DIN != 64 || a.L != 4 || a.act != 1 || !a.xlds || a.sched || (variant != 1 && variant != 2)) return ZK_EINVAL;
+  const bool train = a.phi_out != nullptr;
   const void* fn = nullptr;
-  if (uni_kind == 1 && a.NG == 16 && a.n_chunks == 48) fn = (const void*)ar_static_kernel<UniRqs8>;
-  else if (uni_kind == 0 && a.NG == 8 && a.n_chunks == 17) fn = (const void*)ar_static_kernel<UniAffine>;
+  if (uni_kind == 1 && a.NG == 16 && a.n_chunks == 48) fn = train ? (const void*)ar_static_kernel<UniRqs8, true> : (const void*)ar_static_kernel<UniRqs8>;
+  else if (uni_kind == 0 && a.NG == 8 && a.n_chunks == 17) fn = train ? (const void*)ar_static_kernel<UniAffine, true> : (const void*)ar_static_kernel<UniAffine>;
   else return ZK_EINVAL;
   a.l1rev = variant == 2;
   hipError_t e = hipSuccess;
@@ -342,6 +376,26 @@ int zk_ar_static_skip(int uni_kind, int variant, uint32_t* out) {
     for (int o = 0; o < 4; ++o) out[n++] = (1u << (4 * (o + 1))) - 1u;
   for (int g = 0; g < ng; ++g) out[n++] = (1u << (fpl * (g + 1))) - 1u;
   return n;
+}
+
+// Conditioner-only (training) launch of the static kernel: phi [N, D * total] = net(x) in module order plus the three hidden
+// activations h1, h2, h3 [N, 256] in the stream's sorted unit order, for the backward pass of zuko_amd/train.py.  Same stream,
+// bias image and feature map as zk_ar_forward(variant = 1 | 2); x rows 16-byte addressable, ldx % 4 == 0.
+int zk_ar_forward_train(int uni_kind, int64_t N, const void* x, int64_t ldx, void* h1, void* h2, void* h3, void* phi, int64_t ldphi, const void* wstream,
+                        const void* bias, int bias_floats, const int32_t* featmap, int n_chunks, int variant, void* stream) {
+  if (N <= 0) return 0;
+  if ((uni_kind != 0 && uni_kind != 1) || !h1 || !h2 || !h3 || !phi || ldx % 4 || ((uintptr_t)x % 16) || ((uintptr_t)h1 % 16) || ((uintptr_t)h2 % 16) || ((uintptr_t)h3 % 16)) return ZK_EINVAL;
+  zk::ArArgs a{};
+  a.N = N; a.D = 64; a.DIN = 64; a.x = (const float*)x; a.ldx = ldx;
+  a.stream = (const float*)wstream; a.bias = (const float*)bias; a.featmap = featmap;
+  a.L = 4; a.NG = uni_kind == 1 ? 16 : 8; a.n_chunks = n_chunks; a.act = 1; a.bias_floats = bias_floats;
+  a.n_tiles = (N + 127) / 128;
+  a.xs = 68; a.xlds = 1;
+  a.act_out[0] = (float*)h1; a.act_out[1] = (float*)h2; a.act_out[2] = (float*)h3; a.phi_out = (float*)phi; a.ldphi = ldphi;
+  const int lds = (ARS_NR * ARS_CH * AR_TF + bias_floats + 1024 + 256 + 8 * 16 * a.xs) * (int)sizeof(float);  // ring | bias | feature map | (skip words) | row tiles
+  if (lds > 160 * 1024) return ZK_EINVAL;
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  return zk::ar_static_launch(a, uni_kind, variant, lds, grid, (hipStream_t)stream);
 }
 
 // The per-tile pattern of the stream the static kernel consumes (ArPlan.fine_tilemask of zuko_amd/fused.py): out[(l * 4 + otg) * 16 + it]

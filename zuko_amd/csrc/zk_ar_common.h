@@ -35,6 +35,11 @@ struct ArArgs {
   int32_t* bin_out;  // diagnostic instantiation only: bin index [N, D] and the K+1 search-axis knots [N, D, K+1]
   float* knots_out;
   int l1rev;         // static-shape kernel only: the first layer's block pattern is that of a descending feature order
+  // static-shape kernel, conditioner-only (training) instantiation: the hidden activations [N, 256] (units in the stream's
+  // sorted order) and the packed parameters phi [N, D * total] (module order) are written out; y / ladj are not
+  float* act_out[3];
+  float* phi_out;
+  int64_t ldphi;
 };
 
 __device__ __forceinline__ float act_f32(float v, int act) {

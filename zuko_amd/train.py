@@ -53,9 +53,8 @@ class SortedPlan:
             for i, m in enumerate(masks):
                 dep = ((m.detach().cpu().double() @ dep) > 0).double()
                 if i + 1 < n:
-                    perm = torch.argsort(dep.sum(dim=1), stable=True)
-                    dep = dep[perm]
-                    perms.append(perm)
+                    # (dep stays in the module's unit order: the next mask's columns index it)
+                    perms.append(torch.argsort(dep.sum(dim=1), stable=True))
                 else:
                     perms.append(None)
         else:
@@ -158,6 +157,66 @@ class SortedPlan:
         return out
 
 
+_FUSED_TRAIN = weakref.WeakKeyDictionary()  # SortedPlan -> FusedAR (static-shape kernel) or False
+
+
+def _fused_forward_state(plan: "SortedPlan", lins, device):
+    """The static-shape fused kernel (csrc/fused_ar_static.hip, conditioner-only instantiation) for the forward of this
+    network under autograd, or None: the conditioner of MaskedAutoregressiveTransform(64, hidden_features=[256] * 3) with a
+    spline or affine head.  Its hidden activations come out in the kernel's sorted unit order, which is this plan's (both sort
+    stably by dependency count) — checked once against the layer-wise kernels on a random batch."""
+    import os
+
+    if os.environ.get("ZUKO_AMD_NO_FUSED_TRAIN", "0") == "1":
+        return None
+    st = _FUSED_TRAIN.get(plan)
+    if st is None:
+        st = False
+        try:
+            from . import fused
+
+            shapes = plan.shapes
+            feats = shapes[0][1]
+            total = shapes[-1][0] // max(feats, 1)
+            layout = fused.uni_layout("affine", 2) if total == 2 else (fused.uni_layout("rqs", total, 8) if total == 23 else None)
+            ok = (len(lins) == 4 and plan.act == 1 and feats == 64 and shapes[-1][0] == feats * total and layout is not None
+                  and all(getattr(l, "mask", None) is not None for l in lins) and all(s[0] == 256 for s in shapes[:-1]))
+            if ok:
+                fp = fused.build_plan([l.mask for l in lins], feats, layout)
+                cand = fused.FusedAR(fp, device, 1, 1.0, 1e-3) if fp is not None else None
+                if cand is not None and cand.static_variant:
+                    cand.refresh(lins)
+                    g = torch.Generator(device="cpu").manual_seed(0)
+                    xt = torch.randn(200, feats, generator=g).to(device)
+                    with torch.no_grad():
+                        hs_f, phi_f = _fused_forward(cand, xt, shapes[-1][0])
+                        ws, _, bs = plan.gather(lins)
+                        h = xt
+                        same = True
+                        for l in range(4):
+                            h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l < 3 else 0)
+                            ref = hs_f[l] if l < 3 else phi_f
+                            same = same and bool(torch.allclose(ref, h, rtol=1e-4, atol=1e-4))
+                    if same:
+                        st = cand
+        except Exception:
+            st = False
+        _FUSED_TRAIN[plan] = st
+    return st or None
+
+
+def _fused_forward(st, x: Tensor, out_features: int):
+    """([h1, h2, h3] sorted-domain activations, phi) from one launch of zk_ar_forward_train."""
+    p = st.plan
+    N = x.shape[0]
+    hs = [torch.empty((N, 256), dtype=torch.float32, device=x.device) for _ in range(3)]
+    phi = torch.empty((N, out_features), dtype=torch.float32, device=x.device)
+    err = _C.lib().zk_ar_forward_train(p.layout.kind, N, _ptr(x), x.stride(0), _ptr(hs[0]), _ptr(hs[1]), _ptr(hs[2]), _ptr(phi), out_features,
+                                       _ptr(st.fine_stream), _ptr(st.bias), st.bias_floats, _ptr(st.featmap), p.fine_n_chunks, st.static_variant, _stream())
+    _C.check(err, "zk_ar_forward_train")
+    return hs, phi
+
+
 class ConditionerFn(torch.autograd.Function):
     """phi = net(x) for a plain (linear, activation)* network; x [N, in] contiguous fp32.  Inputs after `x`: weight_0,
     bias_0 (or None), weight_1, ... in layer order."""
@@ -166,11 +225,17 @@ class ConditionerFn(torch.autograd.Function):
     def forward(ctx, plan: SortedPlan, lins, x: Tensor, *params):
         n = len(lins)
         ws, wts, bs = plan.gather(lins)
-        hs = [x]
-        h = x
-        for l in range(n):
-            h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l + 1 < n else 0)
-            hs.append(h)
+        st = _fused_forward_state(plan, lins, x.device) if (x.shape[1] == 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+        if st is not None:  # whole forward in one launch of the static-shape kernel
+            st.refresh(lins)
+            acts, h = _fused_forward(st, x, plan.shapes[-1][0])
+            hs = [x, *acts, h]
+        else:
+            hs = [x]
+            h = x
+            for l in range(n):
+                h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l + 1 < n else 0)
+                hs.append(h)
         ctx.plan, ctx.n = plan, n
         ctx.has_bias = [b is not None for b in bs]
         ctx.save_for_backward(*hs[:-1], *wts)
