@@ -440,8 +440,9 @@ class FusedAR:
             return variant
         return 0
 
-    def refresh(self, linears) -> None:
-        """(Re)build the weight stream / bias image if any parameter changed since the last call."""
+    def refresh(self, linears, fine_only: bool = False) -> None:
+        """(Re)build the weight stream / bias image if any parameter changed since the last call.  fine_only (training forward,
+        which re-gathers every step): only the static-shape kernel's stream."""
         from . import _C
         from .ops import _ptr, _stream
 
@@ -458,7 +459,8 @@ class FusedAR:
             mask = m.mask.contiguous().view(torch.uint8)
             n = self.gather[l].numel()
             dst = self.stream[self.plan.layer_block0[l] * 256 :]
-            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), n, _ptr(dst), _stream()), "zk_gather_f32")
+            if not (fine_only and self.static_variant):
+                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), n, _ptr(dst), _stream()), "zk_gather_f32")
             if self.static_variant:
                 fdst = self.fine_stream[self.plan.fine_layer_block0[l] * 256 :]
                 _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel(), _ptr(fdst), _stream()), "zk_gather_f32")

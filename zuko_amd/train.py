@@ -105,19 +105,24 @@ class SortedPlan:
 
     # ---- device work -------------------------------------------------------------------------------------------
 
-    def gather(self, lins):
-        """Sorted, masked weights Ws_l [out, in], their transposes [in, out] and sorted biases (fresh tensors)."""
+    def gather(self, lins, forward: bool = True):
+        """Sorted, masked weights Ws_l [out, in], their transposes [in, out] and sorted biases (fresh tensors).  forward=False:
+        only what the backward pass reads (the transposes; ws entries are None, biases are reported as present / absent)."""
         lib = _C.lib()
         ws, wts, bs = [], [], []
         for l, lin in enumerate(lins):
             out_f, in_f = self.shapes[l]
             w = lin.weight.detach().contiguous()
-            ws_l = torch.empty((out_f, in_f), dtype=torch.float32, device=self.device)
             wt_l = torch.empty((in_f, out_f), dtype=torch.float32, device=self.device)
-            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(self.mask_u8[l]), _ptr(self.idx_w[l]), out_f * in_f, _ptr(ws_l), _stream()), "zk_gather_f32")
             _C.check(lib.zk_gather_f32(_ptr(w), _ptr(self.mask_u8[l]), _ptr(self.idx_wt[l]), out_f * in_f, _ptr(wt_l), _stream()), "zk_gather_f32")
-            ws.append(ws_l)
             wts.append(wt_l)
+            if not forward:
+                ws.append(None)
+                bs.append(None if lin.bias is None else True)
+                continue
+            ws_l = torch.empty((out_f, in_f), dtype=torch.float32, device=self.device)
+            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(self.mask_u8[l]), _ptr(self.idx_w[l]), out_f * in_f, _ptr(ws_l), _stream()), "zk_gather_f32")
+            ws.append(ws_l)
             if lin.bias is None:
                 bs.append(None)
             else:
@@ -224,10 +229,10 @@ class ConditionerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: SortedPlan, lins, x: Tensor, *params):
         n = len(lins)
-        ws, wts, bs = plan.gather(lins)
         st = _fused_forward_state(plan, lins, x.device) if (x.shape[1] == 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+        ws, wts, bs = plan.gather(lins, forward=st is None)
         if st is not None:  # whole forward in one launch of the static-shape kernel
-            st.refresh(lins)
+            st.refresh(lins, fine_only=True)
             acts, h = _fused_forward(st, x, plan.shapes[-1][0])
             hs = [x, *acts, h]
         else:
