@@ -55,6 +55,20 @@ def test_gemm_skip_wgrad_colsum(dev, N, IN, OUT):
     assert torch.equal(plan.wgrad(0, g, x), dw), "wgrad must be deterministic"
     cs = plan.colsum(g)
     assert torch.allclose(cs.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
+    pr, seen = plan.pairs[0].cpu(), set()
+    flag = torch.zeros(pr.shape[0], dtype=torch.uint8)
+    for k in range(pr.shape[0]):
+        if int(pr[k, 0]) not in seen:
+            seen.add(int(pr[k, 0]))
+            flag[k] = 1
+    plan.cs_flag = [flag.to(dev) if len(seen) == ob else None]
+    dw2, db2 = plan.wgrad(0, g, x, want_bias=True)  # bias gradient from the same pass over g
+    assert torch.equal(dw2, dw)
+    if plan.cs_flag[0] is not None:
+        assert torch.allclose(db2.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
+        assert torch.equal(plan.wgrad(0, g, x, want_bias=True)[1], db2), "deterministic"
+    else:
+        assert db2 is None
 
 
 @pytest.mark.parametrize("kind", ["nsf64", "maf_ctx", "coupling"])

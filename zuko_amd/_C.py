@@ -48,6 +48,7 @@ SIGNATURES = {
     "zk_gemm_f32_skip": [L, I, I, P, L, P, P, P, I, P, L, I, P, L, P],
     "zk_wgrad_slices": [L, I],
     "zk_wgrad_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P],
+    "zk_wgrad_bias_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P, P, P, P],
     "zk_colsum_slices": [L],
     "zk_colsum_f32": [L, I, P, L, P, P, I, P],
     "zk_ar_lds_bytes": [I, I],

@@ -232,6 +232,11 @@ struct WgradArgs {
   int64_t S;              // rows per slice (even)
   int nslices;
   float* partial;         // [nslices][npairs][128 x 128]
+  // optional bias gradient (column sums of g) from the same pass over g: blocks with cs_flag[p] != 0 (one per out block) also
+  // add up the 128 columns of their G tiles; cs_partial [nslices][cs_ld]
+  const uint8_t* cs_flag;
+  float* cs_partial;
+  int cs_ld;
 };
 
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
@@ -263,6 +268,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
   const bool vg = (a.ldg % 4 == 0) && ((((uintptr_t)a.g) & 15) == 0) && (go + 4 <= a.OUT);
   const bool vh = (a.ldh % 4 == 0) && ((((uintptr_t)a.h) & 15) == 0) && (hc + 4 <= a.IN);
   float4 rg[4], rh[4];
+  // bias gradient: in the designated blocks thread t < 128 adds up column t of every G tile out of LDS (one register; a float4 share per
+  // loader thread would take the kernel past 128 VGPRs, i.e. from four to three blocks per CU)
+  const bool do_cs = a.cs_flag && a.cs_flag[p] && tid < 128;
+  float csum = 0.f;
   auto gload = [&](int64_t n0) {
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -288,6 +297,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
     }
     __syncthreads();
     if (n0 + 32 < n_end) gload(n0 + 32);
+    if (do_cs) {
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) csum += Gs[k][tid];
+    }
 #pragma unroll 4
     for (int kp = 0; kp < 16; ++kp) {
       float av[2], bv[2];
@@ -302,6 +315,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
     }
     __syncthreads();
   }
+  if (do_cs) a.cs_partial[(size_t)s * a.cs_ld + ob * 128 + tid] = csum;
   // acc[m][n][r] = D[i = 8 (r >> 2) + 4 (lane >> 5) + (r & 3)][j = lane & 31] of the (m, n) 32 x 32 sub-block
   float* dst = a.partial + ((size_t)s * a.npairs + p) * (128 * 128);
 #pragma unroll
@@ -387,11 +401,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t N, int C, c
     if (c < C) partial[(size_t)s * C + c] = sum;
   }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(int C, int nslices, const float* partial, float* out, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(int C, int nslices, const float* partial, float* out, int accumulate, int ld = 0) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
+  const size_t stride = ld ? (size_t)ld : (size_t)C;
   float sum = 0.f;
-  for (int s = 0; s < nslices; ++s) sum += partial[(size_t)s * C + c];
+  for (int s = 0; s < nslices; ++s) sum += partial[(size_t)s * stride + c];
   out[c] = accumulate ? out[c] + sum : sum;
 }
 
@@ -435,10 +450,11 @@ int zk_wgrad_slices(int64_t N, int npairs) {
 
 // dw[OUT, IN] (+)= mask .* (g^T h): g [N, OUT], h [N, IN]; pairs = the (128 x 128) blocks of dw to compute (device, int32 [npairs][2]);
 // the blocks not listed are left untouched (the caller zero-fills dw once).  Deterministic.
-int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
-                 float* partial, const uint8_t* mask, void* dw, int accumulate, void* stream) {
+static int wgrad_launch(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
+                        float* partial, const uint8_t* mask, void* dw, int accumulate, const uint8_t* cs_flag, float* cs_partial, void* db, void* stream) {
   if (N <= 0 || npairs <= 0) return 0;
   WgradArgs a{};
+  a.cs_flag = cs_flag; a.cs_partial = cs_partial; a.cs_ld = (out_features + 127) / 128 * 128;
   a.N = N; a.OUT = out_features; a.IN = in_features; a.g = (const float*)g; a.ldg = ldg; a.h = (const float*)h; a.ldh = ldh; a.pairs = pairs; a.npairs = npairs;
   a.nslices = zk_wgrad_slices(N, npairs);
   a.S = ((N + a.nslices - 1) / a.nslices + 15) / 16 * 16;
@@ -448,7 +464,22 @@ int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, in
   hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)npairs * 64), dim3(256), 0, st, out_features, in_features, pairs, npairs, a.nslices, (const float*)partial, mask,
                      (float*)dw, accumulate);
+  if (cs_flag) hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((out_features + 255) / 256)), dim3(256), 0, st, out_features, a.nslices, (const float*)cs_partial, (float*)db, 0, a.cs_ld);
   return ZK_LAUNCH_CHECK();
+}
+
+int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
+                 float* partial, const uint8_t* mask, void* dw, int accumulate, void* stream) {
+  return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, nullptr, nullptr, nullptr, stream);
+}
+
+// zk_wgrad_f32 plus the bias gradient db[OUT] = sum_n g[n, :] from the same pass over g (it replaces a separate zk_colsum_f32 over g):
+// cs_flag [npairs] (device, uint8) marks ONE pair per out block (every out block must have one); cs_partial: workspace of
+// zk_wgrad_slices(N, npairs) * ceil(OUT / 128) * 128 floats.  Deterministic.
+int zk_wgrad_bias_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
+                      float* partial, const uint8_t* mask, void* dw, int accumulate, const uint8_t* cs_flag, float* cs_partial, void* db, void* stream) {
+  if (!cs_flag || !cs_partial || !db) return ZK_EINVAL;
+  return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, cs_flag, cs_partial, db, stream);
 }
 
 // out[c] (+)= sum_n x[n, c];  workspace: >= zk_colsum_slices(N) * C floats

@@ -62,6 +62,7 @@ class SortedPlan:
         self.perms = perms
         self.idx_w, self.idx_wt, self.idx_b, self.kskip_f, self.kskip_b, self.pairs, self.mask_s, self.shapes = [], [], [], [], [], [], [], shapes
         self.mask_u8 = []
+        self.cs_flag = []
         prev = None
         for i, (out_f, in_f) in enumerate(shapes):
             rows = perms[i] if perms[i] is not None else torch.arange(out_f)
@@ -79,7 +80,17 @@ class SortedPlan:
             pad = torch.zeros((ob * 128, ib * 128), dtype=torch.bool)
             pad[:out_f, :in_f] = ms
             live = pad.reshape(ob, 128, ib, 128).any(dim=3).any(dim=1)
-            self.pairs.append(live.nonzero().to(torch.int32).contiguous().to(device))
+            pr = live.nonzero().to(torch.int32).contiguous()
+            self.pairs.append(pr.to(device))
+            # one designated pair per out block also sums the columns of g (bias gradient); needs every out block present
+            flag = torch.zeros(pr.shape[0], dtype=torch.uint8)
+            seen = set()
+            for k in range(pr.shape[0]):
+                o = int(pr[k, 0])
+                if o not in seen:
+                    seen.add(o)
+                    flag[k] = 1
+            self.cs_flag.append(flag.to(device) if len(seen) == ob else None)
             self.mask_s.append(None if m is None else ms.to(torch.uint8).contiguous().to(device))
             self.mask_u8.append(None if m is None else m.detach().to(device=device, dtype=torch.uint8).contiguous())
             prev = perms[i]
@@ -139,8 +150,9 @@ class SortedPlan:
         _C.check(err, "zk_gemm_f32_skip")
         return y
 
-    def wgrad(self, l: int, g: Tensor, h: Tensor) -> Tensor:
-        """Sorted-domain weight gradient dWs_l [out, in] (zeros where the mask is false)."""
+    def wgrad(self, l: int, g: Tensor, h: Tensor, want_bias: bool = False):
+        """Sorted-domain weight gradient dWs_l [out, in] (zeros where the mask is false).  want_bias: returns (dWs_l, dbs_l) with the
+        sorted-domain bias gradient from the same pass over g (None when some 128-row out block has no live weight block)."""
         lib = _C.lib()
         out_f, in_f = self.shapes[l]
         N = g.shape[0]
@@ -149,9 +161,16 @@ class SortedPlan:
         dw = torch.zeros((out_f, in_f), dtype=torch.float32, device=g.device)
         ns = lib.zk_wgrad_slices(N, npairs)
         partial = torch.empty(max(1, ns) * npairs * 128 * 128, dtype=torch.float32, device=g.device)
+        if want_bias and self.cs_flag[l] is not None and npairs > 0:
+            cs_partial = torch.empty(max(1, ns) * (-(-out_f // 128) * 128), dtype=torch.float32, device=g.device)
+            db = torch.empty(out_f, dtype=torch.float32, device=g.device)
+            err = lib.zk_wgrad_bias_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(self.mask_s[l]), _ptr(dw), 0,
+                                        _ptr(self.cs_flag[l]), _ptr(cs_partial), _ptr(db), _stream())
+            _C.check(err, "zk_wgrad_bias_f32")
+            return dw, db
         err = lib.zk_wgrad_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(self.mask_s[l]), _ptr(dw), 0, _stream())
         _C.check(err, "zk_wgrad_f32")
-        return dw
+        return (dw, None) if want_bias else dw
 
     def colsum(self, g: Tensor) -> Tensor:
         lib = _C.lib()
@@ -255,13 +274,16 @@ class ConditionerFn(torch.autograd.Function):
         grads: list = [None] * (2 * n)
         for l in range(n - 1, -1, -1):
             out_f, in_f = plan.shapes[l]
+            want_b = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
+            dbs = None
             if ctx.needs_input_grad[3 + 2 * l]:
-                dws = plan.wgrad(l, g, hs[l])
+                dws, dbs = plan.wgrad(l, g, hs[l], want_bias=True) if want_b else (plan.wgrad(l, g, hs[l]), None)
                 dw = torch.empty(out_f * in_f, dtype=torch.float32, device=g.device)
                 dw[plan.idx_w64[l]] = dws.reshape(-1)  # scatter back to the module's unit order (a bijection)
                 grads[2 * l] = dw.reshape(out_f, in_f)
-            if ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]:
-                dbs = plan.colsum(g)
+            if want_b:
+                if dbs is None:
+                    dbs = plan.colsum(g)
                 db = torch.empty(out_f, dtype=torch.float32, device=g.device)
                 db[plan.idx_b64[l]] = dbs
                 grads[2 * l + 1] = db
