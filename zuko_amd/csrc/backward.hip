@@ -34,16 +34,18 @@ __device__ __forceinline__ Dual7 operator-(const Dual7& a, const Dual7& b) { Dua
 __device__ __forceinline__ Dual7 operator*(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v * b.v;
 #pragma unroll
   for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-__device__ __forceinline__ Dual7 operator/(const Dual7& a, const Dual7& b) { Dual7 r; const float ib = 1.f / b.v; r.v = a.v * ib;
+// (reciprocals, exponentials and logarithms of the adjoint use the hardware approximations — v_rcp / v_exp / v_log, ~1 ulp — like the
+//  forward's rqs_lean: with IEEE division and ocml expf the kernel was VALU-bound at 2.6 TB/s; gradients are compared at 2e-4)
+__device__ __forceinline__ Dual7 operator/(const Dual7& a, const Dual7& b) { Dual7 r; const float ib = __builtin_amdgcn_rcpf(b.v); r.v = a.v * ib;
 #pragma unroll
   for (int i = 0; i < 7; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
-__device__ __forceinline__ Dual7 dlog(const Dual7& a) { Dual7 r; r.v = logf(a.v); const float ia = 1.f / a.v;
+__device__ __forceinline__ Dual7 dlog(const Dual7& a) { Dual7 r; r.v = __logf(a.v); const float ia = __builtin_amdgcn_rcpf(a.v);
 #pragma unroll
   for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * ia; return r; }
 
 __device__ __forceinline__ float softclip_grad(float v, float c_abs) {  // d/dv [ v / (1 + |v| / c) ]
-  const float t = 1.f + fabsf(v) / c_abs;
-  return 1.f / (t * t);
+  const float t = 1.f + fabsf(v) * __builtin_amdgcn_rcpf(c_abs);
+  return __builtin_amdgcn_rcpf(t * t);
 }
 
 struct BwdArgs {
@@ -60,7 +62,7 @@ struct BwdArgs {
 };
 
 template <int K> __device__ __forceinline__ void rqs_backward_element(const float* p, float x, float gyv, float glv, float bound, float ls, float& gxv, float* g) {
-  typedef MathIEEE<float> M;
+  typedef MathFast M;
   constexpr int TOTAL = 3 * K - 1;
   float kx[K + 1], ky[K + 1], kd[K + 1], pw[K], ph[K];
   // forward recompute, keeping the softmax probabilities
@@ -70,8 +72,8 @@ template <int K> __device__ __forceinline__ void rqs_backward_element(const floa
     for (int j = 0; j < K; ++j) { v[j] = softclip2<float, M>(p[off + j], ls); m = (j == 0) ? v[0] : fmaxf(m, v[j]); }
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < K; ++j) { v[j] = expf(v[j] - m); s += v[j]; }
-    const float r = 1.f / s;
+    for (int j = 0; j < K; ++j) { v[j] = __expf(v[j] - m); s += v[j]; }
+    const float r = __builtin_amdgcn_rcpf(s);
     float cum = 0.f;
     knot[0] = -bound;
 #pragma unroll
