@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bin-report", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
                     help="cfg2 = the headline NSF workload (default, the only graded line); cfg3 = MAF(64,T=8,H=256x3); "
                          "cfg4 = RealNVP(256,T=16,H=512x3); cfg5 = NSF(1024,T=12,K=16,H=1024x3) in bf16 (use --batch-log2 19) — "
@@ -126,9 +126,12 @@ def init_ranks(args):
 # --------------------------------------------------------------------------------------------------
 
 
-def cpu_baseline(flow_cpu, seconds: float) -> dict:
-    """The oracle (a restatement of the reference on PyTorch-CPU ops, bitwise equal to it in the
-    build container: tests/golden/make_golden.py) timed on this host: chunks of 2^12 rows of the same workload."""
+def cpu_baseline(flow_cpu, seconds: float):
+    """The oracle (a restatement of the reference on PyTorch-CPU ops, bitwise equal to it in the build container:
+    tests/golden/make_golden.py) timed on this host on chunks of 2^12, 2^14 and 2^16 rows of the same workload (SURVEY
+    8d: the reference degrades at larger chunks; `value` is the best of the three).  Returns (json dict, sample) where
+    `sample` holds the chunk tensors and the oracle's outputs on them — the SAME rows then go through the GPU path
+    (parity_report)."""
     import torch
 
     from oracle import zuko_oracle as O
@@ -136,49 +139,143 @@ def cpu_baseline(flow_cpu, seconds: float) -> dict:
     ncpu = os.cpu_count() or 1
     sd = {k: v for k, v in flow_cpu.state_dict().items() if v is not None}
     spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(BINS), FEATURES)
-    chunk = 1 << 12
-    x = torch.randn(chunk, FEATURES, generator=torch.Generator().manual_seed(1))
+    chunks = [1 << 12, 1 << 14, 1 << 16]
+    xall = torch.randn(chunks[-1], FEATURES, generator=torch.Generator().manual_seed(1))
+    keep = {}
 
-    def once() -> float:
+    def once(n: int) -> float:
+        x = xall[:n]
         t0 = time.perf_counter()
-        O.flow_log_prob(spec, x)
-        return time.perf_counter() - t0
+        z, ladj = O.flow_forward(spec, x)  # (= the body of O.flow_log_prob: zuko/distributions.py:115-119)
+        lp = O.diag_normal_log_prob(z, spec.loc, spec.scale) + ladj
+        dt = time.perf_counter() - t0
+        keep[n] = (z, ladj, lp)
+        return dt
 
     # PyTorch-CPU does not scale to hundreds of threads on these small ops (measured on the 256-thread EPYC 9575F
     # host: 16 threads are fastest, all 256 are ~700x slower): pick the fastest of a bounded sweep up to 64 threads,
     # dropping a candidate as soon as its first pass is 3x off the best, then spend the rest of the budget there.
     best_t, best = None, float("inf")
     sweep = {}
+    per_chunk = {}
     with torch.no_grad():
         for threads in sorted({t for t in (4, 8, 16, 32, 64) if 1 <= t <= ncpu} or {1}):
             torch.set_num_threads(threads)
-            first = once()
+            first = once(chunks[0])
             if first > 3.0 * best:
-                sweep[threads] = chunk / first
+                sweep[threads] = chunks[0] / first
                 continue
-            t = min(once(), once())
-            sweep[threads] = chunk / t
+            t = min(once(chunks[0]), once(chunks[0]))
+            sweep[threads] = chunks[0] / t
             if t < best:
                 best_t, best = threads, t
         threads = best_t
         torch.set_num_threads(threads)
-        times = []
-        t_end = time.perf_counter() + seconds
-        while time.perf_counter() < t_end or len(times) < 3:
-            times.append(once())
-    times.sort()
-    med = times[len(times) // 2]
-    return {
-        "value": chunk / med,
+        # budget: 40 % on the 2^12 chunk (>= 3 passes), 25 % on 2^14 (>= 2), the rest on 2^16 (>= 1; one pass is 3-15 s)
+        for n, share, least in ((chunks[0], 0.40, 3), (chunks[1], 0.25, 2), (chunks[2], 0.35, 1)):
+            times = []
+            t_end = time.perf_counter() + seconds * share
+            while time.perf_counter() < t_end or len(times) < least:
+                times.append(once(n))
+            times.sort()
+            per_chunk[n] = (times[len(times) // 2], len(times))
+    rates = {n: n / med for n, (med, _) in per_chunk.items()}
+    n_best = max(rates, key=rates.get)
+    out = {
+        "value": rates[n_best],
         "unit": "samples/s",
         "cores": threads,
         "host_cpus": ncpu,
         "kind": "port",
         "pinned_bitwise": True,  # the port equals the live reference bit for bit (fixtures regenerated by tests/golden/make_golden.py)
         "thread_sweep_samples_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
-        "sample": f"{len(times)} x chunk of 2^12 rows (median) at the fastest thread count of the sweep, same model; the reference degrades at larger chunks (SURVEY 6)",
+        "chunk_sweep_samples_per_s": {f"2^{n.bit_length() - 1}": round(r, 1) for n, r in rates.items()},
+        "chunk_passes": {f"2^{n.bit_length() - 1}": per_chunk[n][1] for n in per_chunk},
+        "extrapolated_seconds_for_2^20": (1 << 20) / rates[n_best],
+        "sample": f"median over {per_chunk[n_best][1]} passes of a 2^{n_best.bit_length() - 1}-row chunk (best of the 2^12 / 2^14 / 2^16 sweep) at the fastest thread count of the sweep, same model, same rows the GPU parity block uses",
         "cpu_model": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown"),
     }
+    return out, {"x": xall, "spec": spec, "out": keep}
+
+
+# --------------------------------------------------------------------------------------------------
+# parity of the GPU path with the oracle, measured in this run on the rows the CPU baseline timed
+# --------------------------------------------------------------------------------------------------
+
+
+def parity_report(flow, x_dev, sample, dev) -> dict:
+    """(a) The chunks the CPU baseline timed (2^12, 2^14, 2^16 rows) through the GPU flow as batches of their own;
+    (b) 16 slices of 256 rows spread over the FULL benchmark batch (first rows, the middle, the last 256 rows: tail tiles
+    of the persistent grid) taken from ONE evaluation of the whole batch, against the oracle on the same rows, in fp32
+    (north_star's bar: log_prob within 1e-5 relative) and in float64 (how far each fp32 evaluation is from the exact one)."""
+    import torch
+
+    from oracle import zuko_oracle as O
+
+    spec, xall, keep = sample["spec"], sample["x"], sample["out"]
+    rep = {"bar": "log_prob max relative error <= 1e-5 (north_star); z / ladj reported as absolute errors next to the fp32 reference's own distance from float64"}
+    worst_lp = worst_z = worst_l = 0.0
+    rows = 0
+    with torch.no_grad():
+        chunks = {}
+        for n, (z_o, l_o, lp_o) in sorted(keep.items()):
+            xg = xall[:n].to(dev)
+            dist = flow()
+            lp = dist.log_prob(xg).cpu()
+            z, ladj = dist.transform.call_and_ladj(xg)
+            z, ladj = z.cpu(), ladj.cpu()
+            e_lp = float(((lp - lp_o).abs() / lp_o.abs()).max())
+            e_z, e_l = float((z - z_o).abs().max()), float((ladj - l_o).abs().max())
+            chunks[f"2^{n.bit_length() - 1}"] = {"rows": n, "log_prob_max_rel": e_lp, "z_max_abs": e_z, "ladj_max_abs": e_l}
+            worst_lp, worst_z, worst_l = max(worst_lp, e_lp), max(worst_z, e_z), max(worst_l, e_l)
+            rows += n
+        rep["cpu_baseline_chunks"] = chunks
+        # deep-batch slices out of one evaluation of the whole batch
+        B = x_dev.shape[0]
+        nsl, width = 16, 256
+        starts = sorted({min(B - width, (B - width) * i // (nsl - 1)) for i in range(nsl)}) if B >= nsl * width else [0]
+        idx = torch.cat([torch.arange(s, min(s + width, B)) for s in starts])
+        dist = flow()
+        lp_full = dist.log_prob(x_dev)
+        z_full, l_full = dist.transform.call_and_ladj(x_dev)
+        idx_d = idx.to(dev)
+        lp, z, ladj = lp_full[idx_d].cpu(), z_full[idx_d].cpu(), l_full[idx_d].cpu()
+        del lp_full, z_full, l_full
+        xs = x_dev[idx_d].cpu()
+        z_o, l_o = O.flow_forward(spec, xs)
+        lp_o = O.diag_normal_log_prob(z_o, spec.loc, spec.scale) + l_o
+        e_lp = float(((lp - lp_o).abs() / lp_o.abs()).max())
+        e_z, e_l = float((z - z_o).abs().max()), float((ladj - l_o).abs().max())
+        deep = {"rows": int(idx.numel()), "slices": len(starts), "slice_rows": width, "first_row_of_last_slice": int(starts[-1]), "batch": int(B),
+                "log_prob_max_rel": e_lp, "z_max_abs": e_z, "ladj_max_abs": e_l}
+        worst_lp, worst_z, worst_l = max(worst_lp, e_lp), max(worst_z, e_z), max(worst_l, e_l)
+        rows += int(idx.numel())
+        try:  # float64 oracle on the same slices: error of the HIP path and of the fp32 reference against it
+            import dataclasses
+
+            def f64(o):
+                if isinstance(o, torch.Tensor):
+                    return o.double() if o.is_floating_point() else o
+                if dataclasses.is_dataclass(o) and not isinstance(o, type):
+                    return type(o)(**{f.name: f64(getattr(o, f.name)) for f in dataclasses.fields(o)})
+                if isinstance(o, (list, tuple)):
+                    return type(o)(f64(v) for v in o)
+                return o
+
+            s64 = f64(spec)
+            z64, l64 = O.flow_forward(s64, xs.double())
+            lp64 = O.diag_normal_log_prob(z64, s64.loc, s64.scale) + l64
+            mx = lambda a, b: float((a.double() - b).abs().max())
+            deep["vs_float64_oracle"] = {
+                "z_max_abs": {"hip": mx(z, z64), "reference_fp32": mx(z_o, z64)},
+                "ladj_max_abs": {"hip": mx(ladj, l64), "reference_fp32": mx(l_o, l64)},
+                "log_prob_max_rel": {"hip": float(((lp.double() - lp64).abs() / lp64.abs()).max()), "reference_fp32": float(((lp_o.double() - lp64).abs() / lp64.abs()).max())},
+            }
+        except Exception as exc:  # the float64 side report must never break the line
+            deep["vs_float64_oracle"] = {"error": repr(exc)}
+        rep["deep_batch_slices"] = deep
+    rep.update(rows=rows, log_prob_max_rel=worst_lp, z_max_abs=worst_z, ladj_max_abs=worst_l, ok=bool(worst_lp <= 1e-5))
+    return rep
 
 
 # --------------------------------------------------------------------------------------------------
@@ -371,16 +468,31 @@ def main() -> None:
                 gen = torch.Generator(device=dev).manual_seed(3)
                 phi = torch.randn(B, features, 3 * BINS - 1, generator=gen, device=dev)
                 w, h, d = phi[..., :BINS], phi[..., BINS : 2 * BINS], phi[..., 2 * BINS :]
+                # phi through non-temporal loads (library default) and through plain loads, interleaved in one process: which one
+                # is faster differs between boxes by a few percent (BENCH_r01 0.75 / BENCH_r02 0.65 of 8 TB/s on the same kernel)
+                variants = {"nt": [], "plain": []}
+                prev = os.environ.get("ZUKO_AMD_K1_NT")
                 with torch.no_grad():
-                    ops.rqs_forward(x, w, h, d, reduce=True)
-                    _C.PROFILE = {}
-                    for _ in range(5):
+                    for name in ("nt", "plain"):
+                        os.environ["ZUKO_AMD_K1_NT"] = "1" if name == "nt" else "0"
                         ops.rqs_forward(x, w, h, d, reduce=True)
-                    torch.cuda.synchronize()
-                recs = _C.PROFILE.get("zk_rqs_forward", [])
-                _C.PROFILE = None
-                ts = [a.elapsed_time(b) for a, b, _ in recs]
-                kernels[f"zk_rqs_forward {B} {features} {BINS}"] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), "standalone": True}
+                    for _ in range(5):
+                        for name in ("nt", "plain"):
+                            os.environ["ZUKO_AMD_K1_NT"] = "1" if name == "nt" else "0"
+                            _C.PROFILE = {}
+                            ops.rqs_forward(x, w, h, d, reduce=True)
+                            torch.cuda.synchronize()
+                            variants[name] += [a.elapsed_time(b) for a, b, _ in _C.PROFILE.get("zk_rqs_forward", [])]
+                            _C.PROFILE = None
+                if prev is None:
+                    os.environ.pop("ZUKO_AMD_K1_NT", None)
+                else:
+                    os.environ["ZUKO_AMD_K1_NT"] = prev
+                med = {k: sorted(v)[len(v) // 2] for k, v in variants.items()}
+                pick = min(med, key=med.get)
+                kernels[f"zk_rqs_forward {B} {features} {BINS}"] = {"calls": len(variants[pick]), "avg_ms": sum(variants[pick]) / len(variants[pick]), "standalone": True, "phi_loads": pick,
+                                                                    "median_ms_by_phi_load_policy": {k: round(v, 4) for k, v in med.items()},
+                                                                    "library_default": "nt (ZUKO_AMD_K1_NT=0 selects plain loads)"}
                 del phi, w, h, d
             except Exception as exc:  # never let the side measurement break the headline line
                 _C.PROFILE = None
@@ -438,8 +550,12 @@ def main() -> None:
             except Exception as exc:
                 out["bin_index"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
-            out["cpu_baseline"] = cpu_baseline(flow_cpu, args.cpu_seconds)
+            out["cpu_baseline"], sample = cpu_baseline(flow_cpu, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            try:
+                out["parity"] = parity_report(flow, x, sample, dev)
+            except Exception as exc:
+                out["parity"] = {"error": repr(exc), "ok": False}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

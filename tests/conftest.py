@@ -13,6 +13,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -37,6 +39,16 @@ def pytest_sessionstart(session):
     except Exception:
         if not os.path.exists(lib):
             raise
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured error ratios of every parity comparison -> gpurun_out/parity_report.json (tests/parity.py)."""
+    try:
+        import parity
+
+        parity.dump_report()
+    except Exception:
+        pass
 
 
 def golden(name: str) -> dict:

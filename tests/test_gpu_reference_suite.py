@@ -1,7 +1,7 @@
 """GPU: the reference's own test strategy (tests/test_flows.py, tests/test_nn.py,
 tests/test_transforms.py — mathematical self-consistency) re-stated for zuko_amd in float32 on the device.
-Gradients through the inverse (rsample) and through SOS / Bernstein transforms are not implemented;
-those parts are exercised forward-only (ladj against a finite-difference Jacobian)."""
+Gradients (log_prob, rsample, SOS / Bernstein adjoints) have their own value checks against autograd through the oracle in
+tests/test_gpu_backward.py; here ladj is checked against a finite-difference Jacobian as the reference's tests do."""
 
 from functools import partial
 

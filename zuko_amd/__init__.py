@@ -26,6 +26,7 @@ def invalidate(module) -> None:
         _ar._FUSED_CACHE.pop(m, None)
         m.__dict__.pop("_bf16_plan_cache", None)
         m.__dict__.pop("_coupling_cache", None)
+        m.__dict__.pop("_split_cache", None)
         from . import train as _train
         from .flows import coupling as _cp
 

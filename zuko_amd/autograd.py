@@ -17,6 +17,7 @@ intermediates).
 from __future__ import annotations
 
 import torch
+from torch.autograd.function import once_differentiable
 from torch import Tensor
 
 from . import _C
@@ -180,6 +181,7 @@ class UnivariateFn(torch.autograd.Function):
         return y, ladj
 
     @staticmethod
+    @once_differentiable  # raw-pointer HIP kernels on detached data: double backward (create_graph=True) must raise, not return graph-less grads
     def backward(ctx, gy, gl):
         xe, phi = ctx.saved_tensors
         gy_c = None if gy is None else gy.expand(xe.shape).contiguous()
@@ -206,6 +208,7 @@ class BernsteinFn(torch.autograd.Function):
         return y, ladj
 
     @staticmethod
+    @once_differentiable  # raw-pointer HIP kernels on detached data: double backward (create_graph=True) must raise, not return graph-less grads
     def backward(ctx, gy, gl):
         xe, phi = ctx.saved_tensors
         gy_c = None if gy is None else gy.expand(xe.shape).contiguous()
@@ -232,6 +235,7 @@ class UnivariatePackedFn(torch.autograd.Function):
         return y, ladj
 
     @staticmethod
+    @once_differentiable  # raw-pointer HIP kernels on detached data: double backward (create_graph=True) must raise, not return graph-less grads
     def backward(ctx, gy, gl):
         xe, phi = ctx.saved_tensors
         gy_c = None if gy is None else gy.expand(xe.shape).contiguous()
@@ -261,6 +265,7 @@ class UnivariateInverseFn(torch.autograd.Function):
         return x
 
     @staticmethod
+    @once_differentiable  # raw-pointer HIP kernels on detached data: double backward (create_graph=True) must raise, not return graph-less grads
     def backward(ctx, gx):
         x, phi = ctx.saved_tensors
         _, ladj = _fwd_any(ctx.meta, x, phi, False)
@@ -291,6 +296,7 @@ class LinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable  # raw-pointer HIP kernels on detached data: double backward (create_graph=True) must raise, not return graph-less grads
     def backward(ctx, gy):
         x, weight, mask, y = ctx.saved_tensors
         mask = mask if mask.numel() else None
@@ -328,6 +334,7 @@ class DiagNormalLogProbFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # raw-pointer HIP kernels on detached data: double backward (create_graph=True) must raise, not return graph-less grads
     def backward(ctx, g):
         z, loc, scale = ctx.saved_tensors
         D = z.shape[-1]

@@ -61,6 +61,25 @@ struct BwdArgs {
   int64_t iters;
 };
 
+// gv[0..6] = gy * dy/d(.) + gl * dladj/d(.) for (.) = x, x0, x1, y0, y1, d0, d1 of the active bin (zuko/transforms.py:554-567),
+// in 7-wide forward-mode dual numbers
+__device__ __forceinline__ void rqs_local_vjp(float x, float x0, float x1, float y0, float y1, float d0, float d1, float gyv, float glv, float (&gv)[7]) {
+  const Dual7 X = dvar(x, 0), X0 = dvar(x0, 1), X1 = dvar(x1, 2), Y0 = dvar(y0, 3), Y1 = dvar(y1, 4), D0 = dvar(d0, 5), D1 = dvar(d1, 6);
+  const Dual7 one = dconst(1.f), two = dconst(2.f);
+  const Dual7 w = X1 - X0, h = Y1 - Y0;
+  const Dual7 s = h / w;
+  const Dual7 z = (X - X0) / w;
+  const Dual7 omz = one - z;
+  const Dual7 zz = z * omz;
+  const Dual7 den = s + (D0 + D1 - two * s) * zz;
+  const Dual7 num = s * z * z + D0 * zz;
+  const Dual7 y = Y0 + h * num / den;
+  const Dual7 jac = s * s * (two * s * zz + D0 * omz * omz + D1 * z * z) / (den * den);
+  const Dual7 lad = dlog(jac);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) gv[i] = gyv * y.d[i] + glv * lad.d[i];
+}
+
 template <int K> __device__ __forceinline__ void rqs_backward_element(const float* p, float x, float gyv, float glv, float bound, float ls, float& gxv, float* g) {
   typedef MathFast M;
   constexpr int TOTAL = 3 * K - 1;
@@ -88,22 +107,8 @@ template <int K> __device__ __forceinline__ void rqs_backward_element(const floa
 #pragma unroll
   for (int i = 0; i < TOTAL; ++i) g[i] = 0.f;
   if (!inside) { gxv = gyv; return; }  // identity outside [-B, B]: y = x, ladj = 0, no parameter gradient
-  // local map in dual numbers: variables 0..6 = x, x0, x1, y0, y1, d0, d1
-  const Dual7 X = dvar(x, 0), X0 = dvar(x0, 1), X1 = dvar(x1, 2), Y0 = dvar(y0, 3), Y1 = dvar(y1, 4), D0 = dvar(d0, 5), D1 = dvar(d1, 6);
-  const Dual7 one = dconst(1.f), two = dconst(2.f);
-  const Dual7 w = X1 - X0, h = Y1 - Y0;
-  const Dual7 s = h / w;
-  const Dual7 z = (X - X0) / w;
-  const Dual7 omz = one - z;
-  const Dual7 zz = z * omz;
-  const Dual7 den = s + (D0 + D1 - two * s) * zz;
-  const Dual7 num = s * z * z + D0 * zz;
-  const Dual7 y = Y0 + h * num / den;
-  const Dual7 jac = s * s * (two * s * zz + D0 * omz * omz + D1 * z * z) / (den * den);
-  const Dual7 lad = dlog(jac);
   float gv[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) gv[i] = gyv * y.d[i] + glv * lad.d[i];
+  rqs_local_vjp(x, x0, x1, y0, y1, d0, d1, gyv, glv, gv);
   gxv = gv[0];
   // knots -> softmax probabilities: kx_j = B (2 sum_{i<j} p_i - 1): only knots k and k+1 carry gradient
   const float twoB = 2.f * bound;
@@ -209,6 +214,59 @@ template <int KIND, int K> __global__ __launch_bounds__(256) void uni_backward_k
   }
 }
 
+// Any bin count up to 64 (zuko/transforms.py:469-477 accepts any `bins`): one lane per element, knots and softmax probabilities
+// in run-time indexed local arrays, parameters read from / gradients written to global memory directly.  A slow path next to the
+// K = 4 / 8 / 16 instantiations above, with the same arithmetic (max-subtracted softmax, strict-count bin search, the same
+// local vector-Jacobian product).
+#define ZK_BWD_MAXK 64
+__global__ __launch_bounds__(256) void rqs_backward_generic_kernel(BwdArgs a, int K) {
+  const int total = 3 * K - 1;
+  const int64_t total_elems = a.N * a.D;
+  const float bound = a.bound, ls = a.ls;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_elems; e += (int64_t)gridDim.x * 256) {
+    const float* p = a.phi + e * total;
+    float* g = a.gphi + e * total;
+    float kn[2][ZK_BWD_MAXK + 1], pr[2][ZK_BWD_MAXK], kd[ZK_BWD_MAXK + 1];
+    for (int ax = 0; ax < 2; ++ax) {
+      float m = softclip2<float>(p[ax * K], ls);
+      for (int j = 1; j < K; ++j) m = fmaxf(m, softclip2<float>(p[ax * K + j], ls));
+      float ssum = 0.f;
+      for (int j = 0; j < K; ++j) { pr[ax][j] = expf(softclip2<float>(p[ax * K + j], ls) - m); ssum += pr[ax][j]; }
+      float cum = 0.f;
+      kn[ax][0] = -bound;
+      for (int j = 0; j < K; ++j) { pr[ax][j] /= ssum; cum += pr[ax][j]; kn[ax][j + 1] = bound * (2.f * cum - 1.f); }
+    }
+    kd[0] = kd[K] = 1.f;
+    for (int j = 1; j < K; ++j) kd[j] = expf(softclip<float>(p[2 * K + j - 1], ls));
+    const float x = a.x[e];
+    const float glv = a.gl ? (a.gl_reduced ? a.gl[e / a.D] : a.gl[e]) : 0.f;
+    const float gyv = a.gy ? a.gy[e] : 0.f;
+    int cnt = 0;
+    for (int j = 0; j <= K; ++j) cnt += (kn[0][j] < x) ? 1 : 0;
+    const int k = cnt - 1;
+    for (int i = 0; i < total; ++i) g[i] = 0.f;
+    if (!(k >= 0 && k < K)) { a.gx[e] = gyv; continue; }  // identity outside [-B, B] (and for NaN: no knot compares below it)
+    float gv[7];
+    rqs_local_vjp(x, kn[0][k], kn[0][k + 1], kn[1][k], kn[1][k + 1], kd[k], kd[k + 1], gyv, glv, gv);
+    a.gx[e] = gv[0];
+    const float twoB = 2.f * bound;
+    float dotw = 0.f, doth = 0.f;
+    for (int i = 0; i < K; ++i) {
+      dotw += pr[0][i] * twoB * ((i < k ? gv[1] : 0.f) + (i <= k ? gv[2] : 0.f));
+      doth += pr[1][i] * twoB * ((i < k ? gv[3] : 0.f) + (i <= k ? gv[4] : 0.f));
+    }
+    const float cw = fabsf(ls) * 0.5f, cd = fabsf(ls);
+    for (int i = 0; i < K; ++i) {
+      const float gw = twoB * ((i < k ? gv[1] : 0.f) + (i <= k ? gv[2] : 0.f));
+      const float gh = twoB * ((i < k ? gv[3] : 0.f) + (i <= k ? gv[4] : 0.f));
+      g[i] = pr[0][i] * (gw - dotw) * softclip_grad(p[i], cw);
+      g[K + i] = pr[1][i] * (gh - doth) * softclip_grad(p[K + i], cw);
+    }
+    if (k >= 1) g[2 * K + k - 1] = gv[5] * kd[k] * softclip_grad(p[2 * K + k - 1], cd);
+    if (k + 1 <= K - 1) g[2 * K + k] = gv[6] * kd[k + 1] * softclip_grad(p[2 * K + k], cd);
+  }
+}
+
 // gz[n, d] = -g[n] (z - loc) / scale^2 ; the ladj gradient is g itself (done by the caller)
 __global__ __launch_bounds__(256) void normal_backward_kernel(int64_t N, int64_t D, const float* z, const float* loc, const float* scale, const float* g, float* gz) {
   const int64_t total = N * D;
@@ -251,7 +309,7 @@ using namespace zk;
 
 extern "C" {
 
-// kind 0 = affine (phi [N, D, 2] = [shift, scale]), 1 = RQS (phi [N, D, 3K-1], K in {4, 8, 16}); fp32, packed phi/gphi.
+// kind 0 = affine (phi [N, D, 2] = [shift, scale]), 1 = RQS (phi [N, D, 3K-1]; K in {4, 8, 16} LDS-staged, any other K <= 64 generic); fp32, packed phi/gphi.
 int zk_univariate_backward(int kind, int64_t N, int64_t D, int K, double bound, double slope, const void* x, const void* phi, const void* gy, const void* gl,
                            int gl_reduced, void* gx, void* gphi, void* stream) {
   if (N <= 0 || D <= 0) return 0;
@@ -273,7 +331,10 @@ int zk_univariate_backward(int kind, int64_t N, int64_t D, int K, double bound, 
   else if (kind == 1 && K == 4) hipLaunchKernelGGL((uni_backward_kernel<1, 4>), dim3(grid), dim3(256), lds, st, a);
   else if (kind == 1 && K == 8) hipLaunchKernelGGL((uni_backward_kernel<1, 8>), dim3(grid), dim3(256), lds, st, a);
   else if (kind == 1 && K == 16) hipLaunchKernelGGL((uni_backward_kernel<1, 16>), dim3(grid), dim3(256), lds, st, a);
-  else return ZK_EINVAL;
+  else if (kind == 1 && K >= 1 && K <= ZK_BWD_MAXK) {
+    const int64_t nb = (N * D + 255) / 256;
+    hipLaunchKernelGGL(rqs_backward_generic_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, st, a, K);
+  } else return ZK_EINVAL;
   return ZK_LAUNCH_CHECK();
 }
 

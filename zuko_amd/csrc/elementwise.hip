@@ -554,13 +554,15 @@ struct RqsStreamArgs {
 };
 
 #ifndef ZK_NT
-#define ZK_NT 1  /* phi is streamed once: non-temporal loads keep it from displacing x / y lines in L2 */
+#define ZK_NT NT  /* template parameter: phi is streamed once, non-temporal loads keep it from displacing x / y lines in L2 */
 #endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint32x4_t __attribute__((ext_vector_type(4)));
 // LM: 0 no ladj, 1 ladj[N, D], 2 ladj[N] with D == 64 (one row per tile), 3 ladj[N] for any other admissible D
 // BF: x, phi and y are bf16 in HBM (cfg5); the LDS image, the arithmetic and ladj stay fp32
-template <int K, bool INV, int LM, bool BF> __global__ __launch_bounds__(256) void rqs_stream_kernel(RqsStreamArgs a) {
+// NT: phi through non-temporal loads (default; ZUKO_AMD_K1_NT=0 selects the plain-load instantiation of the fp32 kernels —
+// the two are timed side by side by bench.py, the faster one differs between boxes by a few percent)
+template <int K, bool INV, int LM, bool BF, bool NT = true> __global__ __launch_bounds__(256) void rqs_stream_kernel(RqsStreamArgs a) {
   constexpr int TOTAL = 3 * K - 1;
   constexpr int TILE_V = (BF ? 8 : 16) * TOTAL;  // 16-byte vectors per tile
   constexpr int NV = (TILE_V + 63) / 64;         // dwordx4 loads per lane per tile
@@ -672,13 +674,21 @@ static int zk_stream_chunk_shift(int lm) {
   return e ? atoi(e) : (lm == 2 ? 6 : 0);
 }
 
-template <int K, bool INV, int LM, bool BF = false> static int launch_rqs_stream_k(RqsStreamArgs a, hipStream_t st) {
+static bool zk_stream_nt() {
+  const char* e = getenv("ZUKO_AMD_K1_NT");  // (read per call: bench.py times both)
+  return !(e && e[0] == '0');
+}
+
+template <int K, bool INV, int LM, bool BF = false, bool NT = true> static int launch_rqs_stream_k(RqsStreamArgs a, hipStream_t st) {
+  if constexpr (NT && !BF) {
+    if (!zk_stream_nt()) return launch_rqs_stream_k<K, INV, LM, BF, false>(a, st);
+  }
   constexpr int TOTAL = 3 * K - 1;
   const size_t lds = (size_t)4 * 64 * TOTAL * sizeof(float);
   static int per_cu = 0;  // resident blocks per CU for this instantiation (device query, once)
   if (per_cu == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rqs_stream_kernel<K, INV, LM, BF>, 256, lds) != hipSuccess || nb < 1) nb = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rqs_stream_kernel<K, INV, LM, BF, NT>, 256, lds) != hipSuccess || nb < 1) nb = 4;
     per_cu = nb;
   }
   const int64_t per_row = a.D > 64 ? a.D / 64 : 1;
@@ -696,7 +706,7 @@ template <int K, bool INV, int LM, bool BF = false> static int launch_rqs_stream
     int64_t iters = (a.tiles + W - 1) / W;
     a.iters = (iters + per_row - 1) / per_row * per_row;
   }
-  hipLaunchKernelGGL((rqs_stream_kernel<K, INV, LM, BF>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((rqs_stream_kernel<K, INV, LM, BF, NT>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   return ZK_LAUNCH_CHECK();
 }
 template <int K, bool BF = false> static int launch_rqs_stream_fwd(const RqsStreamArgs& a, hipStream_t st) {

@@ -274,6 +274,16 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             return None
         return self.lazy.fused_state(x.device)
 
+    def _check_widths(self, x: Tensor, st) -> None:
+        """The reference's F.linear raises on a feature / context width the conditioner was not built for (zuko/nn.py:217-218);
+        the fused kernels walk a weight stream laid out for `plan.din` inputs, so the same misuse must raise here too."""
+        D = self.lazy.features
+        C = 0 if self.c is None else self.c.shape[-1]
+        din = getattr(getattr(st, "plan", None), "din", None)
+        if x.shape[-1] != D or (din is not None and D + C != din):
+            raise RuntimeError(f"zuko_amd: input of {x.shape[-1]} features + {C} context columns given to a conditioner built for "
+                               f"{D} features + {(din - D) if din is not None else '?'} context columns")
+
     def _bf16_spline(self, x: Tensor):
         """bf16 storage path (cfg5): conditioner on bf16 MFMA, the spline in the last layer's epilogue — phi stays on chip."""
         lazy = self.lazy
@@ -302,6 +312,7 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         if st is None:
             out = self._bf16_spline(x)
             return out if out is not None else super().call_and_ladj(x)
+        self._check_widths(x, st)
         lazy, c = self.lazy, self.c
         D = lazy.features
         if c is not None:
@@ -352,6 +363,7 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         st = self._fused(y)
         if st is None:
             return super()._inverse(y)
+        self._check_widths(y, st)
         lazy, c = self.lazy, self.c
         D = lazy.features
         if c is not None:

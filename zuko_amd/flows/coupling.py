@@ -75,6 +75,16 @@ class GeneralCouplingTransform(LazyTransform):
     def forward(self, c: Tensor | None = None) -> Transform:
         return FusedCouplingTransform(self, c)
 
+    def split_indices(self) -> tuple[Tensor, Tensor]:
+        """(idx_a, idx_b) of zuko/transforms.py:1037-1038, computed once per version of the `mask` buffer (nonzero() is a
+        device -> host synchronisation)."""
+        key = (self.mask._version, self.mask.data_ptr(), str(self.mask.device))
+        cached = self.__dict__.get("_split_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, self.mask.nonzero().squeeze(-1), (~self.mask).nonzero().squeeze(-1))
+            self.__dict__["_split_cache"] = cached
+        return cached[1], cached[2]
+
     def fused_state(self, device: torch.device):
         """Plan + device tables of the fused coupling kernel (csrc/fused_coupling.hip), or None when the layer does not fit it
         (affine univariate with default shapes, plain (Linear, activation)* conditioner, widths <= 512, inputs <= 256)."""
@@ -117,9 +127,20 @@ class FusedCouplingTransform(CouplingTransform):
     (zk_coupling_forward) when no gradient is required and the layer fits; otherwise the layer-wise kernels through `meta`."""
 
     def __init__(self, lazy: GeneralCouplingTransform, c: Tensor | None) -> None:
-        super().__init__(partial(lazy.meta, c), lazy.mask)
+        # (not CouplingTransform.__init__: its two mask.nonzero() calls are a device -> host sync per forward, 16 per
+        #  RealNVP step; the split indices are cached per mask version and only the layer-wise path reads them)
+        Transform.__init__(self)
+        self.meta = partial(lazy.meta, c)
         self.lazy = lazy
         self.c = c
+
+    @property
+    def idx_a(self) -> Tensor:
+        return self.lazy.split_indices()[0]
+
+    @property
+    def idx_b(self) -> Tensor:
+        return self.lazy.split_indices()[1]
 
     def _fused(self, x: Tensor, inverse: bool):
         """(result, ladj of the forward map) from the fused kernel, or None when the layer-wise path has to be taken."""
@@ -132,6 +153,9 @@ class FusedCouplingTransform(CouplingTransform):
         if st is None:
             return None
         D = x.shape[-1]
+        feats, ctx = int(lazy.mask.numel()), (0 if c is None else c.shape[-1])
+        if D != feats or ctx != st.plan.context:  # (the reference's F.linear raises on these, zuko/nn.py:15)
+            raise RuntimeError(f"zuko_amd: input of {D} features + {ctx} context columns given to a coupling transform built for {feats} + {st.plan.context}")
         if c is not None:
             xb, cb = broadcast(x, c, ignore=1)
         else:

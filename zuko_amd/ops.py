@@ -161,8 +161,8 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
     if not want_bins and AG.needs_grad(x, widths, heights, derivatives):
         _require_device(x, widths, heights, derivatives)
         _no_bf16_grad(x, widths)
-        if K not in (4, 8, 16):
-            raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
+        if K > 64:
+            raise NotImplementedError("zuko_amd: spline backward is built for up to 64 bins")
         if _packed_ok(x, packed, 3 * K - 1):
             return AG.UnivariatePackedFn.apply((1, bound, slope, (K, K, K - 1), ()), reduce, x, packed)
         return AG.UnivariateFn.apply(1, bound, slope, reduce, x, widths, heights, derivatives)
@@ -185,8 +185,8 @@ def rqs_inverse(y: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
     if not want_bins and AG.needs_grad(y, widths, heights, derivatives):
         _require_device(y, widths, heights, derivatives)
         _no_bf16_grad(y, widths)
-        if K not in (4, 8, 16):
-            raise NotImplementedError("zuko_amd: spline backward is built for 4, 8 or 16 bins")
+        if K > 64:
+            raise NotImplementedError("zuko_amd: spline backward is built for up to 64 bins")
         return AG.UnivariateInverseFn.apply(1, bound, slope, (), y, widths, heights, derivatives)
     pr = _Prepared(y, [(widths, 1), (heights, 1), (derivatives, 1)])
     x = pr.out()

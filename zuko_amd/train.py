@@ -19,6 +19,7 @@ from __future__ import annotations
 import ctypes
 
 import torch
+from torch.autograd.function import once_differentiable
 from torch import Tensor
 
 from . import _C
@@ -67,6 +68,8 @@ class SortedPlan:
         for i, (out_f, in_f) in enumerate(shapes):
             rows = perms[i] if perms[i] is not None else torch.arange(out_f)
             cols = prev if prev is not None else torch.arange(in_f)
+            if out_f * in_f >= 2**31:
+                raise ValueError(f"zuko_amd: layer {i} has {out_f} x {in_f} >= 2^31 weights: the sorted-domain gather tables are int32")
             idx = (rows[:, None] * in_f + cols[None, :]).to(torch.int32)  # sorted [out, in] -> position in W.flatten()
             m = masks[i]
             ms = torch.ones((out_f, in_f), dtype=torch.bool) if m is None else m.detach().cpu().bool()[rows][:, cols]
@@ -163,7 +166,7 @@ class SortedPlan:
         partial = torch.empty(max(1, ns) * npairs * 128 * 128, dtype=torch.float32, device=g.device)
         if want_bias and self.cs_flag[l] is not None and npairs > 0:
             cs_partial = torch.empty(max(1, ns) * (-(-out_f // 128) * 128), dtype=torch.float32, device=g.device)
-            db = torch.empty(out_f, dtype=torch.float32, device=g.device)
+            db = torch.zeros(out_f, dtype=torch.float32, device=g.device)  # (zeros: the kernel returns early on an empty batch, the reference yields zeros)
             err = lib.zk_wgrad_bias_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(self.mask_s[l]), _ptr(dw), 0,
                                         _ptr(self.cs_flag[l]), _ptr(cs_partial), _ptr(db), _stream())
             _C.check(err, "zk_wgrad_bias_f32")
@@ -266,6 +269,7 @@ class ConditionerFn(torch.autograd.Function):
         return h
 
     @staticmethod
+    @once_differentiable  # raw-pointer HIP kernels on detached data: double backward (create_graph=True) must raise, not return graph-less grads
     def backward(ctx, g_phi: Tensor):
         plan, n = ctx.plan, ctx.n
         saved = ctx.saved_tensors
