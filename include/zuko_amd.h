@@ -224,28 +224,29 @@ int zk_ar_inverse_incremental(int uni_kind, int n_hidden, int64_t N, int D, int 
 int zk_ar_inc_lds_bytes(int bias_floats, int nit);
 /* dynamic LDS bytes zk_ar_forward will request for `variant` and a bias image of `bias_floats` floats. */
 int zk_ar_lds_bytes(int variant, int bias_floats);
-/* Static-shape instantiation of zk_ar_forward (`variant` = 1 or 2; csrc/fused_ar_static.hip): the conditioner of
- * MaskedAutoregressiveTransform(features = 64, hidden_features = [256] * 3), no context, ReLU, uni_kind 0 or 1 — the block
- * pattern of its masks (zuko/nn.py:270-295 with the hidden units sorted by dependency count) is fixed, so the kernel is
- * straight-line code.  zk_ar_static_skip writes the skip words (same layout as zk_ar_forward's `skip`: 4 per hidden layer,
- * then one per feature group; at most 28) a plan MUST have for that variant and returns their count (0: no such kernel):
- * variant 1 = first-layer pattern of an ascending feature order, 2 = of a descending one.  The caller compares its plan
- * against them once; zk_ar_forward itself only checks the shape arguments.  Results are bit-identical to variant 0 (the
- * tiles the static stream drops hold zeros only). */
-int zk_ar_static_skip(int uni_kind, int variant, uint32_t* out_words);
-/* The static kernel consumes a PER-TILE stream: inside a kept (out-group, input tile) block of hidden layers 2 and 3 only the
- * 16x16 tiles that hold non-zero weights are streamed (ArPlan.fine_gather of zuko_amd/fused.py; 48 chunks for uni_kind 1, 17
- * for uni_kind 0 — pass THAT stream and chunk count with variant 1 / 2).  zk_ar_static_tiles writes the pattern it is compiled
- * for: out[(l * 4 + otg) * 16 + it] = 4-bit mask of the out tiles of group otg multiplied by input tile it of hidden layer l
- * (192 bytes; returns 192, or 0 if there is no such kernel).  Rows of x and y must be 16-byte addressable (EINVAL otherwise). */
-int zk_ar_static_tiles(int uni_kind, int variant, uint8_t* out_masks);
-/* Conditioner-only launch of the static kernel for the training forward (zuko_amd/train.py): phi [N, 64 * total] = net(x) in
- * module order (what the last MaskedLinear of zuko/nn.py:221-318 returns) and the hidden activations h1, h2, h3 [N, 256] with the
- * units in the stream's dependency-sorted order, which the mask-aware dgrad / wgrad kernels consume.  Same per-tile stream, bias
- * image, feature map, chunk count and variant as zk_ar_forward(variant = 1 | 2); the univariate map is not evaluated. */
-int zk_ar_forward_train(int uni_kind, int64_t N, const void* x, int64_t ldx, void* h1, void* h2, void* h3, void* phi, int64_t ldphi,
-                        const void* wstream, const void* bias, int bias_floats, const int32_t* featmap, int n_chunks, int variant,
-                        void* stream);
+/* zk_ar_forward through a GENERATED static-shape kernel.  With the hidden units sorted by dependency count the block pattern of
+ * a MaskedMLP's masks (zuko/nn.py:270-295) is fixed per (features, context, hidden widths, order, univariate map), so the pass
+ * over a wave tile can be straight-line code.  csrc/fused_ar_static_impl.h holds that kernel as a template over a struct of
+ * constexpr tables; zuko_amd/static_ar.py writes the tables of a plan into a one-kernel translation unit, compiles it (hipcc,
+ * gfx950) into zuko_amd/lib/ars/ars_<signature>.so — ahead of time for the BASELINE.json conditioners, on first use otherwise —
+ * and passes the address of its `zk_ars_launch` symbol here as `launcher`.  rev != 0 selects the alternative first-layer pattern
+ * the kernel was generated with (a descending feature order mirrors the input tiles).  The kernel consumes the plan's PER-TILE
+ * stream (only the 16x16 tiles that hold non-zero weights; ArPlan.fine_gather of zuko_amd/fused.py) of n_chunks chunks, re-checks
+ * D / DIN / n_layers / n_groups / n_chunks against the shape it was generated for (hipErrorInvalidValue on a mismatch or on a
+ * kernel built against another ArArgs layout) and needs 16-byte addressable rows of y when it stages rows through LDS (D % 4 == 0).
+ * ReLU conditioners; uni_kind 0 / 1 / 2 / 4; hidden widths up to 512 (the generic zk_ar_forward stops at 256).  Results are
+ * bit-identical to zk_ar_forward on the same plan (the tiles the per-tile stream drops hold zeros only). */
+int zk_ar_forward_static(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y,
+                         int64_t ldy, void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats,
+                         const int32_t* featmap, int n_layers, int n_groups, int n_chunks, double bound, double slope, void* stream);
+/* Conditioner-only launch of a generated static-shape kernel for the training forward (zuko_amd/train.py): phi [N, D * total] =
+ * net(x) in module order (what the last MaskedLinear of zuko/nn.py:221-318 returns) and the hidden activations h_l [N, width_l]
+ * (n_layers - 1 <= 3 of them; h2 / h3 may be NULL beyond that) with the units in the stream's dependency-sorted order, which the
+ * mask-aware dgrad / wgrad kernels consume.  Same launcher, per-tile stream, bias image, feature map and chunk count as
+ * zk_ar_forward_static; the univariate map is not evaluated. */
+int zk_ar_forward_train(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* h1,
+                        void* h2, void* h3, void* phi, int64_t ldphi, const void* wstream, const void* bias, int bias_floats,
+                        const int32_t* featmap, int n_layers, int n_groups, int n_chunks, void* stream);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
 int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Per-launch time of one autoregressive transform on (a) its generated static-shape kernel, (b) the generic tile-skipping kernel
+(widths <= 256) and (c) the layer-wise kernels, with the fraction of the fp32-MFMA peak on the non-zero weights.
+
+    python scripts/static_shapes_bench.py [log2 batch]      -> one JSON line per shape
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import zuko_amd.flows as F
+from zuko_amd.flows import autoregressive as AR
+from zuko_amd.nn import MaskedLinear
+
+PEAK = 157.3e12
+SHAPES = [("nsf", 64, 0, [256] * 3), ("maf", 64, 0, [256] * 3), ("nsf", 3, 5, [128] * 3), ("nsf", 32, 0, [256, 256]), ("nsf", 32, 0, [512, 512]), ("maf", 16, 0, [128, 128]),
+          ("nsf", 128, 0, [256] * 3), ("nsf", 64, 8, [256] * 2), ("nsf", 16, 0, [512] * 3)]
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    lb = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    dev = torch.device("cuda:0")
+    os.environ["ZUKO_AMD_JIT_MIN_ROWS"] = "1"
+    for kind, D, C, hidden in SHAPES:
+        N = 1 << (lb if max(hidden) <= 256 or True else lb - 1)
+        torch.manual_seed(0)
+        flow = (F.NSF(D, C, transforms=2, bins=8, hidden_features=hidden) if kind == "nsf" else F.MAF(D, C, transforms=2, hidden_features=hidden)).to(dev)
+        x = torch.randn(N, D, device=dev)
+        c = torch.randn(N, C, device=dev) if C else None
+        lazy = flow.transform.transforms[0]
+        nnz = 2 * sum(int(m.mask.sum()) for m in lazy.hyper if isinstance(m, MaskedLinear))
+        rec = {"shape": f"{kind}({D}, ctx {C}, {hidden})", "rows": N, "nnz_flop_per_row": nnz}
+        with torch.no_grad():
+            t0 = time.time()
+            t = lazy(c)
+            st = t._fused(x)
+            rec["jit_or_load_s"] = round(time.time() - t0, 2)
+            rec["static"] = None if st is None or st.static is None else {"waves": st.static[0].meta["WAVES"], "xlds": st.static[0].meta["XLDS"]}
+            if st is not None and st.static is not None:
+                ms = timed(lambda: lazy(c).call_and_ladj(x))
+                rec["static_ms"] = round(ms, 4)
+                rec["static_frac_nnz"] = round(N * nnz / (ms * 1e-3) / PEAK, 4)
+                y_s, l_s = lazy(c).call_and_ladj(x)
+            if st is not None and st.generic_ok:
+                keep, st.static = st.static, None
+                ms = timed(lambda: lazy(c).call_and_ladj(x))
+                y_g, l_g = lazy(c).call_and_ladj(x)
+                st.static = keep
+                rec["generic_ms"] = round(ms, 4)
+                rec["generic_frac_nnz"] = round(N * nnz / (ms * 1e-3) / PEAK, 4)
+                if keep is not None:
+                    rec["bit_identical"] = bool(torch.equal(y_s, y_g) and torch.equal(l_s, l_g))
+            if N * D * lazy.total * 4 <= 24 << 30:  # layer-wise: phi [N, D * total] through HBM
+                os.environ["ZUKO_AMD_NO_STATIC_AR"] = "1"
+                AR._FUSED_CACHE.pop(lazy, None)
+                if max(hidden) > 256 or True:
+                    from functools import partial
+
+                    from zuko_amd.transforms import AutoregressiveTransform
+
+                    lw = lambda: AutoregressiveTransform(partial(lazy.meta, c), lazy.passes).call_and_ladj(x)
+                    ms = timed(lw, reps=3)
+                    rec["layerwise_ms"] = round(ms, 4)
+                os.environ.pop("ZUKO_AMD_NO_STATIC_AR")
+                AR._FUSED_CACHE.pop(lazy, None)
+        print(json.dumps(rec), flush=True)
+        del flow, x, c
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

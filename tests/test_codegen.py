@@ -111,20 +111,61 @@ def _check_raw_reads(s: str, prefix: str):
     return stats
 
 
+def _isa_of_generated(cfgs):
+    """ISA of the static-shape kernels zuko_amd/static_ar.py generates for `cfgs` (cached per source + header hash)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from zuko_amd import static_ar
+
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    jobs = []
+    for cfg in cfgs:
+        (pa, lay), (pd, _) = static_ar._plans_for(*cfg)
+        ta, td = static_ar.tables(pa, lay.kind), static_ar.tables(pd, lay.kind)
+        (ca, la), (cd, ld) = static_ar._split(ta), static_ar._split(td)
+        src = static_ar.emit(ta, ld if (ca == cd and la != ld) else None)
+        h = hashlib.sha256((src + static_ar._header_digest()).encode()).hexdigest()[:16]
+        out = os.path.join(ROOT, "zuko_amd", "lib", f"ars_isa.{h}.s")
+        jobs.append((src, out, ta))
+
+    def build(job):
+        src, out, _ = job
+        if not os.path.exists(out):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            hip = out[:-2] + ".hip"
+            with open(hip, "w") as f:
+                f.write(src)
+            subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "--cuda-device-only", "-S",
+                            hip, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        return list(zip(ex.map(build, jobs), (j[2] for j in jobs)))
+
+
 def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
-    """fused_ar_static.hip issues its weight-tile reads from inline assembly and makes them usable through an
-    `s_waitcnt lgkmcnt(n)` it places itself: a register copy inserted between the two by the allocator would read data
-    that has not arrived."""
+    """The generated static-shape kernels (csrc/fused_ar_static_impl.h instantiated on the tables of zuko_amd/static_ar.py) issue
+    their weight-tile reads from inline assembly and make them usable through an `s_waitcnt lgkmcnt(n)` they place themselves: a
+    register copy inserted between the two by the allocator would read data that has not arrived.  Checked on the ISA of the
+    headline conditioner (cfg2, spline), cfg3 (affine map) and the 512-wide one-wavefront-per-SIMD instantiation; also: every
+    streamed tile is read exactly once and multiplied by four k-steps, and no kernel spills."""
     import re
 
-    s = _isa_of("fused_ar_static.hip")
-    stats = _check_raw_reads(s, "_ZN2zk16ar_static_kernel")
-    # density + conditioner-only (training) instantiation for each of the two univariate maps; every streamed tile is read once and
-    # multiplied by four k-steps (1176 - 46 / 432 - 46 all-zero tiles)
-    assert len(stats) == 4 and sorted(set(stats)) == [(386, 1544), (1130, 4520)]
-    for name in re.findall(r"\.amdhsa_kernel (_ZN2zk16ar_static_kernel\S+)", s):
-        k = s.index(".amdhsa_kernel " + name)
-        assert ".amdhsa_private_segment_fixed_size 0" in s[k : s.index(".end_amdhsa_kernel", k)]
+    cfgs = [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("rqs", 32, 0, (512, 512), 8)]
+    want = {0: [(1130, 4520)] * 2, 1: [(386, 1544)] * 2}  # density + conditioner-only (training) instantiation (1176 - 46 / 432 - 46 all-zero tiles dropped)
+    for i, (s, t) in enumerate(_isa_of_generated(cfgs)):
+        stats = _check_raw_reads(s, "_ZN2zk10ars_kernel")
+        tiles = sum(bin(m).count("1") for m in t["S_MASK"]) + t["GOFF"][-1] * {0: 1, 1: 6}[t["uni"]]
+        assert stats and all(st == (tiles, 4 * tiles) for st in stats), (cfgs[i], stats, tiles)
+        if i in want:
+            assert stats == want[i]
+        else:
+            assert len(stats) == 1  # (no training instantiation for the wide kernel)
+        for name in re.findall(r"\.amdhsa_kernel (_ZN2zk10ars_kernel\S+)", s):
+            k = s.index(".amdhsa_kernel " + name)
+            assert ".amdhsa_private_segment_fixed_size 0" in s[k : s.index(".end_amdhsa_kernel", k)]
 
 
 @pytest.mark.parametrize("tu,prefix,extra,n_kernels", [

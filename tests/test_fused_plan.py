@@ -172,36 +172,104 @@ def test_coupling_plan_simulation_matches_oracle(D, ctx, hidden):
     assert np.abs(ys - yo.numpy()).max() < 1e-12 and np.abs(ls - lo.numpy()).max() < 1e-12
 
 
-@pytest.mark.parametrize("kind", ["nsf", "maf"])
-def test_static_kernel_pattern_is_the_plan_of_cfg2_and_cfg3(kind):
-    """zk_ar_static_skip() (csrc/fused_ar_static.hip) must describe exactly the plan fused.py builds for the conditioner of
-    cfg2 / cfg3 — for both feature orders zuko alternates between (zuko/flows/autoregressive.py:121-125) — and nothing else."""
-    import ctypes
+def _walk_static_tables(t, stream, bias_img, inp, rev_l0=None):
+    """Pure-numpy walk of the weight stream exactly as csrc/fused_ar_static_impl.h does it from the GENERATED tables (step lists,
+    stream positions from the popcounts of the tile masks, last-layer groups): returns the accumulators of every feature group
+    [n, NG, NT, 16].  A wrong table shows up as a difference from fused.simulate(), which walks the plan itself."""
+    n = inp.shape[0]
+    tiles = stream.reshape(-1, 64, 4)  # [tile][lane][r]
+    A = lambda b: tiles[b].reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)  # lane (i, q), r -> A[i][4 q + r]
+    T = t["TMAX"]
+    cur = np.zeros((n, T * 16))
+    cur[:, : inp.shape[1]] = inp
+    soff = np.concatenate([[0], np.cumsum(t["NS"])])
+    for l in range(t["NH"]):
+        out = np.zeros((n, T * 16))
+        out[:, : t["BIAS_STRIDE"]] += bias_img[l * t["BIAS_STRIDE"] : (l + 1) * t["BIAS_STRIDE"]][None, : T * 16] if T * 16 <= t["BIAS_STRIDE"] else 0
+        pos = t["BASE"][l]
+        for s_ in range(t["NS"][l]):
+            otg, it, m = t["S_OTG"][soff[l] + s_], t["S_IT"][soff[l] + s_], t["S_MASK"][soff[l] + s_]
+            if l == 0 and rev_l0 is not None:
+                it = rev_l0[s_]
+            for tt in range(4):
+                if m >> tt & 1:
+                    out[:, (otg * 4 + tt) * 16 : (otg * 4 + tt + 1) * 16] += cur[:, it * 16 : it * 16 + 16] @ A(pos).T
+                    pos += 1
+        cur = np.maximum(out, 0)
+    nt = {0: 1, 1: 6, 2: 3, 4: 6}[t["uni"]]
+    acc = np.zeros((n, t["NG"], nt, 16))
+    bl = bias_img[t["NH"] * t["BIAS_STRIDE"] :].reshape(t["NG"], nt, 16)
+    pos = t["LAST_BASE"]
+    for g in range(t["NG"]):
+        acc[:, g] += bl[g][None]
+        for it in t["G_IT"][t["GOFF"][g] : t["GOFF"][g + 1]]:
+            for tt in range(nt):
+                acc[:, g, tt] += cur[:, it * 16 : it * 16 + 16] @ A(pos).T
+                pos += 1
+    return acc
 
-    from zuko_amd import _C, fused
-    from zuko_amd.flows import MAF, NSF
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("rqs", 3, 5, (128, 128, 128), 8), ("rqs", 32, 0, (512, 512), 8),
+                                 ("rqs", 20, 3, (100, 72), 8), ("affine", 7, 0, (40,), 0)])
+def test_static_kernel_tables_describe_the_plan(cfg):
+    """zuko_amd/static_ar.py:tables() — what a generated static-shape kernel is compiled from — against the plan it came from, for
+    both feature orders zuko alternates between (zuko/flows/autoregressive.py:121-125): the table-driven walk of the per-tile stream
+    reproduces phi of fused.simulate() (which walks the plan) and of the masked network itself, including widths that are not
+    multiples of 16 / 64, a context, a single hidden layer and the 512-wide plan only the static kernels cover."""
+    from zuko_amd import fused, static_ar
+
+    kind, D, C, hidden, bins = cfg
+    plans = static_ar._plans_for(kind, D, C, hidden, bins)
+    tabs = [static_ar.tables(p, lay.kind) for p, lay in plans]
+    assert all(t is not None for t in tabs)
+    (ca, la), (cd, ld) = static_ar._split(tabs[0]), static_ar._split(tabs[1])
+    if cfg[:4] in (("rqs", 64, 0, (256, 256, 256)), ("affine", 64, 0, (256, 256, 256))):
+        assert ca == cd and la != ld, "cfg2 / cfg3: one kernel serves both orders through its alternative first-layer pattern"
+        assert tabs[0]["NCHUNK"] == (48 if kind == "rqs" else 17) and tabs[0]["NS"] == [10, 40, 40]
+    rng = np.random.default_rng(5)
+    for (plan, lay), t in zip(plans, tabs):
+        assert t["WAVES"] == (4 if max(hidden) > 256 else 8) and t["NCHUNK"] == plan.fine_n_chunks
+        masks = None
+    # numerical walk: random weights on the plan's masks
+    import torch
+    from zuko_amd.flows.autoregressive import MaskedAutoregressiveTransform
     from zuko_amd.nn import MaskedLinear
+    from zuko_amd.transforms import MonotonicAffineTransform, MonotonicRQSTransform
 
-    torch.manual_seed(0)
-    flow = NSF(64, 0, transforms=2, bins=8, hidden_features=[256] * 3) if kind == "nsf" else MAF(64, 0, transforms=2, hidden_features=[256] * 3)
-    layout = fused.uni_layout("rqs", 23, 8) if kind == "nsf" else fused.uni_layout("affine", 2)
-    words = (ctypes.c_uint32 * 28)()
-    for i, lazy in enumerate(flow.transform.transforms):
-        plan = fused.build_plan([m.mask for m in lazy.hyper if isinstance(m, MaskedLinear)], 64, layout)
-        assert plan.n_chunks == (50 if kind == "nsf" else 19) and plan.fine_n_chunks == (48 if kind == "nsf" else 17)
-        n = _C.lib().zk_ar_static_skip(layout.kind, 1 + i, words)
-        assert n == len(plan.skip) and [int(words[j]) for j in range(n)] == [int(v) for v in plan.skip]
-        tiles = (ctypes.c_uint8 * 192)()
-        assert _C.lib().zk_ar_static_tiles(layout.kind, 1 + i, tiles) == 192
-        assert np.array_equal(np.frombuffer(tiles, dtype=np.uint8), plan.fine_tilemask.reshape(-1))
-        # the per-tile stream is the block stream minus tiles that hold zeros only
-        dropped = sum(len(g) for g in plan.gather) // 256 - sum(len(g) for g in plan.fine_gather) // 256
-        assert dropped == 2 * (160 - 137) + 2 * 24 - 2 * 7 or dropped > 0
-    other = NSF(48, 0, transforms=1, bins=8, hidden_features=[256] * 3).transform.transforms[0]
-    plan = fused.build_plan([m.mask for m in other.hyper if isinstance(m, MaskedLinear)], 48, fused.uni_layout("rqs", 23, 8))
-    n = _C.lib().zk_ar_static_skip(1, 1, words)
-    assert [int(words[j]) for j in range(n)] != [int(v) for v in plan.skip][:n] or n != len(plan.skip)
-    assert _C.lib().zk_ar_static_skip(2, 1, words) == 0 and _C.lib().zk_ar_static_skip(1, 3, words) == 0
+    for i, order in enumerate((torch.arange(D), torch.flipud(torch.arange(D)))):
+        if kind == "affine":
+            tr = MaskedAutoregressiveTransform(D, C, order=order, hidden_features=list(hidden), univariate=MonotonicAffineTransform, shapes=[(), ()])
+        else:
+            tr = MaskedAutoregressiveTransform(D, C, order=order, hidden_features=list(hidden), univariate=MonotonicRQSTransform, shapes=[(bins,), (bins,), (bins - 1,)])
+        lins = [m for m in tr.hyper if isinstance(m, MaskedLinear)]
+        M = [m.mask.numpy().astype(bool) for m in lins]
+        W = [rng.standard_normal(m.shape) for m in M]
+        B = [rng.standard_normal(m.shape[0]) for m in M]
+        plan, lay = plans[i]
+        t = tabs[i]
+        x = rng.standard_normal((5, D + C))
+        fine = np.concatenate([np.where(g >= 0, (W[l] * M[l]).reshape(-1)[np.maximum(g, 0)], 0.0) for l, g in enumerate(plan.fine_gather)])
+        bias_img = np.concatenate([np.where(g >= 0, B[l][np.maximum(g, 0)], 0.0) for l, g in enumerate(plan.bias_gather)])
+        acc = _walk_static_tables(t, fine, bias_img, x)
+        h = x
+        for l in range(len(M)):
+            h = h @ (W[l] * M[l]).T + B[l]
+            if l + 1 < len(M):
+                h = np.maximum(h, 0)
+        phi = h.reshape(5, D, lay.total)
+        per_group = 4 * lay.fpl
+        for g in range(plan.n_groups):
+            for tt in range(lay.nt):
+                for r in range(16):
+                    m = 4 * tt + (r & 3)
+                    fi, p_ = divmod(m, lay.total)
+                    if fi < lay.fpl:
+                        f = plan.featmap[g * per_group + (r >> 2) * lay.fpl + fi]
+                        if f >= 0:
+                            assert np.allclose(acc[:, g, tt, r], phi[:, f, p_], rtol=1e-9, atol=1e-9), (cfg, i, g, tt, r)
+    # the emitted source carries exactly these tables
+    src = static_ar.emit(tabs[0], None if la == ld or ca != cd else ld)
+    assert f"NCHUNK = {tabs[0]['NCHUNK']}" in src and "zk_ars_launch" in src and ("HAS_ALT = true" in src) == (ca == cd and la != ld)
 
 
 def test_training_plan_sorts_units_by_their_true_dependency_count():

@@ -645,40 +645,105 @@ def test_fused_coupling_kernel(dev, D, ctx, hidden, N, monkeypatch):
     assert torch.isnan(lb[1]) and torch.isnan(yb.cpu()[1, ~a_cols]).all()
 
 
+STATIC_CASES = [("nsf", 64, 0, [256] * 3), ("maf", 64, 0, [256] * 3), ("nsf", 3, 5, [128] * 3), ("nsf", 32, 0, [256, 256]), ("maf", 16, 0, [128, 128]),
+                ("nsf", 20, 3, [100, 72]), ("maf", 7, 2, [40])]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["nsf", "maf"])
-@pytest.mark.parametrize("N", [1, 127, 129, 1000, 40000])
-def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, kind, N):
-    """csrc/fused_ar_static.hip (straight-line code for the block pattern of cfg2 / cfg3) against the tile-skipping generic
-    kernel on the same plan: y and ladj must agree bit for bit, for both feature orders, ragged batches and poisoned rows."""
+@pytest.mark.parametrize("case", STATIC_CASES, ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}")
+@pytest.mark.parametrize("N", [1, 129, 1000, 40000])
+def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, case, N, monkeypatch):
+    """The generated static-shape kernels (csrc/fused_ar_static_impl.h on the tables of zuko_amd/static_ar.py: straight-line code
+    for ONE conditioner's block pattern) against the tile-skipping generic kernel on the same plan: y and ladj must agree bit for
+    bit, for both feature orders, ragged batches and poisoned rows — for the prebuilt BASELINE.json conditioners (cfg2, cfg3, cfg1
+    with its context and 3 features) and for shapes compiled on first use (widths that are not multiples of 16 / 64, a context that
+    straddles a tile, one hidden layer)."""
     from zuko_amd.flows import MAF, NSF
     from zuko_amd.nn import MaskedLinear
 
+    kind, D, C, hidden = case
+    monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")  # unlisted shapes: compile now (hipcc, ~15 s each, cached in zuko_amd/lib/ars/)
     torch.manual_seed(3)
-    flow = (NSF(64, 0, transforms=2, bins=8, hidden_features=[256] * 3) if kind == "nsf" else MAF(64, 0, transforms=2, hidden_features=[256] * 3)).to(dev)
-    x = (torch.randn(N, 64, generator=torch.Generator().manual_seed(N)) * 1.5).to(dev)
+    flow = (NSF(D, C, transforms=2, bins=8, hidden_features=hidden) if kind == "nsf" else MAF(D, C, transforms=2, hidden_features=hidden)).to(dev)
+    g = torch.Generator().manual_seed(N)
+    din = D + C
+    inp = torch.zeros(N, -(-din // 4) * 4)
+    inp[:, :din] = torch.randn(N, din, generator=g) * 1.5
+    inp = inp.to(dev)
     if N >= 127:
-        x[5, 7] = float("nan")
-        x[100, 63] = float("inf")
+        inp[5, min(7, D - 1)] = float("nan")
+        inp[100, din - 1] = float("inf")
     for i, lazy in enumerate(flow.transform.transforms):
         st = lazy.fused_state(dev)
+        assert st is not None and st.ready(1 << 20) and st.static is not None, "a static-shape kernel must be available for this conditioner"
         st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
-        assert st.static_variant == 1 + i, "the static kernel must be selected for this conditioner"
+        if case[:2] in (("nsf", 64), ("maf", 64)):
+            assert st.static_variant == 1 + i, "cfg2 / cfg3: ONE kernel, the descending order through its alternative first-layer pattern"
         out = []
-        for variant in (st.static_variant, 0):
-            keep, st.static_variant = st.static_variant, variant
-            y, ladj = torch.full((N, 64), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
-            st.run(x, y, ladj, False)
-            st.static_variant = keep
+        keep = st.static
+        for static in (keep, None):
+            st.static = static
+            y, ladj = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+            st.run(inp, y, ladj, False)
             out.append((y, ladj))
+        st.static = keep
         torch.cuda.synchronize()
         same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))
         assert same(out[0][0], out[1][0]) and same(out[0][1], out[1][1]), f"transform {i}: static kernel differs from the generic one"
         # accumulate semantic
         l2 = out[0][1].clone()
-        st.run(x, torch.empty_like(x), l2, True)
+        st.run(inp, torch.empty(N, D, device=dev), l2, True)
         ref = out[0][1] + out[0][1]
         assert same(l2[~torch.isnan(ref)], ref[~torch.isnan(ref)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,ctx,hidden", [(32, 0, [512, 512]), (24, 8, [384, 512, 320])])
+def test_wide_conditioners_run_fused(dev, D, ctx, hidden, monkeypatch):
+    """Hidden widths beyond the generic fused kernel's 256 (the reference accepts any `hidden_features`, zuko/nn.py:258-264): up to 512
+    the layer runs in ONE launch of a static-shape kernel (one wavefront per SIMD, 32 + 32 activation tiles) instead of
+    materialising phi.  Against the layer-wise HIP kernels and the oracle (fp32 + float64, measured bar), ragged batch."""
+    import zuko_amd.flows as F
+
+    monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
+    torch.manual_seed(D)
+    flow = F.NSF(D, ctx, transforms=2, bins=8, hidden_features=hidden)
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(8), D)
+    spec64 = to_f64(spec)
+    flow = flow.to(dev)
+    g = torch.Generator().manual_seed(2)
+    N = 1000 + 37
+    x = torch.randn(N, D, generator=g) * 1.2
+    c = torch.randn(N, ctx, generator=g) if ctx else None
+    cg = None if c is None else c.to(dev)
+    with torch.no_grad():
+        for lazy in flow.transform.transforms:
+            t = lazy(cg)
+            st = t._fused(x.to(dev))
+            assert st is not None and not st.generic_ok and st.static is not None and st.static[0].meta["WAVES"] == 4
+        z, ladj = flow(cg).transform.call_and_ladj(x.to(dev))
+        lp = flow(cg).log_prob(x.to(dev))
+        from zuko_amd.flows import autoregressive as _ar
+
+        monkeypatch.setenv("ZUKO_AMD_NO_STATIC_AR", "1")  # layer-wise kernels (phi through HBM)
+        for lazy in flow.transform.transforms:
+            _ar._FUSED_CACHE.pop(lazy, None)
+        z_l, ladj_l = flow(cg).transform.call_and_ladj(x.to(dev))
+        monkeypatch.delenv("ZUKO_AMD_NO_STATIC_AR")
+        for lazy in flow.transform.transforms:
+            _ar._FUSED_CACHE.pop(lazy, None)
+        zo, lo = O.flow_forward(spec, x, c)
+        z64, l64 = O.flow_forward(spec64, d64(x), d64(c))
+        tag = f"wide D={D} ctx={ctx} H={hidden}"
+        assert_parity(z, zo, z64, f"{tag}: z fused")
+        assert_parity(ladj, lo, l64, f"{tag}: ladj fused")
+        assert_parity(z_l, zo, z64, f"{tag}: z layer-wise")
+        assert_parity(lp, O.flow_log_prob(spec, x, c), O.flow_log_prob(spec64, d64(x), d64(c)), f"{tag}: log_prob")
+        # inverse: layer-wise sweeps (no fused inverse at this width), round trip
+        c64 = None if c is None else c[:64]
+        xr = flow(None if cg is None else cg[:64]).transform.inv(z[:64])
+        assert_parity(xr, O.flow_inverse(spec, z[:64].cpu(), c64), O.flow_inverse(spec64, d64(z[:64]), d64(c64)), f"{tag}: inverse")
 
 
 @pytest.mark.gpu

@@ -52,9 +52,8 @@ SIGNATURES = {
     "zk_colsum_slices": [L],
     "zk_colsum_f32": [L, I, P, L, P, P, I, P],
     "zk_ar_lds_bytes": [I, I],
-    "zk_ar_static_skip": [I, I, P],
-    "zk_ar_static_tiles": [I, I, P],
-    "zk_ar_forward_train": [I, L, P, L, P, P, P, P, L, P, P, I, P, I, I, P],
+    "zk_ar_forward_static": [P, I, I, L, I, I, P, L, P, L, P, I, P, P, I, P, I, I, I, F, F, P],
+    "zk_ar_forward_train": [P, I, I, L, I, I, P, L, P, P, P, P, L, P, P, I, P, I, I, I, P],
     "zk_ar_forward": [I, L, I, I, P, L, P, L, P, I, P, P, I, P, P, I, I, I, I, F, F, I, P],
     "zk_ar_forward_diag": [I, L, I, I, P, L, P, L, P, P, P, I, P, P, I, I, I, I, F, F, P, P, P],
     "zk_ar_inverse_sweep": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, I, P],

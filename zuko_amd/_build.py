@@ -28,7 +28,6 @@ SOURCES = {
     "linear.hip": [],
     "linear_bf16.hip": ["-ffp-contract=off"],  # its spline epilogue must round like elementwise.hip's
     "fused_ar.hip": ["-ffp-contract=off"],
-    "fused_ar_static.hip": ["-ffp-contract=off"],
     "backward.hip": [],
     "train.hip": [],
     # (pragma-unroll-threshold: the 8 x 32 tile loop of a 512-wide layer exceeds the default cap of forced unrolling; a
@@ -115,7 +114,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print("[zuko_amd build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    prebuild_static(verbose)
     return out
+
+
+def prebuild_static(verbose: bool = True) -> None:
+    """Static-shape instantiations of the fused autoregressive kernel for the BASELINE.json conditioners and a few common
+    shapes (zuko_amd/static_ar.py: PREBUILT): generated + compiled into zuko_amd/lib/ars/, a no-op when they are current.
+    Runs in a child process because it imports the package (which needs the library that was just linked)."""
+    code = "import sys; sys.path.insert(0, %r); import zuko_amd.static_ar as s; s.prebuild(verbose=%r)" % (os.path.dirname(HERE), bool(verbose))
+    subprocess.run([sys.executable, "-c", code], check=True)
 
 
 if __name__ == "__main__":

@@ -90,7 +90,8 @@ template <int CH, int NR> struct RingT {
 
 extern __shared__ __attribute__((aligned(16))) float ar_lds[];
 
-int ar_static_launch(ArArgs& a, int uni_kind, int variant, int lds, unsigned grid, hipStream_t stream);  // fused_ar_static.hip
+// launcher exported by a generated static-shape kernel (csrc/fused_ar_static_impl.h: ars_launch; zuko_amd/static_ar.py builds them)
+typedef int (*ars_launch_fn)(const ArArgs* a, int abi, int args_bytes, int train, void* stream);
 
 // one masked layer with <= 256 inputs / outputs: out = W in + bias, tiles skipped per (group of 4 out tiles, in tile)
 template <class Src>
@@ -376,6 +377,11 @@ int zk_ar_lds_bytes(int variant, int bias_floats) { return (ar_base_lds_floats(b
 
 // uni_kind: 0 = affine (total 2), 1 = RQS with 8 bins (total 23); contract in include/zuko_amd.h.
 struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and the prefix of the network they depend on
+  const void* static_fn = nullptr;  // launcher of a generated static-shape kernel: the launch goes there after the argument checks
+  int rev = 0;                      // ... with the alternative first-layer pattern (descending feature order)
+  float* act_out[3] = {nullptr, nullptr, nullptr};  // ... conditioner-only (training) instantiation: hidden activations and phi
+  float* phi_out = nullptr;
+  int64_t ldphi = 0;
   int32_t* bin_out = nullptr;  // diagnostic launch (forward, spline maps): bin index + search knots
   float* knots_out = nullptr;
   const int* sched = nullptr;
@@ -389,7 +395,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
                      int n_layers, int n_groups, int n_chunks, int act, double bound, double slope, int variant, void* stream) {
   if (N <= 0) return 0;
   if (n_groups * 8 > 1024 || n_groups > 256) return ZK_EINVAL;
-  if (n_layers < 2 || DIN > 256 || DIN < D || DIN % 4 || ldx % 4 || ((uintptr_t)x % 16) || n_chunks < 1) return ZK_EINVAL;
+  if (n_layers < 2 || DIN > (part.static_fn ? 512 : 256) || DIN < D || DIN % 4 || ldx % 4 || ((uintptr_t)x % 16) || n_chunks < 1) return ZK_EINVAL;
   ArArgs a{};
   a.N = N; a.D = D; a.DIN = DIN;
   a.x = (const float*)x; a.ldx = ldx;
@@ -411,8 +417,15 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   a.dbg = (variant >> 8) & 0xff;  // probe build only (-DZK_AR_TIMING=1): bit0 skip univariate math, bit3 / bit4 phase timestamps
   if ((variant & 0xff) != 0) return ZK_EINVAL;
 #else
-  if (variant < 0 || variant > 2) return ZK_EINVAL;  // 0 = generic kernel, 1 / 2 = static-shape kernel (fused_ar_static.hip)
+  if (variant != 0) return ZK_EINVAL;  // reserved
 #endif
+  if (part.static_fn) {  // a generated static-shape kernel: it derives its own tiling / LDS size from its Shape and re-checks the dimensions
+    if (inverse || part.sched || part.bin_out || part.knots_out) return ZK_EINVAL;
+    a.l1rev = part.rev;
+    for (int l = 0; l < 3; ++l) a.act_out[l] = part.act_out[l];
+    a.phi_out = part.phi_out; a.ldphi = part.ldphi;
+    return ((ars_launch_fn)part.static_fn)(&a, ARS_ABI, (int)sizeof(ArArgs), part.phi_out != nullptr, stream);
+  }
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
   a.xs = ((D + 3) / 4) * 4 + 4;  // +4 words: 16-byte aligned rows whose stride is not a multiple of 32 banks
   const bool vec_ok = (D % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)y % 16 == 0) && (!inverse || ((ldyin % 4 == 0) && ((uintptr_t)yin % 16 == 0)));
@@ -420,12 +433,6 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   const int lds = (ar_base_lds_floats(bias_floats) + (a.xlds ? 8 * 16 * a.xs : 0)) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
-#if !ZK_AR_TIMING
-  if (variant != 0) {  // the caller has compared its plan's skip words with zk_ar_static_skip()
-    if (inverse || part.sched || part.bin_out || part.knots_out) return ZK_EINVAL;
-    return ar_static_launch(a, uni_kind, variant, lds, grid, (hipStream_t)stream);  // (needs 16-byte addressable rows: EINVAL otherwise)
-  }
-#endif
   const void* fn = nullptr;
 #define ZK_AR_PICK(UNI)                                                                                                                     \
   (inverse ? (a.xlds ? (const void*)ar_kernel<UNI, true, Ring24x3, true> : (const void*)ar_kernel<UNI, true, Ring24x3, false>)            \
@@ -470,6 +477,33 @@ int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_
                   double bound, double slope, int variant, void* stream) {
   return ar_launch(ArPartial{}, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
                    n_chunks, act, bound, slope, variant, stream);
+}
+
+// zk_ar_forward through a generated static-shape kernel (zuko_amd/static_ar.py): `launcher` is the address of the `zk_ars_launch`
+// symbol of the kernel's shared object, `rev` selects the alternative first-layer pattern the kernel was generated with (descending
+// feature order).  wstream is the PER-TILE stream of the plan (ArPlan.fine_gather), n_chunks its length.  The kernel re-checks
+// D / DIN / n_layers / n_groups / n_chunks against the shape it was generated for and returns hipErrorInvalidValue on a mismatch.
+int zk_ar_forward_static(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj, int accumulate,
+                         const void* wstream, const void* bias, int bias_floats, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, double bound, double slope,
+                         void* stream) {
+  if (!launcher) return ZK_EINVAL;
+  ArPartial part;
+  part.static_fn = launcher; part.rev = rev;
+  return ar_launch(part, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, nullptr, featmap, n_layers, n_groups,
+                   n_chunks, 1, bound, slope, 0, stream);
+}
+
+// Conditioner-only (training) launch of a generated static-shape kernel: phi [N, D * total] = net(x) in module order plus the hidden
+// activations h_l [N, width_l] (up to three; units in the stream's sorted order), for the backward pass of zuko_amd/train.py.
+int zk_ar_forward_train(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* h1, void* h2, void* h3, void* phi, int64_t ldphi,
+                        const void* wstream, const void* bias, int bias_floats, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, void* stream) {
+  if (!launcher || !phi || !h1 || n_layers < 2 || n_layers > 4 || (n_layers > 2 && !h2) || (n_layers > 3 && !h3)) return ZK_EINVAL;
+  if (((uintptr_t)h1 % 16) || ((uintptr_t)h2 % 16) || ((uintptr_t)h3 % 16)) return ZK_EINVAL;
+  ArPartial part;
+  part.static_fn = launcher; part.rev = rev;
+  part.act_out[0] = (float*)h1; part.act_out[1] = (float*)h2; part.act_out[2] = (float*)h3; part.phi_out = (float*)phi; part.ldphi = ldphi;
+  return ar_launch(part, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, nullptr, 0, nullptr, 0, wstream, bias, bias_floats, nullptr, featmap, n_layers, n_groups,
+                   n_chunks, 1, 1.0, 1e-3, 0, stream);
 }
 
 // Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3): identical kernel template and arithmetic, plus

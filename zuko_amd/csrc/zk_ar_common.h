@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AR_TF 256 /* floats per tile image */
 #define AR_WAVES 8
 #define AR_T 16   /* activation tiles (256 units) */
+#define ARS_ABI 3 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
 
 struct ArArgs {
   int64_t N;
@@ -34,8 +35,8 @@ struct ArArgs {
   int64_t n_tiles;
   int32_t* bin_out;  // diagnostic instantiation only: bin index [N, D] and the K+1 search-axis knots [N, D, K+1]
   float* knots_out;
-  int l1rev;         // static-shape kernel only: the first layer's block pattern is that of a descending feature order
-  // static-shape kernel, conditioner-only (training) instantiation: the hidden activations [N, 256] (units in the stream's
+  int l1rev;         // static-shape kernels only: the first layer follows the pattern's ALTERNATIVE input tiles (descending feature order)
+  // static-shape kernels, conditioner-only (training) instantiation: the hidden activations [N, width_l] (units in the stream's
   // sorted order) and the packed parameters phi [N, D * total] (module order) are written out; y / ladj are not
   float* act_out[3];
   float* phi_out;

@@ -231,7 +231,10 @@ class MaskedAutoregressiveTransform(LazyTransform):
             codes = {_act_code(a) for a in acts}
             if lay is not None and simple and len(codes) == 1 and None not in codes and all(l.weight.dtype == torch.float32 for l in lins):
                 variant = fused.default_variant()
-                plan = fused.build_plan([l.mask for l in lins], self.features, lay[0], fused.chunk_of(variant), align_groups=inverse)
+                # conditioners wider than 256 (up to 512) have no generic kernel: forward only, through a static-shape kernel (zuko_amd/static_ar.py)
+                wide = max([l.weight.shape[0] for l in lins[:-1]] + [lins[0].weight.shape[1]]) > fused.MAX_WIDTH
+                plan = None if (wide and inverse) else fused.build_plan([l.mask for l in lins], self.features, lay[0], fused.chunk_of(variant), align_groups=inverse,
+                                                                        max_width=fused.MAX_WIDTH_WIDE if wide else fused.MAX_WIDTH)
                 if plan is not None:
                     state = fused.FusedAR(plan, device, codes.pop(), lay[1], lay[2], variant)
                     if inverse:
@@ -267,12 +270,21 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         self.lazy = lazy
         self.c = c
 
-    def _fused(self, x: Tensor):
+    def _fused(self, x: Tensor, need_generic: bool = False):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1):
             return None
         if torch.is_grad_enabled() and (x.requires_grad or (self.c is not None and self.c.requires_grad) or any(p.requires_grad for p in self.lazy.hyper.parameters())):
             return None
-        return self.lazy.fused_state(x.device)
+        st = self.lazy.fused_state(x.device)
+        if st is None:
+            return None
+        rows = x.numel() // max(x.shape[-1], 1)
+        if self.c is not None and self.c.dim() > 1:
+            rows = max(rows, self.c.numel() // max(self.c.shape[-1], 1))
+        # (large batches may compile the conditioner's static-shape kernel here; conditioners wider than the generic kernel need one)
+        if not st.ready(rows) or (need_generic and not st.generic_ok):
+            return None
+        return st
 
     def _check_widths(self, x: Tensor, st) -> None:
         """The reference's F.linear raises on a feature / context width the conditioner was not built for (zuko/nn.py:217-218);
@@ -360,7 +372,7 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
     def _inverse_impl(self, y: Tensor, want_ladj: bool):
         """`passes` sweeps x <- meta(x).inv(y) from x = 0 (zuko/transforms.py:994-1000): one incremental launch when the
         conditioner fits the aligned-tile plan, else one fused launch per (partial) sweep, updating the buffer in place."""
-        st = self._fused(y)
+        st = self._fused(y, need_generic=True)  # (the sweeps below run on the generic kernel)
         if st is None:
             return super()._inverse(y)
         self._check_widths(y, st)

@@ -32,7 +32,8 @@ from torch import Tensor
 TILE = 16
 CHUNK = 24  # tiles per LDS-ring chunk; multiple of every group size used (4 and 6)
 GROUP_HIDDEN = 4  # out tiles processed together in the hidden layers
-MAX_WIDTH = 256  # activations live in 16 tiles x 4 registers per lane
+MAX_WIDTH = 256  # generic kernel: activations live in 16 tiles x 4 registers per lane, two wavefronts per SIMD
+MAX_WIDTH_WIDE = 512  # static-shape kernels only (one wavefront per SIMD, 32 + 32 activation tiles): zuko_amd/static_ar.py
 
 
 @dataclass
@@ -90,8 +91,10 @@ class ArPlan:
     fine_layer_block0: list = None
     fine_n_blocks: int = 0
     fine_n_chunks: int = 0
-    fine_tilemask: np.ndarray = None  # uint8 [n_layers - 1, 4, 16]: bit t = out tile 4 otg + t multiplies in tile it
+    fine_tilemask: np.ndarray = None  # uint8 [n_layers - 1, max_width / 64, max_width / 16]: bit t = out tile 4 otg + t multiplies in tile it
     fine_kept_tiles: int = 0       # tiles of the per-tile stream (without chunk padding)
+    max_width: int = MAX_WIDTH     # 256: the generic kernel can run the plan; 512: static-shape kernels only
+    widths: list = None            # hidden widths (units per hidden layer)
 
 
 def _deps(masks: list[np.ndarray]) -> list[np.ndarray]:
@@ -105,7 +108,7 @@ def _deps(masks: list[np.ndarray]) -> list[np.ndarray]:
     return out
 
 
-def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int = CHUNK, align_groups: bool = False) -> ArPlan | None:
+def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int = CHUNK, align_groups: bool = False, max_width: int = MAX_WIDTH) -> ArPlan | None:
     """masks[l]: bool [out_l, in_l] of the conditioner's linear layers (last: features*total rows).
     `chunk`: tiles per LDS-ring chunk each layer is padded to.  `align_groups`: additionally start
     every last-layer group on a chunk boundary and record per-group / per-out-group stream positions,
@@ -116,8 +119,9 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         return None
     din = M[0].shape[1]
     widths = [m.shape[0] for m in M[:-1]]
-    if din > MAX_WIDTH or any(w > MAX_WIDTH for w in widths) or M[-1].shape[0] != features * layout.total:
+    if din > max_width or any(w > max_width for w in widths) or M[-1].shape[0] != features * layout.total:
         return None
+    n_otg, n_itile = max_width // TILE // GROUP_HIDDEN, max_width // TILE
     deps = _deps(M)
 
     # unit permutations (stable sort by dependency count) and padded index lists (-1 = padding)
@@ -173,7 +177,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
 
     fine_gather, fine_layer_block0 = [], []
     fine_cursor = 0
-    tilemask = np.zeros((L - 1, MAX_WIDTH // TILE // GROUP_HIDDEN, MAX_WIDTH // TILE), dtype=np.uint8)
+    tilemask = np.zeros((L - 1, n_otg, n_itile), dtype=np.uint8)
 
     def finish_fine_layer(blocks: list[np.ndarray]) -> None:
         nonlocal fine_cursor
@@ -194,7 +198,7 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         n_it = len(in_cols) // TILE
         blocks = []
         fblocks = []
-        for otg in range(MAX_WIDTH // TILE // GROUP_HIDDEN):
+        for otg in range(n_otg):
             bits = 0
             ots = [otg * GROUP_HIDDEN + t for t in range(GROUP_HIDDEN)]
             if ots[0] < n_ot:
@@ -221,11 +225,11 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
             otg_blocks_end[l].append(len(blocks))
         finish_layer(blocks)
         finish_fine_layer(fblocks)
-        b = -np.ones(MAX_WIDTH, dtype=np.int64)
+        b = -np.ones(max_width, dtype=np.int64)
         b[: len(rows_all)] = rows_all
         bias_gather.append(b.astype(np.int32))
         bias_off.append(bias_cursor)
-        bias_cursor += MAX_WIDTH
+        bias_cursor += max_width
         in_cols = rows_all
 
     # last layer: group g, tile t, tile row i  <->  feature slot / parameter
@@ -294,6 +298,8 @@ def build_plan(masks: list[Tensor], features: int, layout: UniLayout, chunk: int
         fine_n_chunks=0 if align_groups else fine_cursor // chunk,
         fine_tilemask=tilemask,
         fine_kept_tiles=0 if align_groups else fine_kept,
+        max_width=max_width,
+        widths=widths,
     )
 
 
@@ -337,15 +343,17 @@ def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], 
     for l, g in enumerate(plan.bias_gather):
         bias_img.append(np.where(g >= 0, biases[l][np.maximum(g, 0)], 0.0))
     n = inp.shape[0]
-    cur = np.zeros((n, MAX_WIDTH))
+    MW = plan.max_width
+    n_otg, n_itile = MW // TILE // GROUP_HIDDEN, MW // TILE
+    cur = np.zeros((n, MW))
     cur[:, : plan.din] = inp
     lay = plan.layout
     for l in range(plan.n_layers - 1):
         b = plan.layer_block0[l]
-        out = np.zeros((n, MAX_WIDTH))
-        for otg in range(4):
-            bits = int(plan.skip[l * 4 + otg])
-            for it in range(16):
+        out = np.zeros((n, MW))
+        for otg in range(n_otg):
+            bits = int(plan.skip[l * n_otg + otg])
+            for it in range(n_itile):
                 if bits >> it & 1:
                     for t in range(GROUP_HIDDEN):
                         ot = otg * GROUP_HIDDEN + t
@@ -360,8 +368,8 @@ def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], 
     per_group = 4 * lay.fpl
     for g in range(plan.n_groups):
         acc = np.zeros((n, lay.nt, 16))
-        bits = int(plan.skip[(plan.n_layers - 1) * 4 + g])
-        for it in range(16):
+        bits = int(plan.skip[(plan.n_layers - 1) * n_otg + g])
+        for it in range(n_itile):
             if bits >> it & 1:
                 for t in range(lay.nt):
                     blk = stream[b]
@@ -412,44 +420,53 @@ class FusedAR:
         self.bias_floats = plan.bias_off[-1] + len(plan.bias_gather[-1])
         self.bias = torch.empty(self.bias_floats, dtype=torch.float32, device=device)
         self._stamp = None
-        self.static_variant = self._static_variant()
-        if self.static_variant:  # the static-shape kernel reads its own (per-tile) stream
-            self.fine_gather = [torch.from_numpy(g).to(device) for g in plan.fine_gather]
-            self.fine_stream = torch.empty(plan.fine_n_blocks * 256, dtype=torch.float32, device=device)
+        self._fine_stamp = None
+        self.generic_ok = plan.max_width <= MAX_WIDTH  # (wider plans exist only for the static-shape kernels)
+        self.static = None          # (StaticKernel, rev) of zuko_amd/static_ar.py once one has been found / compiled
+        self._static_tried_rows = -1
+        self.fine_gather = self.fine_stream = None
+        self._acquire_static(None)  # kernels already on disk (prebuilt or compiled earlier) are used whatever the batch size
 
-    def _static_variant(self) -> int:
-        """1 / 2 when the plan is exactly the block pattern the static-shape kernel (csrc/fused_ar_static.hip) is compiled for."""
-        import ctypes
-        import os
+    @property
+    def static_variant(self) -> int:
+        """0: generic kernel; 1 / 2: a static-shape kernel with its primary / alternative first-layer pattern."""
+        return 0 if self.static is None else 1 + self.static[1]
 
-        from . import _C
+    def _acquire_static(self, rows) -> None:
+        """Look the plan's static-shape kernel up (zuko_amd/static_ar.py); `rows` >= the JIT threshold allows compiling it."""
+        from . import static_ar
 
-        p = self.plan
-        if os.environ.get("ZUKO_AMD_NO_STATIC_AR", "0") == "1" or self.act != 1 or p.n_layers != 4 or p.features != 64 or p.din != 64 or p.layout.kind not in (0, 1):
-            return 0
-        if p.fine_gather is None:
-            return 0
-        words = (ctypes.c_uint32 * 28)()
-        tiles = (ctypes.c_uint8 * 192)()
-        for variant in (1, 2):
-            n = _C.lib().zk_ar_static_skip(p.layout.kind, variant, words)
-            if n != len(p.skip) or any(int(words[i]) != int(p.skip[i]) for i in range(n)):
-                continue
-            if _C.lib().zk_ar_static_tiles(p.layout.kind, variant, tiles) != 192 or not np.array_equal(np.frombuffer(tiles, dtype=np.uint8), p.fine_tilemask.reshape(-1)):
-                continue
-            return variant
-        return 0
+        if self.static is not None or self.plan.fine_gather is None or (rows is not None and rows <= self._static_tried_rows):
+            return
+        if rows is not None:
+            self._static_tried_rows = rows if rows < static_ar.jit_min_rows() else 1 << 62
+        found = static_ar.lookup(self.plan, self.plan.layout.kind, self.act, rows)
+        if found is not None:
+            self.static = found
+            self.fine_gather = [torch.from_numpy(g).to(self.device) for g in self.plan.fine_gather]
+            self.fine_stream = torch.empty(self.plan.fine_n_blocks * 256, dtype=torch.float32, device=self.device)
+            self._fine_stamp = None
+
+    def ready(self, rows: int) -> bool:
+        """Whether run() can be served: always for plans the generic kernel covers; for wider ones only with a static-shape kernel
+        (compiled now if `rows` makes it worth it)."""
+        if self.static is None:
+            self._acquire_static(rows)
+        return self.generic_ok or self.static is not None
 
     def refresh(self, linears, fine_only: bool = False) -> None:
-        """(Re)build the weight stream / bias image if any parameter changed since the last call.  fine_only (training forward,
-        which re-gathers every step): only the static-shape kernel's stream."""
+        """(Re)build the weight streams / bias image if any parameter changed since they were last gathered.  The generic (block)
+        stream and the static-shape kernels' per-tile stream carry separate stamps; fine_only (training forward, which re-gathers
+        every step) skips the generic one."""
         from . import _C
         from .ops import _ptr, _stream
 
         from .nn import _param_stamp
 
         stamp = _param_stamp(linears)
-        if stamp == self._stamp:
+        want_generic = self.generic_ok and not (fine_only and self.static is not None) and stamp != self._stamp
+        want_fine = self.static is not None and stamp != self._fine_stamp
+        if not (want_generic or want_fine):
             return
         lib = _C.lib()
         for l, m in enumerate(linears):
@@ -457,11 +474,10 @@ class FusedAR:
             if not w.is_contiguous():
                 w = w.contiguous()
             mask = m.mask.contiguous().view(torch.uint8)
-            n = self.gather[l].numel()
-            dst = self.stream[self.plan.layer_block0[l] * 256 :]
-            if not (fine_only and self.static_variant):
-                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), n, _ptr(dst), _stream()), "zk_gather_f32")
-            if self.static_variant:
+            if want_generic:
+                dst = self.stream[self.plan.layer_block0[l] * 256 :]
+                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), self.gather[l].numel(), _ptr(dst), _stream()), "zk_gather_f32")
+            if want_fine:
                 fdst = self.fine_stream[self.plan.fine_layer_block0[l] * 256 :]
                 _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel(), _ptr(fdst), _stream()), "zk_gather_f32")
             nb = self.bias_gather[l].numel()
@@ -470,7 +486,10 @@ class FusedAR:
                 bdst[:nb].zero_()
             else:
                 _C.check(lib.zk_gather_f32(_ptr(m.bias.detach().contiguous()), None, _ptr(self.bias_gather[l]), nb, _ptr(bdst), _stream()), "zk_gather_f32")
-        self._stamp = stamp
+        if want_generic:
+            self._stamp = stamp
+        if want_fine:
+            self._fine_stamp = stamp
 
     def run(self, inp: Tensor, y: Tensor, ladj: Tensor | None, accumulate: bool) -> None:
         """inp [N, DINP] (cat(x, c), zero-padded to a multiple of 4 columns), y [N, D], ladj [N]."""
@@ -479,13 +498,22 @@ class FusedAR:
 
         p = self.plan
         N = inp.shape[0]
-        # static-shape kernel: rows of x and y 16-byte addressable (the generic kernel has an instantiation for the other case)
-        variant = self.static_variant if (inp.shape[1] == 64 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0) else 0
-        stream, n_chunks = (self.fine_stream, p.fine_n_chunks) if variant else (self.stream, p.n_chunks)
+        if self.static is not None:
+            kern, rev = self.static
+            # (a static-shape kernel that stages rows through LDS needs them 16-byte addressable; the generic kernel has an instantiation for the other case)
+            if not kern.meta["XLDS"] or (y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0):
+                err = _C.lib().zk_ar_forward_static(
+                    kern.launcher, rev, p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
+                    _ptr(self.fine_stream), _ptr(self.bias), self.bias_floats, _ptr(self.featmap), p.n_layers, p.n_groups, p.fine_n_chunks, self.bound, self.slope, _stream(),
+                )
+                _C.check(err, "zk_ar_forward_static")
+                return
+        if not self.generic_ok:
+            raise RuntimeError("zuko_amd: this conditioner is wider than the generic fused kernel covers and has no static-shape kernel (FusedAR.ready() was not consulted)")
         err = _C.lib().zk_ar_forward(
             p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
-            _ptr(stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, n_chunks,
-            self.act, self.bound, self.slope, variant, _stream(),
+            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
+            self.act, self.bound, self.slope, 0, _stream(),
         )
         _C.check(err, "zk_ar_forward")
 

@@ -203,26 +203,29 @@ def _fused_forward_state(plan: "SortedPlan", lins, device):
             from . import fused
 
             shapes = plan.shapes
-            feats = shapes[0][1]
-            total = shapes[-1][0] // max(feats, 1)
-            layout = fused.uni_layout("affine", 2) if total == 2 else (fused.uni_layout("rqs", total, 8) if total == 23 else None)
-            ok = (len(lins) == 4 and plan.act == 1 and feats == 64 and shapes[-1][0] == feats * total and layout is not None
-                  and all(getattr(l, "mask", None) is not None for l in lins) and all(s[0] == 256 for s in shapes[:-1]))
+            din = shapes[0][1]
+            # (no context: the conditioner's inputs are the features; affine head = 2, 8-bin spline head = 23 parameters per feature)
+            total = {2 * din: 2, 23 * din: 23}.get(shapes[-1][0], 0)
+            feats = din
+            layout = fused.uni_layout("affine", 2) if total == 2 else fused.uni_layout("rqs", 23, 8)
+            ok = (total and 2 <= len(lins) <= 4 and plan.act == 1 and din % 4 == 0
+                  and all(getattr(l, "mask", None) is not None for l in lins) and all(s[0] % 16 == 0 and s[0] <= fused.MAX_WIDTH for s in shapes[:-1]))
             if ok:
                 fp = fused.build_plan([l.mask for l in lins], feats, layout)
                 cand = fused.FusedAR(fp, device, 1, 1.0, 1e-3) if fp is not None else None
-                if cand is not None and cand.static_variant:
+                if cand is not None and cand.static is not None and cand.static[0].meta["TRAIN_OK"]:
                     cand.refresh(lins)
                     g = torch.Generator(device="cpu").manual_seed(0)
-                    xt = torch.randn(200, feats, generator=g).to(device)
+                    xt = torch.randn(200, din, generator=g).to(device)
                     with torch.no_grad():
                         hs_f, phi_f = _fused_forward(cand, xt, shapes[-1][0])
                         ws, _, bs = plan.gather(lins)
                         h = xt
                         same = True
-                        for l in range(4):
-                            h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l < 3 else 0)
-                            ref = hs_f[l] if l < 3 else phi_f
+                        n = len(lins)
+                        for l in range(n):
+                            h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l + 1 < n else 0)
+                            ref = hs_f[l] if l + 1 < n else phi_f
                             same = same and bool(torch.allclose(ref, h, rtol=1e-4, atol=1e-4))
                     if same:
                         st = cand
@@ -233,13 +236,16 @@ def _fused_forward_state(plan: "SortedPlan", lins, device):
 
 
 def _fused_forward(st, x: Tensor, out_features: int):
-    """([h1, h2, h3] sorted-domain activations, phi) from one launch of zk_ar_forward_train."""
+    """([h_1, ...] sorted-domain hidden activations, phi) from one launch of zk_ar_forward_train (a static-shape kernel of
+    zuko_amd/static_ar.py in its conditioner-only instantiation)."""
     p = st.plan
     N = x.shape[0]
-    hs = [torch.empty((N, 256), dtype=torch.float32, device=x.device) for _ in range(3)]
+    hs = [torch.empty((N, w), dtype=torch.float32, device=x.device) for w in p.widths]
     phi = torch.empty((N, out_features), dtype=torch.float32, device=x.device)
-    err = _C.lib().zk_ar_forward_train(p.layout.kind, N, _ptr(x), x.stride(0), _ptr(hs[0]), _ptr(hs[1]), _ptr(hs[2]), _ptr(phi), out_features,
-                                       _ptr(st.fine_stream), _ptr(st.bias), st.bias_floats, _ptr(st.featmap), p.fine_n_chunks, st.static_variant, _stream())
+    kern, rev = st.static
+    hp = [_ptr(h) for h in hs] + [None] * (3 - len(hs))
+    err = _C.lib().zk_ar_forward_train(kern.launcher, rev, p.layout.kind, N, p.features, x.shape[1], _ptr(x), x.stride(0), hp[0], hp[1], hp[2], _ptr(phi), out_features,
+                                       _ptr(st.fine_stream), _ptr(st.bias), st.bias_floats, _ptr(st.featmap), p.n_layers, p.n_groups, p.fine_n_chunks, _stream())
     _C.check(err, "zk_ar_forward_train")
     return hs, phi
 
@@ -251,7 +257,7 @@ class ConditionerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: SortedPlan, lins, x: Tensor, *params):
         n = len(lins)
-        st = _fused_forward_state(plan, lins, x.device) if (x.shape[1] == 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+        st = _fused_forward_state(plan, lins, x.device) if (x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
         ws, wts, bs = plan.gather(lins, forward=st is None)
         if st is not None:  # whole forward in one launch of the static-shape kernel
             st.refresh(lins, fine_only=True)
