@@ -85,6 +85,46 @@ def relaunch_under_torchrun(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def bind_cpu_to_gpu(local: int, world: int) -> dict:
+    """Pin this rank's host threads to the cores of the NUMA node its GPU hangs off (sysfs: the PCI device's local_cpulist), or,
+    when that is unknown, to an even slice of the host's cores — eight ranks left unpinned share the launcher's cores and cross
+    sockets for every launch.  Best effort: returns what was done for the JSON line."""
+    import torch
+
+    info = {"bound": False}
+    try:
+        ncpu = os.cpu_count() or 1
+        cpus = None
+        if torch.cuda.is_available() and local < torch.cuda.device_count():
+            pr = torch.cuda.get_device_properties(local)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            path = f"/sys/bus/pci/devices/{bdf}/local_cpulist"
+            info["pci"] = bdf
+            if os.path.exists(path):
+                cpus = set()
+                for part in open(path).read().strip().split(","):
+                    if part:
+                        lo, _, hi = part.partition("-")
+                        cpus |= set(range(int(lo), int(hi or lo) + 1))
+                node = f"/sys/bus/pci/devices/{bdf}/numa_node"
+                if os.path.exists(node):
+                    info["numa_node"] = int(open(node).read().strip())
+        if not cpus or len(cpus) >= ncpu:  # no topology information: an even slice per rank
+            per = max(1, ncpu // max(world, 1))
+            cpus = set(range(local * per, min(ncpu, (local + 1) * per)))
+            info["source"] = "even slice"
+        else:
+            info["source"] = "local_cpulist"
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info.update(bound=True, cpus=len(cpus), first_cpu=min(cpus))
+    except Exception as exc:  # never fatal
+        info["error"] = repr(exc)
+    return info
+
+
 def init_ranks(args):
     """(rank, world, local device index, dist module or None).  One process per GPU."""
     import torch
@@ -114,10 +154,15 @@ def init_ranks(args):
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s); "
                          "set ZUKO_BENCH_SINGLE_DEVICE=1 ZUKO_BENCH_BACKEND=gloo for a single-GPU dry run of the multi-rank path")
     torch.cuda.set_device(local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group(backend)
+
+    def form_group():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+
+    # the group is formed by main() AFTER rank 0 has measured the same workload alone (the reference point of the weak-scaling efficiency)
+    dist._zuko_form_group = form_group
     return rank, world, local, dist
 
 
@@ -372,12 +417,17 @@ def main() -> None:
     rank, world, local, dist = init_ranks(args)
     if os.environ.get("ZUKO_BENCH_LAUNCH_SELFTEST") == "1":
         got = 1
+        aff = bind_cpu_to_gpu(int(os.environ.get("LOCAL_RANK", 0)), world)  # (no GPU here: the even-slice branch)
+        bound = torch.tensor([1.0 if aff.get("bound") else 0.0, float(aff.get("first_cpu", -1))])
+        firsts = [bound.clone() for _ in range(world)]
         if dist is not None:
             t = torch.ones(1)
             dist.all_reduce(t)
             got = int(t.item())
+            dist.all_gather(firsts, bound)
         if rank == 0:
-            print(json.dumps({"selftest": True, "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist else 1, "allreduce_of_ones": got}))
+            print(json.dumps({"selftest": True, "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist else 1, "allreduce_of_ones": got,
+                              "ranks_bound": int(sum(f[0].item() for f in firsts)), "first_cpu_per_rank": [int(f[1].item()) for f in firsts]}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -411,6 +461,22 @@ def main() -> None:
             if dist is not None and collective:
                 dist.all_reduce(nll)  # the only collective: one f64 scalar over RCCL/xGMI
         return nll
+
+    affinity = bind_cpu_to_gpu(local, world) if torch.cuda.device_count() >= world else {"bound": False, "source": "single-device dry run"}
+    solo = None
+    if dist is not None and hasattr(dist, "_zuko_form_group"):
+        if rank == 0:  # the SAME per-GPU workload on rank 0 alone, before the group exists: what N-GPU weak scaling is measured against
+            k = min(args.steps, 20)
+            for _ in range(min(args.warmup, 5)):
+                step(collective=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step(collective=False)
+            torch.cuda.synchronize()
+            solo = {"steps": k, "ms_per_step": (time.perf_counter() - t0) / k * 1e3}
+            solo["value"] = B / (solo["ms_per_step"] * 1e-3)
+        dist._zuko_form_group()
 
     def fence():
         if dist is not None:
@@ -450,14 +516,19 @@ def main() -> None:
         for name, recs in prof.items():
             groups, variants = {}, {}
             for a, b, cargs in recs:
-                if name == "zk_linear_bf16_rqs":  # N, in, panels, K, features
+                shown = name
+                if name in ("zk_ar_forward", "zk_ar_forward_static", "zk_coupling_forward"):  # argument blocks (include/zuko_amd.h)
+                    blk = cargs[0]
+                    sizes = (blk.N, blk.D, blk.DIN) if name != "zk_coupling_forward" else (blk.N, blk.D, blk.C)
+                    shown = "zk_ar_forward" if name != "zk_coupling_forward" else name  # (generic and static-shape instantiation of the same layer kernel)
+                elif name == "zk_linear_bf16_rqs":  # N, in, panels, K, features
                     sizes = (cargs[0], cargs[1], cargs[2], cargs[8], cargs[9])
                 else:
                     sizes = cargs[0:3] if name == "zk_linear_bf16" else cargs[1:4]  # (dtype-less signature)
-                key = (name,) + tuple(v for v in sizes if isinstance(v, int))
+                key = (shown,) + tuple(int(v) for v in sizes if isinstance(v, int))
                 groups.setdefault(key, []).append(a.elapsed_time(b))
-                if name == "zk_ar_forward":  # variant argument: 0 = generic tile-skipping kernel, 1 / 2 = static-shape kernel (csrc/fused_ar_static.hip)
-                    variants.setdefault(key, set()).add("static-shape" if cargs[21] else "generic")
+                if shown == "zk_ar_forward":
+                    variants.setdefault(key, set()).add("static-shape" if name == "zk_ar_forward_static" else "generic")
             for key, ts in groups.items():
                 kernels[" ".join(map(str, key))] = {"calls": len(ts), "avg_ms": sum(ts) / len(ts), **({"bf16": True} if bf16 else {}),
                                                     **({"instantiation": "+".join(sorted(variants[key]))} if key in variants else {})}
@@ -543,7 +614,11 @@ def main() -> None:
             },
             "kernels": extra,
             "nll": nll_value,
+            "cpu_affinity": affinity,
         }
+        if solo is not None:  # (the driver computes scaling efficiency from its own per-N runs; this is the same ratio from ONE invocation)
+            out["rank0_alone_before_group"] = solo
+            out["weak_scaling_efficiency"] = value / world / solo["value"]
         if world == 1 and args.config == "cfg2" and not args.no_bin_report:
             try:
                 out["bin_index"] = bin_report(flow, flow_cpu, x, dev)

@@ -153,27 +153,70 @@ int zk_linear_bf16_rqs(int64_t N, int in_features, int panels, const void* h, in
  *             (degree-sorted, tile-skipped weight stream of 1 KiB MFMA A-operand images, bias image,
  *             per-group skip bitmasks, feature regrouping of the last layer); wstream and bias are
  *             produced on the device by zk_gather_f32 from the module's weight / mask / bias tensors.
- *   variant   reserved, must be 0
- *   limits    DIN <= 256, every hidden width <= 256, >= 1 hidden layer.                             */
-int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
-                  int accumulate, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
-                  const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
-                  int variant, void* stream);
+ *   limits    DIN <= 256, every hidden width <= 256, >= 1 hidden layer.
+ *
+ * ARGUMENT BLOCK.  The fused entry points take ONE versioned struct instead of 20-28 positional arguments (a transposed pair of
+ * ints is a silent wrong answer; a mis-named field is a compile error / a Python KeyError): set struct_size = sizeof(the struct)
+ * and version = 1, fill the fields the entry point reads (listed per function), leave the rest zero.  The library rejects a
+ * struct_size / version it does not know with hipErrorInvalidValue.  zuko_amd/_C.py builds its ctypes.Structure classes by
+ * parsing THESE definitions, so header and binding cannot drift apart. */
+typedef struct zk_ar_args_v1 {
+  uint32_t struct_size;    /* sizeof(zk_ar_args_v1) */
+  uint32_t version;        /* 1 */
+  int32_t uni_kind;        /* see above */
+  int32_t D;               /* features */
+  int32_t DIN;             /* conditioner inputs: features + context, zero-padded to a multiple of 4 */
+  int32_t n_layers;        /* linear layers of the conditioner (hidden + 1) */
+  int32_t n_groups;        /* feature groups of the last layer */
+  int32_t n_chunks;        /* length of wstream in 24-tile chunks */
+  int32_t act;             /* activation code (zuko_amd/nn.py:_act_code; 1 = ReLU) */
+  int32_t bias_floats;     /* floats in the bias image */
+  int32_t accumulate;      /* != 0: ladj += instead of ladj = */
+  int32_t rev;             /* static-shape kernels: 1 = the alternative first-layer pattern (descending feature order) */
+  int32_t n_sched;         /* partial sweeps: entries of sched */
+  int32_t g0;              /* partial sweeps: last-layer groups [g0, g1) */
+  int32_t g1;
+  int32_t reserved;        /* 0 */
+  int64_t N;               /* rows */
+  int64_t ldx;             /* row stride of x (elements, multiple of 4) */
+  int64_t ldy;             /* row stride of y (forward) / of y_in (inverse sweeps) */
+  int64_t ldo;             /* inverse sweeps: row stride of x_out */
+  int64_t ldphi;           /* training forward: row stride of phi */
+  double bound;            /* spline support [-bound, bound] */
+  double slope;            /* softclip slope (zuko/transforms.py:426-432, :469-477) */
+  const void* x;           /* [N, DIN] = cat(x, c) zero-padded; inverse sweeps: the conditioning values x_cond */
+  void* y;                 /* forward: [N, D] result */
+  void* ladj;              /* [N] or NULL */
+  const void* y_in;        /* inverse sweeps: [N, D] values to invert */
+  void* x_out;             /* inverse sweeps: [N, D] result (may alias x) */
+  const void* wstream;     /* weight stream of the plan (zuko_amd/fused.py); static-shape kernels: the PER-TILE stream */
+  const void* bias;        /* bias image */
+  const uint32_t* skip;    /* skip words (generic kernel) */
+  const int32_t* featmap;  /* feature regrouping of the last layer */
+  int32_t* bin_out;        /* diagnostic launch: [N, D] bin indices */
+  float* knots_out;        /* diagnostic launch: [N, D, K + 1] search-axis knots */
+  const int32_t* sched;    /* partial sweeps: DEVICE array of stream-chunk ids in consumption order */
+  const int32_t* olim;     /* partial sweeps: HOST array, per hidden layer the last out-group to compute */
+  const void* launcher;    /* static-shape kernels: address of the generated kernel's zk_ars_launch */
+  void* h1;                /* training forward: hidden activations [N, width_l] (h2 / h3 NULL beyond n_layers - 1) */
+  void* h2;
+  void* h3;
+  void* phi;               /* training forward: [N, D * total] */
+} zk_ar_args_v1;
+
+/* y, ladj of one layer on the generic tile-skipping kernel.  Reads: uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream,
+ * bias, bias_floats, skip, featmap, n_layers, n_groups, n_chunks, act, bound, slope. */
+int zk_ar_forward(const zk_ar_args_v1* args, void* stream);
 /* Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3, LDS-staged tiles: D % 4 == 0): the same kernel
- * template and arithmetic plus bin_out[N, D] (int32) and knots_out[N, D, K+1] (fp32), as zk_rqs_diag. */
-int zk_ar_forward_diag(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj,
-                       const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap,
-                       int n_layers, int n_groups, int n_chunks, int act, double bound, double slope, int32_t* bin_out,
-                       float* knots_out, void* stream);
+ * template and arithmetic plus bin_out[N, D] (int32) and knots_out[N, D, K+1] (fp32), as zk_rqs_diag.  Reads additionally:
+ * bin_out, knots_out (accumulate is ignored). */
+int zk_ar_forward_diag(const zk_ar_args_v1* args, void* stream);
 /* One sweep of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000, the body of its loop):
  *     x_out = univariate(*unpack(MaskedMLP(x_cond))).inv(y)
- * x_cond [N, DIN] as `x` of zk_ar_forward (features first, context after), y [N, D] the values to
- * invert, x_out [N, D] (row stride ldo); x_out may alias x_cond, so `passes` sweeps over one
- * zero-initialised buffer reproduce the reference loop.  Other arguments as zk_ar_forward. */
-int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy,
-                        void* x_out, int64_t ldo, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
-                        const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
-                        int variant, void* stream);
+ * x (= x_cond) [N, DIN] as for zk_ar_forward (features first, context after), y_in [N, D] (row stride ldy) the values to
+ * invert, x_out [N, D] (row stride ldo); x_out may alias x, so `passes` sweeps over one zero-initialised buffer reproduce the
+ * reference loop.  Other fields as zk_ar_forward (y, ladj, accumulate unused). */
+int zk_ar_inverse_sweep(const zk_ar_args_v1* args, void* stream);
 /* Partial inverse sweep (the "wavefront" form of AutoregressiveTransform._inverse, SURVEY 7 hard part 4):
  * like zk_ar_inverse_sweep, but only the features of last-layer groups [g0, g1) are updated and only
  * the prefix of the conditioner they depend on is evaluated.  The plan must be built with
@@ -181,10 +224,7 @@ int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_c
  * n_sched stream-chunk ids in consumption order, `olim` a HOST array with, per hidden layer, the last
  * out-group (of 4 tiles) to compute (fused.partial_schedule).  Running it for s = 0..passes-1 on the
  * groups that hold the features of order s gives the same x as `passes` full sweeps. */
-int zk_ar_inverse_partial(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy,
-                          void* x_out, int64_t ldo, const void* wstream, const void* bias, int bias_floats, const uint32_t* skip,
-                          const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act, double bound, double slope,
-                          const int32_t* sched, int n_sched, const int32_t* olim, int g0, int g1, int variant, void* stream);
+int zk_ar_inverse_partial(const zk_ar_args_v1* args, void* stream);
 /* ---- fused coupling transform (NICE / RealNVP) ------------------------------------------------------------------------ *
  * Replaces GeneralCouplingTransform.meta + CouplingTransform.call_and_ladj (zuko/flows/coupling.py:128-136,
  * zuko/transforms.py:1040-1048, :1068-1073) with the affine univariate (zuko/transforms.py:436-446): split by index maps,
@@ -196,18 +236,42 @@ int zk_ar_inverse_partial(int uni_kind, int64_t N, int D, int DIN, const void* x
  *   tiles / widths (host, n_layers - 1 ints): 16-row output tiles and true width of every hidden layer;
  *   bias_off (host, n_layers ints); wstream / bias: zuko_amd/coupling_plan.py (zk_gather_f32 from the module's parameters);
  *   static_ok != 0 allows the shape-specialised instantiation (ReLU, 128 inputs, hidden 512s) when the shapes match. */
-int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy,
-                        void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off,
-                        const int32_t* amap, int nit, const int32_t* fmap, int n_groups, int n_layers, const int32_t* tiles,
-                        const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream);
+typedef struct zk_coupling_args_v1 {
+  uint32_t struct_size;    /* sizeof(zk_coupling_args_v1) */
+  uint32_t version;        /* 1 */
+  int32_t D;               /* features */
+  int32_t C;               /* context columns */
+  int32_t nit;             /* 16-column input tiles of the conditioner */
+  int32_t n_groups;        /* groups of 8 transformed slots */
+  int32_t n_layers;        /* linear layers */
+  int32_t n_chunks;        /* length of wstream in chunks */
+  int32_t act;             /* activation code */
+  int32_t bias_floats;
+  int32_t accumulate;      /* != 0: ladj += */
+  int32_t static_ok;       /* != 0 allows the shape-specialised instantiation when the shapes match */
+  int64_t N;
+  int64_t ldx;             /* row stride of `in` */
+  int64_t ldc;             /* row stride of ctx */
+  int64_t ldy;             /* row stride of `out` */
+  double slope;
+  const void* in;          /* forward: x [N, D]; inverse: y [N, D] */
+  const void* ctx;         /* [N, C] or NULL */
+  void* out;               /* forward: y; inverse: x */
+  void* ladj;              /* [N] or NULL: log|det dy/dx| of the FORWARD map (also from the inverse launch, at the solution) */
+  const void* wstream;
+  const void* bias;
+  const int32_t* bias_off; /* HOST, n_layers ints */
+  const int32_t* amap;     /* DEVICE [nit * 16] */
+  const int32_t* fmap;     /* DEVICE [n_groups * 8] */
+  const int32_t* tiles;    /* HOST, n_layers - 1 ints: 16-row output tiles of every hidden layer */
+  const int32_t* widths;   /* HOST, n_layers - 1 ints: true width of every hidden layer */
+} zk_coupling_args_v1;
+int zk_coupling_forward(const zk_coupling_args_v1* args, void* stream);
 /* The inverse of the same coupling transform (CouplingTransform._inverse, zuko/transforms.py:1050-1056), same plan and arguments:
- * y_in [N, D] -> x [N, D]; the conditioner sees the pass-through half, which both directions share, the moved half is mapped back
- * by x_b = (y_b - shift) exp(-softclip(scale)).  ladj (optional) = log|det dy/dx| of the FORWARD map at the solution (negate it for
- * the inverse transform), the convention of zk_ar_inverse_incremental. */
-int zk_coupling_inverse(int64_t N, int D, int C, const void* y_in, int64_t ldy, const void* ctx, int64_t ldc, void* x, int64_t ldx,
-                        void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off,
-                        const int32_t* amap, int nit, const int32_t* fmap, int n_groups, int n_layers, const int32_t* tiles,
-                        const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream);
+ * in = y [N, D] -> out = x [N, D]; the conditioner sees the pass-through half, which both directions share, the moved half is mapped
+ * back by x_b = (y_b - shift) exp(-softclip(scale)).  ladj (optional) = log|det dy/dx| of the FORWARD map at the solution (negate it
+ * for the inverse transform), the convention of zk_ar_inverse_incremental. */
+int zk_coupling_inverse(const zk_coupling_args_v1* args, void* stream);
 /* INCREMENTAL inverse: the whole loop of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000) in one launch whose
  * multiply-add count is ~1.5x ONE density evaluation (every off-diagonal weight tile is multiplied once per sample; only the
  * diagonal tiles of a 4-feature group are iterated).  Needs the aligned-tile plan of zuko_amd/incremental.py
@@ -217,10 +281,34 @@ int zk_coupling_inverse(int64_t N, int D, int C, const void* y_in, int64_t ldy, 
  *   zuko/distributions.py:129-138);
  *   uni_kind 0 affine, 1 / 2 / 3 spline with 8 / 4 / 16 bins; n_hidden 1..3; D <= 68, D + C <= 256;
  *   bias_off: HOST array of n_hidden + 1 offsets into the bias image; featmap [4 n_groups], prog [n_groups][36]: device. */
-int zk_ar_inverse_incremental(int uni_kind, int n_hidden, int64_t N, int D, int C, const void* y, int64_t ldy, const void* ctx,
-                              int64_t ldc, void* x, int64_t ldx, void* ladj, const void* wstream, const void* bias, int bias_floats,
-                              const int32_t* bias_off, const int32_t* featmap, const int32_t* prog, int n_groups, int n_chunks, int act,
-                              double bound, double slope, void* stream);
+typedef struct zk_ar_inc_args_v1 {
+  uint32_t struct_size;    /* sizeof(zk_ar_inc_args_v1) */
+  uint32_t version;        /* 1 */
+  int32_t uni_kind;
+  int32_t n_hidden;
+  int32_t D;
+  int32_t C;
+  int32_t n_groups;
+  int32_t n_chunks;
+  int32_t act;
+  int32_t bias_floats;
+  int64_t N;
+  int64_t ldy;
+  int64_t ldc;
+  int64_t ldx;
+  double bound;
+  double slope;
+  const void* y;           /* [N, D] values to invert */
+  const void* ctx;         /* [N, C] or NULL */
+  void* x;                 /* [N, D] result */
+  void* ladj;              /* [N] or NULL */
+  const void* wstream;
+  const void* bias;
+  const int32_t* bias_off; /* HOST, n_hidden + 1 ints */
+  const int32_t* featmap;  /* DEVICE [4 n_groups] */
+  const int32_t* prog;     /* DEVICE [n_groups][36] */
+} zk_ar_inc_args_v1;
+int zk_ar_inverse_incremental(const zk_ar_inc_args_v1* args, void* stream);
 int zk_ar_inc_lds_bytes(int bias_floats, int nit);
 /* dynamic LDS bytes zk_ar_forward will request for `variant` and a bias image of `bias_floats` floats. */
 int zk_ar_lds_bytes(int variant, int bias_floats);
@@ -236,17 +324,15 @@ int zk_ar_lds_bytes(int variant, int bias_floats);
  * kernel built against another ArArgs layout) and needs 16-byte addressable rows of y when it stages rows through LDS (D % 4 == 0).
  * ReLU conditioners; uni_kind 0 / 1 / 2 / 4; hidden widths up to 512 (the generic zk_ar_forward stops at 256).  Results are
  * bit-identical to zk_ar_forward on the same plan (the tiles the per-tile stream drops hold zeros only). */
-int zk_ar_forward_static(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y,
-                         int64_t ldy, void* ladj, int accumulate, const void* wstream, const void* bias, int bias_floats,
-                         const int32_t* featmap, int n_layers, int n_groups, int n_chunks, double bound, double slope, void* stream);
+/* Reads: launcher, rev, uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream, bias, bias_floats, featmap, n_layers, n_groups,
+ * n_chunks, bound, slope. */
+int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream);
 /* Conditioner-only launch of a generated static-shape kernel for the training forward (zuko_amd/train.py): phi [N, D * total] =
  * net(x) in module order (what the last MaskedLinear of zuko/nn.py:221-318 returns) and the hidden activations h_l [N, width_l]
  * (n_layers - 1 <= 3 of them; h2 / h3 may be NULL beyond that) with the units in the stream's dependency-sorted order, which the
  * mask-aware dgrad / wgrad kernels consume.  Same launcher, per-tile stream, bias image, feature map and chunk count as
  * zk_ar_forward_static; the univariate map is not evaluated. */
-int zk_ar_forward_train(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* h1,
-                        void* h2, void* h3, void* phi, int64_t ldphi, const void* wstream, const void* bias, int bias_floats,
-                        const int32_t* featmap, int n_layers, int n_groups, int n_chunks, void* stream);
+int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
 int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);
@@ -290,19 +376,22 @@ int zk_act_backward(int64_t n, const void* y, const void* gout, int act, void* g
  * zk_wgrad_f32:  dw[OUT, IN] (+)= mask .* (g[N, OUT]^T h[N, IN]) restricted to the 128 x 128 blocks listed in `pairs`
  *   (device int32 [npairs][2] = (out block, in block)); other blocks are not written.  Split over
  *   zk_wgrad_slices(N, npairs) sample slices whose partial blocks go to `partial` (>= slices * npairs * 16384 floats)
- *   and are summed in slice order (deterministic).  mask: uint8 [OUT, IN] or NULL.
+ *   and are summed in slice order (deterministic).  mask: uint8 [OUT, IN] or NULL.  rows / cols (device int32 [OUT] / [IN], or
+ *   NULL = identity): the product is formed on a row / column permuted weight (units sorted by dependency count) and element (o, c)
+ *   is WRITTEN to dw[rows[o], cols[c]], i.e. where the module keeps that weight — no scatter pass afterwards.
  * zk_colsum_f32:  out[C] (+)= sum_n x[n, c] (bias gradients); workspace >= zk_colsum_slices(N) * C floats. */
 int zk_gemm_f32_skip(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* w, const uint64_t* kskip,
                      const void* bias, int act, const void* gate, int64_t ldg, int gate_act, void* y, int64_t ldy, void* stream);
 int zk_wgrad_slices(int64_t N, int npairs);
 int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh,
-                 const int32_t* pairs, int npairs, float* partial, const uint8_t* mask, void* dw, int accumulate, void* stream);
+                 const int32_t* pairs, int npairs, float* partial, const uint8_t* mask, void* dw, int accumulate, const int32_t* rows,
+                 const int32_t* cols, void* stream);
 /* zk_wgrad_f32 plus the bias gradient db[OUT] = sum_n g[n, :] from the same pass over g (replaces a separate zk_colsum_f32 over g;
  * zuko/nn.py:217-218 under autograd).  cs_flag [npairs] (device, uint8) marks ONE pair per 128-row out block — every out block
  * needs one; cs_partial: workspace of zk_wgrad_slices(N, npairs) * ceil(OUT / 128) * 128 floats.  Deterministic. */
 int zk_wgrad_bias_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh,
                       const int32_t* pairs, int npairs, float* partial, const uint8_t* mask, void* dw, int accumulate,
-                      const uint8_t* cs_flag, float* cs_partial, void* db, void* stream);
+                      const uint8_t* cs_flag, float* cs_partial, void* db, const int32_t* rows, const int32_t* cols, void* stream);
 int zk_colsum_slices(int64_t N);
 int zk_colsum_f32(int64_t N, int C, const void* x, int64_t ld, float* workspace, void* out, int accumulate, void* stream);
 

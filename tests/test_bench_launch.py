@@ -25,10 +25,15 @@ def _run(args, env_extra, timeout):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
 def test_gpus_flag_spawns_ranks(n):
+    """1, 2, 3 and the full node's 8 ranks (gloo): every rank joins, and every rank pins itself to its own slice of the host's cores
+    (on a GPU box: the cores local to its GPU's NUMA node)."""
     out = _run(["--gpus", str(n)], {"ZUKO_BENCH_LAUNCH_SELFTEST": "1"}, 300)
     assert out["n_gpus"] == n and out["rccl_world_size"] == n and out["allreduce_of_ones"] == n
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= n:
+        assert out["ranks_bound"] == n and len(set(out["first_cpu_per_rank"])) == n, out
 
 
 def test_world_size_mismatch_is_an_error():

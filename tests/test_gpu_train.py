@@ -49,10 +49,17 @@ def test_gemm_skip_wgrad_colsum(dev, N, IN, OUT):
     pad[:OUT, :IN] = mask.cpu()
     plan.pairs = [pad.reshape(ob, 128, ib, 128).any(3).any(1).nonzero().to(torch.int32).contiguous().to(dev)]
     plan.mask_s = [mask.to(torch.uint8).contiguous()]
+    plan.idx_b, plan.cols_dev = [None], [None]  # identity: dW in the operands' own order
     dw = plan.wgrad(0, g, x)
     refw = (g.double().t() @ x.double()) * mask
     assert torch.allclose(dw.double(), refw, rtol=1e-5, atol=2e-5 * refw.abs().max().item())
     assert torch.equal(plan.wgrad(0, g, x), dw), "wgrad must be deterministic"
+    # row / column permutations: element (o, c) is written to dW[rows[o], cols[c]] (the module's unit order), bit for bit the same values
+    rp, cp_ = torch.randperm(OUT, generator=gen), torch.randperm(IN, generator=gen)
+    plan.idx_b, plan.cols_dev = [rp.to(torch.int32).to(dev)], [cp_.to(torch.int32).to(dev)]
+    dwp = plan.wgrad(0, g, x)
+    assert torch.equal(dwp[rp.to(dev)][:, cp_.to(dev)], dw)
+    plan.idx_b, plan.cols_dev = [None], [None]
     cs = plan.colsum(g)
     assert torch.allclose(cs.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
     pr, seen = plan.pairs[0].cpu(), set()

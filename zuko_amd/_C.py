@@ -21,6 +21,61 @@ I = c_int
 L = c_int64
 F = c_double
 
+# ---- versioned argument blocks: the ctypes.Structure classes are built by PARSING include/zuko_amd.h, so the binding
+#      cannot drift from the header (field order, types, sizes) --------------------------------------------------------
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "zuko_amd.h")
+_CTYPES = {"uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "double": ctypes.c_double, "float": ctypes.c_float,
+           "int": ctypes.c_int}
+
+
+def _parse_structs(path: str) -> dict:
+    import re
+
+    text = open(path).read()
+    out = {}
+    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} (\w+);", text, flags=re.S):
+        name, body = m.group(3), re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            fm = re.match(r"(?:const\s+)?(\w+)\s*(\*?)\s*(\w+)$", decl)
+            if not fm:
+                raise ImportError(f"zuko_amd: cannot parse field '{decl}' of {name} in {path}")
+            typ, star, fname = fm.groups()
+            fields.append((fname, c_void_p if star else _CTYPES[typ]))
+        out[name] = type(name, (ctypes.Structure,), {"_fields_": fields})
+    return out
+
+
+STRUCTS = _parse_structs(_HEADER)
+_VERSION = {"zk_ar_args_v1": 1, "zk_coupling_args_v1": 1, "zk_ar_inc_args_v1": 1}
+
+
+def args(struct: str, **fields):
+    """A filled argument block: struct_size / version set, every keyword must name a field (a typo raises instead of being ignored);
+    tensors' data pointers as ints / c_void_p, HOST int arrays as ctypes arrays (kept alive on the returned object)."""
+    cls = STRUCTS[struct]
+    a = cls()
+    a.struct_size, a.version = ctypes.sizeof(cls), _VERSION[struct]
+    names = {f for f, _ in cls._fields_}
+    keep = []
+    for k, v in fields.items():
+        if k not in names:
+            raise KeyError(f"zuko_amd: {struct} has no field '{k}'")
+        if isinstance(v, ctypes.Array):
+            keep.append(v)
+            v = ctypes.cast(v, c_void_p)
+        if isinstance(v, c_void_p):
+            v = v.value
+        setattr(a, k, 0 if v is None else v)
+    a._keep = keep
+    return a
+
+
+_AR, _CP, _INC = POINTER(STRUCTS["zk_ar_args_v1"]), POINTER(STRUCTS["zk_coupling_args_v1"]), POINTER(STRUCTS["zk_ar_inc_args_v1"])
+
 # symbol -> argument types (return type is always int = hipError_t)
 SIGNATURES = {
     "zk_rqs_forward": [I, L, L, I, F, F, P, P, L, L, P, L, L, P, L, L, P, P, I, P, P],
@@ -47,21 +102,21 @@ SIGNATURES = {
     "zk_bernstein_backward": [L, L, I, I, F, P, P, P, P, I, P, P, P],
     "zk_gemm_f32_skip": [L, I, I, P, L, P, P, P, I, P, L, I, P, L, P],
     "zk_wgrad_slices": [L, I],
-    "zk_wgrad_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P],
-    "zk_wgrad_bias_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P, P, P, P],
+    "zk_wgrad_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P, P, P],
+    "zk_wgrad_bias_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P, P, P, P, P, P],
     "zk_colsum_slices": [L],
     "zk_colsum_f32": [L, I, P, L, P, P, I, P],
     "zk_ar_lds_bytes": [I, I],
-    "zk_ar_forward_static": [P, I, I, L, I, I, P, L, P, L, P, I, P, P, I, P, I, I, I, F, F, P],
-    "zk_ar_forward_train": [P, I, I, L, I, I, P, L, P, P, P, P, L, P, P, I, P, I, I, I, P],
-    "zk_ar_forward": [I, L, I, I, P, L, P, L, P, I, P, P, I, P, P, I, I, I, I, F, F, I, P],
-    "zk_ar_forward_diag": [I, L, I, I, P, L, P, L, P, P, P, I, P, P, I, I, I, I, F, F, P, P, P],
-    "zk_ar_inverse_sweep": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, I, P],
-    "zk_coupling_forward": [L, I, I, P, L, P, L, P, L, P, I, P, P, I, POINTER(c_int), P, I, P, I, I, POINTER(c_int), POINTER(c_int), I, I, F, I, P],
-    "zk_coupling_inverse": [L, I, I, P, L, P, L, P, L, P, I, P, P, I, POINTER(c_int), P, I, P, I, I, POINTER(c_int), POINTER(c_int), I, I, F, I, P],
-    "zk_ar_inverse_incremental": [I, I, L, I, I, P, L, P, L, P, L, P, P, P, I, POINTER(c_int), P, P, I, I, I, F, F, P],
+    "zk_ar_forward_static": [_AR, P],
+    "zk_ar_forward_train": [_AR, P],
+    "zk_ar_forward": [_AR, P],
+    "zk_ar_forward_diag": [_AR, P],
+    "zk_ar_inverse_sweep": [_AR, P],
+    "zk_coupling_forward": [_CP, P],
+    "zk_coupling_inverse": [_CP, P],
+    "zk_ar_inverse_incremental": [_INC, P],
     "zk_ar_inc_lds_bytes": [I, I],
-    "zk_ar_inverse_partial": [I, L, I, I, P, L, P, L, P, L, P, P, I, P, P, I, I, I, I, F, F, P, I, POINTER(c_int), I, I, I, P],
+    "zk_ar_inverse_partial": [_AR, P],
 }
 
 

@@ -239,10 +239,10 @@ class FusedCoupling:
         y = torch.empty((N, p.features), dtype=torch.float32, device=x.device)
         ladj = torch.empty(N, dtype=torch.float32, device=x.device)
         fn = _C.lib().zk_coupling_inverse if inverse else _C.lib().zk_coupling_forward
-        err = fn(
-            N, p.features, p.context, _ptr(x), x.stride(0), _ptr(ctx), 0 if ctx is None else ctx.stride(0), _ptr(y), p.features, _ptr(ladj), 0,
-            _ptr(self.stream), _ptr(self.bias), self.bias.numel(), self.bias_off, _ptr(self.amap), p.nit, _ptr(self.fmap), p.n_groups, p.n_layers,
-            self.tiles, self.widths, p.n_chunks, self.act, self.slope, 1, _stream(),
-        )
+        a = _C.args("zk_coupling_args_v1", N=N, D=p.features, C=p.context, **{"in": _ptr(x)}, ldx=x.stride(0), ctx=_ptr(ctx), ldc=0 if ctx is None else ctx.stride(0), out=_ptr(y),
+                    ldy=p.features, ladj=_ptr(ladj), accumulate=0, wstream=_ptr(self.stream), bias=_ptr(self.bias), bias_floats=self.bias.numel(), bias_off=self.bias_off,
+                    amap=_ptr(self.amap), nit=p.nit, fmap=_ptr(self.fmap), n_groups=p.n_groups, n_layers=p.n_layers, tiles=self.tiles, widths=self.widths, n_chunks=p.n_chunks,
+                    act=self.act, slope=self.slope, static_ok=1)
+        err = fn(a, _stream())
         _C.check(err, "zk_coupling_inverse" if inverse else "zk_coupling_forward")
         return y, ladj

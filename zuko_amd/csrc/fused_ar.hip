@@ -24,6 +24,7 @@
 //     registers; y is stored, ladj reduced over q with two shuffles and over groups in a register.
 //
 // Host-side planning (permutations, stream order, skip masks): zuko_amd/fused.py.
+#include "../../include/zuko_amd.h"
 #include "zk_ar_common.h"
 #include <mutex>
 #include <type_traits>
@@ -472,59 +473,65 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   return ZK_LAUNCH_CHECK();
 }
 
-int zk_ar_forward(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj, int accumulate, const void* wstream,
-                  const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act,
-                  double bound, double slope, int variant, void* stream) {
-  return ar_launch(ArPartial{}, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
-                   n_chunks, act, bound, slope, variant, stream);
+// (argument block: include/zuko_amd.h — every entry point checks struct_size / version before it reads a field)
+static bool ar_args_ok(const zk_ar_args_v1* p) { return p && p->struct_size == sizeof(zk_ar_args_v1) && p->version == 1; }
+
+static int ar_launch_v1(const ArPartial& part, bool inverse, const zk_ar_args_v1& p, void* stream) {
+  return ar_launch(part, inverse, p.uni_kind, p.N, p.D, p.DIN, p.x, p.ldx, inverse ? p.y_in : nullptr, inverse ? p.ldy : 0, inverse ? p.x_out : p.y, inverse ? p.ldo : p.ldy,
+                   inverse ? nullptr : p.ladj, p.accumulate, p.wstream, p.bias, p.bias_floats, p.skip, p.featmap, p.n_layers, p.n_groups, p.n_chunks, p.act, p.bound, p.slope, 0,
+                   stream);
+}
+
+int zk_ar_forward(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args)) return ZK_EINVAL;
+  return ar_launch_v1(ArPartial{}, false, *args, stream);
+}
+
+// Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3): identical kernel template and arithmetic, plus
+// bin_out[N, D] (k = #(knots < x) - 1, zuko/transforms.py:521-523) and knots_out[N, D, K+1] (the horizontal knots the
+// search compared).  Lets the tests assert the bin index of the FUSED path on its own knots.
+int zk_ar_forward_diag(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args)) return ZK_EINVAL;
+  ArPartial part;
+  part.bin_out = args->bin_out; part.knots_out = args->knots_out;
+  zk_ar_args_v1 p = *args;
+  p.accumulate = 0;
+  return ar_launch_v1(part, false, p, stream);
 }
 
 // zk_ar_forward through a generated static-shape kernel (zuko_amd/static_ar.py): `launcher` is the address of the `zk_ars_launch`
 // symbol of the kernel's shared object, `rev` selects the alternative first-layer pattern the kernel was generated with (descending
 // feature order).  wstream is the PER-TILE stream of the plan (ArPlan.fine_gather), n_chunks its length.  The kernel re-checks
 // D / DIN / n_layers / n_groups / n_chunks against the shape it was generated for and returns hipErrorInvalidValue on a mismatch.
-int zk_ar_forward_static(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj, int accumulate,
-                         const void* wstream, const void* bias, int bias_floats, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, double bound, double slope,
-                         void* stream) {
-  if (!launcher) return ZK_EINVAL;
+int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args) || !args->launcher) return ZK_EINVAL;
   ArPartial part;
-  part.static_fn = launcher; part.rev = rev;
-  return ar_launch(part, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, accumulate, wstream, bias, bias_floats, nullptr, featmap, n_layers, n_groups,
-                   n_chunks, 1, bound, slope, 0, stream);
+  part.static_fn = args->launcher; part.rev = args->rev;
+  zk_ar_args_v1 p = *args;
+  p.act = 1; p.skip = nullptr;
+  return ar_launch_v1(part, false, p, stream);
 }
 
 // Conditioner-only (training) launch of a generated static-shape kernel: phi [N, D * total] = net(x) in module order plus the hidden
 // activations h_l [N, width_l] (up to three; units in the stream's sorted order), for the backward pass of zuko_amd/train.py.
-int zk_ar_forward_train(const void* launcher, int rev, int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* h1, void* h2, void* h3, void* phi, int64_t ldphi,
-                        const void* wstream, const void* bias, int bias_floats, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, void* stream) {
-  if (!launcher || !phi || !h1 || n_layers < 2 || n_layers > 4 || (n_layers > 2 && !h2) || (n_layers > 3 && !h3)) return ZK_EINVAL;
-  if (((uintptr_t)h1 % 16) || ((uintptr_t)h2 % 16) || ((uintptr_t)h3 % 16)) return ZK_EINVAL;
+int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args) || !args->launcher || !args->phi || !args->h1) return ZK_EINVAL;
+  const int n_layers = args->n_layers;
+  if (n_layers < 2 || n_layers > 4 || (n_layers > 2 && !args->h2) || (n_layers > 3 && !args->h3)) return ZK_EINVAL;
+  if (((uintptr_t)args->h1 % 16) || ((uintptr_t)args->h2 % 16) || ((uintptr_t)args->h3 % 16)) return ZK_EINVAL;
   ArPartial part;
-  part.static_fn = launcher; part.rev = rev;
-  part.act_out[0] = (float*)h1; part.act_out[1] = (float*)h2; part.act_out[2] = (float*)h3; part.phi_out = (float*)phi; part.ldphi = ldphi;
-  return ar_launch(part, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, nullptr, 0, nullptr, 0, wstream, bias, bias_floats, nullptr, featmap, n_layers, n_groups,
-                   n_chunks, 1, 1.0, 1e-3, 0, stream);
-}
-
-// Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3): identical kernel template and arithmetic, plus
-// bin_out[N, D] (k = #(knots < x) - 1, zuko/transforms.py:521-523) and knots_out[N, D, K+1] (the horizontal knots the
-// search compared).  Lets the tests assert the bin index of the FUSED path on its own knots.
-int zk_ar_forward_diag(int uni_kind, int64_t N, int D, int DIN, const void* x, int64_t ldx, void* y, int64_t ldy, void* ladj, const void* wstream,
-                       const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups, int n_chunks, int act,
-                       double bound, double slope, int32_t* bin_out, float* knots_out, void* stream) {
-  ArPartial part;
-  part.bin_out = bin_out; part.knots_out = knots_out;
-  return ar_launch(part, false, uni_kind, N, D, DIN, x, ldx, nullptr, 0, y, ldy, ladj, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
-                   n_chunks, act, bound, slope, 0, stream);
+  part.static_fn = args->launcher; part.rev = args->rev;
+  part.act_out[0] = (float*)args->h1; part.act_out[1] = (float*)args->h2; part.act_out[2] = (float*)args->h3; part.phi_out = (float*)args->phi; part.ldphi = args->ldphi;
+  zk_ar_args_v1 p = *args;
+  p.act = 1; p.skip = nullptr; p.y = nullptr; p.ldy = 0; p.ladj = nullptr; p.accumulate = 0; p.bound = 1.0; p.slope = 1e-3;
+  return ar_launch_v1(part, false, p, stream);
 }
 
 // One sweep of the autoregressive inverse (zuko/transforms.py:997-998): x_out = univariate(conditioner(x_cond)).inv(y).
 // x_out may alias x_cond (a wave reads its rows of x_cond completely before it writes them).
-int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy, void* x_out, int64_t ldo,
-                        const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups,
-                        int n_chunks, int act, double bound, double slope, int variant, void* stream) {
-  return ar_launch(ArPartial{}, true, uni_kind, N, D, DIN, x_cond, ldx, y, ldy, x_out, ldo, nullptr, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
-                   n_chunks, act, bound, slope, variant, stream);
+int zk_ar_inverse_sweep(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args)) return ZK_EINVAL;
+  return ar_launch_v1(ArPartial{}, true, *args, stream);
 }
 
 // Partial inverse sweep: as zk_ar_inverse_sweep, but only the features of last-layer groups [g0, g1)
@@ -534,14 +541,11 @@ int zk_ar_inverse_sweep(int uni_kind, int64_t N, int D, int DIN, const void* x_c
 // After sweep p of the reference loop only the features of order <= p are final and only they matter
 // to later sweeps, so running, for s = 0..passes-1, the partial sweep of the groups holding order s
 // yields the same x as `passes` full sweeps at a fraction of the work (hard part 4).
-int zk_ar_inverse_partial(int uni_kind, int64_t N, int D, int DIN, const void* x_cond, int64_t ldx, const void* y, int64_t ldy, void* x_out, int64_t ldo,
-                          const void* wstream, const void* bias, int bias_floats, const uint32_t* skip, const int32_t* featmap, int n_layers, int n_groups,
-                          int n_chunks, int act, double bound, double slope, const int32_t* sched, int n_sched, const int32_t* olim, int g0, int g1,
-                          int variant, void* stream) {
+int zk_ar_inverse_partial(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args) || !args->sched || !args->olim) return ZK_EINVAL;
   ArPartial part;
-  part.sched = sched; part.n_sched = n_sched; part.olim = olim; part.g0 = g0; part.g1 = g1;
-  return ar_launch(part, true, uni_kind, N, D, DIN, x_cond, ldx, y, ldy, x_out, ldo, nullptr, 0, wstream, bias, bias_floats, skip, featmap, n_layers, n_groups,
-                   n_chunks, act, bound, slope, variant, stream);
+  part.sched = args->sched; part.n_sched = args->n_sched; part.olim = args->olim; part.g0 = args->g0; part.g1 = args->g1;
+  return ar_launch_v1(part, true, *args, stream);
 }
 
 }  // extern "C"

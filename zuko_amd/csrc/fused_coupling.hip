@@ -16,6 +16,7 @@
 //     conditioner's B operands are gathered from it (idx_a), the affine map overwrites the moved columns (idx_b) in
 //     place, and the image leaves as whole rows.
 // Host-side planning (stream order, bias image, index maps): zuko_amd/coupling_plan.py.
+#include "../../include/zuko_amd.h"
 #include "zk_univariate.h"
 
 #include <type_traits>
@@ -644,21 +645,16 @@ static int cp_launch(int inverse, int64_t N, int D, int C, const void* x, int64_
 }
 
 
-int zk_coupling_forward(int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy, void* ladj, int accumulate,
-                        const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* amap, int nit, const int32_t* fmap,
-                        int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream) {
-  return cp_launch(0, N, D, C, x, ldx, ctx, ldc, y, ldy, ladj, accumulate, wstream, bias, bias_floats, bias_off, amap, nit, fmap, n_groups, n_layers, tiles, widths,
-                   n_chunks, act, slope, static_ok, stream);
+static int cp_launch_v1(int inverse, const zk_coupling_args_v1* p, void* stream) {
+  if (!p || p->struct_size != sizeof(zk_coupling_args_v1) || p->version != 1) return ZK_EINVAL;
+  return cp_launch(inverse, p->N, p->D, p->C, p->in, p->ldx, p->ctx, p->ldc, p->out, p->ldy, p->ladj, p->accumulate, p->wstream, p->bias, p->bias_floats, p->bias_off, p->amap,
+                   p->nit, p->fmap, p->n_groups, p->n_layers, p->tiles, p->widths, p->n_chunks, p->act, p->slope, p->static_ok, stream);
 }
 
-// The inverse of the same transform (CouplingTransform._inverse, zuko/transforms.py:1050-1056): `y_in` [N, D] in, x [N, D] out —
-// the conditioner sees the pass-through half, which both directions share; ladj (optional) = log|det dy/dx| of the FORWARD map at the
-// solution (the caller negates it for the inverse transform), as zk_ar_inverse_incremental returns it.
-int zk_coupling_inverse(int64_t N, int D, int C, const void* y_in, int64_t ldy, const void* ctx, int64_t ldc, void* x, int64_t ldx, void* ladj, int accumulate,
-                        const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* amap, int nit, const int32_t* fmap,
-                        int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream) {
-  return cp_launch(1, N, D, C, y_in, ldy, ctx, ldc, x, ldx, ladj, accumulate, wstream, bias, bias_floats, bias_off, amap, nit, fmap, n_groups, n_layers, tiles, widths,
-                   n_chunks, act, slope, static_ok, stream);
-}
+int zk_coupling_forward(const zk_coupling_args_v1* args, void* stream) { return cp_launch_v1(0, args, stream); }
+
+// CouplingTransform._inverse (zuko/transforms.py:1050-1056): same launch with the affine map of the moved half inverted; ladj = the
+// FORWARD map's log-determinant at the solution.
+int zk_coupling_inverse(const zk_coupling_args_v1* args, void* stream) { return cp_launch_v1(1, args, stream); }
 
 }  // extern "C"

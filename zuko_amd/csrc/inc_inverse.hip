@@ -17,6 +17,7 @@
 // (launch_bounds(256, 1)), four wavefronts = 64 samples per workgroup sharing the weight ring.
 // The kernel also accumulates log|dy/dx| of the forward map at the solution, so rsample_and_log_prob
 // (zuko/distributions.py:129-138) needs no second pass.
+#include "../../include/zuko_amd.h"
 #include "zk_univariate.h"
 #include <type_traits>
 #include <utility>
@@ -376,9 +377,15 @@ int zk_ar_inc_lds_bytes(int bias_floats, int nit) { return inc_lds_floats(bias_f
 // x[N, D] = f^{-1}(y[N, D] | ctx[N, C]) of one masked autoregressive transform, and (optionally) ladj[N] = sum over features
 // of log|dy/dx| of the forward map at x.  uni_kind: 0 affine, 1 / 2 / 3 RQS with 8 / 4 / 16 bins.  wstream / bias / featmap
 // / prog / bias_off (host, n_hidden + 1 ints) / n_groups / n_chunks: the plan of zuko_amd/incremental.py.
-int zk_ar_inverse_incremental(int uni_kind, int n_hidden, int64_t N, int D, int C, const void* y, int64_t ldy, const void* ctx, int64_t ldc, void* x, int64_t ldx,
-                              void* ladj, const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* featmap,
-                              const int32_t* prog, int n_groups, int n_chunks, int act, double bound, double slope, void* stream) {
+int zk_ar_inverse_incremental(const zk_ar_inc_args_v1* args, void* stream) {
+  if (!args || args->struct_size != sizeof(zk_ar_inc_args_v1) || args->version != 1) return ZK_EINVAL;  // (argument block: include/zuko_amd.h)
+  const int uni_kind = args->uni_kind, n_hidden = args->n_hidden, D = args->D, C = args->C, n_groups = args->n_groups, n_chunks = args->n_chunks, act = args->act,
+            bias_floats = args->bias_floats;
+  const int64_t N = args->N, ldy = args->ldy, ldc = args->ldc, ldx = args->ldx;
+  const void *y = args->y, *ctx = args->ctx, *wstream = args->wstream, *bias = args->bias;
+  void *x = args->x, *ladj = args->ladj;
+  const int32_t *bias_off = args->bias_off, *featmap = args->featmap, *prog = args->prog;
+  const double bound = args->bound, slope = args->slope;
   if (N <= 0) return 0;
   if (n_hidden < 1 || n_hidden > 3 || n_groups < 1 || n_groups > IN_T || D < 1 || D > 4 * IN_T || C < 0 || D + C > 256 || n_chunks < 1 || (C > 0 && !ctx)) return ZK_EINVAL;
   IncArgs a{};

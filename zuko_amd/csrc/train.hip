@@ -331,8 +331,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
 }
 
 // dW[o, i] (+)= mask[o, i] * sum_s partial[s][p][...] in slice order (deterministic); 64 blocks of 256 elements per pair
+// rows / cols (optional): the gradient is computed on a row / column PERMUTED weight (zuko_amd/train.py: units sorted by dependency
+// count) but written where the module keeps it: element (o, c) goes to dw[rows[o], cols[c]] — no scatter pass afterwards
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int OUT, int IN, const int32_t* pairs, int npairs, int nslices, const float* partial,
-                                                           const uint8_t* mask, float* dw, int accumulate) {
+                                                           const uint8_t* mask, float* dw, int accumulate, const int32_t* rows, const int32_t* cols) {
   const int p = blockIdx.x >> 6;
   const int e = ((blockIdx.x & 63) << 8) + threadIdx.x;
   const int ob = pairs[2 * p], ib = pairs[2 * p + 1];
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int OUT, int IN, cons
   for (; s < nslices; ++s) sum += src[(size_t)s * stride];
   const size_t idx = (size_t)o * IN + c;
   if (mask && !mask[idx]) sum = 0.f;
-  dw[idx] = accumulate ? dw[idx] + sum : sum;
+  const size_t dst = (size_t)(rows ? rows[o] : o) * IN + (cols ? cols[c] : c);
+  dw[dst] = accumulate ? dw[dst] + sum : sum;
 }
 
 // column sums: out[c] = sum_n x[n, c] (bias gradients), two passes with a fixed reduction order
@@ -461,7 +464,8 @@ int zk_wgrad_slices(int64_t N, int npairs) {
 // dw[OUT, IN] (+)= mask .* (g^T h): g [N, OUT], h [N, IN]; pairs = the (128 x 128) blocks of dw to compute (device, int32 [npairs][2]);
 // the blocks not listed are left untouched (the caller zero-fills dw once).  Deterministic.
 static int wgrad_launch(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
-                        float* partial, const uint8_t* mask, void* dw, int accumulate, const uint8_t* cs_flag, float* cs_partial, void* db, void* stream) {
+                        float* partial, const uint8_t* mask, void* dw, int accumulate, const uint8_t* cs_flag, float* cs_partial, void* db, const int32_t* rows, const int32_t* cols,
+                        void* stream) {
   if (N <= 0 || npairs <= 0) return 0;
   WgradArgs a{};
   a.cs_flag = cs_flag; a.cs_partial = cs_partial; a.cs_ld = (out_features + 127) / 128 * 128;
@@ -473,23 +477,24 @@ static int wgrad_launch(int64_t N, int out_features, int in_features, const void
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)npairs * 64), dim3(256), 0, st, out_features, in_features, pairs, npairs, a.nslices, (const float*)partial, mask,
-                     (float*)dw, accumulate);
+                     (float*)dw, accumulate, rows, cols);
   if (cs_flag) hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((out_features + 255) / 256)), dim3(256), 0, st, out_features, a.nslices, (const float*)cs_partial, (float*)db, 0, a.cs_ld);
   return ZK_LAUNCH_CHECK();
 }
 
 int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
-                 float* partial, const uint8_t* mask, void* dw, int accumulate, void* stream) {
-  return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, nullptr, nullptr, nullptr, stream);
+                 float* partial, const uint8_t* mask, void* dw, int accumulate, const int32_t* rows, const int32_t* cols, void* stream) {
+  return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, nullptr, nullptr, nullptr, rows, cols, stream);
 }
 
 // zk_wgrad_f32 plus the bias gradient db[OUT] = sum_n g[n, :] from the same pass over g (it replaces a separate zk_colsum_f32 over g):
 // cs_flag [npairs] (device, uint8) marks ONE pair per out block (every out block must have one); cs_partial: workspace of
 // zk_wgrad_slices(N, npairs) * ceil(OUT / 128) * 128 floats.  Deterministic.
 int zk_wgrad_bias_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,
-                      float* partial, const uint8_t* mask, void* dw, int accumulate, const uint8_t* cs_flag, float* cs_partial, void* db, void* stream) {
+                      float* partial, const uint8_t* mask, void* dw, int accumulate, const uint8_t* cs_flag, float* cs_partial, void* db, const int32_t* rows,
+                      const int32_t* cols, void* stream) {
   if (!cs_flag || !cs_partial || !db) return ZK_EINVAL;
-  return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, cs_flag, cs_partial, db, stream);
+  return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, cs_flag, cs_partial, db, rows, cols, stream);
 }
 
 // out[c] (+)= sum_n x[n, c];  workspace: >= zk_colsum_slices(N) * C floats

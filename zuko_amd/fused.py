@@ -502,32 +502,33 @@ class FusedAR:
             kern, rev = self.static
             # (a static-shape kernel that stages rows through LDS needs them 16-byte addressable; the generic kernel has an instantiation for the other case)
             if not kern.meta["XLDS"] or (y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0):
-                err = _C.lib().zk_ar_forward_static(
-                    kern.launcher, rev, p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
-                    _ptr(self.fine_stream), _ptr(self.bias), self.bias_floats, _ptr(self.featmap), p.n_layers, p.n_groups, p.fine_n_chunks, self.bound, self.slope, _stream(),
-                )
-                _C.check(err, "zk_ar_forward_static")
+                a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
+                            y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate), wstream=_ptr(self.fine_stream), bias=_ptr(self.bias),
+                            bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=p.fine_n_chunks, act=1,
+                            bound=self.bound, slope=self.slope)
+                _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
                 return
         if not self.generic_ok:
             raise RuntimeError("zuko_amd: this conditioner is wider than the generic fused kernel covers and has no static-shape kernel (FusedAR.ready() was not consulted)")
-        err = _C.lib().zk_ar_forward(
-            p.layout.kind, N, p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj), int(accumulate),
-            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, 0, _stream(),
-        )
-        _C.check(err, "zk_ar_forward")
+        a = self._generic_args(N=N, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0), y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate))
+        _C.check(_C.lib().zk_ar_forward(a, _stream()), "zk_ar_forward")
+
+    def _generic_args(self, **io):
+        """The argument block of the generic kernel's entry points (include/zuko_amd.h: zk_ar_args_v1): the plan's tables + `io`."""
+        from . import _C
+        from .ops import _ptr
+
+        p = self.plan
+        return _C.args("zk_ar_args_v1", uni_kind=p.layout.kind, D=p.features, wstream=_ptr(self.stream), bias=_ptr(self.bias), bias_floats=self.bias_floats, skip=_ptr(self.skip),
+                       featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=p.n_chunks, act=self.act, bound=self.bound, slope=self.slope, **io)
 
     def run_diag(self, inp: Tensor, y: Tensor, ladj: Tensor, bins: Tensor, knots: Tensor) -> None:
         """As run(), through the diagnostic twin of the kernel: also fills bins [N, D] int32 and knots [N, D, K+1]."""
         from . import _C
         from .ops import _ptr, _stream
 
-        p = self.plan
-        err = _C.lib().zk_ar_forward_diag(
-            p.layout.kind, inp.shape[0], p.features, inp.shape[1], _ptr(inp), inp.stride(0), _ptr(y), y.stride(0), _ptr(ladj),
-            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, _ptr(bins), _ptr(knots), _stream(),
-        )
+        a = self._generic_args(N=inp.shape[0], DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0), y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), bin_out=_ptr(bins), knots_out=_ptr(knots))
+        err = _C.lib().zk_ar_forward_diag(a, _stream())
         _C.check(err, "zk_ar_forward_diag")
 
     def run_inverse_sweep(self, buf: Tensor, y: Tensor) -> None:
@@ -535,12 +536,8 @@ class FusedAR:
         from . import _C
         from .ops import _ptr, _stream
 
-        p = self.plan
-        err = _C.lib().zk_ar_inverse_sweep(
-            p.layout.kind, buf.shape[0], p.features, buf.shape[1], _ptr(buf), buf.stride(0), _ptr(y), y.stride(0), _ptr(buf), buf.stride(0),
-            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, 0, _stream(),
-        )
+        a = self._generic_args(N=buf.shape[0], DIN=buf.shape[1], x=_ptr(buf), ldx=buf.stride(0), y_in=_ptr(y), ldy=y.stride(0), x_out=_ptr(buf), ldo=buf.stride(0))
+        err = _C.lib().zk_ar_inverse_sweep(a, _stream())
         _C.check(err, "zk_ar_inverse_sweep")
 
     # ---- partial (wavefront) inverse ---------------------------------------------------------------
@@ -580,11 +577,8 @@ class FusedAR:
         if entry is None:
             return
         off, n_sched, olim, g0, g1 = entry
-        p = self.plan
         sched_ptr = ctypes.c_void_p(self.sched_dev.data_ptr() + 4 * off)
-        err = _C.lib().zk_ar_inverse_partial(
-            p.layout.kind, buf.shape[0], p.features, buf.shape[1], _ptr(buf), buf.stride(0), _ptr(y), y.stride(0), _ptr(buf), buf.stride(0),
-            _ptr(self.stream), _ptr(self.bias), self.bias_floats, _ptr(self.skip), _ptr(self.featmap), p.n_layers, p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, sched_ptr, n_sched, olim, g0, g1, 0, _stream(),
-        )
+        a = self._generic_args(N=buf.shape[0], DIN=buf.shape[1], x=_ptr(buf), ldx=buf.stride(0), y_in=_ptr(y), ldy=y.stride(0), x_out=_ptr(buf), ldo=buf.stride(0),
+                               sched=sched_ptr, n_sched=n_sched, olim=olim, g0=g0, g1=g1)
+        err = _C.lib().zk_ar_inverse_partial(a, _stream())
         _C.check(err, "zk_ar_inverse_partial")

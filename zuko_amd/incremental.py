@@ -406,10 +406,10 @@ class IncAR:
         x = torch.empty((N, p.features), dtype=torch.float32, device=y.device)
         ladj = torch.empty(N, dtype=torch.float32, device=y.device) if want_ladj else None
         C = 0 if ctx is None else ctx.shape[1]
-        err = _C.lib().zk_ar_inverse_incremental(
-            p.layout.kind, p.n_hidden, N, p.features, C, _ptr(y), y.stride(0), _ptr(ctx), 0 if ctx is None else ctx.stride(0), _ptr(x), p.features,
-            _ptr(ladj), _ptr(self.stream), _ptr(self.bias), self.bias.numel(), self.bias_off, _ptr(self.featmap), _ptr(self.prog), p.n_groups, p.n_chunks,
-            self.act, self.bound, self.slope, _stream(),
-        )
+        a = _C.args("zk_ar_inc_args_v1", uni_kind=p.layout.kind, n_hidden=p.n_hidden, N=N, D=p.features, C=C, y=_ptr(y), ldy=y.stride(0), ctx=_ptr(ctx),
+                    ldc=0 if ctx is None else ctx.stride(0), x=_ptr(x), ldx=p.features, ladj=_ptr(ladj), wstream=_ptr(self.stream), bias=_ptr(self.bias),
+                    bias_floats=self.bias.numel(), bias_off=self.bias_off, featmap=_ptr(self.featmap), prog=_ptr(self.prog), n_groups=p.n_groups, n_chunks=p.n_chunks,
+                    act=self.act, bound=self.bound, slope=self.slope)
+        err = _C.lib().zk_ar_inverse_incremental(a, _stream())
         _C.check(err, "zk_ar_inverse_incremental")
         return x, ladj

@@ -64,6 +64,7 @@ class SortedPlan:
         self.idx_w, self.idx_wt, self.idx_b, self.kskip_f, self.kskip_b, self.pairs, self.mask_s, self.shapes = [], [], [], [], [], [], [], shapes
         self.mask_u8 = []
         self.cs_flag = []
+        self.cols_dev = []  # sorted column -> module column of every layer (idx_b holds the rows)
         prev = None
         for i, (out_f, in_f) in enumerate(shapes):
             rows = perms[i] if perms[i] is not None else torch.arange(out_f)
@@ -76,6 +77,7 @@ class SortedPlan:
             self.idx_w.append(idx.reshape(-1).contiguous().to(device))
             self.idx_wt.append(idx.t().reshape(-1).contiguous().to(device))
             self.idx_b.append(rows.to(torch.int32).to(device))
+            self.cols_dev.append(cols.to(torch.int32).to(device))
             kf, kb = (None, None) if m is None else (self._kskip(ms), self._kskip(ms.t().contiguous()))
             self.kskip_f.append(None if kf is None else kf.to(device))
             self.kskip_b.append(None if kb is None else kb.to(device))
@@ -97,7 +99,6 @@ class SortedPlan:
             self.mask_s.append(None if m is None else ms.to(torch.uint8).contiguous().to(device))
             self.mask_u8.append(None if m is None else m.detach().to(device=device, dtype=torch.uint8).contiguous())
             prev = perms[i]
-        self.idx_w64 = [t.long() for t in self.idx_w]
         self.idx_b64 = [t.long() for t in self.idx_b]
         self.kept = [float(k.shape[0]) / (-(-s[0] // 128) * -(-s[1] // 128)) for k, s in zip(self.pairs, shapes)]
 
@@ -154,8 +155,9 @@ class SortedPlan:
         return y
 
     def wgrad(self, l: int, g: Tensor, h: Tensor, want_bias: bool = False):
-        """Sorted-domain weight gradient dWs_l [out, in] (zeros where the mask is false).  want_bias: returns (dWs_l, dbs_l) with the
-        sorted-domain bias gradient from the same pass over g (None when some 128-row out block has no live weight block)."""
+        """Weight gradient dW_l [out, in] in the MODULE's unit order (zeros where the mask is false): computed on the sorted-domain
+        operands, written through the row / column permutations by the reduction kernel.  want_bias: returns (dW_l, dbs_l) with the
+        SORTED-domain bias gradient from the same pass over g (None when some 128-row out block has no live weight block)."""
         lib = _C.lib()
         out_f, in_f = self.shapes[l]
         N = g.shape[0]
@@ -168,10 +170,11 @@ class SortedPlan:
             cs_partial = torch.empty(max(1, ns) * (-(-out_f // 128) * 128), dtype=torch.float32, device=g.device)
             db = torch.zeros(out_f, dtype=torch.float32, device=g.device)  # (zeros: the kernel returns early on an empty batch, the reference yields zeros)
             err = lib.zk_wgrad_bias_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(self.mask_s[l]), _ptr(dw), 0,
-                                        _ptr(self.cs_flag[l]), _ptr(cs_partial), _ptr(db), _stream())
+                                        _ptr(self.cs_flag[l]), _ptr(cs_partial), _ptr(db), _ptr(self.idx_b[l]), _ptr(self.cols_dev[l]), _stream())
             _C.check(err, "zk_wgrad_bias_f32")
             return dw, db
-        err = lib.zk_wgrad_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(self.mask_s[l]), _ptr(dw), 0, _stream())
+        err = lib.zk_wgrad_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(self.mask_s[l]), _ptr(dw), 0,
+                               _ptr(self.idx_b[l]), _ptr(self.cols_dev[l]), _stream())
         _C.check(err, "zk_wgrad_f32")
         return (dw, None) if want_bias else dw
 
@@ -244,8 +247,10 @@ def _fused_forward(st, x: Tensor, out_features: int):
     phi = torch.empty((N, out_features), dtype=torch.float32, device=x.device)
     kern, rev = st.static
     hp = [_ptr(h) for h in hs] + [None] * (3 - len(hs))
-    err = _C.lib().zk_ar_forward_train(kern.launcher, rev, p.layout.kind, N, p.features, x.shape[1], _ptr(x), x.stride(0), hp[0], hp[1], hp[2], _ptr(phi), out_features,
-                                       _ptr(st.fine_stream), _ptr(st.bias), st.bias_floats, _ptr(st.featmap), p.n_layers, p.n_groups, p.fine_n_chunks, _stream())
+    a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
+                phi=_ptr(phi), ldphi=out_features, wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap), n_layers=p.n_layers,
+                n_groups=p.n_groups, n_chunks=p.fine_n_chunks, act=1)
+    err = _C.lib().zk_ar_forward_train(a, _stream())
     _C.check(err, "zk_ar_forward_train")
     return hs, phi
 
@@ -287,10 +292,8 @@ class ConditionerFn(torch.autograd.Function):
             want_b = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
             dbs = None
             if ctx.needs_input_grad[3 + 2 * l]:
-                dws, dbs = plan.wgrad(l, g, hs[l], want_bias=True) if want_b else (plan.wgrad(l, g, hs[l]), None)
-                dw = torch.empty(out_f * in_f, dtype=torch.float32, device=g.device)
-                dw[plan.idx_w64[l]] = dws.reshape(-1)  # scatter back to the module's unit order (a bijection)
-                grads[2 * l] = dw.reshape(out_f, in_f)
+                # (the reduction kernel writes dW where the module keeps it: no scatter back from the sorted order)
+                grads[2 * l], dbs = plan.wgrad(l, g, hs[l], want_bias=True) if want_b else (plan.wgrad(l, g, hs[l]), None)
             if want_b:
                 if dbs is None:
                     dbs = plan.colsum(g)
