@@ -31,6 +31,16 @@ typedef float f32x16_b __attribute__((ext_vector_type(16)));
 #define BBM 256
 #define BBN 256
 #define BBK 64
+// measured variants of the k loop / epilogue (scripts/cfg5_variants.sh builds and times each; the defaults are what won)
+#ifndef ZK_BF16_SPREAD
+#define ZK_BF16_SPREAD 0  /* 1: the eight DMAs of the next k-tile are issued two at a time between the MFMA blocks instead of all after the barrier */
+#endif
+#ifndef ZK_BF16_PRIO
+#define ZK_BF16_PRIO 0    /* 1: s_setprio 1 around every MFMA block */
+#endif
+#ifndef ZK_BF16_EPI3
+#define ZK_BF16_EPI3 0    /* 1: spline epilogue in chunks of 96 / 96 / 64 samples (three rounds of up to 480 elements) instead of 2 x 128 (four rounds) */
+#endif
 #define B_STAGE_BYTES (2 * 256 * 128)  /* A panel 256 rows x 128 B + B panel 256 rows x 128 B */
 
 struct LinBf16Args {
@@ -168,6 +178,13 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
       gB[i] = reinterpret_cast<const char*>(a.w + (int64_t)rb * a.IN) + c * 16;
     }
   };
+  auto issue_pair = [&](int kt, int stage, int i) {  // one quarter of a wave's share of a stage: 8 rows of the A panel, 8 of the B panel
+    unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wave * 32) * 128;
+    unsigned char* sB = sA + 256 * 128;
+    const int64_t koff = (int64_t)kt * (BBK * 2);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + koff), (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[i] + koff), (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
+  };
   auto issue = [&](int kt, int stage) {
     unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wave * 32) * 128;
     unsigned char* sB = sA + 256 * 128;
@@ -208,7 +225,9 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
       const int ktn = next_live(lmask, kt + 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMAs of this stage have landed (and my stores of the previous tile left)
       __syncthreads();                                   // everybody's have; the other stage / the epilogue image is free again
+#if !ZK_BF16_SPREAD
       if (ktn < KT) issue(ktn, stage ^ 1);
+#endif
       const unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wm * 128) * 128;
       const unsigned char* sB = lin_bf16_lds + stage * B_STAGE_BYTES + 256 * 128 + (wn * 64) * 128;
       // fragments of k16 step kk+1 are requested before the MFMAs of step kk (register double buffer)
@@ -229,11 +248,22 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         if (kk < 3) ZK_BF16_FRAGS((kk + 1) & 1, kk + 1);
+#if ZK_BF16_SPREAD
+        // a wave that issues a DMA issues nothing else for ~100 cycles: two at a time, in front of its own MFMA block, so that the
+        // partner wave of the SIMD has the matrix pipe meanwhile (all eight right after the barrier stall both waves at once)
+        if (ktn < KT) issue_pair(ktn, stage ^ 1, kk);
+#endif
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (the scheduler would sink it to its uses)
+#if ZK_BF16_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+#if ZK_BF16_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef ZK_BF16_FRAGS
@@ -282,6 +312,59 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
       constexpr int TOTAL = 3 * SK - 1, FP = 256 / TOTAL, ROUNDS = (FP + 3) / 4;
       unsigned char* simg = lin_bf16_lds + B_STAGE_BYTES;                       // [128 samples][S_ROWB]
       float* ljs = reinterpret_cast<float*>(lin_bf16_lds + B_STAGE_BYTES + 128 * S_ROWB);  // [FP][128]
+      if constexpr (ZK_BF16_EPI3 != 0 && FP * 96 <= 512) {
+      // chunks of 3 / 3 / 2 sample blocks of 32 (block b = wm * 4 + i): 480 / 480 / 320 (sample, feature) elements for 512 threads
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) {
+        const int b_lo = 3 * c, b_hi = c == 2 ? 8 : 3 * c + 3, ns = (b_hi - b_lo) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int blk = wm * 4 + i;
+          if (blk >= b_lo && blk < b_hi) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const u32x2_b bv = bias4[j][q];
+                const float b0 = __builtin_bit_cast(float, bv.x << 16), b1 = __builtin_bit_cast(float, bv.x & 0xffff0000u);
+                const float b2 = __builtin_bit_cast(float, bv.y << 16), b3 = __builtin_bit_cast(float, bv.y & 0xffff0000u);
+                const u32x2_b pk = {pack_bf16x2(acc[i][j][4 * q + 0] + b0, acc[i][j][4 * q + 1] + b1),
+                                    pack_bf16x2(acc[i][j][4 * q + 2] + b2, acc[i][j][4 * q + 3] + b3)};
+                *reinterpret_cast<u32x2_b*>(simg + ((blk - b_lo) * 32 + fr) * S_ROWB + (wn * 64 + j * 32 + q * 8 + kg * 4) * 2) = pk;
+              }
+          }
+        }
+        __syncthreads();
+        {
+          const int s_ = tid % 96 < ns ? tid % 96 : 0, fl = tid / 96;  // (ns = 96 or 64; 512 threads cover 5 features x 96 samples + 32 spare)
+          const bool on = fl < FP && (tid % 96) < ns;
+          const int feat = by_c * FP + fl;
+          const int64_t row = (int64_t)bx_c * BBM + b_lo * 32 + s_;
+          if (on) {
+            float lj = 0.f;
+            if (feat < a.D && row < a.N) {
+              float p[TOTAL];
+              const unsigned short* src = reinterpret_cast<const unsigned short*>(simg + s_ * S_ROWB + fl * TOTAL * 2);
+#pragma unroll
+              for (int t = 0; t < TOTAL; ++t) p[t] = __builtin_bit_cast(float, (unsigned)src[t] << 16);
+              const float xv = (float)a.sx[row * a.ldsx + feat];
+              float yv;
+              rqs_lean<SK, false>([&](int t) { return p[t]; }, [&](int t) { return p[SK + t]; }, [&](int t) { return p[2 * SK + t]; }, a.lc, xv, yv, lj);
+              a.sy[row * a.ldsy + feat] = (__bf16)yv;
+            }
+            ljs[fl * 128 + s_] = lj;
+          }
+        }
+        __syncthreads();
+        if (tid < ns) {
+          const int64_t row = (int64_t)bx_c * BBM + b_lo * 32 + tid;
+          float sum = 0.f;
+#pragma unroll
+          for (int fl = 0; fl < FP; ++fl) sum += ljs[fl * 128 + tid];
+          if (row < a.N) a.partial[(size_t)by_c * a.N + row] = sum;
+        }
+      }
+      } else {
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
         if (wm == h) {  // the four waves that hold samples [128 h, 128 h + 128) of the tile
@@ -329,6 +412,7 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
           for (int fl = 0; fl < FP; ++fl) sum += ljs[fl * 128 + tid];
           if (row < a.N) a.partial[(size_t)by_c * a.N + row] = sum;
         }
+      }
       }
     } else
     if (!(a.dbg & 2))
