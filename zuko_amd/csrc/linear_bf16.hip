@@ -33,7 +33,23 @@ typedef float f32x16_b __attribute__((ext_vector_type(16)));
 #define BBK 64
 // measured variants of the k loop / epilogue (scripts/cfg5_variants.sh builds and times each; the defaults are what won)
 #ifndef ZK_BF16_SPREAD
-#define ZK_BF16_SPREAD 0  /* 1: the eight DMAs of the next k-tile are issued two at a time between the MFMA blocks instead of all after the barrier */
+#define ZK_BF16_SPREAD 1  /* 1: the eight DMAs of the next k-tile are issued two at a time between the MFMA blocks instead of all after the barrier
+                             (measured at cfg5's last layer, N = 2^19: 38.9 -> 35.6 ms; hidden layers 1.03 -> 0.95 ms) */
+#endif
+#ifndef ZK_BF16_XPRE
+#define ZK_BF16_XPRE 0    /* 1: the x values of a thread's (sample, feature) elements are requested before the epilogue's first image write, not inside each round */
+#endif
+#ifndef ZK_BF16_ABLATE
+#define ZK_BF16_ABLATE 0  /* probe builds only (WRONG results; scripts/cfg5_variants.sh): 1 = no spline epilogue, 2 = epilogue without the spline arithmetic,
+                             3 = k loop without MFMAs, 4 = k loop without the stage DMAs, 5 = epilogue without the x loads / y stores, 6 = epilogue without
+                             the image writes — what each part costs a tile */
+#endif
+#ifndef ZK_BF16_DMA1
+#define ZK_BF16_DMA1 0    /* (with ZK_BF16_ROT) 1: one DMA in front of every MFMA block and one in its middle, instead of two in front */
+#endif
+#ifndef ZK_BF16_ROT
+#define ZK_BF16_ROT 0     /* 1: rotated k loop — fragment reads from inline assembly with counted lgkmcnt waits, and the last MFMA block of k-tile t
+                             issued AFTER the barrier of k-tile t + 1, behind that tile's first fragment reads (covers their latency) */
 #endif
 #ifndef ZK_BF16_PRIO
 #define ZK_BF16_PRIO 0    /* 1: s_setprio 1 around every MFMA block */
@@ -185,6 +201,12 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + koff), (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[i] + koff), (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
   };
+  auto issue_one = [&](int kt, int stage, int i, int which) {  // which = 0: 8 rows of the A panel, 1: of the B panel
+    unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wave * 32) * 128;
+    const int64_t koff = (int64_t)kt * (BBK * 2);
+    if (which == 0) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + koff), (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[i] + koff), (__attribute__((address_space(3))) void*)(sA + 256 * 128 + i * 1024), 16, 0, 0);
+  };
   auto issue = [&](int kt, int stage) {
     unsigned char* sA = lin_bf16_lds + stage * B_STAGE_BYTES + (wave * 32) * 128;
     unsigned char* sB = sA + 256 * 128;
@@ -219,6 +241,95 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#if ZK_BF16_ROT
+    // ---- k loop, rotated: two LDS stages, one barrier per live k-tile --------------------------------------------------------
+    // Per k-tile a wave reads 4 x 6 fragments (ds_read_b128) and issues 4 x 8 MFMAs.  The reads are issued from inline assembly and
+    // return RAW registers (the compiler does not know they are LDS operations and inserts no wait; with LDS-DMAs in flight every
+    // wait it inserts itself is lgkmcnt(0), which serialises the prefetched fragments with the MFMAs that should cover them); a
+    // block becomes usable through frag_settle<N>() = s_waitcnt lgkmcnt(N), N = the younger reads allowed to stay in flight (LDS
+    // operations of a wave complete in order).  The loop is rotated by one block: MFMA block 3 of k-tile t is issued after the
+    // barrier of k-tile t + 1, right behind that tile's first six reads, whose latency it covers.
+    int stage = 0;
+    bf16x8 fa[2][4], fb[2][2];
+    bool pending = false;  // MFMA block 3 of the previous k-tile (operands in buffer 1) not issued yet
+    const unsigned lane_row = (unsigned)fr * 128u, swz = (unsigned)((fr >> 1) & 7);
+    unsigned offA[4], offB[4];  // LDS byte address of this lane's fragment chunk for kk = 0..3 (stage 0); rows i * 32 ride the immediate offset
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const unsigned ch = (((unsigned)(kk * 2 + kg)) ^ swz) << 4;
+      const unsigned base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)lin_bf16_lds);
+      offA[kk] = base + (unsigned)(wm * 128) * 128u + lane_row + ch;
+      offB[kk] = base + 256u * 128u + (unsigned)(wn * 64) * 128u + lane_row + ch;
+    }
+#define ZK_RD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define ZK_FRAGS_RAW(buf, kk)                                                     \
+  {                                                                               \
+    const unsigned a_ = offA[kk] + (unsigned)stage * B_STAGE_BYTES, b_ = offB[kk] + (unsigned)stage * B_STAGE_BYTES; \
+    ZK_RD(fa[buf][0], a_, 0); ZK_RD(fa[buf][1], a_, 4096); ZK_RD(fa[buf][2], a_, 8192); ZK_RD(fa[buf][3], a_, 12288); \
+    ZK_RD(fb[buf][0], b_, 0); ZK_RD(fb[buf][1], b_, 4096);                        \
+  }
+#define ZK_SETTLE(buf, n)                                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[buf][0]), "+v"(fa[buf][1]), "+v"(fa[buf][2]), "+v"(fa[buf][3]), "+v"(fb[buf][0]), "+v"(fb[buf][1]) : "n"(n)); \
+  __builtin_amdgcn_sched_barrier(0)
+#define ZK_MFMA_BLOCK(buf)                                                                                                        \
+  {                                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+  }
+#if ZK_BF16_DMA1
+#define ZK_DMA_FRONT(q) if (ktn < KT) issue_one(ktn, stage ^ 1, q, 0)
+#define ZK_MFMA_BLOCK_Q(buf, q)                                                                                                   \
+  {                                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    if (ktn < KT) issue_one(ktn, stage ^ 1, q, 1);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    _Pragma("unroll") for (int i = 2; i < 4; ++i)                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+  }
+#else
+#define ZK_DMA_FRONT(q) if (ktn < KT) issue_pair(ktn, stage ^ 1, q)
+#define ZK_MFMA_BLOCK_Q(buf, q) ZK_MFMA_BLOCK(buf)
+#endif
+    while (kt < KT) {
+      const int ktn = next_live(lmask, kt + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMAs of this stage have landed (and my stores of the previous tile left)
+      __syncthreads();                                   // everybody's have; the other stage / the epilogue image is free again
+      ZK_FRAGS_RAW(0, 0);
+      ZK_DMA_FRONT(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (pending) { ZK_MFMA_BLOCK_Q(1, 0); }            // block 3 of the previous k-tile (settled before the barrier) covers the reads above
+#if ZK_BF16_DMA1
+      else if (ktn < KT) issue_one(ktn, stage ^ 1, 0, 1);
+#endif
+      ZK_FRAGS_RAW(1, 1);
+      ZK_DMA_FRONT(1);
+      ZK_SETTLE(0, 6);
+      ZK_MFMA_BLOCK_Q(0, 1);
+      ZK_FRAGS_RAW(0, 2);
+      ZK_DMA_FRONT(2);
+      ZK_SETTLE(1, 6);
+      ZK_MFMA_BLOCK_Q(1, 2);
+      ZK_FRAGS_RAW(1, 3);
+      ZK_DMA_FRONT(3);
+      ZK_SETTLE(0, 6);
+      ZK_MFMA_BLOCK_Q(0, 3);
+      ZK_SETTLE(1, 0);                                   // block 3's operands are in registers: the stage may be overwritten after the next barrier
+      pending = true;
+      stage ^= 1;
+      kt = ktn;
+    }
+    if (pending) ZK_MFMA_BLOCK(1);
+#undef ZK_DMA_FRONT
+#undef ZK_MFMA_BLOCK_Q
+#undef ZK_RD
+#undef ZK_FRAGS_RAW
+#undef ZK_SETTLE
+#undef ZK_MFMA_BLOCK
+#else
     // ---- k loop: two LDS stages, one barrier per live k-tile ---------------------------------------
     int stage = 0;
     while (kt < KT) {
@@ -251,16 +362,23 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
 #if ZK_BF16_SPREAD
         // a wave that issues a DMA issues nothing else for ~100 cycles: two at a time, in front of its own MFMA block, so that the
         // partner wave of the SIMD has the matrix pipe meanwhile (all eight right after the barrier stall both waves at once)
-        if (ktn < KT) issue_pair(ktn, stage ^ 1, kk);
+        if (ZK_BF16_ABLATE != 4 && ktn < KT) issue_pair(ktn, stage ^ 1, kk);
 #endif
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (the scheduler would sink it to its uses)
 #if ZK_BF16_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
+#if ZK_BF16_ABLATE == 3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[kk & 1][i]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[kk & 1][j]));
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+#endif
 #if ZK_BF16_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -271,6 +389,7 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
       kt = ktn;
     }
 
+#endif
     // ---- hand-over: the next tile's first stage goes out before this tile's epilogue ----------------
     __syncthreads();  // every wave is done reading the stage buffers
     const int bx_c = bx, by_c = by;
@@ -308,6 +427,12 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
     const int col_w = by_c * BBN + wn * 64;
     const bool vec_ok = (a.ldy % 8 == 0) && ((((uintptr_t)a.y) & 15) == 0);
     const bool relu = a.act == 1;
+    if constexpr (SK > 0 && ZK_BF16_ABLATE == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else
     if constexpr (SK > 0) {
       constexpr int TOTAL = 3 * SK - 1, FP = 256 / TOTAL, ROUNDS = (FP + 3) / 4;
       unsigned char* simg = lin_bf16_lds + B_STAGE_BYTES;                       // [128 samples][S_ROWB]
@@ -365,8 +490,26 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
         }
       }
       } else {
+#if ZK_BF16_XPRE
+      // x of every element this thread will evaluate (2 halves x ROUNDS rounds): scattered 2-byte loads whose latency would otherwise sit
+      // inside each round with two waves per SIMD to cover it — requested here, they land during the image writes
+      float xp[2 * ROUNDS];
+#pragma unroll
+      for (int k = 0; k < 2 * ROUNDS; ++k) {
+        const int id = tid + 512 * (k % ROUNDS);
+        const int s_ = id & 127, fl = id >> 7, feat = by_c * FP + fl;
+        const int64_t row = (int64_t)bx_c * BBM + (k / ROUNDS) * 128 + s_;
+        xp[k] = (fl < FP && feat < a.D && row < a.N) ? (float)a.sx[row * a.ldsx + feat] : 0.f;
+      }
+#endif
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
+        if (ZK_BF16_ABLATE == 6) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else
         if (wm == h) {  // the four waves that hold samples [128 h, 128 h + 128) of the tile
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -396,10 +539,28 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
               const unsigned short* src = reinterpret_cast<const unsigned short*>(simg + s_ * S_ROWB + fl * TOTAL * 2);
 #pragma unroll
               for (int t = 0; t < TOTAL; ++t) p[t] = __builtin_bit_cast(float, (unsigned)src[t] << 16);
+#if ZK_BF16_XPRE
+              float xv = 0.f;
+#pragma unroll
+              for (int k = 0; k < 2 * ROUNDS; ++k) xv = (k == h * ROUNDS + rd) ? xp[k] : xv;
+#elif ZK_BF16_ABLATE == 5
+              const float xv = 0.25f;
+#else
               const float xv = (float)a.sx[row * a.ldsx + feat];
+#endif
               float yv;
+#if ZK_BF16_ABLATE == 2
+              yv = xv; lj = 0.f;
+#pragma unroll
+              for (int t = 0; t < TOTAL; ++t) { yv += p[t]; lj += p[t] * 0.5f; }
+#else
               rqs_lean<SK, false>([&](int t) { return p[t]; }, [&](int t) { return p[SK + t]; }, [&](int t) { return p[2 * SK + t]; }, a.lc, xv, yv, lj);
+#endif
+#if ZK_BF16_ABLATE == 5
+              lj += yv;
+#else
               a.sy[row * a.ldsy + feat] = (__bf16)yv;
+#endif
             }
             ljs[fl * 128 + s_] = lj;
           }
