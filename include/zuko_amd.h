@@ -102,9 +102,9 @@ int zk_sos_inverse(int dtype, int64_t N, int64_t D, int P, int L1, double slope,
  * theta is the UNCONSTRAINED [N, D, M]; NC = M + 2 (unbounded) or M + 5 (bounded) constrained coefficients.  NC in
  * {6, 8, 10, 13, 14, 18, 21, 22, 34, 37} run register-resident de Casteljau instantiations, any other NC <= 72 a
  * generic (slower) kernel with the same arithmetic; larger NC returns hipErrorInvalidValue. */
-int zk_bernstein_forward(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, const void* x,
+int zk_bernstein_forward(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, double eps, const void* x,
                          const void* theta, int64_t t_sN, int64_t t_sD, void* y, void* ladj, int ladj_reduced, void* stream);
-int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, int n_bisect, const void* y,
+int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, double eps, int n_bisect, const void* y,
                          const void* theta, int64_t t_sN, int64_t t_sD, void* x, void* stream);
 
 /* ---- conditioner layer: F.linear(x, mask * weight, bias) + activation (zuko/nn.py:217-218, 13-15) - *
@@ -352,7 +352,7 @@ int zk_univariate_backward(int kind, int64_t N, int64_t D, int K, double bound, 
 int zk_sos_backward(int64_t N, int64_t D, int P, int L1, double slope, const double* gl_nodes01, const double* gl_weights01,
                     int has_const, const void* x, const void* params, const void* gy, const void* gl, int gl_reduced, void* gx,
                     void* gparams, void* stream);
-int zk_bernstein_backward(int64_t N, int64_t D, int M, int bounded, double bound, const void* x, const void* theta, const void* gy,
+int zk_bernstein_backward(int64_t N, int64_t D, int M, int bounded, double bound, double eps, const void* x, const void* theta, const void* gy,
                           const void* gl, int gl_reduced, void* gx, void* gtheta, void* stream);
 /* Adjoint seeds of an INVERSE univariate map x = f^{-1}(y) (gradients through rsample; inverse function theorem):
  * gy[e] = gx[e] * exp(-ladj[e]) with ladj = log f'(x), seed[e] = -gy[e] (zk_univariate_backward(x, phi, gy = seed) then

@@ -256,7 +256,8 @@ def _bern_poly(u: Tensor, theta: Tensor, basis) -> Tensor:
     return torch.mean(basis.log_prob(u.unsqueeze(-1)).exp() * theta, dim=-1)
 
 
-def _bern_tails(theta: Tensor, bounded: bool, bound: float):
+def _bern_tails(theta: Tensor, bounded: bool, bound: float, eps: float = None):
+    eps = BERN_EPS if eps is None else eps
     """Offsets/slopes used for the linear extrapolation. transforms.py:685-701 / :820-831."""
     if bounded:
         off = (theta.new_tensor(-bound), theta.new_tensor(bound))
@@ -266,23 +267,24 @@ def _bern_tails(theta: Tensor, bounded: bool, bound: float):
     dtheta = order * (theta[..., 1:] - theta[..., :-1])
     basis = _bern_basis(order, theta.dtype, theta.device)
     dbasis = _bern_basis(order - 1, theta.dtype, theta.device)
-    ends = [theta.new_tensor(BERN_EPS), theta.new_tensor(1 - BERN_EPS)]
+    ends = [theta.new_tensor(eps), theta.new_tensor(1 - eps)]
     off = tuple(_bern_poly(e, theta, basis) for e in ends)
     slp = tuple(_bern_poly(e, dtheta, dbasis) for e in ends)
     return off, slp
 
 
-def bern_f(theta: Tensor, x: Tensor, bounded: bool, bound: float = 5.0) -> Tensor:
-    """Polynomial inside (eps, 1-eps), straight lines outside. transforms.py:742-760."""
+def bern_f(theta: Tensor, x: Tensor, bounded: bool, bound: float = 5.0, eps: float = None) -> Tensor:
+    """Polynomial inside (eps, 1-eps), straight lines outside. transforms.py:742-760 (eps: MonotonicTransform's kwarg, :594)."""
+    eps = BERN_EPS if eps is None else eps
     basis = _bern_basis(theta.shape[-1] - 1, theta.dtype, theta.device)
-    off, slp = _bern_tails(theta, bounded, bound)
+    off, slp = _bern_tails(theta, bounded, bound, eps)
     u = (x + bound) / (2 * bound)
-    lo = u <= BERN_EPS
-    hi = u >= 1 - BERN_EPS
+    lo = u <= eps
+    hi = u >= 1 - eps
     safe = torch.where(lo | hi, 0.5 * torch.ones_like(u), u)
     y = _bern_poly(safe, theta, basis)
-    y_lo = slp[0] * (u - BERN_EPS) + off[0]
-    y_hi = slp[1] * (u - 1 + BERN_EPS) + off[1]
+    y_lo = slp[0] * (u - eps) + off[0]
+    y_hi = slp[1] * (u - 1 + eps) + off[1]
     y = torch.where(lo, y_lo, y)
     return torch.where(hi, y_hi, y)
 
@@ -291,24 +293,25 @@ def bern_constrain(theta_unc: Tensor, bounded: bool, bound: float = 5.0) -> Tens
     return bern_theta_bounded(theta_unc, bound) if bounded else bern_theta_unbounded(theta_unc)
 
 
-def bern_forward(theta_unc: Tensor, x: Tensor, bounded: bool, bound: float = 5.0):
+def bern_forward(theta_unc: Tensor, x: Tensor, bounded: bool, bound: float = 5.0, eps: float = None):
     """(y, ladj); ladj is log of the autograd derivative, as transforms.py:623-637 does."""
     theta = bern_constrain(theta_unc.detach(), bounded, bound)
     with torch.enable_grad():
         xr = x.detach().clone().requires_grad_()
-        y = bern_f(theta, xr, bounded, bound)
+        y = bern_f(theta, xr, bounded, bound, eps)
         (jac,) = torch.autograd.grad(y, xr, torch.ones_like(y))
     return y.detach(), jac.log()
 
 
-def bern_inverse(theta_unc: Tensor, y: Tensor, bounded: bool, bound: float = 5.0) -> Tensor:
-    """24-step bisection on [-B, B] + closed-form tails. transforms.py:762-777, :609-617."""
+def bern_inverse(theta_unc: Tensor, y: Tensor, bounded: bool, bound: float = 5.0, eps: float = None) -> Tensor:
+    """ceil(log2(2B / eps))-step (24 at the defaults) bisection on [-B, B] + closed-form tails. transforms.py:762-777, :609-617."""
+    eps = BERN_EPS if eps is None else eps
     theta = bern_constrain(theta_unc, bounded, bound)
-    off, slp = _bern_tails(theta, bounded, bound)
-    n = math.ceil(math.log2(2 * bound / BERN_EPS))
-    x = bisect(lambda t: bern_f(theta, t, bounded, bound), y, -bound, bound, n)
-    x_lo = ((y - off[0]) / slp[0] + BERN_EPS) * 2 * bound - bound
-    x_hi = ((y - off[1]) / slp[1] - BERN_EPS + 1) * 2 * bound - bound
+    off, slp = _bern_tails(theta, bounded, bound, eps)
+    n = math.ceil(math.log2(2 * bound / eps))
+    x = bisect(lambda t: bern_f(theta, t, bounded, bound, eps), y, -bound, bound, n)
+    x_lo = ((y - off[0]) / slp[0] + eps) * 2 * bound - bound
+    x_hi = ((y - off[1]) / slp[1] - eps + 1) * 2 * bound - bound
     x = torch.where(y <= off[0], x_lo, x)
     return torch.where(y >= off[1], x_hi, x)
 

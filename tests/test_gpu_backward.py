@@ -229,3 +229,40 @@ def test_rqs_backward_any_bin_count(dev, K):
     for mine, ref, what in zip(leaves2 + [yv], l64b + [yv64], ("widths", "heights", "derivatives", "y")):
         err = ((mine.grad.cpu().double() - ref.grad).abs().max() / ref.grad.abs().max()).item()
         assert err < 1e-3, f"K={K} inverse grad {what}: {err:.2e}"
+
+
+def test_bf16_module_trains(dev):
+    """`flow.to(torch.bfloat16)` under autograd (the reference trains in whatever dtype the module is in, zuko tests/test_flows.py:17-29):
+    the adjoint kernels are float32, so the bf16 module runs them on float32 copies of its operands and receives bf16 gradients through
+    the casts.  Every parameter gets a finite gradient that points the way the float32 module's does, and an Adam step lowers the loss."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(2)
+    f32 = F.NSF(8, 3, transforms=2, bins=8, hidden_features=[64, 64]).to(dev)
+    bf = F.NSF(8, 3, transforms=2, bins=8, hidden_features=[64, 64])
+    bf.load_state_dict(f32.state_dict())
+    bf = bf.to(dev).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(1)
+    x, c = (torch.randn(512, 8, generator=g) * 0.8).to(dev), torch.randn(512, 3, generator=g).to(dev)
+    (-f32(c).log_prob(x).mean()).backward()
+    loss = -bf(c.to(torch.bfloat16)).log_prob(x.to(torch.bfloat16)).mean()
+    loss.backward()
+    cos = []
+    for (k, p32), (_, pb) in zip(f32.named_parameters(), bf.named_parameters()):
+        assert pb.grad is not None and pb.grad.dtype == torch.bfloat16 and torch.isfinite(pb.grad).all(), k
+        a, b = p32.grad.flatten().double(), pb.grad.flatten().double()
+        if a.norm() > 0:
+            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm().clamp_min(1e-30))), k))
+    assert min(cos)[0] > 0.9, f"bf16 gradients disagree with the float32 module's: {sorted(cos)[:3]}"
+    opt = torch.optim.SGD(bf.parameters(), lr=5e-2)
+    l0 = loss.item()
+    for _ in range(5):
+        opt.step()
+        opt.zero_grad()
+        loss = -bf(c.to(torch.bfloat16)).log_prob(x.to(torch.bfloat16)).mean()
+        loss.backward()
+    assert loss.item() < l0, (l0, loss.item())
+    # rsample through the bf16 module is differentiable too (zuko tests/test_flows.py:46-54)
+    bf.zero_grad()
+    bf(c[:8].to(torch.bfloat16)).rsample().float().square().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in bf.parameters())

@@ -243,6 +243,34 @@ def test_bernstein_golden(dev, tag, name):
         assert_f64(xi, g["x_inv"], f"{name} golden f64: inverse (24-step bisection: interval 10 / 2^24)", 10.0 / 2**24)
 
 
+@pytest.mark.parametrize("bounded", [False, True])
+@pytest.mark.parametrize("eps", [1e-3, 2e-2])
+def test_bernstein_eps_is_a_run_time_argument(dev, bounded, eps):
+    """`eps` (MonotonicTransform's kwarg, zuko/transforms.py:594: continuation margin + bisection depth) away from its default: forward,
+    ladj and inverse in float64 against the oracle (whose eps argument is pinned to the live reference in tests/test_integration_option2.py),
+    with inputs inside the widened margins and beyond the bound; float32 against the measured bar."""
+    import zuko_amd.transforms as ZT
+
+    g = torch.Generator().manual_seed(7)
+    theta = torch.randn(64, 3, 17 if bounded else 16, generator=g, dtype=torch.float64)
+    x = torch.randn(64, 3, generator=g, dtype=torch.float64) * 3.5
+    x[0, 0], x[0, 1], x[1, 0], x[1, 1] = 4.99, -4.995, 5.2, -5.5
+    cls = ZT.BoundedBernsteinTransform if bounded else ZT.BernsteinTransform
+    oy, ol = O.bern_forward(theta, x, bounded, eps=eps)
+    ox = O.bern_inverse(theta, oy, bounded, eps=eps)
+    with torch.no_grad():
+        t = cls(theta.to(dev), eps=eps)
+        y, ladj = t.call_and_ladj(x.to(dev))
+        assert_f64(y, oy, f"bernstein eps={eps} bounded={bounded} f64: y")
+        assert_f64(ladj, ol, f"bernstein eps={eps} bounded={bounded} f64: ladj")
+        assert_f64(t.inv(oy.to(dev)), ox, f"bernstein eps={eps} bounded={bounded} f64: inverse", 10.0 / 2 ** (np.ceil(np.log2(10.0 / eps)) - 1))
+        t32 = cls(theta.float().to(dev), eps=eps)
+        y32, l32 = t32.call_and_ladj(x.float().to(dev))
+        ry, rl = O.bern_forward(theta.float(), x.float(), bounded, eps=eps)
+        assert_parity(y32, ry, oy, f"bernstein eps={eps} bounded={bounded} f32: y")
+        assert_parity(l32, rl, ol, f"bernstein eps={eps} bounded={bounded} f32: ladj")
+
+
 def test_normal_log_prob_and_sum(dev):
     from zuko_amd import ops
 

@@ -62,3 +62,24 @@ def test_real_zuko_coupling_with_hip_affine(zuko):
     t = zuko.flows.GeneralCouplingTransform(6, 0, univariate=ZT.MonotonicAffineTransform, shapes=[(), ()], hidden_features=[16])
     assert "MonotonicAffineTransform" in repr(t)
     assert type(t()).__name__ == "CouplingTransform"
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+def test_oracle_bernstein_follows_the_reference_for_any_eps(zuko, bounded):
+    """`eps` is a constructor kwarg of the reference's Bernstein transforms (MonotonicTransform, zuko/transforms.py:594): it moves the
+    linear-continuation margin and sets the bisection depth.  The oracle's eps argument (what the GPU test of the kernels' run-time eps
+    is checked against) must follow the live reference bit for bit, in float64, also away from the default."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import zuko_oracle as O
+
+    g = torch.Generator().manual_seed(3)
+    theta = torch.randn(40, 3, 17 if bounded else 16, generator=g, dtype=torch.float64)
+    x = torch.randn(40, 3, generator=g, dtype=torch.float64) * 3.5
+    x[0, 0], x[0, 1], x[1, 0] = 4.99, -4.995, 5.2  # inside the widened margins / beyond the bound
+    cls = zuko.transforms.BoundedBernsteinTransform if bounded else zuko.transforms.BernsteinTransform
+    for eps in (1e-6, 1e-3, 2e-2):
+        t = cls(theta, eps=eps)
+        y, ladj = t.call_and_ladj(x)
+        oy, ol = O.bern_forward(theta, x, bounded, eps=eps)
+        assert torch.equal(y, oy) and torch.equal(ladj, ol), eps
+        assert torch.equal(t.inv(y), O.bern_inverse(theta, y, bounded, eps=eps)), eps

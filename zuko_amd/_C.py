@@ -86,8 +86,8 @@ SIGNATURES = {
     "zk_affine_inverse": [I, L, L, F, P, P, L, L, P, L, L, P, P],
     "zk_sos_forward": [I, L, L, I, I, F, POINTER(c_double), POINTER(c_double), P, P, L, L, P, L, L, P, P, I, P],
     "zk_sos_inverse": [I, L, L, I, I, F, POINTER(c_double), POINTER(c_double), I, P, P, L, L, P, L, L, P, P],
-    "zk_bernstein_forward": [I, L, L, I, I, F, P, P, L, L, P, P, I, P],
-    "zk_bernstein_inverse": [I, L, L, I, I, F, I, P, P, L, L, P, P],
+    "zk_bernstein_forward": [I, L, L, I, I, F, F, P, P, L, L, P, P, I, P],
+    "zk_bernstein_inverse": [I, L, L, I, I, F, F, I, P, P, L, L, P, P],
     "zk_linear": [I, L, I, I, P, L, P, P, P, I, P, L, P],
     "zk_linear_bf16": [L, I, I, P, L, P, P, P, I, P, L, P],
     "zk_linear_bf16_rqs": [L, I, I, P, L, P, P, P, I, I, F, F, P, L, P, L, P, P, P],
@@ -99,7 +99,7 @@ SIGNATURES = {
     "zk_act_backward": [L, P, P, I, P, P],
     "zk_inverse_seed": [L, P, P, P, P, P],
     "zk_sos_backward": [L, L, I, I, F, POINTER(c_double), POINTER(c_double), I, P, P, P, P, I, P, P, P],
-    "zk_bernstein_backward": [L, L, I, I, F, P, P, P, P, I, P, P, P],
+    "zk_bernstein_backward": [L, L, I, I, F, F, P, P, P, P, I, P, P, P],
     "zk_gemm_f32_skip": [L, I, I, P, L, P, P, P, I, P, L, I, P, L, P],
     "zk_wgrad_slices": [L, I],
     "zk_wgrad_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P, P, P],

@@ -93,7 +93,7 @@ def _fwd_any(meta, xe, phi, reduce):
             return ops.rqs_forward(xe, pc[0], pc[1], pc[2], bound, slope, reduce)
         if kind == 2:
             return ops.sos_forward(xe, pc[0], pc[1] if extra[2] else None, slope, reduce)
-        return ops.bernstein_forward(xe, pc[0], extra[0], bound, reduce)
+        return ops.bernstein_forward(xe, pc[0], extra[0], bound, reduce, eps=extra[1] if len(extra) > 1 else ops.BERN_EPS)
 
 
 def _inv_any(meta, ye, phi):
@@ -108,7 +108,7 @@ def _inv_any(meta, ye, phi):
             return ops.rqs_inverse(ye, pc[0], pc[1], pc[2], bound, slope)
         if kind == 2:
             return ops.sos_inverse(ye, pc[0], pc[1] if extra[2] else None, slope)
-        return ops.bernstein_inverse(ye, pc[0], extra[0], bound)
+        return ops.bernstein_inverse(ye, pc[0], extra[0], bound, eps=extra[1] if len(extra) > 1 else ops.BERN_EPS)
 
 
 def _adj_any(meta, xe, phi, gy, gl, reduce):
@@ -133,7 +133,10 @@ def _adj_any(meta, xe, phi, gy, gl, reduce):
         _C.check(err, "zk_sos_backward")
     else:
         M = sizes[0]
-        err = lib.zk_bernstein_backward(N, D, M, int(extra[0]), bound, _ptr(xe), _ptr(phi), _ptr(gy), _ptr(gl), int(reduce), _ptr(gx), _ptr(gphi), _stream())
+        from .ops import BERN_EPS
+
+        err = lib.zk_bernstein_backward(N, D, M, int(extra[0]), bound, float(extra[1]) if len(extra) > 1 else BERN_EPS, _ptr(xe), _ptr(phi), _ptr(gy), _ptr(gl), int(reduce),
+                                        _ptr(gx), _ptr(gphi), _stream())
         if err == 1:
             raise NotImplementedError("zuko_amd: the Bernstein adjoint kernel is built for the BPF defaults (bounded with 17 / unbounded with 16 unconstrained coefficients)")
         _C.check(err, "zk_bernstein_backward")
@@ -196,9 +199,9 @@ class BernsteinFn(torch.autograd.Function):
     """(y, ladj) of the (bounded) Bernstein polynomial (kind 3; `bounded` travels in meta.extra)."""
 
     @staticmethod
-    def forward(ctx, bounded: bool, bound: float, reduce: bool, x: Tensor, theta: Tensor):
+    def forward(ctx, bounded, bound: float, reduce: bool, x: Tensor, theta: Tensor):
         _require_f32(x, theta)
-        meta, parts = _meta_of(3, bound, 0.0, [theta], (bounded,))
+        meta, parts = _meta_of(3, bound, 0.0, [theta], tuple(bounded) if isinstance(bounded, tuple) else (bounded,))  # (bounded[, eps])
         batch = torch.broadcast_shapes(x.shape, theta.shape[:-1])
         xe = x.expand(batch).contiguous()
         phi = _packed([theta.detach()], batch)

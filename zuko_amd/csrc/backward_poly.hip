@@ -71,7 +71,7 @@ struct PolyBwdArgs {
   float* gx;           // [N, D]
   float* gp;           // [N, D, total]
   int total;
-  float bound, slope;
+  float bound, slope, eps;
   int P, L1, has_const, bounded;
   double node[ZK_SOS_MAX_NODES], weight[ZK_SOS_MAX_NODES];
 };
@@ -110,9 +110,10 @@ template <int NC, int M, bool BOUNDED> __global__ __launch_bounds__(64) void ber
     const T bound = T(a.bound);
     if (BOUNDED) bern_theta_bounded<T, NC>(ld, bound, th);
     else bern_theta_unbounded<T, NC>(ld, th);
-    const BernTails<T> tails = bern_tails<T, NC>(th, BOUNDED, bound);
+    const T eps = T(a.eps);
+    const BernTails<T> tails = bern_tails<T, NC>(th, BOUNDED, bound, eps);
     T y, dydx;
-    bern_fwd<T, NC>(th, tails, bound, T::var(a.x[e], 0), y, dydx);
+    bern_fwd<T, NC>(th, tails, bound, T::var(a.x[e], 0), y, dydx, eps);
     const T l = t_log<T>(dydx);
     const float gyv = a.gy ? a.gy[e] : 0.f;
     const float glv = a.gl ? (a.gl_reduced ? a.gl[e / a.D] : a.gl[e]) : 0.f;
@@ -145,12 +146,13 @@ int zk_sos_backward(int64_t N, int64_t D, int P, int L1, double slope, const dou
 
 // Bernstein adjoint (fp32): theta [N, D, M] unconstrained; built for the BPF defaults — bounded with M = 17 (22 coefficients)
 // and unbounded with M = 16 (18 coefficients).
-int zk_bernstein_backward(int64_t N, int64_t D, int M, int bounded, double bound, const void* x, const void* theta, const void* gy, const void* gl,
+int zk_bernstein_backward(int64_t N, int64_t D, int M, int bounded, double bound, double eps, const void* x, const void* theta, const void* gy, const void* gl,
                           int gl_reduced, void* gx, void* gtheta, void* stream) {
   if (N <= 0 || D <= 0) return 0;
+  if (!(eps > 0.0 && eps < 0.5)) return ZK_EINVAL;
   PolyBwdArgs a{};
   a.N = N; a.D = D; a.x = (const float*)x; a.p = (const float*)theta; a.gy = (const float*)gy; a.gl = (const float*)gl; a.gl_reduced = gl_reduced;
-  a.gx = (float*)gx; a.gp = (float*)gtheta; a.total = M; a.bound = (float)bound; a.bounded = bounded;
+  a.gx = (float*)gx; a.gp = (float*)gtheta; a.total = M; a.bound = (float)bound; a.bounded = bounded; a.eps = (float)eps;
   const int64_t nb = (N * D + 63) / 64;
   const unsigned grid = (unsigned)(nb > 16384 ? 16384 : nb);
   if (bounded && M == 17) hipLaunchKernelGGL((bern_backward_kernel<22, 17, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, a);

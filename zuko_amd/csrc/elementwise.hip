@@ -43,6 +43,7 @@ struct UniArgs {
   double bound, ls;
   int n_bisect;
   int bounded;
+  double eps;      // Bernstein: width of the linear continuation's margin in [0, 1] coordinates (zuko/transforms.py:594)
   int K;           // runtime bin count for the generic RQS path
   const void* extra;  // optional additive constant [N, D] strides in seg[2] (shifted SOS)
   RqsLeanConst lc;    // fp32 spline constants (rqs_lean)
@@ -203,8 +204,7 @@ template <typename T, bool INV> struct BernGenericOp {
     dval = T(NC - 1) * (b[1] - b[0]);
     val = v * b[0] + u * b[1];
   }
-  static __device__ void fwd(const T* th, int NC, const BernTails<T>& t, T bound, T x, T& y, T& dydx) {
-    const T eps = T(ZK_BERN_EPS);
+  static __device__ void fwd(const T* th, int NC, const BernTails<T>& t, T bound, T x, T& y, T& dydx, T eps) {
     T u = (x + bound) / (T(2) * bound);
     bool lo = u <= eps;
     bool hi = u >= T(1) - eps;
@@ -222,7 +222,7 @@ template <typename T, bool INV> struct BernGenericOp {
   template <typename A> static __device__ void run(const A& a, const Ld<T> (&ld)[3], T in, T& out, T& ladj, int& k, int64_t e) {
     k = 0;
     const int NC = a.K;  // constrained coefficients
-    const T bound = T(a.bound);
+    const T bound = T(a.bound), eps = T(a.eps);
     T th[ZK_BERN_NCMAX];
     if (a.bounded) {  // bern_theta_bounded
       const int n = NC - 5;
@@ -253,14 +253,13 @@ template <typename T, bool INV> struct BernGenericOp {
     }
     BernTails<T> t;
     if (a.bounded) { t.off0 = -bound; t.off1 = bound; t.slp0 = T(2) * bound; t.slp1 = T(2) * bound; }
-    else { eval(th, NC, T(ZK_BERN_EPS), t.off0, t.slp0); eval(th, NC, T(1) - T(ZK_BERN_EPS), t.off1, t.slp1); }
+    else { eval(th, NC, eps, t.off0, t.slp0); eval(th, NC, T(1) - eps, t.off1, t.slp1); }
     if (INV) {
-      const T eps = T(ZK_BERN_EPS);
       T lo = -bound, hi = bound;
       for (int it = 0; it < a.n_bisect; ++it) {
         T mid = (lo + hi) / T(2);
         T fy, d;
-        fwd(th, NC, t, bound, mid, fy, d);
+        fwd(th, NC, t, bound, mid, fy, d, eps);
         bool below = fy < in;
         lo = below ? mid : lo;
         hi = below ? hi : mid;
@@ -274,7 +273,7 @@ template <typename T, bool INV> struct BernGenericOp {
       ladj = T(0);
     } else {
       T d;
-      fwd(th, NC, t, bound, in, out, d);
+      fwd(th, NC, t, bound, in, out, d, eps);
       ladj = t_log(d);
     }
   }
@@ -911,20 +910,22 @@ int zk_sos_inverse(int dtype, int64_t N, int64_t D, int P, int L1, double slope,
                      (launch_sos<double, true>(a, P, L1, slope, gl_nodes01, gl_weights01, constant != nullptr, st)));
 }
 
-int zk_bernstein_forward(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, const void* x, const void* theta, int64_t t_sN, int64_t t_sD,
+int zk_bernstein_forward(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, double eps, const void* x, const void* theta, int64_t t_sN, int64_t t_sD,
                          void* y, void* ladj, int ladj_reduced, void* stream) {
+  if (!(eps > 0.0 && eps < 0.5)) return ZK_EINVAL;
   UniArgs a = base_args(N, D, x, y, ladj, ladj_reduced, nullptr);
   a.seg[0] = {theta, t_sN, t_sD}; a.seg[1] = a.seg[0]; a.seg[2] = a.seg[0];
-  a.bound = bound; a.bounded = bounded;
+  a.bound = bound; a.bounded = bounded; a.eps = eps;
   hipStream_t st = (hipStream_t)stream;
   return ZK_DISPATCH(dtype, (launch_bern<float, false>(a, M, st)), (launch_bern<double, false>(a, M, st)));
 }
 
-int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, int n_bisect, const void* y, const void* theta, int64_t t_sN,
+int zk_bernstein_inverse(int dtype, int64_t N, int64_t D, int M, int bounded, double bound, double eps, int n_bisect, const void* y, const void* theta, int64_t t_sN,
                          int64_t t_sD, void* x, void* stream) {
+  if (!(eps > 0.0 && eps < 0.5)) return ZK_EINVAL;
   UniArgs a = base_args(N, D, y, x, nullptr, 0, nullptr);
   a.seg[0] = {theta, t_sN, t_sD}; a.seg[1] = a.seg[0]; a.seg[2] = a.seg[0];
-  a.bound = bound; a.bounded = bounded; a.n_bisect = n_bisect;
+  a.bound = bound; a.bounded = bounded; a.n_bisect = n_bisect; a.eps = eps;
   hipStream_t st = (hipStream_t)stream;
   return ZK_DISPATCH(dtype, (launch_bern<float, true>(a, M, st)), (launch_bern<double, true>(a, M, st)));
 }

@@ -407,7 +407,7 @@ template <typename T, typename Ld> __device__ __forceinline__ T sos_inv(const So
 // ---------------------------------------------------------------------------------------------
 // Bernstein polynomial.  NC = number of CONSTRAINED coefficients (order M = NC-1).
 // ---------------------------------------------------------------------------------------------
-#define ZK_BERN_EPS 1e-6
+#define ZK_BERN_EPS 1e-6  /* default of zuko/transforms.py:594; the entry points take eps at run time */
 
 template <typename T> __device__ __forceinline__ T softplus(T v) {  // torch softplus, beta=1, threshold=20
   return v > T(20) ? v : t_log1p(t_exp(v));
@@ -483,21 +483,20 @@ template <typename T, int NC> __device__ __forceinline__ void bern_eval(const T 
 template <typename T> struct BernTails { T off0, off1, slp0, slp1; };
 
 // offsets/slopes of the linear continuation (transforms.py:685-701 unbounded, :820-831 bounded)
-template <typename T, int NC> __device__ __forceinline__ BernTails<T> bern_tails(const T (&th)[NC], bool bounded, T bound) {
+template <typename T, int NC> __device__ __forceinline__ BernTails<T> bern_tails(const T (&th)[NC], bool bounded, T bound, T eps = T(ZK_BERN_EPS)) {
   BernTails<T> t;
   if (bounded) {
     t.off0 = -bound; t.off1 = bound; t.slp0 = T(2) * bound; t.slp1 = T(2) * bound;
   } else {
-    bern_eval<T, NC>(th, T(ZK_BERN_EPS), t.off0, t.slp0);
-    bern_eval<T, NC>(th, T(1) - T(ZK_BERN_EPS), t.off1, t.slp1);
+    bern_eval<T, NC>(th, eps, t.off0, t.slp0);
+    bern_eval<T, NC>(th, T(1) - eps, t.off1, t.slp1);
   }
   return t;
 }
 
 // y = f(x) and dy/dx (transforms.py:742-760; derivative = what autograd yields at :623-637)
 template <typename T, int NC>
-__device__ __forceinline__ void bern_fwd(const T (&th)[NC], const BernTails<T>& t, T bound, T x, T& y, T& dydx) {
-  const T eps = T(ZK_BERN_EPS);
+__device__ __forceinline__ void bern_fwd(const T (&th)[NC], const BernTails<T>& t, T bound, T x, T& y, T& dydx, T eps = T(ZK_BERN_EPS)) {
   T u = (x + bound) / (T(2) * bound);
   bool lo = u <= eps;
   bool hi = u >= T(1) - eps;
@@ -514,13 +513,12 @@ __device__ __forceinline__ void bern_fwd(const T (&th)[NC], const BernTails<T>& 
 }
 
 // x = f^{-1}(y): n-step bisection on [-B, B] + closed-form tails (transforms.py:762-777, :609-617)
-template <typename T, int NC> __device__ __forceinline__ T bern_inv(const T (&th)[NC], const BernTails<T>& t, T bound, T y, int n) {
-  const T eps = T(ZK_BERN_EPS);
+template <typename T, int NC> __device__ __forceinline__ T bern_inv(const T (&th)[NC], const BernTails<T>& t, T bound, T y, int n, T eps = T(ZK_BERN_EPS)) {
   T a = -bound, b = bound;
   for (int it = 0; it < n; ++it) {
     T mid = (a + b) / T(2);
     T fy, d;
-    bern_fwd<T, NC>(th, t, bound, mid, fy, d);
+    bern_fwd<T, NC>(th, t, bound, mid, fy, d, eps);
     bool below = fy < y;
     a = below ? mid : a;
     b = below ? b : mid;

@@ -51,10 +51,25 @@ def _require_device(*ts: Tensor) -> None:
             )
 
 
-def _no_bf16_grad(*ts: Tensor) -> None:
-    if any(t is not None and t.dtype == torch.bfloat16 for t in ts):
-        raise NotImplementedError("zuko_amd: the bfloat16 path is inference-only (gradients are built for float32 / float64); "
-                                  "evaluate under torch.no_grad() or train in float32")
+def _bf16_trains_in_f32(fn):
+    """bfloat16 operands under autograd.  The reference trains in whatever dtype the module is in (zuko tests/test_flows.py:17-29);
+    the adjoint kernels here are float32, so a call that needs gradients runs on float32 copies of its bf16 operands (`.float()`
+    is differentiable: gradients reach bf16 leaves through the casts, as torch.autocast would arrange it) and its transformed
+    values (first result) are rounded back to bf16; log-determinants stay float32, as on the bf16 inference path."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        ts = [a for a in list(args) + list(kw.values()) if isinstance(a, Tensor)]
+        if torch.is_grad_enabled() and any(t.dtype == torch.bfloat16 for t in ts) and any(t.requires_grad for t in ts):
+            up = lambda a: a.float() if isinstance(a, Tensor) and a.dtype == torch.bfloat16 else a
+            out = fn(*[up(a) for a in args], **{k: up(v) for k, v in kw.items()})
+            if isinstance(out, tuple):
+                return (out[0].to(torch.bfloat16),) + tuple(out[1:])
+            return out.to(torch.bfloat16)
+        return fn(*args, **kw)
+
+    return wrapped
 
 
 def _no_grad_only(*ts: Tensor) -> None:
@@ -149,6 +164,7 @@ def _packed_ok(x: Tensor, packed: Tensor | None, total: int) -> bool:
     return packed is not None and packed.dim() >= 2 and packed.shape[-1] == total and x.dim() >= 1 and tuple(torch.broadcast_shapes(x.shape, packed.shape[:-1])) == tuple(packed.shape[:-1])
 
 
+@_bf16_trains_in_f32
 def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor, bound: float = 5.0, slope: float = 1e-3,
                 reduce: bool = False, want_bins: bool = False, packed: Tensor | None = None):
     """(y, ladj[, k]) — see include/zuko_amd.h:zk_rqs_forward.  `packed`: the phi[..., D, 3K-1] tensor the three parameter
@@ -160,7 +176,6 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
 
     if not want_bins and AG.needs_grad(x, widths, heights, derivatives):
         _require_device(x, widths, heights, derivatives)
-        _no_bf16_grad(x, widths)
         if K > 64:
             raise NotImplementedError("zuko_amd: spline backward is built for up to 64 bins")
         if _packed_ok(x, packed, 3 * K - 1):
@@ -178,13 +193,13 @@ def rqs_forward(x: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor,
     return (y, ladj, bins) if want_bins else (y, ladj)
 
 
+@_bf16_trains_in_f32
 def rqs_inverse(y: Tensor, widths: Tensor, heights: Tensor, derivatives: Tensor, bound: float = 5.0, slope: float = 1e-3, want_bins: bool = False):
     K = widths.shape[-1]
     from . import autograd as AG
 
     if not want_bins and AG.needs_grad(y, widths, heights, derivatives):
         _require_device(y, widths, heights, derivatives)
-        _no_bf16_grad(y, widths)
         if K > 64:
             raise NotImplementedError("zuko_amd: spline backward is built for up to 64 bins")
         return AG.UnivariateInverseFn.apply(1, bound, slope, (), y, widths, heights, derivatives)
@@ -236,6 +251,7 @@ def rqs_from_knots(v: Tensor, horizontal: Tensor, vertical: Tensor, slopes: Tens
 # ------------------------------------------------------------------------------------------------
 
 
+@_bf16_trains_in_f32
 def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3, reduce: bool = False, packed: Tensor | None = None):
     from . import autograd as AG
 
@@ -252,6 +268,7 @@ def affine_forward(x: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3,
     return y, ladj
 
 
+@_bf16_trains_in_f32
 def affine_inverse(y: Tensor, shift: Tensor, scale: Tensor, slope: float = 1e-3) -> Tensor:
     from . import autograd as AG
 
@@ -284,6 +301,7 @@ SOS_BOUND = 10.0
 SOS_EPS = 1e-6
 
 
+@_bf16_trains_in_f32
 def sos_forward(x: Tensor, a: Tensor, constant: Tensor | None = None, slope: float = 1e-3, reduce: bool = False):
     from . import autograd as AG
 
@@ -303,6 +321,7 @@ def sos_forward(x: Tensor, a: Tensor, constant: Tensor | None = None, slope: flo
     return y, ladj
 
 
+@_bf16_trains_in_f32
 def sos_inverse(y: Tensor, a: Tensor, constant: Tensor | None = None, slope: float = 1e-3) -> Tensor:
     from . import autograd as AG
 
@@ -331,33 +350,37 @@ BERN_EPS = 1e-6
 BERN_NC_MAX = 72  # ZK_BERN_NCMAX of csrc/elementwise.hip
 
 
-def bernstein_forward(x: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0, reduce: bool = False):
+@_bf16_trains_in_f32
+def bernstein_forward(x: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0, reduce: bool = False, eps: float = BERN_EPS):
+    """`eps`: margin (in [0, 1] coordinates) beyond which the polynomial is continued linearly (zuko/transforms.py:594, :742-760)."""
     from . import autograd as AG
 
     if AG.needs_grad(x, theta):
         _require_device(x, theta)
-        return AG.BernsteinFn.apply(bool(bounded), bound, reduce, x, theta)
+        return AG.BernsteinFn.apply((bool(bounded), float(eps)), bound, reduce, x, theta)
     M = theta.shape[-1]
     pr = _Prepared(x, [(theta, 1)])
     y, ladj = pr.out(), pr.out_ladj(reduce)
     (t, tn, td) = pr.params[0]
-    err = _C.lib().zk_bernstein_forward(pr.code, pr.N, pr.D, M, int(bounded), bound, _ptr(pr.x), _ptr(t), tn, td, _ptr(y), _ptr(ladj), int(reduce), _stream())
+    err = _C.lib().zk_bernstein_forward(pr.code, pr.N, pr.D, M, int(bounded), bound, float(eps), _ptr(pr.x), _ptr(t), tn, td, _ptr(y), _ptr(ladj), int(reduce), _stream())
     _C.check(err, "zk_bernstein_forward")
     return y, ladj
 
 
-def bernstein_inverse(y: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0) -> Tensor:
+@_bf16_trains_in_f32
+def bernstein_inverse(y: Tensor, theta: Tensor, bounded: bool, bound: float = 5.0, eps: float = BERN_EPS) -> Tensor:
+    """Bisection on [-B, B] to the precision `eps` of the reference (n = ceil(log2(2B / eps)) steps, zuko/transforms.py:609-617)."""
     from . import autograd as AG
 
     if AG.needs_grad(y, theta):
         _require_device(y, theta)
-        return AG.UnivariateInverseFn.apply(3, bound, 0.0, (bool(bounded),), y, theta)
+        return AG.UnivariateInverseFn.apply(3, bound, 0.0, (bool(bounded), float(eps)), y, theta)
     M = theta.shape[-1]
     pr = _Prepared(y, [(theta, 1)])
     x = pr.out()
-    n_bisect = math.ceil(math.log2(2 * bound / BERN_EPS))  # transforms.py:615
+    n_bisect = math.ceil(math.log2(2 * bound / eps))  # transforms.py:615
     (t, tn, td) = pr.params[0]
-    err = _C.lib().zk_bernstein_inverse(pr.code, pr.N, pr.D, M, int(bounded), bound, n_bisect, _ptr(pr.x), _ptr(t), tn, td, _ptr(x), _stream())
+    err = _C.lib().zk_bernstein_inverse(pr.code, pr.N, pr.D, M, int(bounded), bound, float(eps), n_bisect, _ptr(pr.x), _ptr(t), tn, td, _ptr(x), _stream())
     _C.check(err, "zk_bernstein_inverse")
     return x
 
@@ -367,13 +390,13 @@ def bernstein_inverse(y: Tensor, theta: Tensor, bounded: bool, bound: float = 5.
 # ------------------------------------------------------------------------------------------------
 
 
+@_bf16_trains_in_f32
 def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, act: int = 0) -> Tensor:
     """act(x @ (mask * weight).T + bias) over the last dim of x (zuko/nn.py:217-218)."""
     _require_device(x, weight, bias, mask)
     from . import autograd as AG
 
     if AG.needs_grad(x, weight, bias):
-        _no_bf16_grad(x, weight)
         if act not in AG.BACKWARD_ACTS:
             raise NotImplementedError("zuko_amd: this activation cannot be fused when gradients are required")
         return AG.LinearFn.apply(x, weight, bias, mask, act)
@@ -454,6 +477,9 @@ def diag_normal_log_prob(z: Tensor, loc: Tensor, scale: Tensor, ladj: Tensor | N
     from . import autograd as AG
 
     if AG.needs_grad(z, ladj):
+        if z.dtype == torch.bfloat16:  # (bf16 module under autograd: float32 copies, gradients flow back through the casts)
+            z, loc, scale = z.float(), loc.float(), scale.float()
+            ladj = None if ladj is None else ladj.float()
         return AG.DiagNormalLogProbFn.apply(z, loc, scale, ladj)
     if z.dtype == torch.bfloat16:  # bf16 is a storage type here: the density is evaluated and returned in fp32
         z, loc, scale = z.float(), loc.float(), scale.float()

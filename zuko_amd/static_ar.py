@@ -323,6 +323,27 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
     """Compile every PREBUILT kernel that is missing or stale; returns the .so names."""
     from concurrent.futures import ThreadPoolExecutor
 
+    # kernels built against another version of the template / headers can never be selected again: drop them
+    stamp = _header_digest()
+    if os.path.isdir(ARS_DIR):
+        for name in os.listdir(ARS_DIR):
+            if name.endswith(".json"):
+                try:
+                    with open(os.path.join(ARS_DIR, name)) as f:
+                        stale = json.load(f).get("headers") != stamp
+                except (OSError, ValueError):
+                    stale = True
+                if stale:
+                    for ext in (".json", ".so", ".hip"):
+                        try:
+                            os.remove(os.path.join(ARS_DIR, name[: -len(".json")] + ext))
+                        except OSError:
+                            pass
+            elif name.startswith(".lock_"):
+                try:
+                    os.remove(os.path.join(ARS_DIR, name))
+                except OSError:
+                    pass
     work = []
     for kind, features, context, hidden, bins in PREBUILT:
         (pa, layout), (pd, _) = _plans_for(kind, features, context, hidden, bins)

@@ -158,9 +158,9 @@ class BernsteinTransform(_Univariate):
     bounded = False
 
     def __init__(self, theta: Tensor, bound: float = 5.0, **kwargs) -> None:
-        eps = kwargs.pop("eps", ops.BERN_EPS)
-        if eps != ops.BERN_EPS:
-            raise NotImplementedError(f"zuko_amd: the Bernstein kernels are built for eps = {ops.BERN_EPS} (zuko/transforms.py:594 default), got {eps}")
+        self.eps = float(kwargs.pop("eps", ops.BERN_EPS))  # MonotonicTransform's kwarg (zuko/transforms.py:594): continuation margin and bisection precision
+        if not 0.0 < self.eps < 0.5:
+            raise ValueError(f"zuko_amd: eps must lie in (0, 0.5), got {self.eps}")
         super().__init__(**kwargs)
         self.unconstrained_theta = theta
         self.bound = bound
@@ -169,10 +169,10 @@ class BernsteinTransform(_Univariate):
             raise NotImplementedError(f"zuko_amd: Bernstein polynomials are built for up to {ops.BERN_NC_MAX} constrained coefficients, got {nc}")
 
     def _forward(self, x, reduce):
-        return ops.bernstein_forward(x, self.unconstrained_theta, self.bounded, self.bound, reduce)
+        return ops.bernstein_forward(x, self.unconstrained_theta, self.bounded, self.bound, reduce, eps=self.eps)
 
     def _inverse(self, y: Tensor) -> Tensor:
-        return ops.bernstein_inverse(y, self.unconstrained_theta, self.bounded, self.bound)
+        return ops.bernstein_inverse(y, self.unconstrained_theta, self.bounded, self.bound, eps=self.eps)
 
 
 class BoundedBernsteinTransform(BernsteinTransform):
