@@ -183,9 +183,10 @@ template <typename T, int NC, bool INV> struct BernOp {
     const T bound = T(a.bound);
     if (a.bounded) bern_theta_bounded<T, NC>(ld[0], bound, th);
     else bern_theta_unbounded<T, NC>(ld[0], th);
-    BernTails<T> t = bern_tails<T, NC>(th, a.bounded != 0, bound);
-    if (INV) { out = bern_inv<T, NC>(th, t, bound, in, a.n_bisect); ladj = T(0); }
-    else { T d; bern_fwd<T, NC>(th, t, bound, in, out, d); ladj = t_log(d); }
+    const T eps = T(a.eps);
+    BernTails<T> t = bern_tails<T, NC>(th, a.bounded != 0, bound, eps);
+    if (INV) { out = bern_inv<T, NC>(th, t, bound, in, a.n_bisect, eps); ladj = T(0); }
+    else { T d; bern_fwd<T, NC>(th, t, bound, in, out, d, eps); ladj = t_log(d); }
   }
 };
 

@@ -483,7 +483,7 @@ template <typename T, int NC> __device__ __forceinline__ void bern_eval(const T 
 template <typename T> struct BernTails { T off0, off1, slp0, slp1; };
 
 // offsets/slopes of the linear continuation (transforms.py:685-701 unbounded, :820-831 bounded)
-template <typename T, int NC> __device__ __forceinline__ BernTails<T> bern_tails(const T (&th)[NC], bool bounded, T bound, T eps = T(ZK_BERN_EPS)) {
+template <typename T, int NC> __device__ __forceinline__ BernTails<T> bern_tails(const T (&th)[NC], bool bounded, T bound, T eps) {
   BernTails<T> t;
   if (bounded) {
     t.off0 = -bound; t.off1 = bound; t.slp0 = T(2) * bound; t.slp1 = T(2) * bound;
@@ -496,7 +496,7 @@ template <typename T, int NC> __device__ __forceinline__ BernTails<T> bern_tails
 
 // y = f(x) and dy/dx (transforms.py:742-760; derivative = what autograd yields at :623-637)
 template <typename T, int NC>
-__device__ __forceinline__ void bern_fwd(const T (&th)[NC], const BernTails<T>& t, T bound, T x, T& y, T& dydx, T eps = T(ZK_BERN_EPS)) {
+__device__ __forceinline__ void bern_fwd(const T (&th)[NC], const BernTails<T>& t, T bound, T x, T& y, T& dydx, T eps) {
   T u = (x + bound) / (T(2) * bound);
   bool lo = u <= eps;
   bool hi = u >= T(1) - eps;
@@ -513,7 +513,7 @@ __device__ __forceinline__ void bern_fwd(const T (&th)[NC], const BernTails<T>& 
 }
 
 // x = f^{-1}(y): n-step bisection on [-B, B] + closed-form tails (transforms.py:762-777, :609-617)
-template <typename T, int NC> __device__ __forceinline__ T bern_inv(const T (&th)[NC], const BernTails<T>& t, T bound, T y, int n, T eps = T(ZK_BERN_EPS)) {
+template <typename T, int NC> __device__ __forceinline__ T bern_inv(const T (&th)[NC], const BernTails<T>& t, T bound, T y, int n, T eps) {
   T a = -bound, b = bound;
   for (int it = 0; it < n; ++it) {
     T mid = (a + b) / T(2);
