@@ -42,7 +42,7 @@ typedef float f32x16_b __attribute__((ext_vector_type(16)));
 #ifndef ZK_BF16_ABLATE
 #define ZK_BF16_ABLATE 0  /* probe builds only (WRONG results; scripts/cfg5_variants.sh): 1 = no spline epilogue, 2 = epilogue without the spline arithmetic,
                              3 = k loop without MFMAs, 4 = k loop without the stage DMAs, 5 = epilogue without the x loads / y stores, 6 = epilogue without
-                             the image writes — what each part costs a tile */
+                             the image writes, 7 = k loop with fragment reads only, 8 = with MFMAs only, 9 = with DMAs only — what each part costs a tile */
 #endif
 #ifndef ZK_BF16_DMA1
 #define ZK_BF16_DMA1 0    /* (with ZK_BF16_ROT) 1: one DMA in front of every MFMA block and one in its middle, instead of two in front */
@@ -355,24 +355,38 @@ template <bool GENERIC_ACT, int SK> __global__ __launch_bounds__(512, 2) void li
       fb[buf][j] = *reinterpret_cast<const bf16x8*>(sB + r_ * 128 + ((c_ ^ ((r_ >> 1) & 7)) << 4));        \
     }                                                                                                       \
   }
+#if ZK_BF16_ABLATE == 8 || ZK_BF16_ABLATE == 9
+#pragma unroll
+      for (int b_ = 0; b_ < 2; ++b_) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[b_][i] = bf16x8{}; asm volatile("" : "+v"(fa[b_][i])); }  // (opaque zeros: the MFMAs stay)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { fb[b_][j] = bf16x8{}; asm volatile("" : "+v"(fb[b_][j])); }
+      }
+#else
       ZK_BF16_FRAGS(0, 0);
+#endif
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+#if !(ZK_BF16_ABLATE == 8 || ZK_BF16_ABLATE == 9)
         if (kk < 3) ZK_BF16_FRAGS((kk + 1) & 1, kk + 1);
+#endif
 #if ZK_BF16_SPREAD
         // a wave that issues a DMA issues nothing else for ~100 cycles: two at a time, in front of its own MFMA block, so that the
         // partner wave of the SIMD has the matrix pipe meanwhile (all eight right after the barrier stall both waves at once)
-        if (ZK_BF16_ABLATE != 4 && ktn < KT) issue_pair(ktn, stage ^ 1, kk);
+        if (ZK_BF16_ABLATE != 4 && ZK_BF16_ABLATE != 7 && ZK_BF16_ABLATE != 8 && ktn < KT) issue_pair(ktn, stage ^ 1, kk);
 #endif
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (the scheduler would sink it to its uses)
 #if ZK_BF16_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
-#if ZK_BF16_ABLATE == 3
+#if ZK_BF16_ABLATE == 3 || ZK_BF16_ABLATE == 7
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[kk & 1][i]));
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[kk & 1][j]));
+#elif ZK_BF16_ABLATE == 9
+        (void)0;
 #else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
