@@ -293,6 +293,11 @@ PREBUILT = [
     ("rqs", 32, 0, (512, 512), 8),          # widths beyond the generic kernel's 256 (one wavefront per SIMD)
     ("rqs", 32, 0, (256, 256), 8),
     ("affine", 16, 0, (128, 128), 0),
+    # shapes the GPU tests exercise (widths that are not multiples of 16 / 64, a context that straddles a tile, one hidden layer, three
+    # wide layers): built ahead so that `pytest -m gpu` on a fresh box compiles nothing
+    ("rqs", 20, 3, (100, 72), 8),
+    ("affine", 7, 2, (40,), 0),
+    ("rqs", 24, 8, (384, 512, 320), 8),
 ]
 
 
