@@ -322,7 +322,7 @@ int zk_ar_lds_bytes(int variant, int bias_floats);
  * stream (only the 16x16 tiles that hold non-zero weights; ArPlan.fine_gather of zuko_amd/fused.py) of n_chunks chunks, re-checks
  * D / DIN / n_layers / n_groups / n_chunks against the shape it was generated for (hipErrorInvalidValue on a mismatch or on a
  * kernel built against another ArArgs layout) and needs 16-byte addressable rows of y when it stages rows through LDS (D % 4 == 0).
- * ReLU conditioners; uni_kind 0 / 1 / 2 / 4; hidden widths up to 512 (the generic zk_ar_forward stops at 256).  Results are
+ * Any fusable activation (the kernel checks `act` against the one it was generated for); uni_kind 0 / 1 / 2 / 4; hidden widths up to 512 (the generic zk_ar_forward stops at 256).  Results are
  * bit-identical to zk_ar_forward on the same plan (the tiles the per-tile stream drops hold zeros only). */
 /* Reads: launcher, rev, uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream, bias, bias_floats, featmap, n_layers, n_groups,
  * n_chunks, bound, slope. */

@@ -646,11 +646,11 @@ def test_fused_coupling_kernel(dev, D, ctx, hidden, N, monkeypatch):
 
 
 STATIC_CASES = [("nsf", 64, 0, [256] * 3), ("maf", 64, 0, [256] * 3), ("nsf", 3, 5, [128] * 3), ("nsf", 32, 0, [256, 256]), ("maf", 16, 0, [128, 128]),
-                ("nsf", 20, 3, [100, 72]), ("maf", 7, 2, [40])]
+                ("nsf", 20, 3, [100, 72]), ("maf", 7, 2, [40]), ("nsf", 16, 2, [64, 64], "ELU"), ("maf", 12, 0, [48, 32], "Tanh")]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", STATIC_CASES, ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}")
+@pytest.mark.parametrize("case", STATIC_CASES, ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}" + (f"-{c[4]}" if len(c) > 4 else ""))
 @pytest.mark.parametrize("N", [1, 129, 1000, 40000])
 def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, case, N, monkeypatch):
     """The generated static-shape kernels (csrc/fused_ar_static_impl.h on the tables of zuko_amd/static_ar.py: straight-line code
@@ -661,10 +661,11 @@ def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, case, N, m
     from zuko_amd.flows import MAF, NSF
     from zuko_amd.nn import MaskedLinear
 
-    kind, D, C, hidden = case
+    kind, D, C, hidden = case[:4]
+    kw = dict(activation=getattr(torch.nn, case[4])) if len(case) > 4 else {}  # (ELU / tanh: the activation is part of the generated kernel)
     monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")  # unlisted shapes: compile now (hipcc, ~15 s each, cached in zuko_amd/lib/ars/)
     torch.manual_seed(3)
-    flow = (NSF(D, C, transforms=2, bins=8, hidden_features=hidden) if kind == "nsf" else MAF(D, C, transforms=2, hidden_features=hidden)).to(dev)
+    flow = (NSF(D, C, transforms=2, bins=8, hidden_features=hidden, **kw) if kind == "nsf" else MAF(D, C, transforms=2, hidden_features=hidden, **kw)).to(dev)
     g = torch.Generator().manual_seed(N)
     din = D + C
     inp = torch.zeros(N, -(-din // 4) * 4)

@@ -508,7 +508,7 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
   ArPartial part;
   part.static_fn = args->launcher; part.rev = args->rev;
   zk_ar_args_v1 p = *args;
-  p.act = 1; p.skip = nullptr;
+  p.skip = nullptr;  // (act: checked by the kernel against the activation it was generated for)
   return ar_launch_v1(part, false, p, stream);
 }
 

@@ -23,6 +23,7 @@
 //                                 alternative first-layer pattern (HAS_ALT: a descending feature order mirrors the input tiles)
 //   Shape::BASE[l], LAST_BASE     stream position (in tiles) where each layer starts (layers are padded to whole chunks)
 //   Shape::NG, GOFF[g], G_IT      last layer: kept input tiles of every feature group, in stream order
+//   Shape::ACT                    activation between the layers (code of zuko_amd/nn.py:_act_code; 1 = ReLU)
 //   Shape::NCHUNK, WAVES, XLDS    stream length in chunks; wavefronts per workgroup (8: widths <= 256, two per SIMD; 4: widths <= 512,
 //                                 one per SIMD); whether x / y rows are staged through a wave-private LDS image
 #pragma once
@@ -188,10 +189,26 @@ template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ voi
   if constexpr (L < S::NH) {
     ars_hidden<S, L>(ring, bias_lds + L * S::BIAS_STRIDE + 4 * q, in, out, rev);
     constexpr int HTL = S::HT[L], TO = 4 * ((HTL + 3) / 4);
+    if constexpr (S::ACT == 1) {
 #pragma unroll
-    for (int t = 0; t < TO; ++t)
+      for (int t = 0; t < TO; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) in[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
+        for (int r = 0; r < 4; ++r) in[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
+    } else if constexpr (S::ACT == 0) {
+#pragma unroll
+      for (int t = 0; t < TO; ++t) in[t] = out[t];
+    } else {
+      // ELU / tanh / SiLU / GELU / sigmoid / leaky ReLU: the same expressions as the generic kernel (act_f32), inside a loop the compiler
+      // must not unroll over the activation's inline expansion (64-128 copies of tanhf / erff made the generic kernel's epilogue
+      // instruction-cache bound)
+#pragma unroll 1
+      for (int rep = 0; rep < 1; ++rep) {
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in[t][r] = act_f32(out[t][r], S::ACT);
+      }
+    }
     if constexpr (TRAIN) {
       if (live) {
 #pragma unroll
@@ -374,7 +391,7 @@ template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(64 * S
 template <class S, typename Uni> static int ars_launch(const ArArgs* in, int abi, int args_bytes, int train, void* stream) {
   if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;  // kernel built against another version of the library
   ArArgs a = *in;
-  if (a.D != S::D || a.DIN != S::DIN || a.L != S::NH + 1 || a.act != 1 || a.sched || a.NG != S::NG || a.n_chunks != S::NCHUNK) return ZK_EINVAL;
+  if (a.D != S::D || a.DIN != S::DIN || a.L != S::NH + 1 || a.act != S::ACT || a.sched || a.NG != S::NG || a.n_chunks != S::NCHUNK) return ZK_EINVAL;
   if (a.l1rev && !S::HAS_ALT) return ZK_EINVAL;
   if (train && (!S::TRAIN_OK || !a.phi_out)) return ZK_EINVAL;
   a.n_tiles = (a.N + 16 * S::WAVES - 1) / (16 * S::WAVES);

@@ -504,7 +504,7 @@ class FusedAR:
             if not kern.meta["XLDS"] or (y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0):
                 a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
                             y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate), wstream=_ptr(self.fine_stream), bias=_ptr(self.bias),
-                            bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=p.fine_n_chunks, act=1,
+                            bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=p.fine_n_chunks, act=self.act,
                             bound=self.bound, slope=self.slope)
                 _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
                 return

@@ -60,9 +60,9 @@ def _header_digest() -> str:
 # --------------------------------------------------------------------------------------------------------------------
 
 
-def tables(plan, uni_kind: int) -> dict | None:
+def tables(plan, uni_kind: int, act: int = 1) -> dict | None:
     """The Shape tables of one plan (fused.ArPlan with its per-tile stream), or None when no static kernel can be built."""
-    if plan.fine_gather is None or uni_kind not in UNI_TYPES:
+    if plan.fine_gather is None or uni_kind not in UNI_TYPES or act not in range(8):
         return None
     L = plan.n_layers
     NH = L - 1
@@ -105,10 +105,10 @@ def tables(plan, uni_kind: int) -> dict | None:
     if plan.n_groups * plan.layout.fpl * 4 > 1024:
         return None
     return {
-        "uni": int(uni_kind), "D": int(D), "DIN": int(din4), "NIT": int(NIT), "NH": int(NH), "HT": HT, "TMAX": int(TMAX), "NG": int(plan.n_groups),
+        "uni": int(uni_kind), "ACT": int(act), "D": int(D), "DIN": int(din4), "NIT": int(NIT), "NH": int(NH), "HT": HT, "TMAX": int(TMAX), "NG": int(plan.n_groups),
         "NCHUNK": int(plan.fine_n_chunks), "BIAS_STRIDE": int(plan.max_width), "NS": NS, "S_OTG": S_OTG, "S_IT": S_IT, "S_MASK": S_MASK,
         "BASE": [int(b) for b in plan.fine_layer_block0[:NH]], "LAST_BASE": int(plan.fine_layer_block0[NH]), "GOFF": GOFF, "G_IT": G_IT,
-        "WAVES": waves, "XLDS": xlds, "TRAIN_OK": int(NH <= 3 and waves == 8 and all(w % 16 == 0 for w in widths)),
+        "WAVES": waves, "XLDS": xlds, "TRAIN_OK": int(act == 1 and NH <= 3 and waves == 8 and all(w % 16 == 0 for w in widths)),
     }
 
 
@@ -142,7 +142,7 @@ def emit(t: dict, alt: list | None) -> str:
         "namespace {",
         "struct Shape {",
         f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NG = {t['NG']}, NCHUNK = {t['NCHUNK']};",
-        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']};",
+        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, ACT = {t['ACT']};",
         f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = {'true' if alt is not None else 'false'}, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
         _arr("HT", "int", t["HT"]), _arr("NS", "int", t["NS"]), _arr("SOFF", "int", soff), _arr("BASE", "int", t["BASE"]),
         _arr("S_OTG", "unsigned char", t["S_OTG"]), _arr("S_IT", "unsigned char", t["S_IT"]), _arr("S_ALT", "unsigned char", s_alt),
@@ -208,7 +208,7 @@ def compile_kernel(t: dict, alt: list | None, verbose: bool = False) -> dict | N
     sig = _digest({"core": core, "l0": l0, "alt": alt, "headers": stamp})
     os.makedirs(ARS_DIR, exist_ok=True)
     so, meta_path = f"ars_{sig}.so", os.path.join(ARS_DIR, f"ars_{sig}.json")
-    meta = {"so": so, "core": _digest(core), "l0": l0, "alt": alt, "headers": stamp, "uni": t["uni"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"], "WAVES": t["WAVES"],
+    meta = {"so": so, "core": _digest(core), "l0": l0, "alt": alt, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"], "WAVES": t["WAVES"],
             "TRAIN_OK": t["TRAIN_OK"], "XLDS": t["XLDS"]}
     with open(os.path.join(ARS_DIR, f".lock_{sig}"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)  # (several ranks / test workers may want the same kernel at once)
@@ -260,9 +260,9 @@ def jit_min_rows() -> int:
 def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
     """(StaticKernel, rev) for this plan, or None.  Kernels found on disk are used whatever the batch; a missing one is compiled
     when `rows` reaches the JIT threshold."""
-    if act != 1 or os.environ.get("ZUKO_AMD_NO_STATIC_AR", "0") == "1":
+    if os.environ.get("ZUKO_AMD_NO_STATIC_AR", "0") == "1":
         return None
-    t = tables(plan, uni_kind)
+    t = tables(plan, uni_kind, act)
     if t is None:
         return None
     core, l0 = _split(t)
@@ -298,11 +298,14 @@ PREBUILT = [
     ("rqs", 20, 3, (100, 72), 8),
     ("affine", 7, 2, (40,), 0),
     ("rqs", 24, 8, (384, 512, 320), 8),
+    ("rqs", 16, 2, (64, 64), 8, "ELU"),
+    ("affine", 12, 0, (48, 32), 0, "Tanh"),
 ]
 
 
-def _plans_for(kind: str, features: int, context: int, hidden, bins: int):
-    """Plans of the ascending- and descending-order transform of such a flow (MAF / NSF alternate the two)."""
+def _plans_for(kind: str, features: int, context: int, hidden, bins: int, activation: str | None = None):
+    """Plans of the ascending- and descending-order transform of such a flow (MAF / NSF alternate the two).  (The activation does not
+    enter the plan: it is a field of the tables.)"""
     import torch
 
     from . import fused
@@ -350,11 +353,17 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
                 except OSError:
                     pass
     work = []
-    for kind, features, context, hidden, bins in PREBUILT:
+    for entry in PREBUILT:
+        kind, features, context, hidden, bins = entry[:5]
+        import torch
+
+        from .nn import _act_code
+
+        act = _act_code(getattr(torch.nn, entry[5])()) if len(entry) > 5 else 1
         (pa, layout), (pd, _) = _plans_for(kind, features, context, hidden, bins)
-        ta, td = tables(pa, layout.kind), tables(pd, layout.kind)
+        ta, td = tables(pa, layout.kind, act), tables(pd, layout.kind, act)
         if ta is None or td is None:
-            raise RuntimeError(f"zuko_amd.static_ar: no static kernel for the prebuilt shape {(kind, features, context, hidden, bins)}")
+            raise RuntimeError(f"zuko_amd.static_ar: no static kernel for the prebuilt shape {entry}")
         (ca, la), (cdesc, ld) = _split(ta), _split(td)
         if ca == cdesc:
             work.append((ta, None if la == ld else ld))
