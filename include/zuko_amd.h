@@ -202,6 +202,9 @@ typedef struct zk_ar_args_v1 {
   void* h2;
   void* h3;
   void* phi;               /* training forward: [N, D * total] */
+  void* gh1;               /* dgrad chain: gradient of hidden layer l's pre-activations [N, width_l] (outputs; the last one is the input x) */
+  void* gh2;
+  void* gh3;
 } zk_ar_args_v1;
 
 /* y, ladj of one layer on the generic tile-skipping kernel.  Reads: uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream,
@@ -211,6 +214,14 @@ int zk_ar_forward(const zk_ar_args_v1* args, void* stream);
  * template and arithmetic plus bin_out[N, D] (int32) and knots_out[N, D, K+1] (fp32), as zk_rqs_diag.  Reads additionally:
  * bin_out, knots_out (accumulate is ignored). */
 int zk_ar_forward_diag(const zk_ar_args_v1* args, void* stream);
+/* Backward of the conditioner's hidden layers under autograd (what torch.autograd does for MaskedMLP, zuko/nn.py:117-129, layer by
+ * layer): for a ReLU network, g_{l} = (g_{l+1} (W_{l+1} * mask_{l+1})) * [h_l > 0] for every hidden layer and the gradient w.r.t. the
+ * input, in ONE launch of a generated kernel (`launcher` = zk_ars_dgrad_launch of zuko_amd/static_ar.py:chain_kernel).
+ *   x [N, DIN] (row stride ldx) = gradient of the LAST hidden layer's pre-activations, DIN = its width; D = conditioner inputs;
+ *   h1.. (read) the forward's hidden activations, gh1.. (written) the gradients of the earlier hidden layers, both [N, width_l] in the
+ *   sorted unit order of zk_ar_forward_train; y [N, D] (row stride ldy) = gradient w.r.t. the conditioner's input;
+ *   wstream / n_chunks: the kernel's weight stream; n_layers = linear layers of the conditioner (2..4). */
+int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream);
 /* One sweep of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000, the body of its loop):
  *     x_out = univariate(*unpack(MaskedMLP(x_cond))).inv(y)
  * x (= x_cond) [N, DIN] as for zk_ar_forward (features first, context after), y_in [N, D] (row stride ldy) the values to

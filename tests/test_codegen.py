@@ -122,7 +122,7 @@ def _isa_of_generated(cfgs):
         pytest.skip("no hipcc")
     jobs = []
     for cfg in cfgs:
-        (pa, lay), (pd, _) = static_ar._plans_for(*cfg)
+        (pa, lay, _), (pd, _, _) = static_ar._plans_for(*cfg)
         ta, td = static_ar.tables(pa, lay.kind), static_ar.tables(pd, lay.kind)
         (ca, la), (cd, ld) = static_ar._split(ta), static_ar._split(td)
         src = static_ar.emit(ta, ld if (ca == cd and la != ld) else None)

@@ -1,0 +1,83 @@
+"""Tables of the generated dgrad-chain kernel (zuko_amd/static_ar.py: chain_tables; csrc/fused_ar_static_impl.h: ars_dgrad_kernel)
+walked on the CPU: the tile stream + step tables must reproduce g -> (g W_l) * gate, layer after layer, for the masked conditioners
+of the benchmark flows in both feature orders (what torch.autograd computes for zuko/nn.py:117-129)."""
+
+import numpy as np
+import pytest
+import torch
+
+from zuko_amd import static_ar
+from zuko_amd.train import SortedPlan
+
+
+def _walk(t, gathers, weights, masks, g_last, gates):
+    """The kernel's loop nest in numpy.  weights / masks: module-order W_l, mask_l of the chain's layers l = 0 .. n-2."""
+    n1 = t["NH"]
+    vec = np.zeros((t["TMAX"] * 16,))
+    vec[: g_last.shape[0]] = g_last
+    outs = []
+    soff = 0
+    for c in range(n1):
+        l = n1 - 1 - c
+        idx = gathers[c]
+        flat = (weights[l] * masks[l]).reshape(-1)
+        vals = np.where(idx >= 0, flat[np.maximum(idx, 0)], 0.0).reshape(-1, 64, 4)
+        assert vals.shape[0] % 24 == 0 and t["BASE"][c] * 256 == sum(len(g) for g in gathers[:c])
+        out = np.zeros((t["TMAX"] * 16,))
+        k = 0
+        for s in range(soff, soff + t["NS"][c]):
+            otg, it, m4 = t["S_OTG"][s], t["S_IT"][s], t["S_MASK"][s]
+            for b in range(4):
+                if m4 >> b & 1:
+                    A = np.zeros((16, 16))
+                    for lane in range(64):
+                        A[lane % 16, 4 * (lane // 16) : 4 * (lane // 16) + 4] = vals[k, lane]
+                    out[(otg * 4 + b) * 16 : (otg * 4 + b + 1) * 16] += A @ vec[it * 16 : (it + 1) * 16]
+                    k += 1
+        assert not vals[k:].any(), "padding tiles of the last chunk are zero"
+        soff += t["NS"][c]
+        width = t["HT"][c] * 16
+        if c + 1 < n1:
+            out[:width] *= gates[c]
+        outs.append(out[:width].copy())
+        vec = np.zeros_like(vec)
+        vec[:width] = out[:width]
+    return outs
+
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("rqs", 3, 5, (128, 128, 128), 8), ("affine", 16, 0, (128, 128), 0),
+                                 ("rqs", 12, 0, (48,), 8)])
+def test_chain_tables_reproduce_the_layerwise_dgrad(cfg):
+    rng = np.random.default_rng(3)
+    for _, _, lins in static_ar._plans_for(*cfg):
+        n = len(lins)
+        sp = SortedPlan(lins, 1, torch.device("cpu"))
+        tg = static_ar.chain_tables(sp.mask_s_cpu[: n - 1], sp.rows_cpu[: n - 1], sp.cols_cpu[: n - 1])
+        assert tg is not None
+        t, gathers = tg
+        assert t["NH"] == n - 1 and t["DIN"] == lins[n - 2].weight.shape[0] and t["DOUT"] == lins[0].weight.shape[1]
+        W = [l.weight.detach().double().numpy() for l in lins[: n - 1]]
+        M = [l.mask.detach().double().numpy() for l in lins[: n - 1]]
+        g_last_sorted = rng.standard_normal(t["DIN"])
+        gates = [(rng.random(t["HT"][c] * 16) > 0.4).astype(float) for c in range(n - 2)]
+        outs = _walk(t, gathers, W, M, g_last_sorted, gates)
+        # reference in module order: g_{l-1} = (g_l (W_l * mask_l)) * gate_{l-1}, the sorted order only permutes the units
+        g = np.zeros(t["DIN"])
+        g[sp.rows_cpu[n - 2]] = g_last_sorted
+        for c in range(n - 1):
+            l = n - 2 - c
+            g = g @ (W[l] * M[l])
+            if c + 1 < n - 1:
+                gate_m = np.zeros(g.shape[0])
+                gate_m[sp.rows_cpu[l - 1]] = gates[c][: g.shape[0]]
+                g = g * gate_m
+                np.testing.assert_allclose(outs[c][: g.shape[0]], g[sp.rows_cpu[l - 1]], rtol=1e-12, atol=1e-12)
+            else:
+                np.testing.assert_allclose(outs[c][: g.shape[0]], g, rtol=1e-12, atol=1e-12)
+
+
+def test_chain_tables_decline_what_the_kernel_does_not_cover():
+    (_, _, lins), _ = static_ar._plans_for("rqs", 20, 3, (100, 72), 8)   # widths that are not multiples of 16
+    assert static_ar.chain_tables_for(lins) is None
+    (_, _, lins), _ = static_ar._plans_for("rqs", 32, 0, (512, 512), 8)  # wider than a wavefront's 16 register tiles
+    assert static_ar.chain_tables_for(lins) is None

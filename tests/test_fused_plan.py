@@ -219,7 +219,7 @@ def test_static_kernel_tables_describe_the_plan(cfg):
     from zuko_amd import fused, static_ar
 
     kind, D, C, hidden, bins = cfg
-    plans = static_ar._plans_for(kind, D, C, hidden, bins)
+    plans = [pl[:2] for pl in static_ar._plans_for(kind, D, C, hidden, bins)]
     tabs = [static_ar.tables(p, lay.kind) for p, lay in plans]
     assert all(t is not None for t in tabs)
     (ca, la), (cd, ld) = static_ar._split(tabs[0]), static_ar._split(tabs[1])

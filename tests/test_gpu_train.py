@@ -180,3 +180,55 @@ def test_fused_training_forward(dev, kind, monkeypatch):
     assert torch.allclose(gx1, gx0, rtol=1e-4, atol=1e-4 * gx0.abs().max().item())
     for a, b in zip(gp1, gp0):
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * b.abs().max().clamp_min(1e-6).item()), (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("kind", ["nsf_asc", "nsf_desc", "maf_desc", "cfg1", "two_layers"])
+def test_dgrad_chain_matches_the_layerwise_backward(dev, kind, monkeypatch):
+    """zk_ar_dgrad_chain (one generated kernel for the dgrad of every layer but the last) must be selected for the benchmark
+    conditioners and give the layer-wise GEMMs' gradients: d/dx and every parameter gradient, ragged batch, both feature orders."""
+    import zuko_amd.flows as F
+    from zuko_amd import train
+
+    torch.manual_seed(8)
+    if kind.startswith("nsf"):
+        flow = F.NSF(64, 0, transforms=2, bins=8, hidden_features=[256] * 3)
+    elif kind == "maf_desc":
+        flow = F.MAF(64, 0, transforms=2, hidden_features=[256] * 3)
+    elif kind == "cfg1":
+        flow = F.NSF(3, 5, transforms=2, bins=8, hidden_features=[128] * 3)
+    else:
+        flow = F.MAF(16, 0, transforms=2, hidden_features=[128, 128])
+    net = flow.to(dev).transform.transforms[1 if kind.endswith("desc") else 0].hyper
+    plan, lins = train.plan_for(net, dev)
+    N = 1000 + 37
+    assert train._dgrad_chain(plan, lins, N) is not None, "the dgrad chain must be available (prebuilt) for this conditioner"
+    din = lins[0].weight.shape[1]
+    x = torch.randn(N, din, generator=torch.Generator().manual_seed(6)).to(dev)
+    gphi = torch.randn(N, lins[-1].weight.shape[0], generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        xr = x.clone().requires_grad_()
+        out = net(xr)
+        (out * gphi).sum().backward()
+        return xr.grad.clone(), [p.grad.clone() for p in net.parameters()]
+
+    gx1, gp1 = run()
+    monkeypatch.setenv("ZUKO_AMD_NO_DGRAD_CHAIN", "1")
+    gx0, gp0 = run()
+    assert torch.allclose(gx1, gx0, rtol=1e-5, atol=1e-5 * gx0.abs().max().item()), (gx1 - gx0).abs().max().item()
+    for a, b in zip(gp1, gp0):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * b.abs().max().clamp_min(1e-6).item()), (a - b).abs().max().item()
+    # the forward's saved stream, not the parameters at backward time, enters the gradient (as autograd's saved tensors would)
+    xr = x.clone().requires_grad_()
+    monkeypatch.delenv("ZUKO_AMD_NO_DGRAD_CHAIN")
+    out = net(xr)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(3.0)
+    (out * gphi).sum().backward()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.div_(3.0)
+    assert torch.allclose(xr.grad, gx0, rtol=1e-5, atol=1e-5 * gx0.abs().max().item())

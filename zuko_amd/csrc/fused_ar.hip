@@ -527,6 +527,30 @@ int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
   return ar_launch_v1(part, false, p, stream);
 }
 
+// The backward twin of zk_ar_forward_train for a ReLU conditioner: dgrad through every linear layer but the last in ONE launch of a
+// generated kernel (zuko_amd/static_ar.py: chain_kernel; `launcher` = its zk_ars_dgrad_launch).  x = g of the LAST hidden layer's
+// pre-activations [N, DIN = its width]; h1.. = the forward's hidden activations (gates), gh1.. = where the gradient of every earlier
+// hidden layer's pre-activations goes ([N, width_l], sorted unit order), y [N, D] (row stride ldy) = the gradient w.r.t. the
+// conditioner's input.  wstream = the kernel's weight stream (transposed masked weights in its tile order), n_chunks its length.
+typedef int (*ars_dgrad_fn)(const ArArgs* a, int abi, int args_bytes, void* stream);
+int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args) || !args->launcher || !args->x || !args->y || !args->wstream) return ZK_EINVAL;
+  const int n = args->n_layers;
+  if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff) return ZK_EINVAL;
+  if (args->N == 0) return 0;
+  const void* hs[3] = {args->h1, args->h2, args->h3};
+  void* gs[3] = {args->gh1, args->gh2, args->gh3};
+  ArArgs a{};
+  a.x = (const float*)args->x; a.ldx = args->ldx; a.N = args->N; a.D = args->D; a.DIN = args->DIN; a.L = n - 1; a.n_chunks = args->n_chunks;
+  a.stream = (const float*)args->wstream;
+  a.phi_out = (float*)args->y; a.ldphi = args->ldy;
+  for (int c = 0; c + 2 < n; ++c) {  // chain layer c gates with (and yields the gradient of) hidden layer n - 2 - c (1-based)
+    a.gate[c] = (const float*)hs[n - 3 - c];
+    a.act_out[c] = (float*)gs[n - 3 - c];
+  }
+  return ((ars_dgrad_fn)args->launcher)(&a, ARS_ABI, (int)sizeof(ArArgs), stream);
+}
+
 // One sweep of the autoregressive inverse (zuko/transforms.py:997-998): x_out = univariate(conditioner(x_cond)).inv(y).
 // x_out may alias x_cond (a wave reads its rows of x_cond completely before it writes them).
 int zk_ar_inverse_sweep(const zk_ar_args_v1* args, void* stream) {

@@ -387,6 +387,95 @@ template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(64 * S
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must land before the LDS is released
 }
 
+// ---- the backward twin: dgrad through the hidden layers in one launch ------------------------------------------------------------
+// g_{l-1} = (g_l W_l) * relu'(h_{l-1}) for the hidden layers of the conditioner (what autograd derives from zuko/nn.py:217-218 and the
+// ReLUs between them), with the gradients in registers from layer to layer exactly as the activations are in the forward kernel: the
+// chain is itself a masked MLP whose layer matrices are the TRANSPOSED sorted weights (block UPPER triangular: the same tile tables,
+// generated from the transposed masks by zuko_amd/static_ar.py:chain_tables), whose "activation" multiplies by the sign of the saved
+// forward activation, and whose every layer output is stored for the weight gradients.  Input: g of the LAST hidden layer's
+// pre-activations [N, width] (the K = features x total product with the last layer's weight stays a stand-alone GEMM); outputs: g of
+// every earlier hidden layer [N, width_l] and of the conditioner's input [N, DOUT].
+template <class S, int L, class Ring> __device__ __forceinline__ void ars_dgrad_stack(Ring& ring, const float* zero_q, int q, f32x4 (&in)[S::TMAX], f32x4 (&out)[S::TMAX], const ArArgs& a,
+                                                                                      int64_t n, int64_t nc, bool live) {
+  if constexpr (L < S::NH) {
+    ars_hidden<S, L>(ring, zero_q, in, out, false);
+    constexpr int HTL = S::HT[L];
+    if constexpr (L + 1 < S::NH) {
+      const float* grow = a.gate[L] + nc * (HTL * 16) + 4 * q;
+#pragma unroll
+      for (int t = 0; t < HTL; ++t) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(grow + t * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in[t][r] = out[t][r] * (h[r] > 0.f ? 1.f : 0.f);  // (a product, as autograd's: NaN gradients stay NaN)
+      }
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < HTL; ++t) *reinterpret_cast<f32x4*>(a.act_out[L] + n * (HTL * 16) + t * 16 + 4 * q) = in[t];
+      }
+      ars_dgrad_stack<S, L + 1, Ring>(ring, zero_q, q, in, out, a, n, nc, live);
+    } else if (live) {  // gradient w.r.t. the conditioner's input: module column order, DOUT columns
+#pragma unroll
+      for (int t = 0; t < HTL; ++t)
+        if ((t + 1) * 16 <= S::DOUT || t * 16 + 4 * q < S::DOUT) *reinterpret_cast<f32x4*>(a.phi_out + n * a.ldphi + t * 16 + 4 * q) = out[t];
+    }
+  }
+}
+
+template <class S> __global__ __launch_bounds__(512, 2) void ars_dgrad_kernel(ArArgs a) {
+  typedef ArRingS<8> Ring;
+  static_assert(S::NH >= 1 && S::NH <= 4 && S::TMAX <= 16, "dgrad chain: up to three gated layers + the input layer, widths <= 256");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  Ring ring;
+  ring.lds = ars_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < ARS_NR - 1; ++i) ring.issue();
+  ring.slot = ARS_NR - 1;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)ars_lds);
+  ring.cur_off = ring.lds_off;
+  float* zero_lds = ars_lds + ARS_NR * ARS_CH * AR_TF;  // "bias image" of a layer without bias
+  for (int i = tid; i < S::TMAX * 16 + 16; i += 512) zero_lds[i] = 0.f;
+  __syncthreads();
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n = tile * 128 + wave * 16 + j;
+    const bool live = n < a.N;
+    const int64_t nc = live ? n : a.N - 1;
+    const float* grow = a.x + nc * a.ldx;
+    f32x4 in[S::TMAX], out[S::TMAX];
+#pragma unroll
+    for (int it = 0; it < S::NIT; ++it) in[it] = *reinterpret_cast<const f32x4*>(grow + it * 16 + 4 * q);
+    ars_dgrad_stack<S, 0, Ring>(ring, zero_lds + 4 * q, q, in, out, a, n, nc, live);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <class S> static int ars_dgrad_launch(const ArArgs* in, int abi, int args_bytes, void* stream) {
+  if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;
+  ArArgs a = *in;
+  if (a.DIN != S::DIN || a.D != S::DOUT || a.L != S::NH || a.n_chunks != S::NCHUNK || !a.x || !a.phi_out || a.ldx % 4 || a.ldphi % 4 || ((uintptr_t)a.x % 16) ||
+      ((uintptr_t)a.phi_out % 16))
+    return ZK_EINVAL;
+  for (int l = 0; l + 1 < S::NH; ++l)
+    if (!a.gate[l] || !a.act_out[l] || ((uintptr_t)a.gate[l] % 16) || ((uintptr_t)a.act_out[l] % 16)) return ZK_EINVAL;
+  a.n_tiles = (a.N + 127) / 128;
+  const int lds = (ARS_NR * ARS_CH * AR_TF + S::TMAX * 16 + 16) * (int)sizeof(float);
+  const void* fn = (const void*)ars_dgrad_kernel<S>;
+  static bool granted = false;
+  if (!granted) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    granted = true;
+  }
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  void* kargs[] = {&a};
+  hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  return ZK_LAUNCH_CHECK();
+}
+
 // Launch of one instantiation; `a` arrives filled by the main library's argument checks (csrc/fused_ar.hip: zk_ar_forward_static).
 template <class S, typename Uni> static int ars_launch(const ArArgs* in, int abi, int args_bytes, int train, void* stream) {
   if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;  // kernel built against another version of the library

@@ -35,7 +35,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")
-ARS_ABI = 3  # == ARS_ABI of csrc/zk_ar_common.h
+ARS_ABI = 4  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 4: "zk::UniCircRqs8"}  # (16 bins: 12 accumulator tiles per group do not fit the double-buffered last layer)
 _HEADERS = ("fused_ar_static_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
 
@@ -282,6 +282,136 @@ def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# the backward twin: dgrad through the hidden layers (csrc/fused_ar_static_impl.h: ars_dgrad_kernel)
+# --------------------------------------------------------------------------------------------------------------------
+
+
+def chain_tables(masks_sorted: list, rows: list, cols: list):
+    """Tables + gather indices of the dgrad chain of a masked conditioner.
+
+    masks_sorted[l] (bool [out_l, in_l], l = 0 .. n-2: every linear layer but the last) are the masks in the SORTED unit order of
+    zuko_amd/train.py:SortedPlan; rows[l] / cols[l] map a sorted row / column back to the module's (so that the weight stream can be
+    gathered straight from the module's parameters).  Chain layer c multiplies by the TRANSPOSE of layer l = n-2-c.  Returns
+    (tables, gathers) — gathers[c]: int32 index into W_l.flatten() per stream element (-1 = zero), whole 24-tile chunks per layer —
+    or None when the widths do not fit (multiples of 16 up to 256 for the hidden layers, a multiple of 4 for the input)."""
+    n1 = len(masks_sorted)
+    if n1 < 1 or n1 > 4:
+        return None
+    widths_out = [m.shape[0] for m in masks_sorted]
+    if any(w % 16 or w > 256 for w in widths_out) or masks_sorted[0].shape[1] % 4 or masks_sorted[0].shape[1] > 256:
+        return None
+    lane = np.arange(64)
+    li, lq = lane % 16, lane // 16
+    S_OTG, S_IT, S_MASK, NS, HT, BASE, gathers = [], [], [], [], [], [], []
+    cursor = 0
+    for c in range(n1):
+        l = n1 - 1 - c
+        M = np.asarray(masks_sorted[l], dtype=bool)  # [out_l, in_l]
+        out_l, in_l = M.shape
+        n_ot, n_it = -(-in_l // 16), -(-out_l // 16)  # chain outputs = the layer's inputs, chain inputs = the layer's outputs
+        HT.append(n_ot)
+        blocks, n = [], 0
+        for otg in range(-(-n_ot // 4)):
+            for it in range(n_it):
+                m4 = 0
+                for t in range(4):
+                    ot = otg * 4 + t
+                    if ot < n_ot and M[it * 16 : (it + 1) * 16, ot * 16 : (ot + 1) * 16].any():
+                        m4 |= 1 << t
+                if m4:
+                    S_OTG.append(otg), S_IT.append(it), S_MASK.append(m4)
+                    n += 1
+                    for t in range(4):
+                        if m4 >> t & 1:
+                            a_ = (otg * 4 + t) * 16 + li[:, None]                        # chain row  = sorted INPUT unit of layer l
+                            b_ = it * 16 + (4 * lq)[:, None] + np.arange(4)[None, :]      # chain col  = sorted OUTPUT unit of layer l
+                            ok = (a_ < in_l) & (b_ < out_l)
+                            idx = np.where(ok, np.asarray(rows[l])[np.minimum(b_, out_l - 1)] * in_l + np.asarray(cols[l])[np.minimum(a_, in_l - 1)], -1)
+                            blocks.append(idx.reshape(-1))
+        NS.append(n)
+        pad = -(-len(blocks) // 24) * 24 - len(blocks)
+        blocks += [-np.ones(256, dtype=np.int64)] * pad
+        BASE.append(cursor)
+        cursor += len(blocks)
+        gathers.append(np.concatenate(blocks).astype(np.int32) if blocks else np.zeros(0, np.int32))
+    NIT = -(-widths_out[-1] // 16)
+    t = {"chain": 1, "DIN": int(widths_out[-1]), "DOUT": int(masks_sorted[0].shape[1]), "NIT": int(NIT), "NH": n1, "HT": HT, "TMAX": int(4 * -(-max([NIT] + HT) // 4)),
+         "NCHUNK": cursor // 24, "NS": NS, "S_OTG": S_OTG, "S_IT": S_IT, "S_MASK": S_MASK, "BASE": BASE}
+    if t["TMAX"] > 16 or cursor == 0:
+        return None
+    return t, gathers
+
+
+def emit_chain(t: dict) -> str:
+    soff = [0]
+    for n in t["NS"]:
+        soff.append(soff[-1] + n)
+    lines = [
+        "// generated by zuko_amd/static_ar.py — do not edit",
+        '#include "fused_ar_static_impl.h"',
+        "namespace {",
+        "struct Shape {",
+        f"  static constexpr int DIN = {t['DIN']}, DOUT = {t['DOUT']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NCHUNK = {t['NCHUNK']}, WAVES = 8, ACT = 1;",
+        "  static constexpr bool HAS_ALT = false;",
+        _arr("HT", "int", t["HT"]), _arr("NS", "int", t["NS"]), _arr("SOFF", "int", soff), _arr("BASE", "int", t["BASE"]),
+        _arr("S_OTG", "unsigned char", t["S_OTG"]), _arr("S_IT", "unsigned char", t["S_IT"]), _arr("S_ALT", "unsigned char", t["S_IT"]),
+        _arr("S_MASK", "unsigned char", t["S_MASK"]),
+        "};",
+        "}  // namespace",
+        'extern "C" int zk_ars_dgrad_launch(const zk::ArArgs* a, int abi, int args_bytes, void* stream) { return zk::ars_dgrad_launch<Shape>(a, abi, args_bytes, stream); }',
+        "",
+    ]
+    return "\n".join(lines)
+
+
+class ChainKernel:
+    def __init__(self, so: str) -> None:
+        self.so = so
+        self.cdll = ctypes.CDLL(so)
+        self.launcher = ctypes.cast(self.cdll.zk_ars_dgrad_launch, ctypes.c_void_p)
+
+
+_CHAINS: dict[str, ChainKernel] = {}
+
+
+def chain_kernel(t: dict, allow_compile: bool, verbose: bool = False):
+    """The compiled dgrad-chain kernel for tables `t` (lib/ars/arsd_<sig>.so), built on demand when allowed; None otherwise."""
+    stamp = _header_digest()
+    sig = _digest({"t": t, "headers": stamp})
+    so = os.path.join(ARS_DIR, f"arsd_{sig}.so")
+    with _LOCK:
+        k = _CHAINS.get(so)
+        if k is not None:
+            return k
+        if not os.path.exists(so):
+            hipcc = _hipcc()
+            if not allow_compile or hipcc is None:
+                return None
+            os.makedirs(ARS_DIR, exist_ok=True)
+            with open(os.path.join(ARS_DIR, f".lock_{sig}"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if not os.path.exists(so):
+                    src = os.path.join(ARS_DIR, f"arsd_{sig}.hip")
+                    with open(src, "w") as f:
+                        f.write(emit_chain(t))
+                    with open(os.path.join(ARS_DIR, f"arsd_{sig}.json"), "w") as f:
+                        json.dump({"so": f"arsd_{sig}.so", "headers": stamp, "core": "chain", "l0": [], "alt": None, "DIN": t["DIN"], "DOUT": t["DOUT"], "HT": t["HT"]}, f)
+                    tmp = so + f".{os.getpid()}"
+                    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
+                           src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
+                    if verbose:
+                        print("[zuko_amd static_ar]", " ".join(cmd), flush=True)
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                    if r.returncode != 0:
+                        sys.stderr.write(f"[zuko_amd static_ar] hipcc failed for {src}:\n{r.stdout[-2000:]}\n")
+                        return None
+                    os.replace(tmp, so)
+        k = ChainKernel(so)
+        _CHAINS[so] = k
+        return k
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # ahead-of-time list
 # --------------------------------------------------------------------------------------------------------------------
 
@@ -323,8 +453,21 @@ def _plans_for(kind: str, features: int, context: int, hidden, bins: int, activa
             layout = fused.uni_layout("rqs", 3 * bins - 1, bins)
         masks = [m.mask for m in t.hyper if isinstance(m, MaskedLinear)]
         wide = max(list(hidden) + [features + context]) > fused.MAX_WIDTH
-        out.append((fused.build_plan(masks, features, layout, max_width=fused.MAX_WIDTH_WIDE if wide else fused.MAX_WIDTH), layout))
+        out.append((fused.build_plan(masks, features, layout, max_width=fused.MAX_WIDTH_WIDE if wide else fused.MAX_WIDTH), layout, [m for m in t.hyper if isinstance(m, MaskedLinear)]))
     return out
+
+
+def chain_tables_for(lins):
+    """chain_tables of a masked ReLU conditioner given its linear layers (through zuko_amd/train.py:SortedPlan), or None."""
+    import torch
+
+    from .train import SortedPlan
+
+    sp = SortedPlan(lins, 1, torch.device("cpu"))
+    n = len(lins)
+    if n < 2 or n > 4 or any(m is None for m in sp.mask_s_cpu):
+        return None
+    return chain_tables(sp.mask_s_cpu[: n - 1], sp.rows_cpu[: n - 1], sp.cols_cpu[: n - 1])
 
 
 def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
@@ -352,7 +495,7 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
                     os.remove(os.path.join(ARS_DIR, name))
                 except OSError:
                     pass
-    work = []
+    work, chains = [], []
     for entry in PREBUILT:
         kind, features, context, hidden, bins = entry[:5]
         import torch
@@ -360,7 +503,12 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
         from .nn import _act_code
 
         act = _act_code(getattr(torch.nn, entry[5])()) if len(entry) > 5 else 1
-        (pa, layout), (pd, _) = _plans_for(kind, features, context, hidden, bins)
+        (pa, layout, lins_a), (pd, _, lins_d) = _plans_for(kind, features, context, hidden, bins)
+        if act == 1:  # the training backward of the same conditioners (one kernel per feature order)
+            for lins in (lins_a, lins_d):
+                tg = chain_tables_for(lins)
+                if tg is not None and not any(c[0] == tg[0] for c in chains):
+                    chains.append(tg)
         ta, td = tables(pa, layout.kind, act), tables(pd, layout.kind, act)
         if ta is None or td is None:
             raise RuntimeError(f"zuko_amd.static_ar: no static kernel for the prebuilt shape {entry}")
@@ -371,9 +519,10 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
             work += [(ta, None), (td, None)]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         metas = list(ex.map(lambda w: compile_kernel(w[0], w[1], verbose), work))
-    if any(m is None for m in metas):
+        kerns = list(ex.map(lambda tg: chain_kernel(tg[0], True, verbose), chains))
+    if any(m is None for m in metas) or any(k is None for k in kerns):
         raise RuntimeError("zuko_amd.static_ar: a prebuilt static kernel failed to compile")
-    return [m["so"] for m in metas]
+    return [m["so"] for m in metas] + [os.path.basename(k.so) for k in kerns]
 
 
 if __name__ == "__main__":

@@ -65,6 +65,7 @@ class SortedPlan:
         self.mask_u8 = []
         self.cs_flag = []
         self.cols_dev = []  # sorted column -> module column of every layer (idx_b holds the rows)
+        self.rows_cpu, self.cols_cpu, self.mask_s_cpu = [], [], []  # host copies (tables of the dgrad-chain kernel)
         prev = None
         for i, (out_f, in_f) in enumerate(shapes):
             rows = perms[i] if perms[i] is not None else torch.arange(out_f)
@@ -78,6 +79,7 @@ class SortedPlan:
             self.idx_wt.append(idx.t().reshape(-1).contiguous().to(device))
             self.idx_b.append(rows.to(torch.int32).to(device))
             self.cols_dev.append(cols.to(torch.int32).to(device))
+            self.rows_cpu.append(rows.numpy().copy()), self.cols_cpu.append(cols.numpy().copy()), self.mask_s_cpu.append(None if m is None else ms.numpy().copy())
             kf, kb = (None, None) if m is None else (self._kskip(ms), self._kskip(ms.t().contiguous()))
             self.kskip_f.append(None if kf is None else kf.to(device))
             self.kskip_b.append(None if kb is None else kb.to(device))
@@ -120,17 +122,21 @@ class SortedPlan:
 
     # ---- device work -------------------------------------------------------------------------------------------
 
-    def gather(self, lins, forward: bool = True):
+    def gather(self, lins, forward: bool = True, transposes=None):
         """Sorted, masked weights Ws_l [out, in], their transposes [in, out] and sorted biases (fresh tensors).  forward=False:
-        only what the backward pass reads (the transposes; ws entries are None, biases are reported as present / absent)."""
+        only what the backward pass reads (the transposes; ws entries are None, biases are reported as present / absent).
+        transposes: the layers whose transpose is wanted (None = all; the others come back as None)."""
         lib = _C.lib()
         ws, wts, bs = [], [], []
         for l, lin in enumerate(lins):
             out_f, in_f = self.shapes[l]
             w = lin.weight.detach().contiguous()
-            wt_l = torch.empty((in_f, out_f), dtype=torch.float32, device=self.device)
-            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(self.mask_u8[l]), _ptr(self.idx_wt[l]), out_f * in_f, _ptr(wt_l), _stream()), "zk_gather_f32")
-            wts.append(wt_l)
+            if transposes is None or l in transposes:
+                wt_l = torch.empty((in_f, out_f), dtype=torch.float32, device=self.device)
+                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(self.mask_u8[l]), _ptr(self.idx_wt[l]), out_f * in_f, _ptr(wt_l), _stream()), "zk_gather_f32")
+                wts.append(wt_l)
+            else:
+                wts.append(None)
             if not forward:
                 ws.append(None)
                 bs.append(None if lin.bias is None else True)
@@ -255,6 +261,71 @@ def _fused_forward(st, x: Tensor, out_features: int):
     return hs, phi
 
 
+class DgradChain:
+    """Backward of every linear layer but the last in one launch (csrc/fused_ar_static_impl.h: ars_dgrad_kernel; C ABI
+    zk_ar_dgrad_chain): a generated kernel whose weight stream holds the TRANSPOSED sorted masked weights, tile by tile."""
+
+    def __init__(self, plan: SortedPlan, kernel, tables: dict, gathers, device) -> None:
+        self.kernel, self.t = kernel, tables
+        self.idx = [torch.from_numpy(g).to(device) for g in gathers]
+        self.offsets = [b * 256 for b in tables["BASE"]]
+        self.device = device
+
+    def gather(self, plan: SortedPlan, lins) -> Tensor:
+        """The kernel's weight stream from the module's CURRENT parameters (a fresh tensor: the forward saves it for its backward)."""
+        lib = _C.lib()
+        stream = torch.empty(self.t["NCHUNK"] * 24 * 256, dtype=torch.float32, device=self.device)
+        n1 = len(self.idx)
+        for c, idx in enumerate(self.idx):
+            l = n1 - 1 - c
+            w = lins[l].weight.detach().contiguous()
+            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(plan.mask_u8[l]), _ptr(idx), idx.numel(), _ptr(stream[self.offsets[c] :]), _stream()), "zk_gather_f32")
+        return stream
+
+    def run(self, plan: SortedPlan, stream: Tensor, g_last: Tensor, hs):
+        """g_last [N, width] = gradient of the last hidden layer's pre-activations; hs = [x, h_1, ..] as saved by the forward.
+        Returns ([g_1, .., g_last], gx)."""
+        n = len(plan.shapes)
+        N = g_last.shape[0]
+        dev = g_last.device
+        gs = [torch.empty((N, plan.shapes[l][0]), dtype=torch.float32, device=dev) for l in range(n - 2)]
+        gx = torch.empty((N, plan.shapes[0][1]), dtype=torch.float32, device=dev)
+        hp = [_ptr(hs[1 + l]) for l in range(n - 2)] + [None] * 3
+        gp = [_ptr(g) for g in gs] + [None] * 3
+        a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, N=N, D=plan.shapes[0][1], DIN=g_last.shape[1], x=_ptr(g_last), ldx=g_last.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
+                    gh1=gp[0], gh2=gp[1], gh3=gp[2], y=_ptr(gx), ldy=gx.stride(0), wstream=_ptr(stream), n_layers=n, n_chunks=self.t["NCHUNK"], act=1)
+        _C.check(_C.lib().zk_ar_dgrad_chain(a, _stream()), "zk_ar_dgrad_chain")
+        return gs + [g_last], gx
+
+
+_CHAINS = weakref.WeakKeyDictionary()  # SortedPlan -> DgradChain or False
+
+
+def _dgrad_chain(plan: SortedPlan, lins, rows: int):
+    """The dgrad-chain kernel of this network, or None (not a masked ReLU conditioner of 2-4 layers with hidden widths that are
+    multiples of 16 up to 256, kernel not built and compiling not allowed, ZUKO_AMD_NO_DGRAD_CHAIN=1)."""
+    import os
+
+    if os.environ.get("ZUKO_AMD_NO_DGRAD_CHAIN", "0") == "1":
+        return None
+    st = _CHAINS.get(plan)
+    if st is None:
+        st = False
+        n = len(lins)
+        if 2 <= n <= 4 and plan.act == 1 and all(m is not None for m in plan.mask_s_cpu):
+            from . import static_ar
+
+            tg = static_ar.chain_tables(plan.mask_s_cpu[: n - 1], plan.rows_cpu[: n - 1], plan.cols_cpu[: n - 1])
+            if tg is not None:
+                kern = static_ar.chain_kernel(tg[0], allow_compile=static_ar.jit_enabled() and rows >= static_ar.jit_min_rows())
+                if kern is not None:
+                    st = DgradChain(plan, kern, tg[0], tg[1], plan.device)
+                else:
+                    return None  # (not cached: a later, larger batch may be allowed to compile)
+        _CHAINS[plan] = st
+    return st or None
+
+
 class ConditionerFn(torch.autograd.Function):
     """phi = net(x) for a plain (linear, activation)* network; x [N, in] contiguous fp32.  Inputs after `x`: weight_0,
     bias_0 (or None), weight_1, ... in layer order."""
@@ -263,7 +334,10 @@ class ConditionerFn(torch.autograd.Function):
     def forward(ctx, plan: SortedPlan, lins, x: Tensor, *params):
         n = len(lins)
         st = _fused_forward_state(plan, lins, x.device) if (x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
-        ws, wts, bs = plan.gather(lins, forward=st is None)
+        chain = _dgrad_chain(plan, lins, x.shape[0]) if n >= 2 else None
+        ws, wts, bs = plan.gather(lins, forward=st is None, transposes=None if chain is None else {n - 1})
+        if chain is not None:  # (the backward of every layer but the last reads this stream instead of the transposes)
+            wts = [chain.gather(plan, lins), wts[n - 1]]
         if st is not None:  # whole forward in one launch of the static-shape kernel
             st.refresh(lins, fine_only=True)
             acts, h = _fused_forward(st, x, plan.shapes[-1][0])
@@ -274,7 +348,7 @@ class ConditionerFn(torch.autograd.Function):
             for l in range(n):
                 h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l + 1 < n else 0)
                 hs.append(h)
-        ctx.plan, ctx.n = plan, n
+        ctx.plan, ctx.n, ctx.chain = plan, n, chain
         ctx.has_bias = [b is not None for b in bs]
         ctx.save_for_backward(*hs[:-1], *wts)
         return h
@@ -287,6 +361,8 @@ class ConditionerFn(torch.autograd.Function):
         hs, wts = saved[:n], saved[n:]
         g = g_phi.contiguous()
         grads: list = [None] * (2 * n)
+        if ctx.chain is not None:
+            return ConditionerFn._backward_chain(ctx, ctx.chain, g, hs, wts, grads)
         for l in range(n - 1, -1, -1):
             out_f, in_f = plan.shapes[l]
             want_b = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
@@ -305,6 +381,33 @@ class ConditionerFn(torch.autograd.Function):
                 g = plan.gemm(g, wts[l], plan.kskip_b[l], None, 0, hs[l] if l > 0 else None, plan.act if l > 0 else 0)
         gx = g if ctx.needs_input_grad[2] else None
         return (None, None, gx, *grads)
+
+    @staticmethod
+    def _param_grads(ctx, l: int, g: Tensor, h: Tensor, grads: list) -> None:
+        plan = ctx.plan
+        out_f = plan.shapes[l][0]
+        want_b = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
+        dbs = None
+        if ctx.needs_input_grad[3 + 2 * l]:
+            grads[2 * l], dbs = plan.wgrad(l, g, h, want_bias=True) if want_b else (plan.wgrad(l, g, h), None)
+        if want_b:
+            if dbs is None:
+                dbs = plan.colsum(g)
+            db = torch.empty(out_f, dtype=torch.float32, device=g.device)
+            db[plan.idx_b64[l]] = dbs
+            grads[2 * l + 1] = db
+
+    @staticmethod
+    def _backward_chain(ctx, chain: "DgradChain", g: Tensor, hs, wts, grads: list):
+        """Last layer as the layer-wise path (its K = out_features product is a plain GEMM), every other dgrad in one launch."""
+        plan, n = ctx.plan, ctx.n
+        ConditionerFn._param_grads(ctx, n - 1, g, hs[n - 1], grads)
+        stream, wt_last = wts
+        g_last = plan.gemm(g, wt_last, plan.kskip_b[n - 1], None, 0, hs[n - 1], plan.act)
+        gs, gx = chain.run(plan, stream, g_last, hs)
+        for l in range(n - 2, -1, -1):
+            ConditionerFn._param_grads(ctx, l, gs[l], hs[l], grads)
+        return (None, None, gx if ctx.needs_input_grad[2] else None, *grads)
 
 
 def plan_for(module, device: torch.device):
