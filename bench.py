@@ -576,6 +576,13 @@ def main() -> None:
             st = None
         # 16 x 16 x 2 FLOP per streamed tile per sample (the static-shape kernel streams fewer tiles than the generic one)
         executed = None if st is None or not hasattr(st.plan, "kept_tiles") else (st.plan.fine_kept_tiles if getattr(st, "static_variant", 0) else st.plan.kept_tiles) * 512.0
+        split = bool(st is not None and getattr(st, "static", None) is not None and st.static[0].meta.get("split"))
+        if split:  # operand-split kernels: 16 x 32 x 2 f32-equivalent FLOP per streamed block per sample
+            from zuko_amd import static_ar
+
+            tsp = static_ar.split_tables(st.plan, st.plan.layout.kind, st.act)[0]
+            executed = (sum(tsp["NB"]) + tsp["GOFF"][-1] * st.plan.layout.nt) * 1024.0
+        per_transform["split"] = split
         last = [m for m in flow.transform.transforms[0].hyper.modules() if getattr(m, "weight", None) is not None][-1]
         lmask = getattr(last, "mask", None)
         per_transform["last_layer_nnz_frac"] = 1.0 if lmask is None else float(lmask.float().mean())
@@ -596,6 +603,9 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
+            **({"dtype_note": "f32 in, f32 out, f32 accumulation; the conditioner's products run on the bf16 matrix instruction with every f32 operand split into three bf16 numbers "
+                              "(six partial products: the rounding of an f32 dot product, see `parity`); ZUKO_AMD_EXACT_F32=1 selects the f32 matrix instruction"}
+               if (roof or {}).get("f32_instruction_peak") else {}),
             "data": "synthetic",
             "config": {
                 "workload": f"{workload}, batch=2^{args.batch_log2} per GPU, x~N(0,1), seed-0 init",
@@ -608,7 +618,7 @@ def main() -> None:
                 "flop_per_sample_dense": flops["dense"],
                 "flop_per_sample_nonzero_weights": flops["nnz"],
                 "tflops_on_nonzero_weights": value / world * flops["nnz"] / 1e12,
-                "frac_of_mfma_peak_on_nonzero_weights": value / world * flops["nnz"] / 1e12 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS),
+                "frac_of_mfma_peak_on_nonzero_weights": value / world * flops["nnz"] / 1e12 / (roof["peak"] if roof and roof.get("bound") == "mfma" else (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS)),
                 "tflops_dense_equiv": value / world * flops["dense"] / 1e12,
                 "note": "dense_equiv counts masked-out (structurally zero) weights the kernels never multiply; it is NOT a hardware fraction",
             },
@@ -676,13 +686,21 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
             n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
             row.update(bound="mfma", achieved=2.0 * n * fin * fout / t / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
         elif parts[0] in ("zk_ar_forward", "zk_coupling_forward"):
-            row.update(bound="mfma", achieved=float(B) * flop_per_transform["nnz"] / t / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+            split = bool(flop_per_transform.get("split")) and parts[0] == "zk_ar_forward" and "static" in rec.get("instantiation", "")
+            # operand-split kernels: every f32 product = 6 bf16 matrix products (csrc/fused_ar_split_impl.h), so the ceiling for f32-equivalent
+            # FLOP is the dense bf16 peak / 6; the f32 matrix instruction's own peak stays on the line for comparison
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
+            row.update(bound="mfma", achieved=float(B) * flop_per_transform["nnz"] / t / 1e12, peak=peak, unit="TFLOP/s")
+            if split:
+                row["instantiation"] = "static-shape, operand-split (3 x bf16 per f32 operand, 6 partial products, f32 accumulate)"
+                row["peak_basis"] = f"{PEAK_BF16_MFMA_TFLOPS:g} TFLOP/s dense bf16 / 6 matrix products per f32 product; f32-equivalent FLOP"
+                row["f32_instruction_peak"] = PEAK_F32_MFMA_TFLOPS
             row["algorithmic_flop_per_launch"] = float(B) * flop_per_transform["nnz"]
             row["dense_equiv_tflops"] = float(B) * flop_per_transform["dense"] / t / 1e12
             if executed_per_sample and parts[0] == "zk_ar_forward":
                 row["executed_flop_per_launch"] = float(B) * executed_per_sample
                 row["achieved_executed"] = float(B) * executed_per_sample / t / 1e12
-                row["frac_executed"] = row["achieved_executed"] / PEAK_F32_MFMA_TFLOPS
+                row["frac_executed"] = row["achieved_executed"] / peak
         elif parts[0] == "zk_rqs_forward" and len(parts) == 4 and parts[1].isdigit():
             n, d, k = int(parts[1]), int(parts[2]), int(parts[3])
             esz = 2 if rec.get("bf16") else 4
@@ -698,7 +716,7 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
         roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                 "traffic": traffic, "traffic_source": (f"{src}: rocprofv3 --pmc passes of this same command, not re-measured in this run" if src else None),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]}
-        for k in ("instantiation", "algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
+        for k in ("instantiation", "peak_basis", "f32_instruction_peak", "algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
             if k in dom:
                 roof[k] = dom[k]
     return roof, table

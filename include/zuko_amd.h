@@ -347,6 +347,10 @@ int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */
 int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n, void* dst, void* stream);
+/* Weight stream of an operand-split static-shape kernel (zuko_amd/static_ar.py: split_tables; csrc/fused_ar_split_impl.h): every f32
+ * weight as three bf16 numbers h + m + l.  idx [n_blocks * 512] int32 (lane-major, 8 per lane, -1 = zero) into src, mask as
+ * zk_gather_f32; dst receives three 1 KiB images per block. */
+int zk_gather_split_bf16(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n_blocks, void* dst, void* stream);
 
 /* ---- backward (vector-Jacobian products; fp32).  The reference has no backward code: autograd runs
  *      through the ATen ops of zuko/transforms.py:480-490,554-567 (spline), :436-446 (affine),

@@ -291,3 +291,99 @@ def test_training_plan_sorts_units_by_their_true_dependency_count():
         deps = fused._deps([m.mask.numpy().astype(bool) for m in lins])
         for l in range(3):
             assert np.array_equal(plan.perms[l].numpy(), np.argsort(deps[l].sum(axis=1), kind="stable"))
+
+
+def _bf16_round(x: np.ndarray) -> np.ndarray:
+    return torch.from_numpy(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _split3(x: np.ndarray):
+    x = np.asarray(x, dtype=np.float32)
+    h = _bf16_round(x)
+    m = _bf16_round(x - h)
+    l = _bf16_round(x - h - m)
+    return h, m, l
+
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("rqs", 3, 5, (128, 128, 128), 8), ("rqs", 20, 3, (100, 72), 8),
+                                 ("affine", 7, 2, (40,), 0)])
+def test_split_kernel_tables_describe_the_plan(cfg):
+    """Tables + gathers of the operand-split kernels (static_ar.split_tables; csrc/fused_ar_split_impl.h) walked on the CPU exactly as
+    the kernel walks them — blocks of (out tile, in pair) as three bf16 images, six partial products per block — must give the masked
+    MLP's output to f32 accuracy, both feature orders, including widths that are not multiples of 16 / 32 and a context."""
+    from zuko_amd import static_ar
+
+    kind, D, C, hidden, bins = cfg
+    rng = np.random.default_rng(11)
+    for plan, lay, lins in static_ar._plans_for(kind, D, C, hidden, bins):
+        ts = static_ar.split_tables(plan, lay.kind, 1)
+        assert ts is not None
+        t, gathers = ts
+        NH = t["NH"]
+        assert t["NCHUNK"] * 24 == sum(len(g) // 512 for g in gathers) * 3 and all(len(g) % (8 * 512) == 0 for g in gathers)
+        assert [b * 1 for b in t["BASE"]] == [3 * sum(len(g) // 512 for g in gathers[:l]) for l in range(NH)]
+        W = [l.weight.detach().numpy().astype(np.float32) * l.mask.numpy() for l in lins]
+        Bv = [l.bias.detach().numpy().astype(np.float64) for l in lins]
+        x = rng.standard_normal(plan.din).astype(np.float32)
+        # reference: the masked MLP in float64 (module order)
+        h = x.astype(np.float64)
+        for l in range(NH + 1):
+            h = W[l].astype(np.float64) @ h + Bv[l]
+            if l < NH:
+                h = np.maximum(h, 0.0)
+        ref = h
+        # the kernel's walk: activations as tiles of 16 in the plan's sorted unit order
+        def images(l):
+            idx = gathers[l].reshape(-1, 64, 8)
+            flat = W[l].reshape(-1)
+            vals = np.where(idx >= 0, flat[np.maximum(idx, 0)], 0.0).astype(np.float32)
+            return _split3(vals)
+        vec = np.zeros(t["TMAX"] * 16, dtype=np.float32)
+        vec[: plan.din] = x
+        boff = 0
+        for l in range(NH):
+            ah, am, al = images(l)
+            bias_img = np.where(plan.bias_gather[l] >= 0, Bv[l][np.maximum(plan.bias_gather[l], 0)], 0.0)
+            out = bias_img[: t["TMAX"] * 16].astype(np.float64).copy()
+            vh, vm, vl = _split3(vec)
+            for s in range(t["NB"][l]):
+                ot, ip = t["B_OT"][boff + s], t["B_IP"][boff + s]
+                for lane in range(64):
+                    i, kq = lane % 16, lane // 16
+                    units = np.concatenate([np.arange(4) + (2 * ip) * 16 + 4 * kq, np.arange(4) + (2 * ip + 1) * 16 + 4 * kq])
+                    acc = 0.0
+                    for a_, b_ in ((al, vh), (ah, vl), (am, vm), (am, vh), (ah, vm), (ah, vh)):
+                        acc += float(np.dot(a_[s, lane].astype(np.float64), b_[units].astype(np.float64)))
+                    out[ot * 16 + i] += acc
+            assert not ah[t["NB"][l] :].any()
+            boff += t["NB"][l]
+            vec = np.zeros_like(vec)
+            vec[: t["HT"][l] * 16] = np.maximum(out[: t["HT"][l] * 16], 0.0).astype(np.float32)
+        # last layer: group g, tile b, tile row i <-> feature slot / parameter (fused.build_plan)
+        ah, am, al = images(NH)
+        vh, vm, vl = _split3(vec)
+        nt, total, fpl = lay.nt, lay.total, lay.fpl
+        got = np.full(D * total, np.nan)
+        blk = 0
+        bias_last = plan.bias_gather[NH].reshape(-1, nt, 16)
+        for g in range(t["NG"]):
+            acc = np.zeros((nt, 16))
+            for b in range(nt):
+                acc[b] = np.where(bias_last[g, b] >= 0, Bv[NH][np.maximum(bias_last[g, b], 0)], 0.0)
+            for st in range(t["GOFF"][g], t["GOFF"][g + 1]):
+                ip = t["G_IP"][st]
+                for b in range(nt):
+                    for lane in range(64):
+                        i, kq = lane % 16, lane // 16
+                        units = np.concatenate([np.arange(4) + (2 * ip) * 16 + 4 * kq, np.arange(4) + (2 * ip + 1) * 16 + 4 * kq])
+                        for a_, b_ in ((al, vh), (ah, vl), (am, vm), (am, vh), (ah, vm), (ah, vh)):
+                            acc[b, i] += float(np.dot(a_[blk, lane].astype(np.float64), b_[units].astype(np.float64)))
+                    blk += 1
+            for b in range(nt):
+                for i in range(16):
+                    r = bias_last[g, b, i]
+                    if r >= 0:
+                        got[r] = acc[b, i]
+        assert not np.isnan(got).any()
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-6 * scale, (np.abs(got - ref).max(), scale)

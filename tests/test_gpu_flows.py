@@ -664,6 +664,7 @@ def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, case, N, m
     kind, D, C, hidden = case[:4]
     kw = dict(activation=getattr(torch.nn, case[4])) if len(case) > 4 else {}  # (ELU / tanh: the activation is part of the generated kernel)
     monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")  # unlisted shapes: compile now (hipcc, ~15 s each, cached in zuko_amd/lib/ars/)
+    monkeypatch.setenv("ZUKO_AMD_EXACT_F32", "1")     # the f32-instruction kernels (the operand-split ones: test_split_kernels_* below)
     torch.manual_seed(3)
     flow = (NSF(D, C, transforms=2, bins=8, hidden_features=hidden, **kw) if kind == "nsf" else MAF(D, C, transforms=2, hidden_features=hidden, **kw)).to(dev)
     g = torch.Generator().manual_seed(N)
@@ -696,6 +697,60 @@ def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, case, N, m
         st.run(inp, torch.empty(N, D, device=dev), l2, True)
         ref = out[0][1] + out[0][1]
         assert same(l2[~torch.isnan(ref)], ref[~torch.isnan(ref)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", STATIC_CASES, ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}" + (f"-{c[4]}" if len(c) > 4 else ""))
+@pytest.mark.parametrize("N", [1, 129, 1000, 40000])
+def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
+    """The operand-split kernels (csrc/fused_ar_split_impl.h: every f32 operand as three bf16 numbers, six partial products on the
+    bf16 matrix instruction, f32 accumulation) are the default static-shape kernels.  Against float64 they must be as close as the
+    f32-instruction kernel is (measured bar of tests/parity.py with the generic f32 kernel in the reference's place, C = 2), the NaN
+    pattern of poisoned rows must be identical, and `accumulate` must add to ladj."""
+    from zuko_amd.flows import MAF, NSF
+    from zuko_amd.nn import MaskedLinear
+
+    kind, D, C, hidden = case[:4]
+    kw = dict(activation=getattr(torch.nn, case[4])) if len(case) > 4 else {}
+    monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
+    torch.manual_seed(3)
+    flow = (NSF(D, C, transforms=2, bins=8, hidden_features=hidden, **kw) if kind == "nsf" else MAF(D, C, transforms=2, hidden_features=hidden, **kw)).to(dev)
+    g = torch.Generator().manual_seed(N)
+    din = D + C
+    inp = torch.zeros(N, -(-din // 4) * 4)
+    inp[:, :din] = torch.randn(N, din, generator=g) * 1.5
+    if N >= 127:
+        inp[5, min(7, D - 1)] = float("nan")
+        inp[100, din - 1] = float("inf")
+    x_cpu = inp[:, :D]
+    inp = inp.to(dev)
+    for i, lazy in enumerate(flow.transform.transforms):
+        st = lazy.fused_state(dev)
+        assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1, "an operand-split kernel must be selected"
+        st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+        keep = st.static
+        y, ladj = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+        st.run(inp, y, ladj, False)
+        st.static = None
+        y0, ladj0 = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+        st.run(inp, y0, ladj0, False)
+        st.static = keep
+        # float64: the oracle's masked MLP and univariate map in double on the same parameters
+        lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+        act = {"ELU": torch.nn.functional.elu, "Tanh": torch.tanh}[case[4]] if len(case) > 4 else torch.relu
+        uni = O.uni_rqs(8) if kind == "nsf" else O.UNI_AFFINE
+        with torch.no_grad():
+            phi = O.mlp_forward(inp.cpu()[:, :din].double(), [l.weight.detach().cpu().double() for l in lins], [l.bias.detach().cpu().double() for l in lins],
+                                [l.mask.cpu() for l in lins], act=act)
+            y64, l64 = O.univariate_forward(uni, phi.reshape(N, D, uni.total), x_cpu.double())
+            l64 = l64.sum(dim=-1)
+        tag = f"split kernel {case} N={N} transform {i}"
+        assert_parity(y, y0, y64, f"{tag}: y", c=2.0)
+        assert_parity(ladj, ladj0, l64, f"{tag}: ladj", c=2.0)
+        l2 = ladj.clone()
+        st.run(inp, torch.empty(N, D, device=dev), l2, True)
+        ok = ~torch.isnan(ladj)
+        assert torch.equal(l2[ok], (ladj + ladj)[ok])
 
 
 @pytest.mark.gpu

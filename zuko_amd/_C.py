@@ -94,6 +94,7 @@ SIGNATURES = {
     "zk_diag_normal_log_prob": [I, L, L, P, P, P, P, P, P],
     "zk_sum_f64": [I, L, P, F, P, P, P],
     "zk_gather_f32": [P, P, P, L, P, P],
+    "zk_gather_split_bf16": [P, P, P, L, P, P],
     "zk_univariate_backward": [I, L, L, I, F, F, P, P, P, P, I, P, P, P],
     "zk_diag_normal_backward": [L, L, P, P, P, P, P, P],
     "zk_act_backward": [L, P, P, I, P, P],

@@ -354,6 +354,33 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ s
   }
 }
 
+// Weight stream of the operand-split kernels (fused_ar_split_impl.h): per block of 64 lanes x 8 weights, three 1 KiB bf16 images
+// h = bf16(w), m = bf16(w - h), l = bf16(w - h - m) (round to nearest even; both differences are exact in f32).
+__global__ __launch_bounds__(256) void gather_split_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, const int32_t* __restrict__ idx, int64_t n_lanes,
+                                                           uint4* __restrict__ dst) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_lanes; i += (int64_t)gridDim.x * 256) {
+    const int4 k0 = *reinterpret_cast<const int4*>(idx + i * 8), k1 = *reinterpret_cast<const int4*>(idx + i * 8 + 4);
+    const int k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = 0.f;
+      if (k[e] >= 0 && (!mask || mask[k[e]])) v = src[k[e]];
+      const __bf16 hh = (__bf16)v;
+      const float r1 = v - (float)hh;
+      const __bf16 mm = (__bf16)r1;
+      const float r2 = r1 - (float)mm;
+      h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    }
+    const int64_t b = i >> 6;
+    const int lane = (int)(i & 63);
+    dst[(b * 3 + 0) * 64 + lane] = __builtin_bit_cast(uint4, h);
+    dst[(b * 3 + 1) * 64 + lane] = __builtin_bit_cast(uint4, m);
+    dst[(b * 3 + 2) * 64 + lane] = __builtin_bit_cast(uint4, l);
+  }
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -365,6 +392,16 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
   if (n <= 0) return 0;
   int64_t nb = (n + 255) / 256;
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, (const float*)src, mask, idx, n, (float*)dst);
+  return ZK_LAUNCH_CHECK();
+}
+
+// Weight stream of an operand-split static-shape kernel: idx [n_blocks * 512] (lane-major, 8 per lane; -1 = zero) into src, mask as
+// zk_gather_f32; dst receives 3 KiB per block (bf16 images h, m, l of 64 lanes x 8 values).
+int zk_gather_split_bf16(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n_blocks, void* dst, void* stream) {
+  if (n_blocks <= 0) return 0;
+  if (!src || !idx || !dst || ((uintptr_t)idx % 16) || ((uintptr_t)dst % 16)) return ZK_EINVAL;
+  const int64_t n_lanes = n_blocks * 64, nb = (n_lanes + 255) / 256;
+  hipLaunchKernelGGL(gather_split_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, (const float*)src, mask, idx, n_lanes, (uint4*)dst);
   return ZK_LAUNCH_CHECK();
 }
 

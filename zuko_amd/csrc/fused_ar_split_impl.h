@@ -1,0 +1,338 @@
+// zuko_amd — operand-split twin of the static-shape fused autoregressive kernel (fused_ar_static_impl.h):
+//
+//     y, log|dy/dx| = univariate(conditioner(cat(x, c))).call_and_ladj(x)      (zuko/flows/autoregressive.py:207-218)
+//
+// gfx950 has no xf32 / tf32 matrix instruction and its f32 one (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate, which is what
+// bounded the f32 kernels (matrix pipe 83 % busy, profiles/r03).  Here every f32 operand v is written as the exact sum of three bf16
+// numbers h = bf16(v), m = bf16(v - h), l = bf16(v - h - m) (3 x 8 significant bits: |v - h - m - l| <= 2^-25 |v|; both subtractions are
+// exact in f32), and a product a b is evaluated as the six partial products down to 2^-18 relative size
+//
+//     a_l b_h + a_h b_l + a_m b_m + a_m b_h + a_h b_m + a_h b_h        (dropped: a_m b_l + a_l b_m + a_l b_l <= 2^-25 |a b|)
+//
+// on v_mfma_f32_16x16x32_bf16 (bf16 x bf16 is exact in f32; accumulation in f32, smallest terms first).  The result carries the error
+// of an f32 dot product (measured against float64 in tests/ and in bench.py's parity block, next to the reference's own f32 error) at
+// 6/16 of the f32 matrix time.  ZUKO_AMD_EXACT_F32=1 selects the f32-instruction kernels instead.
+//
+// Layout.  A stream BLOCK is one 16 x 32 weight block — out tile ot, the PAIR of in tiles (2 ip, 2 ip + 1) — as three 1 KiB images
+// (h, m, l): lane (i = lane % 16, kq = lane / 16) holds 8 bf16 = weights of out unit i against units 4 kq .. 4 kq + 3 of in tile 2 ip
+// (elements 0-3) and of in tile 2 ip + 1 (elements 4-7).  That is exactly how a lane of the 16-sample wave tile holds the activations
+// (accumulator registers: sample lane % 16, units 4 (lane / 16) + r of every tile), so the B operand of a block is the lane's own
+// registers of the two tiles, converted once per layer: no shuffle, no LDS round trip between layers.  The ring, the chunking and
+// the raw-read / counted-wait idiom are those of fused_ar_static_impl.h (one block = three consecutive images).
+//
+//   Shape::NB[l], BOFF[l], B_OT, B_IP   blocks of hidden layer l in stream order (sorted by out tile): out tile, in pair
+//   Shape::BASE[l], LAST_BASE           stream position (in images) where each layer starts
+//   Shape::GOFF[g], G_IP                last layer: kept in pairs of every feature group (each with Uni::NT blocks)
+#pragma once
+#include "fused_ar_static_impl.h"
+
+namespace zk {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ArxB {  // B operand of one pair of activation tiles
+  bf16x8 h, m, l;
+};
+
+__device__ __forceinline__ void arx_split(const f32x4& lo, const f32x4& hi, ArxB& b) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = e < 4 ? lo[e] : hi[e - 4];
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    b.h[e] = h;
+    b.m[e] = m;
+    b.l[e] = (__bf16)r2;
+  }
+}
+
+#define ARX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), B, C, 0, 0, 0)
+// the six partial products of one block, smallest first (a[0] = h, a[1] = m, a[2] = l images of the weights)
+__device__ __forceinline__ void arx_block(const f32x4 (&a)[3], const ArxB& b, f32x4& c) {
+  ARX_MFMA(a[2], b.h, c);
+  ARX_MFMA(a[0], b.l, c);
+  ARX_MFMA(a[1], b.m, c);
+  ARX_MFMA(a[1], b.h, c);
+  ARX_MFMA(a[0], b.m, c);
+  ARX_MFMA(a[0], b.h, c);
+}
+
+template <class S> struct ArxPat {
+  static constexpr int ot(int l, int s) { return S::B_OT[S::BOFF[l] + s]; }
+  static constexpr int ip(int l, int s) { return S::B_IP[S::BOFF[l] + s]; }
+  static constexpr bool tile_has_blocks(int l, int t) {
+    for (int s = 0; s < S::NB[l]; ++s)
+      if (ot(l, s) == t) return true;
+    return false;
+  }
+};
+
+// one hidden layer: out = W in + bias over the blocks of the generated pattern
+template <class S, int L, class Ring> __device__ __forceinline__ void arx_hidden(Ring& ring, const float* bias_q, const ArxB (&in)[S::TMAX / 2], f32x4 (&out)[S::TMAX]) {
+  typedef ArxPat<S> P;
+  constexpr int NB = S::NB[L], BASE = S::BASE[L], HTL = S::HT[L];
+  ars_for<HTL>([&](auto t_) ARS_ALWAYS_INLINE {
+    constexpr int t = t_;
+    if constexpr (!P::tile_has_blocks(L, t)) out[t] = *reinterpret_cast<const f32x4*>(bias_q + t * 16);  // units that depend on nothing: bias only
+  });
+  if constexpr (NB > 0) {
+    f32x4 a[2][3];
+    ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[0][p] = ring.template read<BASE + decltype(p)::value>(); });
+    ars_for<NB>([&](auto s_) ARS_ALWAYS_INLINE {
+      constexpr int s = s_, ot = P::ot(L, s), ip = P::ip(L, s);
+      if constexpr (s == 0 || P::ot(L, s - 1) != ot) out[ot] = *reinterpret_cast<const f32x4*>(bias_q + ot * 16);  // accumulators start at the bias
+      if constexpr (s + 1 < NB) {
+        ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[(s + 1) & 1][p] = ring.template read<BASE + 3 * (s + 1) + decltype(p)::value>(); });
+        ars_settle<3>(a[s & 1][0], a[s & 1][1], a[s & 1][2]);  // this block's images are in; only the next block's may be outstanding
+      } else {
+        ars_settle<0>(a[s & 1][0], a[s & 1][1], a[s & 1][2]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      arx_block(a[s & 1], in[ip], out[ot]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+}
+
+template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ void arx_hidden_stack(Ring& ring, const float* bias_lds, int q, ArxB (&in)[S::TMAX / 2], f32x4 (&out)[S::TMAX],
+                                                                                                 const ArArgs& a, int64_t n, bool live) {
+  if constexpr (L < S::NH) {
+    arx_hidden<S, L>(ring, bias_lds + L * S::BIAS_STRIDE + 4 * q, in, out);
+    constexpr int HTL = S::HT[L];
+    if constexpr (S::ACT == 1) {
+#pragma unroll
+      for (int t = 0; t < HTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
+    } else if constexpr (S::ACT != 0) {
+      // (a loop the compiler must not unroll over the activation's inline expansion, as in fused_ar_static_impl.h)
+#pragma unroll 1
+      for (int rep = 0; rep < 1; ++rep) {
+#pragma unroll
+        for (int t = 0; t < HTL; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[t][r] = act_f32(out[t][r], S::ACT);
+      }
+    }
+    if constexpr (TRAIN) {
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < HTL; ++t) *reinterpret_cast<f32x4*>(a.act_out[L < 3 ? L : 2] + n * (HTL * 16) + t * 16 + 4 * q) = out[t];
+      }
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < (HTL + 1) / 2; ++p) arx_split(out[2 * p], 2 * p + 1 < HTL ? out[2 * p + 1] : zero, in[p]);
+    arx_hidden_stack<S, L + 1, Ring, TRAIN>(ring, bias_lds, q, in, out, a, n, live);
+  }
+}
+
+// TRAIN: conditioner only — the hidden activations and phi are stored for the backward pass (zuko_amd/train.py)
+template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(512, 2) void arx_kernel(ArArgs a) {
+  typedef ArRingS<8> Ring;
+  static_assert(S::WAVES == 8 && S::TMAX <= 16 && S::TMAX % 2 == 0, "operand-split kernels: widths <= 256, two wavefronts per SIMD");
+  constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL, WAVES = 8;
+  constexpr int NG = S::NG;
+  constexpr int NSTEP = S::GOFF[NG];  // (group, in pair) steps of the last layer, NT blocks each
+  constexpr bool XLDS = S::XLDS;
+  constexpr bool FID_REGS = NG * FPL <= 32;
+  constexpr int DT = (S::D + 15) / 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+
+  Ring ring;
+  float* bias_lds = ars_lds + ARS_NR * ARS_CH * AR_TF;
+  ring.lds = ars_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < ARS_NR - 1; ++i) ring.issue();
+  ring.slot = ARS_NR - 1;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)ars_lds);
+  ring.cur_off = ring.lds_off;
+
+  for (int i = tid; i < a.bias_floats; i += 64 * WAVES) bias_lds[i] = a.bias[i];
+  int* fmap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);  // same LDS layout as the f32 kernels
+  float* xr = reinterpret_cast<float*>(fmap_lds + 1024 + 256) + wave * 16 * a.xs + j * a.xs;
+  for (int i = tid; i < NG * 4 * FPL; i += 64 * WAVES) fmap_lds[i] = a.featmap[i];
+  __syncthreads();
+  const float* bias_last = bias_lds + S::NH * S::BIAS_STRIDE;
+  int fids[FID_REGS ? NG * FPL : 1];
+  if constexpr (FID_REGS) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) fids[i * FPL + fi] = fmap_lds[(i * 4 + q) * FPL + fi];
+  }
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n = tile * (16 * WAVES) + wave * 16 + j;
+    const bool live = n < a.N;
+    const int64_t nc = live ? n : a.N - 1;
+    const float* xrow = a.x + nc * a.ldx;
+
+    ArxB in[S::TMAX / 2];
+    f32x4 out[S::TMAX];
+    float poison = 0.f;
+    {
+      f32x4 xin[S::NIT + 1];
+#pragma unroll
+      for (int it = 0; it < S::NIT; ++it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((it + 1) * 16 <= S::DIN || it * 16 + 4 * q < S::DIN) v = *reinterpret_cast<const f32x4*>(xrow + it * 16 + 4 * q);
+        xin[it] = v;
+      }
+      xin[S::NIT] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // a NaN / inf input turns ALL parameters of its sample into NaN in the reference (x * 0 = NaN, zuko/nn.py:217-218)
+      int bad = 0;
+#pragma unroll
+      for (int it = 0; it < S::NIT; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= !(fabsf(xin[it][r]) < __builtin_inff());
+      bad |= __shfl_xor(bad, 16, 64);
+      bad |= __shfl_xor(bad, 32, 64);
+      if (bad) poison = __builtin_nanf("");
+      if constexpr (XLDS) {
+#pragma unroll
+        for (int it = 0; it < DT; ++it)
+          if ((it + 1) * 16 <= S::D || it * 16 + 4 * q < S::D) *reinterpret_cast<f32x4*>(xr + it * 16 + 4 * q) = xin[it];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int p = 0; p < (S::NIT + 1) / 2; ++p) arx_split(xin[2 * p], xin[2 * p + 1], in[p]);
+    }
+
+    // ---- hidden layers ---------------------------------------------------------------------------------------------
+    arx_hidden_stack<S, 0, Ring, TRAIN>(ring, bias_lds, q, in, out, a, n, live);
+
+    // ---- last layer + univariate transform, one group of 4 * FPL features at a time --------------------------------
+    float lacc = 0.f;
+    f32x4 w[2][3];
+    if constexpr (NSTEP > 0) {
+      ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[0][p] = ring.template read<S::LAST_BASE + decltype(p)::value>(); });
+    }
+    ars_for<NG>([&](auto g_) ARS_ALWAYS_INLINE {
+      constexpr int g = g_, ST0 = S::GOFF[g], GN = S::GOFF[g + 1] - S::GOFF[g];
+      int fid[FPL];
+      float xin[FPL];
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) {
+        if constexpr (FID_REGS) fid[fi] = fids[g * FPL + fi];
+        else fid[fi] = fmap_lds[(g * 4 + q) * FPL + fi];
+        const int fc = fid[fi] < 0 ? 0 : fid[fi];
+        if constexpr (XLDS) xin[fi] = xr[fc];
+        else xin[fi] = xrow[fc];
+      }
+      f32x4 acc[NT];  // the accumulators start at the bias
+      {
+        const float* bg = bias_last + (g * NT) * 16 + 4 * q;
+        ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE { acc[t] = *reinterpret_cast<const f32x4*>(bg + t * 16); });
+      }
+      ars_for<GN>([&](auto i_) ARS_ALWAYS_INLINE {
+        constexpr int st = ST0 + decltype(i_)::value, ip = S::G_IP[st];
+        ars_for<NT>([&](auto t_) ARS_ALWAYS_INLINE {
+          constexpr int t = t_, blk = st * NT + t;
+          if constexpr (blk + 1 < NSTEP * NT) {
+            ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[(blk + 1) & 1][p] = ring.template read<S::LAST_BASE + 3 * (blk + 1) + decltype(p)::value>(); });
+            ars_settle<3>(w[blk & 1][0], w[blk & 1][1], w[blk & 1][2]);
+          } else {
+            ars_settle<0>(w[blk & 1][0], w[blk & 1][1], w[blk & 1][2]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          arx_block(w[blk & 1], in[ip], acc[t]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      float p[4 * NT];
+      ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r];
+      });
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int fi = 0; fi < FPL; ++fi) {
+          const int f = fid[fi];
+          if (f >= 0 && live) {
+            float* dst = a.phi_out + n * a.ldphi + f * TOTAL;
+#pragma unroll
+            for (int i = 0; i < TOTAL; ++i) dst[i] = p[fi * TOTAL + i] + poison;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int fi = 0; fi < FPL; ++fi) Uni::template poison<false>(p, fi * TOTAL, poison);
+        auto ld = [&](int i) { return p[i]; };
+#pragma unroll
+        for (int fi = 0; fi < FPL; ++fi) {
+          const int f = fid[fi];
+          if (f >= 0) {
+            float yv, lj;
+            Uni::fwd(ld, fi * TOTAL, a, xin[fi], yv, lj);
+            if constexpr (XLDS) xr[f] = yv;
+            else if (live) a.y[n * a.ldy + f] = yv;
+            lacc += lj;
+          }
+        }
+      }
+    });
+    if constexpr (XLDS && !TRAIN) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (live) {
+#pragma unroll
+        for (int it = 0; it < DT; ++it)
+          if ((it + 1) * 16 <= S::D || it * 16 + 4 * q < S::D) *reinterpret_cast<f32x4*>(a.y + n * a.ldy + it * 16 + 4 * q) = *reinterpret_cast<const f32x4*>(xr + it * 16 + 4 * q);
+      }
+    }
+    if (!TRAIN && a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must land before the LDS is released
+}
+
+template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi, int args_bytes, int train, void* stream) {
+  if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;  // kernel built against another version of the library
+  ArArgs a = *in;
+  if (a.D != S::D || a.DIN != S::DIN || a.L != S::NH + 1 || a.act != S::ACT || a.sched || a.NG != S::NG || a.n_chunks != S::NCHUNK || a.l1rev) return ZK_EINVAL;
+  if (train && (!S::TRAIN_OK || !a.phi_out)) return ZK_EINVAL;
+  a.n_tiles = (a.N + 127) / 128;
+  a.xs = ((S::D + 3) / 4) * 4 + 4;
+  const bool vec_ok = (S::D % 4 == 0) && (train || ((a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0)));
+  if (S::XLDS != 0 && !vec_ok) return ZK_EINVAL;
+  a.xlds = S::XLDS;
+  const int lds = (ARS_NR * ARS_CH * AR_TF + a.bias_floats + 1024 + 256 + (S::XLDS ? 8 * 16 * a.xs : 0)) * (int)sizeof(float);
+  if (lds > 160 * 1024) return ZK_EINVAL;
+  const void* fn = nullptr;
+  if (train) {
+    if constexpr (S::TRAIN_OK) fn = (const void*)arx_kernel<S, Uni, true>;
+  } else {
+    fn = (const void*)arx_kernel<S, Uni, false>;
+  }
+  if (!fn) return ZK_EINVAL;
+  hipError_t e = hipSuccess;
+  {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    int& g = granted[fn];
+    if (g < lds) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      g = lds;
+    }
+  }
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  void* kargs[] = {&a};
+  e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  return ZK_LAUNCH_CHECK();
+}
+
+}  // namespace zk

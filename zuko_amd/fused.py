@@ -424,7 +424,8 @@ class FusedAR:
         self.generic_ok = plan.max_width <= MAX_WIDTH  # (wider plans exist only for the static-shape kernels)
         self.static = None          # (StaticKernel, rev) of zuko_amd/static_ar.py once one has been found / compiled
         self._static_tried_rows = -1
-        self.fine_gather = self.fine_stream = None
+        self.fine_gather = self.fine_stream = self.fine_offsets = None
+        self.fine_n_chunks = 0
         self._acquire_static(None)  # kernels already on disk (prebuilt or compiled earlier) are used whatever the batch size
 
     @property
@@ -436,15 +437,25 @@ class FusedAR:
         """Look the plan's static-shape kernel up (zuko_amd/static_ar.py); `rows` >= the JIT threshold allows compiling it."""
         from . import static_ar
 
-        if self.static is not None or self.plan.fine_gather is None or (rows is not None and rows <= self._static_tried_rows):
+        # (an f32 static kernel found on disk can still be replaced by the operand-split one once a batch is large enough to compile it)
+        upgradable = self.static is not None and not self.static[0].meta.get("split") and static_ar.split_enabled() and rows is not None
+        if (self.static is not None and not upgradable) or self.plan.fine_gather is None or (rows is not None and rows <= self._static_tried_rows):
             return
         if rows is not None:
             self._static_tried_rows = rows if rows < static_ar.jit_min_rows() else 1 << 62
         found = static_ar.lookup(self.plan, self.plan.layout.kind, self.act, rows)
-        if found is not None:
+        if found is not None and (self.static is None or found[0] is not self.static[0]):
             self.static = found
-            self.fine_gather = [torch.from_numpy(g).to(self.device) for g in self.plan.fine_gather]
-            self.fine_stream = torch.empty(self.plan.fine_n_blocks * 256, dtype=torch.float32, device=self.device)
+            if found[0].meta.get("split"):
+                t, gathers = static_ar.split_tables(self.plan, self.plan.layout.kind, self.act)
+                self.fine_gather = [torch.from_numpy(g).to(self.device) for g in gathers]
+                self.fine_offsets = [b * 256 for b in t["BASE"]] + [t["LAST_BASE"] * 256]
+                self.fine_n_chunks = t["NCHUNK"]
+            else:
+                self.fine_gather = [torch.from_numpy(g).to(self.device) for g in self.plan.fine_gather]
+                self.fine_offsets = [b * 256 for b in self.plan.fine_layer_block0]
+                self.fine_n_chunks = self.plan.fine_n_chunks
+            self.fine_stream = torch.zeros(self.fine_n_chunks * 24 * 256, dtype=torch.float32, device=self.device)
             self._fine_stamp = None
 
     def ready(self, rows: int) -> bool:
@@ -478,8 +489,11 @@ class FusedAR:
                 dst = self.stream[self.plan.layer_block0[l] * 256 :]
                 _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), self.gather[l].numel(), _ptr(dst), _stream()), "zk_gather_f32")
             if want_fine:
-                fdst = self.fine_stream[self.plan.fine_layer_block0[l] * 256 :]
-                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel(), _ptr(fdst), _stream()), "zk_gather_f32")
+                fdst = self.fine_stream[self.fine_offsets[l] :]
+                if self.static[0].meta.get("split"):
+                    _C.check(lib.zk_gather_split_bf16(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel() // 512, _ptr(fdst), _stream()), "zk_gather_split_bf16")
+                else:
+                    _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel(), _ptr(fdst), _stream()), "zk_gather_f32")
             nb = self.bias_gather[l].numel()
             bdst = self.bias[self.plan.bias_off[l] :]
             if m.bias is None:
@@ -504,7 +518,7 @@ class FusedAR:
             if not kern.meta["XLDS"] or (y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0):
                 a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
                             y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate), wstream=_ptr(self.fine_stream), bias=_ptr(self.bias),
-                            bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=p.fine_n_chunks, act=self.act,
+                            bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=self.fine_n_chunks, act=self.act,
                             bound=self.bound, slope=self.slope)
                 _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
                 return

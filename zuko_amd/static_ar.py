@@ -37,7 +37,7 @@ CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")
 ARS_ABI = 4  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 4: "zk::UniCircRqs8"}  # (16 bins: 12 accumulator tiles per group do not fit the double-buffered last layer)
-_HEADERS = ("fused_ar_static_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
+_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
 
 
 def _hipcc() -> str | None:
@@ -110,6 +110,115 @@ def tables(plan, uni_kind: int, act: int = 1) -> dict | None:
         "BASE": [int(b) for b in plan.fine_layer_block0[:NH]], "LAST_BASE": int(plan.fine_layer_block0[NH]), "GOFF": GOFF, "G_IT": G_IT,
         "WAVES": waves, "XLDS": xlds, "TRAIN_OK": int(act == 1 and NH <= 3 and waves == 8 and all(w % 16 == 0 for w in widths)),
     }
+
+
+def split_enabled() -> bool:
+    """Whether the bf16x3 operand-split kernels may be used (ZUKO_AMD_EXACT_F32=1 keeps every product on the f32 matrix instruction)."""
+    return os.environ.get("ZUKO_AMD_EXACT_F32", "0") != "1"
+
+
+def split_tables(plan, uni_kind: int, act: int = 1):
+    """Tables + gather indices of the OPERAND-SPLIT twin of a static-shape kernel (csrc/fused_ar_split_impl.h), or None.
+
+    gfx950 has no xf32 / tf32 matrix instruction; its f32 one runs at 1/16 of the bf16 rate.  The split kernels write every f32
+    operand as h + m + l with three bf16 numbers (8 + 8 + 8 significant bits: exact to 2^-25) and keep the six partial products down to
+    2^-18 (hh, hm, mh, mm, hl, lh) on v_mfma_f32_16x16x32_bf16 with f32 accumulation: f32-grade results at 6/16 of the matrix time.
+    A stream BLOCK is the 16 x 32 weight block (one out tile, one PAIR of in tiles) as three 1 KiB bf16 images (h, m, l); a lane's 8
+    values of a k-group are [4 units of in tile 2 ip | the same 4 units of in tile 2 ip + 1], which is how the activations sit in the
+    accumulator registers.  Returns (tables, gathers): gathers[l] int32 [blocks_l * 512] into W_l.flatten() (-1 = zero), every layer
+    padded to whole 24-image chunks (8 blocks)."""
+    t = tables(plan, uni_kind, act)
+    if t is None or t["WAVES"] != 8:
+        return None
+    cached = getattr(plan, "_split_cache", None)
+    if cached is not None and cached[0] == (uni_kind, act):
+        return cached[1]
+    NH, HT, NIT = t["NH"], t["HT"], t["NIT"]
+    tm = plan.fine_tilemask
+    n_otg, n_itile = tm.shape[1], tm.shape[2]
+    B_OT, B_IP, NB, BASE, gathers = [], [], [], [], []
+    cursor = 0  # in 1 KiB images
+
+    def finish(blocks):
+        nonlocal cursor
+        blocks = blocks + [-np.ones((64, 8), dtype=np.int64)] * (-(-len(blocks) // 8) * 8 - len(blocks))
+        gathers.append(np.stack(blocks).astype(np.int32).reshape(-1) if blocks else np.zeros(0, np.int32))
+        cursor += 3 * len(blocks)
+
+    def pair_block(fg, t0, t1):
+        idx = -np.ones((64, 8), dtype=np.int64)
+        if t0 is not None:
+            idx[:, :4] = fg[t0]
+        if t1 is not None:
+            idx[:, 4:] = fg[t1]
+        return idx
+
+    for l in range(NH):
+        fg = plan.fine_gather[l].reshape(-1, 64, 4)
+        pos, k = {}, 0
+        for otg in range(n_otg):
+            for it in range(n_itile):
+                m = int(tm[l, otg, it])
+                for b in range(4):
+                    if m >> b & 1:
+                        pos[(otg * 4 + b, it)] = k
+                        k += 1
+        n_in = NIT if l == 0 else HT[l - 1]
+        blocks = []
+        for ot in range(HT[l]):
+            for ip in range(-(-n_in // 2)):
+                t0, t1 = pos.get((ot, 2 * ip)), pos.get((ot, 2 * ip + 1))
+                if t0 is None and t1 is None:
+                    continue
+                blocks.append(pair_block(fg, t0, t1))
+                B_OT.append(ot), B_IP.append(ip)
+        NB.append(len(blocks))
+        BASE.append(cursor)
+        finish(blocks)
+    # last layer: group g, kept in-tile it, tile t of the group  ->  group g, kept in-pair ip, tile t
+    nt = plan.layout.nt
+    fg = plan.fine_gather[NH].reshape(-1, 64, 4)
+    G_IP, GOFFP, blocks, k = [], [0], [], 0
+    for g in range(t["NG"]):
+        its = t["G_IT"][t["GOFF"][g] : t["GOFF"][g + 1]]
+        at = {it: k + i * nt for i, it in enumerate(its)}
+        k += len(its) * nt
+        for ip in sorted({it // 2 for it in its}):
+            for b in range(nt):
+                t0, t1 = at.get(2 * ip), at.get(2 * ip + 1)
+                blocks.append(pair_block(fg, None if t0 is None else t0 + b, None if t1 is None else t1 + b))
+            G_IP.append(ip)
+        GOFFP.append(len(G_IP))
+    last_base = cursor
+    finish(blocks)
+    out = dict(t)
+    for key in ("S_OTG", "S_IT", "S_MASK", "NS", "GOFF", "G_IT"):
+        out.pop(key)
+    out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": cursor // 24})
+    plan._split_cache = ((uni_kind, act), (out, gathers))
+    return out, gathers
+
+
+def emit_split(t: dict) -> str:
+    boff = [0]
+    for n in t["NB"]:
+        boff.append(boff[-1] + n)
+    lines = [
+        "// generated by zuko_amd/static_ar.py — do not edit",
+        '#include "fused_ar_split_impl.h"',
+        "namespace {",
+        "struct Shape {",
+        f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NG = {t['NG']}, NCHUNK = {t['NCHUNK']};",
+        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, ACT = {t['ACT']};",
+        f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = false, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
+        _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
+        _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
+        "};",
+        "}  // namespace",
+        f'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {{ return zk::arx_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, train, stream); }}',
+        "",
+    ]
+    return "\n".join(lines)
 
 
 def _split(t: dict):
@@ -238,6 +347,45 @@ def compile_kernel(t: dict, alt: list | None, verbose: bool = False) -> dict | N
     return meta
 
 
+def compile_split(t: dict, verbose: bool = False) -> dict | None:
+    """Build lib/ars/arx_<sig>.so, the operand-split kernel of tables `t` (split_tables); returns its meta or None."""
+    hipcc = _hipcc()
+    if hipcc is None:
+        return None
+    stamp = _header_digest()
+    sig = _digest({"split": t, "headers": stamp})
+    os.makedirs(ARS_DIR, exist_ok=True)
+    so, meta_path = f"arx_{sig}.so", os.path.join(ARS_DIR, f"arx_{sig}.json")
+    meta = {"so": so, "core": "x" + _digest(t), "split": 1, "l0": [], "alt": None, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"],
+            "WAVES": t["WAVES"], "TRAIN_OK": t["TRAIN_OK"], "XLDS": t["XLDS"], "NCHUNK": t["NCHUNK"]}
+    with open(os.path.join(ARS_DIR, f".lock_{sig}"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(os.path.join(ARS_DIR, so)) and os.path.exists(meta_path):
+            return meta
+        src = os.path.join(ARS_DIR, f"arx_{sig}.hip")
+        with open(src, "w") as f:
+            f.write(emit_split(t))
+        tmp = os.path.join(ARS_DIR, f".{so}.{os.getpid()}")
+        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
+               src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
+        if verbose:
+            print("[zuko_amd static_ar]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(f"[zuko_amd static_ar] hipcc failed for {src}:\n{r.stdout[-2000:]}\n")
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
+            return None
+        os.replace(tmp, os.path.join(ARS_DIR, so))
+        with open(meta_path, "w") as f:
+            json.dump(meta, f)
+    global _INDEX
+    _INDEX = None
+    return meta
+
+
 def _load(meta: dict) -> StaticKernel:
     k = _LOADED.get(meta["so"])
     if k is None:
@@ -265,6 +413,19 @@ def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
     t = tables(plan, uni_kind, act)
     if t is None:
         return None
+    allow = rows is not None and rows >= jit_min_rows() and jit_enabled()
+    if split_enabled():  # the operand-split kernel (6/16 of the f32 matrix time) when there is one or one may be built
+        ts = split_tables(plan, uni_kind, act)
+        if ts is not None:
+            cdx = "x" + _digest(ts[0])
+            with _LOCK:
+                idx = _INDEX if _INDEX is not None else _scan()
+                for meta in idx.get(cdx, []):
+                    return _load(meta), 0
+                if allow:
+                    meta = compile_split(ts[0], verbose=os.environ.get("ZUKO_AMD_JIT_VERBOSE", "0") == "1")
+                    if meta is not None:
+                        return _load(meta), 0
     core, l0 = _split(t)
     cd = _digest(core)
     with _LOCK:
@@ -274,7 +435,7 @@ def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
                 return _load(meta), 0
             if meta["alt"] is not None and meta["alt"] == l0:
                 return _load(meta), 1
-        if rows is not None and rows >= jit_min_rows() and jit_enabled():
+        if allow:
             meta = compile_kernel(t, None, verbose=os.environ.get("ZUKO_AMD_JIT_VERBOSE", "0") == "1")
             if meta is not None:
                 return _load(meta), 0
@@ -495,7 +656,7 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
                     os.remove(os.path.join(ARS_DIR, name))
                 except OSError:
                     pass
-    work, chains = [], []
+    work, chains, splits = [], [], []
     for entry in PREBUILT:
         kind, features, context, hidden, bins = entry[:5]
         import torch
@@ -509,6 +670,10 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
                 tg = chain_tables_for(lins)
                 if tg is not None and not any(c[0] == tg[0] for c in chains):
                     chains.append(tg)
+        for pl in (pa, pd):
+            ts = split_tables(pl, layout.kind, act)
+            if ts is not None and not any(x == ts[0] for x in splits):
+                splits.append(ts[0])
         ta, td = tables(pa, layout.kind, act), tables(pd, layout.kind, act)
         if ta is None or td is None:
             raise RuntimeError(f"zuko_amd.static_ar: no static kernel for the prebuilt shape {entry}")
@@ -520,9 +685,10 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         metas = list(ex.map(lambda w: compile_kernel(w[0], w[1], verbose), work))
         kerns = list(ex.map(lambda tg: chain_kernel(tg[0], True, verbose), chains))
-    if any(m is None for m in metas) or any(k is None for k in kerns):
+        xmetas = list(ex.map(lambda t: compile_split(t, verbose), splits))
+    if any(m is None for m in metas + xmetas) or any(k is None for k in kerns):
         raise RuntimeError("zuko_amd.static_ar: a prebuilt static kernel failed to compile")
-    return [m["so"] for m in metas] + [os.path.basename(k.so) for k in kerns]
+    return [m["so"] for m in metas + xmetas] + [os.path.basename(k.so) for k in kerns]
 
 
 if __name__ == "__main__":

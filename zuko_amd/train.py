@@ -255,7 +255,7 @@ def _fused_forward(st, x: Tensor, out_features: int):
     hp = [_ptr(h) for h in hs] + [None] * (3 - len(hs))
     a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
                 phi=_ptr(phi), ldphi=out_features, wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap), n_layers=p.n_layers,
-                n_groups=p.n_groups, n_chunks=p.fine_n_chunks, act=1)
+                n_groups=p.n_groups, n_chunks=st.fine_n_chunks, act=1)
     err = _C.lib().zk_ar_forward_train(a, _stream())
     _C.check(err, "zk_ar_forward_train")
     return hs, phi
