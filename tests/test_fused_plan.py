@@ -320,8 +320,11 @@ def test_split_kernel_tables_describe_the_plan(cfg):
         assert ts is not None
         t, gathers = ts
         NH = t["NH"]
-        assert t["NCHUNK"] * 24 == sum(len(g) // 512 for g in gathers) * 3 and all(len(g) % (8 * 512) == 0 for g in gathers)
-        assert [b * 1 for b in t["BASE"]] == [3 * sum(len(g) // 512 for g in gathers[:l]) for l in range(NH)]
+        images = 3 * (sum(t["NB"]) + t["GOFF"][-1] * lay.nt)
+        assert t["NCHUNK"] == -(-images // t["CH"]), "no chunk of nothing but padding: the ring moves on when a chunk's first image is read"
+        assert t["NCHUNK"] * t["CH"] <= 3 * sum(len(g) // 512 for g in gathers) <= t["STREAM_IMAGES"] < t["NCHUNK"] * t["CH"] + 3
+        assert t["BASE"] == [3 * sum(t["NB"][:l]) for l in range(NH)] and t["LAST_BASE"] == 3 * sum(t["NB"]), "layers follow each other without padding"
+        assert (t["WAVES"], t["CH"]) == static_ar.split_geometry()
         W = [l.weight.detach().numpy().astype(np.float32) * l.mask.numpy() for l in lins]
         Bv = [l.bias.detach().numpy().astype(np.float64) for l in lins]
         x = rng.standard_normal(plan.din).astype(np.float32)

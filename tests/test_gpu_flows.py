@@ -754,6 +754,35 @@ def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_split_kernel_geometries_agree(dev, monkeypatch):
+    """ZUKO_AMD_SPLIT_GEOM: one workgroup of eight wavefronts (24-image chunks, the default) and two workgroups of four per CU (16-image
+    chunks: chunk boundaries fall inside blocks, the stream's tail is not a whole number of blocks) run the same blocks in the same
+    order: bit-identical y / ladj, on a batch of several passes per workgroup."""
+    from zuko_amd.flows import NSF
+    from zuko_amd.nn import MaskedLinear
+
+    N = 70000
+    x = torch.randn(N, 64, generator=torch.Generator().manual_seed(2)).to(dev)
+    outs = []
+    for geom in ("8x24", "4x16"):
+        monkeypatch.setenv("ZUKO_AMD_SPLIT_GEOM", geom)
+        torch.manual_seed(3)
+        flow = NSF(64, 0, transforms=2, bins=8, hidden_features=[256] * 3).to(dev)
+        res = []
+        for lazy in flow.transform.transforms:
+            st = lazy.fused_state(dev)
+            assert st.ready(N) and st.static is not None and st.static[0].meta.get("split") == 1
+            assert f"{st.static[0].meta['WAVES']}x{st.static[0].meta['CH']}" == geom
+            st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+            y, ladj = torch.empty(N, 64, device=dev), torch.empty(N, device=dev)
+            st.run(x, y, ladj, False)
+            res.append((y, ladj))
+        outs.append(res)
+    for (y0, l0), (y1, l1) in zip(*outs):
+        assert torch.equal(y0, y1) and torch.equal(l0, l1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,ctx,hidden", [(32, 0, [512, 512]), (24, 8, [384, 512, 320])])
 def test_wide_conditioners_run_fused(dev, D, ctx, hidden, monkeypatch):
     """Hidden widths beyond the generic fused kernel's 256 (the reference accepts any `hidden_features`, zuko/nn.py:258-264): up to 512

@@ -35,6 +35,10 @@ struct ArxB {  // B operand of one pair of activation tiles
 };
 
 __device__ __forceinline__ void arx_split(const f32x4& lo, const f32x4& hi, ArxB& b) {
+  if (ARX_ABL == 6) {
+    b.h = __builtin_bit_cast(bf16x8, lo); b.m = __builtin_bit_cast(bf16x8, hi); b.l = b.h;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float v = e < 4 ? lo[e] : hi[e - 4];
@@ -51,6 +55,10 @@ __device__ __forceinline__ void arx_split(const f32x4& lo, const f32x4& hi, ArxB
 #define ARX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), B, C, 0, 0, 0)
 // the six partial products of one block, smallest first (a[0] = h, a[1] = m, a[2] = l images of the weights)
 __device__ __forceinline__ void arx_block(const f32x4 (&a)[3], const ArxB& b, f32x4& c) {
+  if (ARX_ABL == 2) {
+    asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]));
+    return;
+  }
   ARX_MFMA(a[2], b.h, c);
   ARX_MFMA(a[0], b.l, c);
   ARX_MFMA(a[1], b.m, c);
@@ -130,10 +138,10 @@ template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ voi
 }
 
 // TRAIN: conditioner only — the hidden activations and phi are stored for the backward pass (zuko_amd/train.py)
-template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(512, 2) void arx_kernel(ArArgs a) {
-  typedef ArRingS<8> Ring;
-  static_assert(S::WAVES == 8 && S::TMAX <= 16 && S::TMAX % 2 == 0, "operand-split kernels: widths <= 256, two wavefronts per SIMD");
-  constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL, WAVES = 8;
+template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(64 * S::WAVES, 2) void arx_kernel(ArArgs a) {
+  typedef ArRingS<S::WAVES, S::CH> Ring;
+  static_assert((S::WAVES == 8 || S::WAVES == 4) && S::TMAX <= 16 && S::TMAX % 2 == 0, "operand-split kernels: widths <= 256, two wavefronts per SIMD");
+  constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL, WAVES = S::WAVES;
   constexpr int NG = S::NG;
   constexpr int NSTEP = S::GOFF[NG];  // (group, in pair) steps of the last layer, NT blocks each
   constexpr bool XLDS = S::XLDS;
@@ -145,7 +153,7 @@ template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(512, 2
   const int j = lane & 15, q = lane >> 4;
 
   Ring ring;
-  float* bias_lds = ars_lds + ARS_NR * ARS_CH * AR_TF;
+  float* bias_lds = ars_lds + ARS_NR * S::CH * AR_TF;
   ring.lds = ars_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
   ring.load_chunk = 0; ring.load_slot = 0;
 #pragma unroll
@@ -271,6 +279,11 @@ template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(512, 2
           const int f = fid[fi];
           if (f >= 0) {
             float yv, lj;
+            if (ARX_ABL == 3) {
+              yv = p[fi * TOTAL] + xin[fi]; lj = p[fi * TOTAL + 1];
+#pragma unroll
+              for (int i = 2; i < TOTAL; ++i) lj += p[fi * TOTAL + i];
+            } else
             Uni::fwd(ld, fi * TOTAL, a, xin[fi], yv, lj);
             if constexpr (XLDS) xr[f] = yv;
             else if (live) a.y[n * a.ldy + f] = yv;
@@ -302,12 +315,12 @@ template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi
   ArArgs a = *in;
   if (a.D != S::D || a.DIN != S::DIN || a.L != S::NH + 1 || a.act != S::ACT || a.sched || a.NG != S::NG || a.n_chunks != S::NCHUNK || a.l1rev) return ZK_EINVAL;
   if (train && (!S::TRAIN_OK || !a.phi_out)) return ZK_EINVAL;
-  a.n_tiles = (a.N + 127) / 128;
+  a.n_tiles = (a.N + 16 * S::WAVES - 1) / (16 * S::WAVES);
   a.xs = ((S::D + 3) / 4) * 4 + 4;
   const bool vec_ok = (S::D % 4 == 0) && (train || ((a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0)));
   if (S::XLDS != 0 && !vec_ok) return ZK_EINVAL;
   a.xlds = S::XLDS;
-  const int lds = (ARS_NR * ARS_CH * AR_TF + a.bias_floats + 1024 + 256 + (S::XLDS ? 8 * 16 * a.xs : 0)) * (int)sizeof(float);
+  const int lds = (ARS_NR * S::CH * AR_TF + a.bias_floats + 1024 + 256 + (S::XLDS ? S::WAVES * 16 * a.xs : 0)) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const void* fn = nullptr;
   if (train) {
@@ -328,9 +341,10 @@ template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi
       g = lds;
     }
   }
-  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  constexpr int MAXG = S::WAVES == 4 ? 512 : 256;  // 4 wavefronts: two independent workgroups per CU (one wavefront per SIMD each)
+  const unsigned grid = (unsigned)(a.n_tiles < MAXG ? a.n_tiles : MAXG);
   void* kargs[] = {&a};
-  e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
+  e = hipLaunchKernel(fn, dim3(grid), dim3(64 * S::WAVES), kargs, lds, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   return ZK_LAUNCH_CHECK();
 }

@@ -37,6 +37,9 @@ namespace zk {
 
 #define ARS_CH 24
 #define ARS_NR 3
+#ifndef ARX_ABL
+#define ARX_ABL 0  // timing ablations of the operand-split kernel (scripts/split_ablate.py): 1 no DMA, 2 no MFMA, 3 no epilogue, 4 no barrier, 5 no LDS reads, 6 no conversions
+#endif
 #define ARS_ALWAYS_INLINE __attribute__((always_inline))
 
 template <class F, int... I> __device__ __forceinline__ void ars_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -66,10 +69,10 @@ template <class S> struct ArsPat {
   static constexpr int n_last_steps() { return S::GOFF[S::NG]; }
 };
 
-template <int WAVES> struct ArRingS {
-  static constexpr int PER = ARS_CH / WAVES;  // consecutive tiles a wave copies per chunk: one address, one M0 value, immediate offsets
+template <int WAVES, int CH = ARS_CH> struct ArRingS {
+  static constexpr int PER = CH / WAVES;  // consecutive tiles a wave copies per chunk: one address, one M0 value, immediate offsets
   static constexpr int PIVOT = PER > 4 ? 4 : 0;  // (signed immediates -4096 .. +1024 around the wave's fifth tile reach six tiles)
-  static_assert(PER * WAVES == ARS_CH && PER <= 6, "ring geometry");
+  static_assert(PER * WAVES == CH && PER <= 6, "ring geometry");
   float* lds;
   const float* stream;
   unsigned cur_off;  // LDS byte address of the slot being read + lane * 16
@@ -83,17 +86,17 @@ template <int WAVES> struct ArRingS {
   }
   __device__ __forceinline__ void issue() {
     const int b0 = wave * PER + PIVOT;
-    dma<0>(stream + ((size_t)load_chunk * ARS_CH + b0) * AR_TF + lane * 4, lds + (load_slot * ARS_CH + b0) * AR_TF);
+    if (ARX_ABL != 1) dma<0>(stream + ((size_t)load_chunk * CH + b0) * AR_TF + lane * 4, lds + (load_slot * CH + b0) * AR_TF);
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
     load_slot = (load_slot + 1 == ARS_NR) ? 0 : load_slot + 1;
   }
   __device__ __forceinline__ void advance() {  // all waves, at the same (static) points of the pass
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((ARS_NR - 2) * PER) : "memory");
-    __builtin_amdgcn_s_barrier();  // (not __syncthreads(): its fence is s_waitcnt vmcnt(0) and would drain the look-ahead DMAs)
+    if (ARX_ABL != 4) __builtin_amdgcn_s_barrier();  // (not __syncthreads(): its fence is s_waitcnt vmcnt(0) and would drain the look-ahead DMAs)
     asm volatile("" ::: "memory");
     issue();
     slot = (slot + 1 == ARS_NR) ? 0 : slot + 1;
-    cur_off = lds_off + (unsigned)(slot * ARS_CH * AR_TF * 4 + lane * 16);
+    cur_off = lds_off + (unsigned)(slot * CH * AR_TF * 4 + lane * 16);
   }
   // Position S inside the pass (static).  The read is issued from inline assembly and returns a RAW value: the compiler does
   // not know it is an LDS operation, so it inserts no wait for it — while a global_load_lds is in flight hipcc turns every
@@ -101,9 +104,14 @@ template <int WAVES> struct ArRingS {
   // value becomes usable through ars_settle<N>() below, which waits until at most N younger LDS operations are outstanding
   // (LDS operations of a wave complete in order) and is the only consumer of the raw registers.
   template <int S> __device__ __forceinline__ f32x4 read() {
-    if constexpr (S % ARS_CH == 0) advance();
+    if constexpr (S % CH == 0) advance();
     f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(cur_off), "n"((S % ARS_CH) * AR_TF * 4));
+    if (ARX_ABL == 5) {
+      asm volatile("v_mov_b32 %0, %1" : "=v"(v[0]) : "v"(cur_off));
+      v[1] = v[2] = v[3] = v[0];
+      return v;
+    }
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(cur_off), "n"((S % CH) * AR_TF * 4));
     return v;
   }
 };

@@ -451,18 +451,19 @@ class FusedAR:
                 self.fine_gather = [torch.from_numpy(g).to(self.device) for g in gathers]
                 self.fine_offsets = [b * 256 for b in t["BASE"]] + [t["LAST_BASE"] * 256]
                 self.fine_n_chunks = t["NCHUNK"]
+                stream_images = t["STREAM_IMAGES"]
             else:
                 self.fine_gather = [torch.from_numpy(g).to(self.device) for g in self.plan.fine_gather]
                 self.fine_offsets = [b * 256 for b in self.plan.fine_layer_block0]
                 self.fine_n_chunks = self.plan.fine_n_chunks
-            self.fine_stream = torch.zeros(self.fine_n_chunks * 24 * 256, dtype=torch.float32, device=self.device)
+                stream_images = self.fine_n_chunks * 24
+            self.fine_stream = torch.zeros(stream_images * 256, dtype=torch.float32, device=self.device)
             self._fine_stamp = None
 
     def ready(self, rows: int) -> bool:
         """Whether run() can be served: always for plans the generic kernel covers; for wider ones only with a static-shape kernel
         (compiled now if `rows` makes it worth it)."""
-        if self.static is None:
-            self._acquire_static(rows)
+        self._acquire_static(rows)  # (no-op once the best kernel for this plan is held or `rows` has been tried)
         return self.generic_ok or self.static is not None
 
     def refresh(self, linears, fine_only: bool = False) -> None:

@@ -24,6 +24,7 @@ import ctypes
 import fcntl
 import hashlib
 import json
+import math
 import os
 import shutil
 import subprocess
@@ -117,6 +118,18 @@ def split_enabled() -> bool:
     return os.environ.get("ZUKO_AMD_EXACT_F32", "0") != "1"
 
 
+def split_geometry() -> tuple:
+    """(wavefronts per workgroup, images per ring chunk) of the operand-split kernels: 8 x 24 = one workgroup of eight wavefronts per CU
+    (two per SIMD) sharing one weight stream; ZUKO_AMD_SPLIT_GEOM=4x16 selects two independent workgroups per CU, one wavefront per
+    SIMD each (twice the weight-stream traffic; measured 3-5 % slower on cfg2, profiles/r03/split_kernel.md)."""
+    g = os.environ.get("ZUKO_AMD_SPLIT_GEOM", "8x24")
+    try:
+        w, c = (int(v) for v in g.split("x"))
+    except ValueError:
+        w, c = 8, 24
+    return (w, c) if (w, c) in ((4, 16), (8, 24), (4, 24), (8, 48)) else (8, 24)
+
+
 def split_tables(plan, uni_kind: int, act: int = 1):
     """Tables + gather indices of the OPERAND-SPLIT twin of a static-shape kernel (csrc/fused_ar_split_impl.h), or None.
 
@@ -131,19 +144,14 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     if t is None or t["WAVES"] != 8:
         return None
     cached = getattr(plan, "_split_cache", None)
-    if cached is not None and cached[0] == (uni_kind, act):
+    if cached is not None and cached[0] == (uni_kind, act, split_geometry()):
         return cached[1]
     NH, HT, NIT = t["NH"], t["HT"], t["NIT"]
     tm = plan.fine_tilemask
     n_otg, n_itile = tm.shape[1], tm.shape[2]
-    B_OT, B_IP, NB, BASE, gathers = [], [], [], [], []
-    cursor = 0  # in 1 KiB images
-
-    def finish(blocks):
-        nonlocal cursor
-        blocks = blocks + [-np.ones((64, 8), dtype=np.int64)] * (-(-len(blocks) // 8) * 8 - len(blocks))
-        gathers.append(np.stack(blocks).astype(np.int32).reshape(-1) if blocks else np.zeros(0, np.int32))
-        cursor += 3 * len(blocks)
+    waves, ch = split_geometry()
+    B_OT, B_IP, NB, BASE, blocks_of = [], [], [], [], []
+    cursor = 0  # in 1 KiB images; the layers follow each other without padding (a chunk boundary may fall anywhere, even inside a block)
 
     def pair_block(fg, t0, t1):
         idx = -np.ones((64, 8), dtype=np.int64)
@@ -174,7 +182,8 @@ def split_tables(plan, uni_kind: int, act: int = 1):
                 B_OT.append(ot), B_IP.append(ip)
         NB.append(len(blocks))
         BASE.append(cursor)
-        finish(blocks)
+        cursor += 3 * len(blocks)
+        blocks_of.append(blocks)
     # last layer: group g, kept in-tile it, tile t of the group  ->  group g, kept in-pair ip, tile t
     nt = plan.layout.nt
     fg = plan.fine_gather[NH].reshape(-1, 64, 4)
@@ -190,12 +199,22 @@ def split_tables(plan, uni_kind: int, act: int = 1):
             G_IP.append(ip)
         GOFFP.append(len(G_IP))
     last_base = cursor
-    finish(blocks)
+    cursor += 3 * len(blocks)
+    # The stream is ceil(images / ch) chunks long: every chunk's first image belongs to a real block (the kernel moves the ring on when
+    # it reads that image, so a chunk of nothing but padding would never be consumed).  The gather kernel writes whole blocks: the
+    # padding blocks may reach up to two images past the last chunk (STREAM_IMAGES is what the buffer must hold).
+    n_chunks = -(-cursor // ch)
+    pad_blocks = -(-(n_chunks * ch - cursor) // 3)
+    blocks_of.append(blocks + [-np.ones((64, 8), dtype=np.int64)] * pad_blocks)
+    stream_images = max(n_chunks * ch, cursor + 3 * pad_blocks)
+    gathers = [np.stack(b).astype(np.int32).reshape(-1) if b else np.zeros(0, np.int32) for b in blocks_of]
     out = dict(t)
     for key in ("S_OTG", "S_IT", "S_MASK", "NS", "GOFF", "G_IT"):
         out.pop(key)
-    out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": cursor // 24})
-    plan._split_cache = ((uni_kind, act), (out, gathers))
+    xlds = int(t["D"] % 4 == 0 and (3 * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * (2 if waves == 4 else 1) <= 160 * 1024)
+    out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
+                "WAVES": waves, "CH": ch, "XLDS": xlds})
+    plan._split_cache = ((uni_kind, act, split_geometry()), (out, gathers))
     return out, gathers
 
 
@@ -209,7 +228,7 @@ def emit_split(t: dict) -> str:
         "namespace {",
         "struct Shape {",
         f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NG = {t['NG']}, NCHUNK = {t['NCHUNK']};",
-        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, ACT = {t['ACT']};",
+        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, ACT = {t['ACT']};",
         f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = false, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
         _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
         _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
@@ -357,7 +376,7 @@ def compile_split(t: dict, verbose: bool = False) -> dict | None:
     os.makedirs(ARS_DIR, exist_ok=True)
     so, meta_path = f"arx_{sig}.so", os.path.join(ARS_DIR, f"arx_{sig}.json")
     meta = {"so": so, "core": "x" + _digest(t), "split": 1, "l0": [], "alt": None, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"],
-            "WAVES": t["WAVES"], "TRAIN_OK": t["TRAIN_OK"], "XLDS": t["XLDS"], "NCHUNK": t["NCHUNK"]}
+            "WAVES": t["WAVES"], "CH": t["CH"], "TRAIN_OK": t["TRAIN_OK"], "XLDS": t["XLDS"], "NCHUNK": t["NCHUNK"]}
     with open(os.path.join(ARS_DIR, f".lock_{sig}"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if os.path.exists(os.path.join(ARS_DIR, so)) and os.path.exists(meta_path):
@@ -682,6 +701,19 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
             work.append((ta, None if la == ld else ld))
         else:
             work += [(ta, None), (td, None)]
+    # the alternative workgroup geometry of the split kernels, for the headline conditioner only (tests/test_gpu_flows.py exercises it)
+    prev = os.environ.get("ZUKO_AMD_SPLIT_GEOM")
+    if prev is None:
+        os.environ["ZUKO_AMD_SPLIT_GEOM"] = "4x16"
+        try:
+            kind, features, context, hidden, bins = PREBUILT[0][:5]
+            for pl, layout, _ in _plans_for(kind, features, context, hidden, bins):
+                pl._split_cache = None
+                ts = split_tables(pl, layout.kind, 1)
+                if ts is not None and not any(x == ts[0] for x in splits):
+                    splits.append(ts[0])
+        finally:
+            del os.environ["ZUKO_AMD_SPLIT_GEOM"]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         metas = list(ex.map(lambda w: compile_kernel(w[0], w[1], verbose), work))
         kerns = list(ex.map(lambda tg: chain_kernel(tg[0], True, verbose), chains))
