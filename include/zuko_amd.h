@@ -222,6 +222,12 @@ int zk_ar_forward_diag(const zk_ar_args_v1* args, void* stream);
  *   sorted unit order of zk_ar_forward_train; y [N, D] (row stride ldy) = gradient w.r.t. the conditioner's input;
  *   wstream / n_chunks: the kernel's weight stream; n_layers = linear layers of the conditioner (2..4). */
 int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream);
+/* The same chain from the gradient of the packed parameters: x [N, DIN = features * total] (row stride ldx) = d loss / d phi, and the
+ * dgrad of the LAST linear layer is part of the launch (its K = features * total input is streamed from global memory, each element read
+ * once).  h1 .. h_{n-1} (read) / gh1 .. gh_{n-1} (written) cover all hidden layers; y [N, D] = gradient w.r.t. the conditioner's input.
+ * `launcher` = zk_ars_dgrad_launch of an operand-split chain kernel (zuko_amd/static_ar.py: chain_split_tables; the products run on the
+ * bf16 matrix instruction with every f32 operand split three ways, as zk_gather_split_bf16 describes). */
+int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream);
 /* One sweep of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000, the body of its loop):
  *     x_out = univariate(*unpack(MaskedMLP(x_cond))).inv(y)
  * x (= x_cond) [N, DIN] as for zk_ar_forward (features first, context after), y_in [N, D] (row stride ldy) the values to

@@ -81,3 +81,72 @@ def test_chain_tables_decline_what_the_kernel_does_not_cover():
     assert static_ar.chain_tables_for(lins) is None
     (_, _, lins), _ = static_ar._plans_for("rqs", 32, 0, (512, 512), 8)  # wider than a wavefront's 16 register tiles
     assert static_ar.chain_tables_for(lins) is None
+
+
+def _bf16(x):
+    return torch.from_numpy(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _split3(x):
+    x = np.asarray(x, dtype=np.float32)
+    h = _bf16(x)
+    m = _bf16(x - h)
+    return h, m, _bf16(x - h - m)
+
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("affine", 16, 0, (128, 128), 0), ("rqs", 12, 0, (48,), 8)])
+def test_split_chain_tables_reproduce_the_whole_dgrad(cfg):
+    """static_ar.chain_split_tables (the operand-split chain over ALL layers, csrc/fused_ar_split_impl.h: arxd_kernel) walked on the CPU:
+    blocks of (out tile, in pair) as three bf16 images, six partial products per block, layer 0 in-pair major with its list of live
+    pairs — must give d loss / d (hidden pre-activations) and d loss / d x of the masked ReLU network to f32 accuracy."""
+    rng = np.random.default_rng(5)
+    for _, _, lins in static_ar._plans_for(*cfg):
+        n = len(lins)
+        sp = SortedPlan(lins, 1, torch.device("cpu"))
+        tg = static_ar.chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu)
+        assert tg is not None
+        t, gathers = tg
+        assert t["NH"] == n and t["DIN0"] == lins[-1].weight.shape[0] and t["DOUT"] == lins[0].weight.shape[1]
+        assert t["BASE"] == [3 * sum(t["NB"][:c]) for c in range(n)] and t["NCHUNK"] == -(-3 * sum(t["NB"]) // t["CH"])
+        assert sorted(set(t["B_IP"][: t["NB"][0]])) == t["P0"] and len(t["P0"]) == t["NP0"]
+        ips = t["B_IP"][: t["NB"][0]]
+        assert all(ips[i] <= ips[i + 1] for i in range(len(ips) - 1)), "layer 0 is in-pair major"
+        W = [(l.weight.detach().numpy() * l.mask.numpy()).astype(np.float32) for l in lins]
+        g_phi = rng.standard_normal(t["DIN0"]).astype(np.float32)
+        gates = [(rng.random(lins[l].weight.shape[0]) > 0.4).astype(np.float64) for l in range(n - 1)]  # module order, per hidden layer
+        # reference (module order)
+        ref, g = [], g_phi.astype(np.float64)
+        for l in range(n - 1, -1, -1):
+            g = g @ W[l].astype(np.float64)
+            if l > 0:
+                g = g * gates[l - 1]
+            ref.append(g)
+        # the kernel's walk (sorted unit order)
+        vec = np.zeros(max(t["DIN0"], t["TMAX"] * 16) + 32, dtype=np.float32)
+        vec[: t["DIN0"]] = g_phi  # (the last layer's rows are in module order: rows[n-1] is the identity)
+        boff = 0
+        for c in range(n):
+            l = n - 1 - c
+            idx = gathers[c].reshape(-1, 64, 8)
+            vals = np.where(idx >= 0, W[l].reshape(-1)[np.maximum(idx, 0)], 0.0).astype(np.float32)
+            ah, am, al = _split3(vals)
+            vh, vm, vl = _split3(vec)
+            out = np.zeros(t["HT"][c] * 16)
+            for s in range(t["NB"][c]):
+                ot, ip = t["B_OT"][boff + s], t["B_IP"][boff + s]
+                for lane in range(64):
+                    i, kq = lane % 16, lane // 16
+                    units = np.concatenate([np.arange(4) + (2 * ip) * 16 + 4 * kq, np.arange(4) + (2 * ip + 1) * 16 + 4 * kq])
+                    for a_, b_ in ((al, vh), (ah, vl), (am, vm), (am, vh), (ah, vm), (ah, vh)):
+                        out[ot * 16 + i] += float(np.dot(a_[s, lane].astype(np.float64), b_[units].astype(np.float64)))
+            boff += t["NB"][c]
+            width = W[l].shape[1]
+            if l > 0:
+                out[:width] *= gates[l - 1][sp.rows_cpu[l - 1]]
+                want = ref[c][sp.rows_cpu[l - 1]]
+            else:
+                want = ref[c]
+            scale = max(1.0, np.abs(want).max())
+            assert np.abs(out[:width] - want).max() <= 4e-6 * scale, (c, np.abs(out[:width] - want).max(), scale)
+            vec = np.zeros_like(vec)
+            vec[:width] = out[:width].astype(np.float32)

@@ -588,6 +588,28 @@ int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream) {
   return ((ars_dgrad_fn)args->launcher)(&a, ARS_ABI, (int)sizeof(ArArgs), stream);
 }
 
+// zk_ar_dgrad_chain extended to the LAST linear layer: x = gradient of the packed parameters phi [N, DIN = features * total] (row stride
+// ldx), h1 .. h_{n-1} the forward's hidden activations (gates), gh1 .. gh_{n-1} receive the gradients of all hidden layers'
+// pre-activations, y the gradient w.r.t. the conditioner's input; `launcher` = zk_ars_dgrad_launch of an operand-split chain kernel
+// (zuko_amd/static_ar.py: chain_split_tables), whose first layer streams x from global memory.
+int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args) || !args->launcher || !args->x || !args->y || !args->wstream) return ZK_EINVAL;
+  const int n = args->n_layers;
+  if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff) return ZK_EINVAL;
+  if (args->N == 0) return 0;
+  const void* hs[3] = {args->h1, args->h2, args->h3};
+  void* gs[3] = {args->gh1, args->gh2, args->gh3};
+  ArArgs a{};
+  a.x = (const float*)args->x; a.ldx = args->ldx; a.N = args->N; a.D = args->D; a.DIN = args->DIN; a.L = n; a.n_chunks = args->n_chunks;
+  a.stream = (const float*)args->wstream;
+  a.phi_out = (float*)args->y; a.ldphi = args->ldy;
+  for (int c = 0; c + 1 < n; ++c) {  // chain layer c gates with (and yields the gradient of) hidden layer n - 1 - c (1-based)
+    a.gate[c] = (const float*)hs[n - 2 - c];
+    a.act_out[c] = (float*)gs[n - 2 - c];
+  }
+  return ((ars_dgrad_fn)args->launcher)(&a, ARS_ABI, (int)sizeof(ArArgs), stream);
+}
+
 // One sweep of the autoregressive inverse (zuko/transforms.py:997-998): x_out = univariate(conditioner(x_cond)).inv(y).
 // x_out may alias x_cond (a wave reads its rows of x_cond completely before it writes them).
 int zk_ar_inverse_sweep(const zk_ar_args_v1* args, void* stream) {

@@ -310,6 +310,148 @@ template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(64 * S
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must land before the LDS is released
 }
 
+// ---- the backward twin: dgrad through EVERY linear layer of the conditioner in one launch -------------------------------------------
+// g_{l-1} = (g_l (W_l * mask_l)) * relu'(h_{l-1}) from the gradient of the packed parameters phi down to the conditioner's input (what
+// autograd derives from zuko/nn.py:217-218 and the ReLUs between the layers), with the operand split of this file.  The chain is itself
+// a masked MLP whose layer matrices are the TRANSPOSED sorted weights (zuko_amd/static_ar.py: chain_split_tables).  Its first layer has
+// features x total inputs (1472 for the 8-bin spline head of 64 features): far more than a wavefront can hold, so that layer walks
+// its blocks IN-PAIR MAJOR and reads the two tiles of g_phi it needs per pair straight from global memory, DEPTH pairs ahead
+// (each element of g_phi is read exactly once per launch); the other layers keep the gradient tiles in registers like the forward.
+//   Shape::DIN0, NP0, P0[]        width of g_phi, in pairs of layer 0 that have blocks, and which pairs these are (in stream order)
+//   Shape::NB[l], BOFF, B_OT, B_IP, BASE   blocks per chain layer (layer 0: in-pair major; others: out-tile major)
+//   Shape::HT[l]                  out tiles of chain layer l (= tiles of the hidden layer whose gradient it yields); DOUT: conditioner inputs
+template <class S> struct ArxdPat {
+  static constexpr int pair_index(int s) {  // position in P0 of the pair block s of layer 0 belongs to
+    int n = 0;
+    for (int i = 1; i <= s; ++i) n += S::B_IP[i] != S::B_IP[i - 1];
+    return n;
+  }
+};
+
+template <class S, class Ring> __device__ __forceinline__ void arxd_first(Ring& ring, const float* grow_q, int q, f32x4 (&out)[S::TMAX]) {
+  typedef ArxdPat<S> P;
+  constexpr int NB = S::NB[0], BASE = S::BASE[0], HTL = S::HT[0], NP = S::NP0, DEPTH = NP < 6 ? NP : 6;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < HTL; ++t) out[t] = zero;
+  f32x4 pf[DEPTH][2];
+  auto fetch = [&](auto j_) ARS_ALWAYS_INLINE {
+    constexpr int j = decltype(j_)::value, ip = S::P0[j];
+    ars_for<2>([&](auto h_) ARS_ALWAYS_INLINE {
+      constexpr int it = 2 * ip + decltype(h_)::value;
+      f32x4 v = zero;
+      if constexpr ((it + 1) * 16 <= S::DIN0) v = *reinterpret_cast<const f32x4*>(grow_q + it * 16);
+      else if constexpr (it * 16 < S::DIN0) {
+        if (it * 16 + 4 * q < S::DIN0) v = *reinterpret_cast<const f32x4*>(grow_q + it * 16);
+      }
+      pf[j % DEPTH][h_] = v;
+    });
+  };
+  ars_for<DEPTH>([&](auto j_) ARS_ALWAYS_INLINE { fetch(j_); });
+  ArxB b;
+  f32x4 a[2][3];
+  ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[0][p] = ring.template read<BASE + decltype(p)::value>(); });
+  ars_for<NB>([&](auto s_) ARS_ALWAYS_INLINE {
+    constexpr int s = s_, ot = S::B_OT[s], j = P::pair_index(s);
+    if constexpr (s == 0 || S::B_IP[s - 1] != S::B_IP[s]) {  // first block of a pair: its two tiles become the B operand, their slots are refilled
+      arx_split(pf[j % DEPTH][0], pf[j % DEPTH][1], b);
+      if constexpr (j + DEPTH < NP) fetch(std::integral_constant<int, j + DEPTH>{});
+    }
+    if constexpr (s + 1 < NB) {
+      ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[(s + 1) & 1][p] = ring.template read<BASE + 3 * (s + 1) + decltype(p)::value>(); });
+      ars_settle<3>(a[s & 1][0], a[s & 1][1], a[s & 1][2]);
+    } else {
+      ars_settle<0>(a[s & 1][0], a[s & 1][1], a[s & 1][2]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    arx_block(a[s & 1], b, out[ot]);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+template <class S, int L, class Ring> __device__ __forceinline__ void arxd_stack(Ring& ring, const float* zero_q, int q, ArxB (&in)[S::TMAX / 2], f32x4 (&out)[S::TMAX], const ArArgs& a,
+                                                                                 int64_t n, int64_t nc, bool live) {
+  if constexpr (L < S::NH) {
+    if constexpr (L > 0) arx_hidden<S, L>(ring, zero_q, in, out);
+    constexpr int HTL = S::HT[L];
+    if constexpr (L + 1 < S::NH) {
+      const float* grow = a.gate[L] + nc * (HTL * 16) + 4 * q;
+#pragma unroll
+      for (int t = 0; t < HTL; ++t) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(grow + t * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] = out[t][r] * (h[r] > 0.f ? 1.f : 0.f);  // (a product, as autograd's: NaN gradients stay NaN)
+      }
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < HTL; ++t) *reinterpret_cast<f32x4*>(a.act_out[L] + n * (HTL * 16) + t * 16 + 4 * q) = out[t];
+      }
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < (HTL + 1) / 2; ++p) arx_split(out[2 * p], 2 * p + 1 < HTL ? out[2 * p + 1] : zero, in[p]);
+      arxd_stack<S, L + 1, Ring>(ring, zero_q, q, in, out, a, n, nc, live);
+    } else if (live) {  // gradient w.r.t. the conditioner's input: module column order, DOUT columns
+#pragma unroll
+      for (int t = 0; t < HTL; ++t)
+        if ((t + 1) * 16 <= S::DOUT || t * 16 + 4 * q < S::DOUT) *reinterpret_cast<f32x4*>(a.phi_out + n * a.ldphi + t * 16 + 4 * q) = out[t];
+    }
+  }
+}
+
+template <class S> __global__ __launch_bounds__(512, 2) void arxd_kernel(ArArgs a) {
+  typedef ArRingS<8, S::CH> Ring;
+  static_assert(S::NH >= 2 && S::NH <= 4 && S::TMAX <= 16 && S::TMAX % 2 == 0 && S::WAVES == 8, "dgrad chain: the last layer + up to three gated layers, widths <= 256");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  Ring ring;
+  ring.lds = ars_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < ARS_NR - 1; ++i) ring.issue();
+  ring.slot = ARS_NR - 1;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)ars_lds);
+  ring.cur_off = ring.lds_off;
+  float* zero_lds = ars_lds + ARS_NR * S::CH * AR_TF;  // "bias image" of a layer without bias
+  for (int i = tid; i < S::TMAX * 16 + 16; i += 512) zero_lds[i] = 0.f;
+  __syncthreads();
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n = tile * 128 + wave * 16 + j;
+    const bool live = n < a.N;
+    const int64_t nc = live ? n : a.N - 1;
+    ArxB in[S::TMAX / 2];
+    f32x4 out[S::TMAX];
+    arxd_first<S>(ring, a.x + nc * a.ldx + 4 * q, q, out);
+    arxd_stack<S, 0, Ring>(ring, zero_lds + 4 * q, q, in, out, a, n, nc, live);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <class S> static int arxd_launch(const ArArgs* in, int abi, int args_bytes, void* stream) {
+  if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;
+  ArArgs a = *in;
+  if (a.DIN != S::DIN0 || a.D != S::DOUT || a.L != S::NH || a.n_chunks != S::NCHUNK || !a.x || !a.phi_out || a.ldx % 4 || a.ldphi % 4 || ((uintptr_t)a.x % 16) ||
+      ((uintptr_t)a.phi_out % 16))
+    return ZK_EINVAL;
+  for (int l = 0; l + 1 < S::NH; ++l)
+    if (!a.gate[l] || !a.act_out[l] || ((uintptr_t)a.gate[l] % 16) || ((uintptr_t)a.act_out[l] % 16)) return ZK_EINVAL;
+  a.n_tiles = (a.N + 127) / 128;
+  const int lds = (ARS_NR * S::CH * AR_TF + S::TMAX * 16 + 16) * (int)sizeof(float);
+  const void* fn = (const void*)arxd_kernel<S>;
+  static bool granted = false;
+  if (!granted) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    granted = true;
+  }
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  void* kargs[] = {&a};
+  hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  return ZK_LAUNCH_CHECK();
+}
+
 template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi, int args_bytes, int train, void* stream) {
   if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;  // kernel built against another version of the library
   ArArgs a = *in;

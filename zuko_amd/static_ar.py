@@ -522,6 +522,85 @@ def chain_tables(masks_sorted: list, rows: list, cols: list):
     return t, gathers
 
 
+def chain_split_tables(masks_sorted: list, rows: list, cols: list):
+    """Tables + gather indices of the operand-split dgrad chain over ALL n linear layers (csrc/fused_ar_split_impl.h: arxd_kernel), from the
+    gradient of the packed parameters down to the conditioner's input.  Arguments as chain_tables, but for every layer l = 0 .. n-1.
+    Chain layer c multiplies by the transpose of layer l = n-1-c; a block is (out tile = 16 sorted INPUT units of layer l, in pair = 32
+    sorted OUTPUT units of layer l) as three bf16 images (split_tables).  Layer 0 is walked in-pair major (its input g_phi is streamed
+    from global memory), the others out-tile major.  Returns (tables, gathers) or None."""
+    n = len(masks_sorted)
+    if n < 2 or n > 4:
+        return None
+    hidden = [m.shape[0] for m in masks_sorted[:-1]]
+    din, dphi = masks_sorted[0].shape[1], masks_sorted[-1].shape[0]
+    if any(w % 16 or w > 256 for w in hidden) or din % 4 or din > 256 or dphi % 4:
+        return None
+    ch = 24
+    lane = np.arange(64)
+    li, lq = lane % 16, lane // 16
+    HT, NB, BASE, B_OT, B_IP, blocks_of, P0 = [], [], [], [], [], [], []
+    cursor = 0
+    for c in range(n):
+        l = n - 1 - c
+        M = np.asarray(masks_sorted[l], dtype=bool)
+        out_l, in_l = M.shape
+        n_ot, n_ip = -(-in_l // 16), -(-(-(-out_l // 16)) // 2)
+        HT.append(n_ot)
+
+        def block(ot, ip):
+            a_ = ot * 16 + li[:, None]                                                        # sorted input unit of layer l
+            e = np.arange(8)[None, :]
+            b_ = (2 * ip + e // 4) * 16 + (4 * lq)[:, None] + e % 4                            # sorted output unit of layer l
+            ok = (a_ < in_l) & (b_ < out_l)
+            return np.where(ok, np.asarray(rows[l])[np.minimum(b_, out_l - 1)] * in_l + np.asarray(cols[l])[np.minimum(a_, in_l - 1)], -1)
+
+        def live(ot, ip):
+            return bool(M[ip * 32 : ip * 32 + 32, ot * 16 : ot * 16 + 16].any())
+
+        order = [(ot, ip) for ip in range(n_ip) for ot in range(n_ot)] if c == 0 else [(ot, ip) for ot in range(n_ot) for ip in range(n_ip)]
+        blocks = []
+        for ot, ip in order:
+            if live(ot, ip):
+                blocks.append(block(ot, ip))
+                B_OT.append(ot), B_IP.append(ip)
+                if c == 0 and (not P0 or P0[-1] != ip):
+                    P0.append(ip)
+        if not blocks:
+            return None
+        NB.append(len(blocks))
+        BASE.append(cursor)
+        cursor += 3 * len(blocks)
+        blocks_of.append(blocks)
+    n_chunks = -(-cursor // ch)
+    pad = -(-(n_chunks * ch - cursor) // 3)
+    blocks_of[-1] = blocks_of[-1] + [-np.ones((64, 8), dtype=np.int64)] * pad
+    t = {"chain": 2, "DIN0": int(dphi), "DOUT": int(din), "NH": n, "HT": HT, "TMAX": int(2 * -(-max(HT) // 2)), "NB": NB, "BASE": BASE, "B_OT": B_OT, "B_IP": B_IP, "NP0": len(P0), "P0": P0,
+         "NCHUNK": n_chunks, "STREAM_IMAGES": max(n_chunks * ch, cursor + 3 * pad), "WAVES": 8, "CH": ch}
+    if t["TMAX"] > 16:
+        return None
+    return t, [np.stack(b).astype(np.int32).reshape(-1) for b in blocks_of]
+
+
+def emit_chain_split(t: dict) -> str:
+    boff = [0]
+    for nb in t["NB"]:
+        boff.append(boff[-1] + nb)
+    lines = [
+        "// generated by zuko_amd/static_ar.py — do not edit",
+        '#include "fused_ar_split_impl.h"',
+        "namespace {",
+        "struct Shape {",
+        f"  static constexpr int DIN0 = {t['DIN0']}, DOUT = {t['DOUT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NCHUNK = {t['NCHUNK']}, WAVES = 8, CH = {t['CH']}, NP0 = {t['NP0']}, ACT = 1;",
+        _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]), _arr("P0", "unsigned char", t["P0"]),
+        _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]),
+        "};",
+        "}  // namespace",
+        'extern "C" int zk_ars_dgrad_launch(const zk::ArArgs* a, int abi, int args_bytes, void* stream) { return zk::arxd_launch<Shape>(a, abi, args_bytes, stream); }',
+        "",
+    ]
+    return "\n".join(lines)
+
+
 def emit_chain(t: dict) -> str:
     soff = [0]
     for n in t["NS"]:
@@ -573,9 +652,9 @@ def chain_kernel(t: dict, allow_compile: bool, verbose: bool = False):
                 if not os.path.exists(so):
                     src = os.path.join(ARS_DIR, f"arsd_{sig}.hip")
                     with open(src, "w") as f:
-                        f.write(emit_chain(t))
+                        f.write(emit_chain_split(t) if t.get("chain") == 2 else emit_chain(t))
                     with open(os.path.join(ARS_DIR, f"arsd_{sig}.json"), "w") as f:
-                        json.dump({"so": f"arsd_{sig}.so", "headers": stamp, "core": "chain", "l0": [], "alt": None, "DIN": t["DIN"], "DOUT": t["DOUT"], "HT": t["HT"]}, f)
+                        json.dump({"so": f"arsd_{sig}.so", "headers": stamp, "core": "chain", "l0": [], "alt": None, "DIN": t.get("DIN", t.get("DIN0")), "DOUT": t["DOUT"], "HT": t["HT"]}, f)
                     tmp = so + f".{os.getpid()}"
                     cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
                            src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
@@ -637,8 +716,8 @@ def _plans_for(kind: str, features: int, context: int, hidden, bins: int, activa
     return out
 
 
-def chain_tables_for(lins):
-    """chain_tables of a masked ReLU conditioner given its linear layers (through zuko_amd/train.py:SortedPlan), or None."""
+def chain_tables_for(lins, full: bool = False):
+    """chain_tables (full: chain_split_tables) of a masked ReLU conditioner given its linear layers (through zuko_amd/train.py:SortedPlan), or None."""
     import torch
 
     from .train import SortedPlan
@@ -647,6 +726,8 @@ def chain_tables_for(lins):
     n = len(lins)
     if n < 2 or n > 4 or any(m is None for m in sp.mask_s_cpu):
         return None
+    if full:
+        return chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu) if sp.shapes[-1][0] % 4 == 0 else None
     return chain_tables(sp.mask_s_cpu[: n - 1], sp.rows_cpu[: n - 1], sp.cols_cpu[: n - 1])
 
 
@@ -686,9 +767,9 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
         (pa, layout, lins_a), (pd, _, lins_d) = _plans_for(kind, features, context, hidden, bins)
         if act == 1:  # the training backward of the same conditioners (one kernel per feature order)
             for lins in (lins_a, lins_d):
-                tg = chain_tables_for(lins)
-                if tg is not None and not any(c[0] == tg[0] for c in chains):
-                    chains.append(tg)
+                for tg in (chain_tables_for(lins), chain_tables_for(lins, full=True)):
+                    if tg is not None and not any(c[0] == tg[0] for c in chains):
+                        chains.append(tg)
         for pl in (pa, pd):
             ts = split_tables(pl, layout.kind, act)
             if ts is not None and not any(x == ts[0] for x in splits):

@@ -262,11 +262,14 @@ def _fused_forward(st, x: Tensor, out_features: int):
 
 
 class DgradChain:
-    """Backward of every linear layer but the last in one launch (csrc/fused_ar_static_impl.h: ars_dgrad_kernel; C ABI
-    zk_ar_dgrad_chain): a generated kernel whose weight stream holds the TRANSPOSED sorted masked weights, tile by tile."""
+    """Backward of the linear layers in one launch of a generated kernel whose weight stream holds the TRANSPOSED sorted masked weights.
+    `full` (operand-split kernel, csrc/fused_ar_split_impl.h: arxd_kernel, C ABI zk_ar_dgrad_full): every layer, from the gradient of the
+    packed parameters; otherwise (csrc/fused_ar_static_impl.h: ars_dgrad_kernel, zk_ar_dgrad_chain) every layer but the last, whose
+    dgrad stays a stand-alone GEMM."""
 
     def __init__(self, plan: SortedPlan, kernel, tables: dict, gathers, device) -> None:
         self.kernel, self.t = kernel, tables
+        self.full = tables.get("chain") == 2
         self.idx = [torch.from_numpy(g).to(device) for g in gathers]
         self.offsets = [b * 256 for b in tables["BASE"]]
         self.device = device
@@ -274,28 +277,35 @@ class DgradChain:
     def gather(self, plan: SortedPlan, lins) -> Tensor:
         """The kernel's weight stream from the module's CURRENT parameters (a fresh tensor: the forward saves it for its backward)."""
         lib = _C.lib()
-        stream = torch.empty(self.t["NCHUNK"] * 24 * 256, dtype=torch.float32, device=self.device)
+        stream = torch.empty((self.t["STREAM_IMAGES"] if self.full else self.t["NCHUNK"] * 24) * 256, dtype=torch.float32, device=self.device)
         n1 = len(self.idx)
         for c, idx in enumerate(self.idx):
             l = n1 - 1 - c
             w = lins[l].weight.detach().contiguous()
-            _C.check(lib.zk_gather_f32(_ptr(w), _ptr(plan.mask_u8[l]), _ptr(idx), idx.numel(), _ptr(stream[self.offsets[c] :]), _stream()), "zk_gather_f32")
+            if self.full:
+                _C.check(lib.zk_gather_split_bf16(_ptr(w), _ptr(plan.mask_u8[l]), _ptr(idx), idx.numel() // 512, _ptr(stream[self.offsets[c] :]), _stream()), "zk_gather_split_bf16")
+            else:
+                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(plan.mask_u8[l]), _ptr(idx), idx.numel(), _ptr(stream[self.offsets[c] :]), _stream()), "zk_gather_f32")
         return stream
 
-    def run(self, plan: SortedPlan, stream: Tensor, g_last: Tensor, hs):
-        """g_last [N, width] = gradient of the last hidden layer's pre-activations; hs = [x, h_1, ..] as saved by the forward.
-        Returns ([g_1, .., g_last], gx)."""
+    def run(self, plan: SortedPlan, stream: Tensor, g_in: Tensor, hs):
+        """g_in: gradient of the packed parameters [N, out_features] (full) or of the last hidden layer's pre-activations [N, width];
+        hs = [x, h_1, ..] as saved by the forward.  Returns ([g_1, .., g_{n-1}] gradients of the hidden pre-activations, gx)."""
         n = len(plan.shapes)
-        N = g_last.shape[0]
-        dev = g_last.device
-        gs = [torch.empty((N, plan.shapes[l][0]), dtype=torch.float32, device=dev) for l in range(n - 2)]
+        N = g_in.shape[0]
+        dev = g_in.device
+        n_out = n - 1 if self.full else n - 2
+        gs = [torch.empty((N, plan.shapes[l][0]), dtype=torch.float32, device=dev) for l in range(n_out)]
         gx = torch.empty((N, plan.shapes[0][1]), dtype=torch.float32, device=dev)
-        hp = [_ptr(hs[1 + l]) for l in range(n - 2)] + [None] * 3
+        hp = [_ptr(hs[1 + l]) for l in range(n_out)] + [None] * 3
         gp = [_ptr(g) for g in gs] + [None] * 3
-        a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, N=N, D=plan.shapes[0][1], DIN=g_last.shape[1], x=_ptr(g_last), ldx=g_last.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
+        a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, N=N, D=plan.shapes[0][1], DIN=g_in.shape[1], x=_ptr(g_in), ldx=g_in.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
                     gh1=gp[0], gh2=gp[1], gh3=gp[2], y=_ptr(gx), ldy=gx.stride(0), wstream=_ptr(stream), n_layers=n, n_chunks=self.t["NCHUNK"], act=1)
+        if self.full:
+            _C.check(_C.lib().zk_ar_dgrad_full(a, _stream()), "zk_ar_dgrad_full")
+            return gs, gx
         _C.check(_C.lib().zk_ar_dgrad_chain(a, _stream()), "zk_ar_dgrad_chain")
-        return gs + [g_last], gx
+        return gs + [g_in], gx
 
 
 _CHAINS = weakref.WeakKeyDictionary()  # SortedPlan -> DgradChain or False
@@ -315,9 +325,17 @@ def _dgrad_chain(plan: SortedPlan, lins, rows: int):
         if 2 <= n <= 4 and plan.act == 1 and all(m is not None for m in plan.mask_s_cpu):
             from . import static_ar
 
+            allow = static_ar.jit_enabled() and rows >= static_ar.jit_min_rows()
+            if static_ar.split_enabled() and plan.shapes[-1][0] % 4 == 0:  # every layer in one launch of the operand-split kernel
+                tg = static_ar.chain_split_tables(plan.mask_s_cpu, plan.rows_cpu, plan.cols_cpu)
+                kern = static_ar.chain_kernel(tg[0], allow_compile=allow) if tg is not None else None
+                if kern is not None:
+                    st = DgradChain(plan, kern, tg[0], tg[1], plan.device)
+                    _CHAINS[plan] = st
+                    return st
             tg = static_ar.chain_tables(plan.mask_s_cpu[: n - 1], plan.rows_cpu[: n - 1], plan.cols_cpu[: n - 1])
             if tg is not None:
-                kern = static_ar.chain_kernel(tg[0], allow_compile=static_ar.jit_enabled() and rows >= static_ar.jit_min_rows())
+                kern = static_ar.chain_kernel(tg[0], allow_compile=allow)
                 if kern is not None:
                     st = DgradChain(plan, kern, tg[0], tg[1], plan.device)
                 else:
@@ -335,9 +353,9 @@ class ConditionerFn(torch.autograd.Function):
         n = len(lins)
         st = _fused_forward_state(plan, lins, x.device) if (x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
         chain = _dgrad_chain(plan, lins, x.shape[0]) if n >= 2 else None
-        ws, wts, bs = plan.gather(lins, forward=st is None, transposes=None if chain is None else {n - 1})
-        if chain is not None:  # (the backward of every layer but the last reads this stream instead of the transposes)
-            wts = [chain.gather(plan, lins), wts[n - 1]]
+        ws, wts, bs = plan.gather(lins, forward=st is None, transposes=None if chain is None else (set() if chain.full else {n - 1}))
+        if chain is not None:  # (the backward reads this stream instead of the transposes; the stand-alone chain keeps the last layer's)
+            wts = [chain.gather(plan, lins)] + ([] if chain.full else [wts[n - 1]])
         if st is not None:  # whole forward in one launch of the static-shape kernel
             st.refresh(lins, fine_only=True)
             acts, h = _fused_forward(st, x, plan.shapes[-1][0])
@@ -402,9 +420,12 @@ class ConditionerFn(torch.autograd.Function):
         """Last layer as the layer-wise path (its K = out_features product is a plain GEMM), every other dgrad in one launch."""
         plan, n = ctx.plan, ctx.n
         ConditionerFn._param_grads(ctx, n - 1, g, hs[n - 1], grads)
-        stream, wt_last = wts
-        g_last = plan.gemm(g, wt_last, plan.kskip_b[n - 1], None, 0, hs[n - 1], plan.act)
-        gs, gx = chain.run(plan, stream, g_last, hs)
+        if chain.full:
+            gs, gx = chain.run(plan, wts[0], g, hs)
+        else:
+            stream, wt_last = wts
+            g_last = plan.gemm(g, wt_last, plan.kskip_b[n - 1], None, 0, hs[n - 1], plan.act)
+            gs, gx = chain.run(plan, stream, g_last, hs)
         for l in range(n - 2, -1, -1):
             ConditionerFn._param_grads(ctx, l, gs[l], hs[l], grads)
         return (None, None, gx if ctx.needs_input_grad[2] else None, *grads)
