@@ -407,7 +407,7 @@ int zk_wgrad_slices(int64_t N, int npairs);
 int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh,
                  const int32_t* pairs, int npairs, float* partial, const uint8_t* mask, void* dw, int accumulate, const int32_t* rows,
                  const int32_t* cols, void* stream);
-/* zk_wgrad_f32 plus the bias gradient db[OUT] = sum_n g[n, :] from the same pass over g (replaces a separate zk_colsum_f32 over g;
+/* zk_wgrad_f32 plus the bias gradient db[rows[o]] = sum_n g[n, o] (db[o] without rows) from the same pass over g (replaces a separate zk_colsum_f32 over g;
  * zuko/nn.py:217-218 under autograd).  cs_flag [npairs] (device, uint8) marks ONE pair per 128-row out block — every out block
  * needs one; cs_partial: workspace of zk_wgrad_slices(N, npairs) * ceil(OUT / 128) * 128 floats.  Deterministic. */
 int zk_wgrad_bias_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh,

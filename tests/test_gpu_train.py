@@ -74,6 +74,9 @@ def test_gemm_skip_wgrad_colsum(dev, N, IN, OUT):
     if plan.cs_flag[0] is not None:
         assert torch.allclose(db2.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
         assert torch.equal(plan.wgrad(0, g, x, want_bias=True)[1], db2), "deterministic"
+        plan.idx_b, plan.cols_dev = [rp.to(torch.int32).to(dev)], [cp_.to(torch.int32).to(dev)]
+        assert torch.equal(plan.wgrad(0, g, x, want_bias=True)[1][rp.to(dev)], db2), "the bias gradient follows the row permutation like dW"
+        plan.idx_b, plan.cols_dev = [None], [None]
     else:
         assert db2 is None
 

@@ -330,6 +330,111 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
       }
 }
 
+// The same block on the bf16 matrix instruction with three-way split operands (csrc/fused_ar_split_impl.h: every f32 value as h + m + l
+// in bf16, six partial products, f32 accumulation — the f32 instruction above runs at 1/16 of the bf16 rate).  The contraction runs over
+// SAMPLES, which are the strided direction of G[N, OUT] and H[N, IN]: each loader thread therefore gathers 8 consecutive samples of ONE
+// unit with 8 dword loads (consecutive threads = consecutive units: every load instruction is coalesced), splits them in registers and
+// writes the three 16-byte bf16 vectors straight into the operand images of v_mfma_f32_16x16x32_bf16 (lane = 16 * sample octet + unit,
+// 8 samples per lane) — no transposition in LDS, operands are plain ds_read_b128.  k tile = 32 samples; a wavefront owns 64 x 64 of the
+// block (4 x 4 tiles) and issues the six terms tile after tile, so no accumulator is touched twice in a row.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void wsplit8(const float (&v)[8], wbf16x8& h, wbf16x8& m, wbf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)v[e];
+    const float r1 = v[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 Gs[8 * 3 * 64];  // [unit block of 16][part h, m, l][lane]: 24 KiB
+  __shared__ __attribute__((aligned(16))) uint4 Hs[8 * 3 * 64];
+  const int p = blockIdx.x % a.npairs, s = blockIdx.x / a.npairs;
+  const int ob = a.pairs[2 * p], ib = a.pairs[2 * p + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t n_begin = (int64_t)s * a.S;
+  int64_t n_end = n_begin + a.S;
+  n_end = n_end < a.N ? n_end : a.N;
+
+  f32x4_t4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t4{0.f, 0.f, 0.f, 0.f};
+
+  // loader: thread -> unit u of the 128, sample octets oc0 and oc0 + 2 of the 4 in a k tile
+  const int u = tid & 127, oc0 = tid >> 7;
+  const int go = ob * 128 + u, hc = ib * 128 + u;
+  const bool g_ok = go < a.OUT, h_ok = hc < a.IN;
+  float rg[2][8], rh[2][8];
+  auto gload = [&](int64_t n0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t n = n0 + (oc0 + 2 * t) * 8 + e;
+        const bool in = n < n_end;
+        rg[t][e] = (in && g_ok) ? a.g[n * a.ldg + go] : 0.f;
+        rh[t][e] = (in && h_ok) ? a.h[n * a.ldh + hc] : 0.f;
+      }
+  };
+  const bool do_cs = a.cs_flag && a.cs_flag[p];
+  float csum = 0.f;
+  const int img = (u >> 4) * 3 * 64 + (u & 15);  // + part * 64 + octet * 16
+  gload(n_begin);
+  for (int64_t n0 = n_begin; n0 < n_end; n0 += 32) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      wbf16x8 hh, mm, ll;
+      wsplit8(rg[t], hh, mm, ll);
+      const int at = img + (oc0 + 2 * t) * 16;
+      Gs[at] = __builtin_bit_cast(uint4, hh); Gs[at + 64] = __builtin_bit_cast(uint4, mm); Gs[at + 128] = __builtin_bit_cast(uint4, ll);
+      wsplit8(rh[t], hh, mm, ll);
+      Hs[at] = __builtin_bit_cast(uint4, hh); Hs[at + 64] = __builtin_bit_cast(uint4, mm); Hs[at + 128] = __builtin_bit_cast(uint4, ll);
+      if (do_cs) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum += rg[t][e];
+      }
+    }
+    __syncthreads();
+    if (n0 + 32 < n_end) gload(n0 + 32);
+    wbf16x8 A[4][3], B[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        A[i][part] = __builtin_bit_cast(wbf16x8, Gs[((wr * 4 + i) * 3 + part) * 64 + lane]);
+        B[i][part] = __builtin_bit_cast(wbf16x8, Hs[((wc * 4 + i) * 3 + part) * 64 + lane]);
+      }
+    // six partial products, smallest first: (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
+#define ZK_WTERM(PA, PB)                                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][PA], B[j][PB], acc[i][j], 0, 0, 0);
+    ZK_WTERM(2, 0) ZK_WTERM(0, 2) ZK_WTERM(1, 1) ZK_WTERM(1, 0) ZK_WTERM(0, 1) ZK_WTERM(0, 0)
+#undef ZK_WTERM
+    __syncthreads();
+  }
+  if (a.cs_flag) {  // (uniform per block: cs_flag[p])
+    if (do_cs) {
+      float* cs = reinterpret_cast<float*>(Gs);
+      cs[tid] = csum;
+      __syncthreads();
+      if (tid < 128) a.cs_partial[(size_t)s * a.cs_ld + ob * 128 + tid] = cs[tid] + cs[tid + 128];
+    }
+  }
+  // acc[i][j][r] = D[row 4 (lane >> 4) + r][col lane & 15] of tile (i, j)
+  float* dst = a.partial + ((size_t)s * a.npairs + p) * (128 * 128);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(wr * 64 + i * 16 + 4 * (lane >> 4) + r) * 128 + wc * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+}
+
 // dW[o, i] (+)= mask[o, i] * sum_s partial[s][p][...] in slice order (deterministic); 64 blocks of 256 elements per pair
 // rows / cols (optional): the gradient is computed on a row / column PERMUTED weight (zuko_amd/train.py: units sorted by dependency
 // count) but written where the module keeps it: element (o, c) goes to dw[rows[o], cols[c]] — no scatter pass afterwards
@@ -404,7 +509,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t N, int C, c
     if (c < C) partial[(size_t)s * C + c] = sum;
   }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(int C, int nslices, const float* partial, float* out, int accumulate, int ld = 0) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(int C, int nslices, const float* partial, float* out, int accumulate, int ld = 0, const int32_t* rows = nullptr) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const size_t stride = ld ? (size_t)ld : (size_t)C;
@@ -420,7 +525,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int C, int nslices, c
     for (int u = 0; u < 8; ++u) sum += v[u];
   }
   for (; s < nslices; ++s) sum += partial[(size_t)s * stride + c];
-  out[c] = accumulate ? out[c] + sum : sum;
+  const int d = rows ? rows[c] : c;  // (sorted-domain column -> where the module keeps it)
+  out[d] = accumulate ? out[d] + sum : sum;
 }
 
 }  // namespace zk
@@ -475,10 +581,18 @@ static int wgrad_launch(int64_t N, int out_features, int in_features, const void
   a.nslices = (int)((N + a.S - 1) / a.S);
   a.partial = partial;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
+  // (operand-split kernel unless ZUKO_AMD_EXACT_F32=1 asks for the f32 matrix instruction; k tiles of 32 samples need S % 32 == 0)
+  static const bool exact = [] { const char* e = getenv("ZUKO_AMD_EXACT_F32"); return e && e[0] == '1'; }();
+  if (exact) {
+    hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
+  } else {
+    a.S = (a.S + 31) / 32 * 32;
+    a.nslices = (int)((N + a.S - 1) / a.S);
+    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)npairs * 64), dim3(256), 0, st, out_features, in_features, pairs, npairs, a.nslices, (const float*)partial, mask,
                      (float*)dw, accumulate, rows, cols);
-  if (cs_flag) hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((out_features + 255) / 256)), dim3(256), 0, st, out_features, a.nslices, (const float*)cs_partial, (float*)db, 0, a.cs_ld);
+  if (cs_flag) hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((out_features + 255) / 256)), dim3(256), 0, st, out_features, a.nslices, (const float*)cs_partial, (float*)db, 0, a.cs_ld, rows);
   return ZK_LAUNCH_CHECK();
 }
 
@@ -487,7 +601,7 @@ int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, in
   return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, nullptr, nullptr, nullptr, rows, cols, stream);
 }
 
-// zk_wgrad_f32 plus the bias gradient db[OUT] = sum_n g[n, :] from the same pass over g (it replaces a separate zk_colsum_f32 over g):
+// zk_wgrad_f32 plus the bias gradient db[rows[o]] = sum_n g[n, o] (db[o] without rows) from the same pass over g (it replaces a separate zk_colsum_f32 over g):
 // cs_flag [npairs] (device, uint8) marks ONE pair per out block (every out block must have one); cs_partial: workspace of
 // zk_wgrad_slices(N, npairs) * ceil(OUT / 128) * 128 floats.  Deterministic.
 int zk_wgrad_bias_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh, const int32_t* pairs, int npairs,

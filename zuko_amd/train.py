@@ -382,18 +382,7 @@ class ConditionerFn(torch.autograd.Function):
         if ctx.chain is not None:
             return ConditionerFn._backward_chain(ctx, ctx.chain, g, hs, wts, grads)
         for l in range(n - 1, -1, -1):
-            out_f, in_f = plan.shapes[l]
-            want_b = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
-            dbs = None
-            if ctx.needs_input_grad[3 + 2 * l]:
-                # (the reduction kernel writes dW where the module keeps it: no scatter back from the sorted order)
-                grads[2 * l], dbs = plan.wgrad(l, g, hs[l], want_bias=True) if want_b else (plan.wgrad(l, g, hs[l]), None)
-            if want_b:
-                if dbs is None:
-                    dbs = plan.colsum(g)
-                db = torch.empty(out_f, dtype=torch.float32, device=g.device)
-                db[plan.idx_b64[l]] = dbs
-                grads[2 * l + 1] = db
+            ConditionerFn._param_grads(ctx, l, g, hs[l], grads)  # (written where the module keeps them: no scatter back from the sorted order)
             if l > 0 or ctx.needs_input_grad[2]:
                 # g_l = (g_{l+1} Ws_l) * act'(h_l): Ws_l^T plays the weight, h_l (a saved activation OUTPUT) the gate
                 g = plan.gemm(g, wts[l], plan.kskip_b[l], None, 0, hs[l] if l > 0 else None, plan.act if l > 0 else 0)
@@ -409,11 +398,10 @@ class ConditionerFn(torch.autograd.Function):
         if ctx.needs_input_grad[3 + 2 * l]:
             grads[2 * l], dbs = plan.wgrad(l, g, h, want_bias=True) if want_b else (plan.wgrad(l, g, h), None)
         if want_b:
-            if dbs is None:
-                dbs = plan.colsum(g)
-            db = torch.empty(out_f, dtype=torch.float32, device=g.device)
-            db[plan.idx_b64[l]] = dbs
-            grads[2 * l + 1] = db
+            if dbs is None:  # (no pass over g to ride on: column sums in the sorted order, scattered to the module's)
+                dbs, srt = torch.empty(out_f, dtype=torch.float32, device=g.device), plan.colsum(g)
+                dbs[plan.idx_b64[l]] = srt
+            grads[2 * l + 1] = dbs
 
     @staticmethod
     def _backward_chain(ctx, chain: "DgradChain", g: Tensor, hs, wts, grads: list):
