@@ -577,6 +577,7 @@ def main() -> None:
         # 16 x 16 x 2 FLOP per streamed tile per sample (the static-shape kernel streams fewer tiles than the generic one)
         executed = None if st is None or not hasattr(st.plan, "kept_tiles") else (st.plan.fine_kept_tiles if getattr(st, "static_variant", 0) else st.plan.kept_tiles) * 512.0
         split = bool(st is not None and getattr(st, "static", None) is not None and st.static[0].meta.get("split"))
+        per_transform["split_coupling"] = bool(st is not None and getattr(st, "split", False) is True)
         if split:  # operand-split kernels: 16 x 32 x 2 f32-equivalent FLOP per streamed block per sample
             from zuko_amd import static_ar
 
@@ -686,7 +687,8 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
             n, fin, fout = int(parts[1]), int(parts[2]), int(parts[3])
             row.update(bound="mfma", achieved=2.0 * n * fin * fout / t / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
         elif parts[0] in ("zk_ar_forward", "zk_coupling_forward"):
-            split = bool(flop_per_transform.get("split")) and parts[0] == "zk_ar_forward" and "static" in rec.get("instantiation", "")
+            split = (bool(flop_per_transform.get("split")) and parts[0] == "zk_ar_forward" and "static" in rec.get("instantiation", "")) or \
+                    (bool(flop_per_transform.get("split_coupling")) and parts[0] == "zk_coupling_forward")
             # operand-split kernels: every f32 product = 6 bf16 matrix products (csrc/fused_ar_split_impl.h), so the ceiling for f32-equivalent
             # FLOP is the dense bf16 peak / 6; the f32 matrix instruction's own peak stays on the line for comparison
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS

@@ -252,7 +252,9 @@ int zk_ar_inverse_partial(const zk_ar_args_v1* args, void* stream);
  *   fmap [n_groups * 8] (device): column of x of every transformed slot, -1 = padding
  *   tiles / widths (host, n_layers - 1 ints): 16-row output tiles and true width of every hidden layer;
  *   bias_off (host, n_layers ints); wstream / bias: zuko_amd/coupling_plan.py (zk_gather_f32 from the module's parameters);
- *   static_ok != 0 allows the shape-specialised instantiation (ReLU, 128 inputs, hidden 512s) when the shapes match. */
+ *   static_ok != 0 allows the shape-specialised instantiation (ReLU, 128 inputs, hidden 512s) when the shapes match; static_ok == 2:
+ *   wstream is that shape's OPERAND-SPLIT stream (zuko_amd/coupling_plan.py: split_gather through zk_gather_split_bf16; three bf16 images per
+ *   16 x 32 weight block) and the launch goes to the bf16-matrix-instruction kernel (six partial products per f32 product, f32 accumulate). */
 typedef struct zk_coupling_args_v1 {
   uint32_t struct_size;    /* sizeof(zk_coupling_args_v1) */
   uint32_t version;        /* 1 */
@@ -265,7 +267,7 @@ typedef struct zk_coupling_args_v1 {
   int32_t act;             /* activation code */
   int32_t bias_floats;
   int32_t accumulate;      /* != 0: ladj += */
-  int32_t static_ok;       /* != 0 allows the shape-specialised instantiation when the shapes match */
+  int32_t static_ok;       /* != 0 allows the shape-specialised instantiation when the shapes match; 2 = wstream is the operand-split stream */
   int64_t N;
   int64_t ldx;             /* row stride of `in` */
   int64_t ldc;             /* row stride of ctx */

@@ -390,3 +390,44 @@ def test_split_kernel_tables_describe_the_plan(cfg):
         assert not np.isnan(got).any()
         scale = np.abs(ref).max()
         assert np.abs(got - ref).max() <= 2e-6 * scale, (np.abs(got - ref).max(), scale)
+
+
+def test_coupling_split_stream_is_the_f32_stream_regrouped():
+    """coupling_plan.build_coupling_plan's operand-split stream (cfg4's shape: 128 inputs, hidden [512] * 3): block (out tile, in pair) =
+    the f32 stream's images of in tiles 2 ip and 2 ip + 1 side by side, in the kernel's step order (4 out tiles x 1 in pair; the last layer
+    group by group), every layer and every group on a chunk boundary."""
+    import zuko_amd.flows as F
+    from zuko_amd import coupling_plan as cp
+
+    torch.manual_seed(1)
+    t = F.RealNVP(256, 0, transforms=2, hidden_features=[512] * 3).transform.transforms[1]
+    lins = list(t.hyper)[0::2]
+    idx_a, idx_b = t.mask.nonzero().squeeze(-1).numpy(), (~t.mask).nonzero().squeeze(-1).numpy()
+    plan = cp.build_coupling_plan([tuple(l.weight.shape) for l in lins], idx_a, idx_b, 256, 0)
+    assert plan.split_gather is not None and plan.split_chunks == (128 + 2 * 512 + 256) * 3 // cp.CHUNK
+    f32 = plan.gather.reshape(-1, 64, 4)
+    sp = plan.split_gather.reshape(-1, 64, 8)
+    pos32 = poss = 0
+    for l in range(3):
+        n_in = 8 if l == 0 else 32
+        for otg in range(8):
+            for ip in range(n_in // 2):
+                for tt in range(4):
+                    for half in range(2):
+                        src = f32[pos32 + (otg * n_in + 2 * ip + half) * 4 + tt]
+                        assert np.array_equal(sp[poss][:, 4 * half : 4 * half + 4], src)
+                    poss += 1
+        pos32 = -(-(pos32 + 8 * n_in * 4) // cp.CHUNK) * cp.CHUNK  # (the f32 stream pads every layer to whole chunks)
+        assert (3 * poss) % cp.CHUNK == 0
+    for g in range(plan.n_groups):
+        for ip in range(16):
+            for half in range(2):
+                assert np.array_equal(sp[poss][:, 4 * half : 4 * half + 4], f32[pos32 + g * 32 + 2 * ip + half])
+            poss += 1
+        assert (3 * poss) % cp.CHUNK == 0
+    assert poss == sp.shape[0]
+    # small or odd shapes keep the f32 stream only
+    t2 = F.RealNVP(12, 2, transforms=1, hidden_features=[40, 70, 24]).transform.transforms[0]
+    l2 = list(t2.hyper)[0::2]
+    p2 = cp.build_coupling_plan([tuple(l.weight.shape) for l in l2], t2.mask.nonzero().squeeze(-1).numpy(), (~t2.mask).nonzero().squeeze(-1).numpy(), 12, 2)
+    assert p2.split_gather is None

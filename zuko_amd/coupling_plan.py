@@ -38,6 +38,9 @@ class CouplingPlan:
     fmap: np.ndarray         # int32 [n_groups * 8]
     features: int
     context: int
+    # operand-split stream (csrc/fused_coupling.hip: coupling_kernel_split; only for the static shape: 128 inputs, hidden [512] * k)
+    split_gather: np.ndarray = None  # int32 [split_blocks * 512] (lane-major, 8 per lane) into the concatenated weights (-1 -> 0)
+    split_chunks: int = 0
 
 
 def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk: int = CHUNK):
@@ -125,6 +128,28 @@ def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk
         lastb.append(np.where(rows >= 0, b_off[L - 1] + np.maximum(rows, 0), -1))
     bias_gather.append(np.concatenate(lastb))
 
+    # operand-split twin of the stream for the static shape: a block = (out tile, PAIR of in tiles) as three bf16 images; hidden layers
+    # in steps of (4 out tiles, 1 in pair), the last layer group by group, pair by pair.  Every layer and every group fills whole chunks.
+    split_gather, split_chunks = None, 0
+    if nit == 8 and all(w == 512 for w in widths):
+        def block(l, rows, ip, in_w):
+            lo, hi = image(l, rows, span(2 * ip, in_w)).reshape(64, 4), image(l, rows, span(2 * ip + 1, in_w)).reshape(64, 4)
+            return np.concatenate([lo, hi], axis=1).reshape(-1)
+
+        sblocks = []
+        for l in range(L - 1):
+            n_in, in_w = (nit, din) if l == 0 else (tiles[l - 1], widths[l - 1])
+            for otg in range(tiles[l] // 4):
+                for ip in range(n_in // 2):
+                    for t in range(4):
+                        sblocks.append(block(l, span(otg * 4 + t, widths[l]), ip, in_w))
+            assert (3 * len(sblocks)) % chunk == 0
+        for g in range(n_groups):
+            for ip in range(tiles[-1] // 2):
+                sblocks.append(block(L - 1, last_rows(g), ip, widths[-1]))
+        assert (3 * len(sblocks)) % chunk == 0
+        split_gather, split_chunks = np.concatenate(sblocks).astype(np.int32), 3 * len(sblocks) // chunk
+
     amap = -np.ones(nit * TILE, dtype=np.int64)
     amap[: len(idx_a)] = idx_a
     for c in range(context):
@@ -134,7 +159,7 @@ def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk
     return CouplingPlan(
         n_layers=L, din=din, nit=nit, widths=widths, tiles=tiles, moved=moved, n_groups=n_groups, gather=gather, n_blocks=len(blocks),
         n_chunks=len(blocks) // chunk, bias_gather=np.concatenate(bias_gather).astype(np.int32), bias_off=bias_off, amap=amap.astype(np.int32),
-        fmap=fmap.astype(np.int32), features=features, context=context,
+        fmap=fmap.astype(np.int32), features=features, context=context, split_gather=split_gather, split_chunks=split_chunks,
     )
 
 
@@ -201,7 +226,15 @@ class FusedCoupling:
         self.bias_gather = torch.from_numpy(plan.bias_gather).to(device)
         self.amap = torch.from_numpy(plan.amap).to(device)
         self.fmap = torch.from_numpy(plan.fmap).to(device)
-        self.stream = torch.empty(plan.n_blocks * 256, dtype=torch.float32, device=device)
+        import os
+
+        # operand-split kernel (6 bf16 matrix products per f32 product) when the plan has its stream; ZUKO_AMD_EXACT_F32=1 keeps the f32 instruction
+        self.split = plan.split_gather is not None and act == 1 and os.environ.get("ZUKO_AMD_EXACT_F32", "0") != "1"
+        if self.split:
+            self.gather = torch.from_numpy(plan.split_gather).to(device)
+            self.stream = torch.empty(plan.split_chunks * CHUNK * 256, dtype=torch.float32, device=device)
+        else:
+            self.stream = torch.empty(plan.n_blocks * 256, dtype=torch.float32, device=device)
         self.bias = torch.empty(len(plan.bias_gather), dtype=torch.float32, device=device)
         nl = plan.n_layers
         self.bias_off = (ctypes.c_int * nl)(*[int(v) for v in plan.bias_off])
@@ -222,7 +255,10 @@ class FusedCoupling:
         lib = _C.lib()
         wcat = torch.cat([l.weight.detach().reshape(-1) for l in lins])
         bcat = torch.cat([(l.bias.detach() if l.bias is not None else torch.zeros(l.weight.shape[0], device=self.device)).reshape(-1) for l in lins])
-        _C.check(lib.zk_gather_f32(_ptr(wcat), None, _ptr(self.gather), self.gather.numel(), _ptr(self.stream), _stream()), "zk_gather_f32")
+        if self.split:
+            _C.check(lib.zk_gather_split_bf16(_ptr(wcat), None, _ptr(self.gather), self.gather.numel() // 512, _ptr(self.stream), _stream()), "zk_gather_split_bf16")
+        else:
+            _C.check(lib.zk_gather_f32(_ptr(wcat), None, _ptr(self.gather), self.gather.numel(), _ptr(self.stream), _stream()), "zk_gather_f32")
         _C.check(lib.zk_gather_f32(_ptr(bcat), None, _ptr(self.bias_gather), self.bias_gather.numel(), _ptr(self.bias), _stream()), "zk_gather_f32")
         self._stamp = stamp
 
@@ -241,8 +277,8 @@ class FusedCoupling:
         fn = _C.lib().zk_coupling_inverse if inverse else _C.lib().zk_coupling_forward
         a = _C.args("zk_coupling_args_v1", N=N, D=p.features, C=p.context, **{"in": _ptr(x)}, ldx=x.stride(0), ctx=_ptr(ctx), ldc=0 if ctx is None else ctx.stride(0), out=_ptr(y),
                     ldy=p.features, ladj=_ptr(ladj), accumulate=0, wstream=_ptr(self.stream), bias=_ptr(self.bias), bias_floats=self.bias.numel(), bias_off=self.bias_off,
-                    amap=_ptr(self.amap), nit=p.nit, fmap=_ptr(self.fmap), n_groups=p.n_groups, n_layers=p.n_layers, tiles=self.tiles, widths=self.widths, n_chunks=p.n_chunks,
-                    act=self.act, slope=self.slope, static_ok=1)
+                    amap=_ptr(self.amap), nit=p.nit, fmap=_ptr(self.fmap), n_groups=p.n_groups, n_layers=p.n_layers, tiles=self.tiles, widths=self.widths,
+                    n_chunks=p.split_chunks if self.split else p.n_chunks, act=self.act, slope=self.slope, static_ok=2 if self.split else 1)
         err = fn(a, _stream())
         _C.check(err, "zk_coupling_inverse" if inverse else "zk_coupling_forward")
         return y, ladj

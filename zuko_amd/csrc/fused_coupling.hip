@@ -584,6 +584,191 @@ template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_ke
 #endif
 }
 
+// ---- operand-split twin of the static-shape path ----------------------------------------------------------------------------------
+// The f32 matrix instruction bounds the kernels above (0.81 of its peak at cfg4, profiles/r03) and runs at 1/16 of the bf16 rate;
+// gfx950 has no tf32.  As in csrc/fused_ar_split_impl.h every f32 operand is written as h + m + l in bf16 (exact to 2^-25) and a
+// product is the six partial products down to 2^-18 on v_mfma_f32_16x16x32_bf16 with f32 accumulation: the error of an f32 dot
+// product at 6/16 of the matrix time.  A stream BLOCK is the 16 x 32 weight block (out tile, PAIR of in tiles) as three 1 KiB bf16
+// images; a lane's 8 values are [4 units of in tile 2 ip | the same 4 units of in tile 2 ip + 1], which is how the activations sit in
+// the accumulator registers, so a layer's D fragments become the next layer's B operands by an in-register conversion.  One
+// wavefront per SIMD: a step is 4 out tiles x 1 in pair (12 images, 24 matrix instructions issued term by term, so the same
+// accumulator is touched every fourth instruction and never waits for its predecessor).
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+struct CpBv {  // B operands (h, m, l parts) of 16 activation pairs, as arrays small enough to be promoted to registers
+  cbf16x8 (&hlo)[8]; cbf16x8 (&hhi)[8]; cbf16x8 (&mlo)[8]; cbf16x8 (&mhi)[8]; cbf16x8 (&llo)[8]; cbf16x8 (&lhi)[8];
+  __device__ __forceinline__ cbf16x8& h(int p) const { return p < 8 ? hlo[p & 7] : hhi[p & 7]; }
+  __device__ __forceinline__ cbf16x8& m(int p) const { return p < 8 ? mlo[p & 7] : mhi[p & 7]; }
+  __device__ __forceinline__ cbf16x8& l(int p) const { return p < 8 ? llo[p & 7] : lhi[p & 7]; }
+};
+__device__ __forceinline__ void cp_split(const f32x4c& lo, const f32x4c& hi, cbf16x8& h, cbf16x8& m, cbf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = e < 4 ? lo[e] : hi[e - 4];
+    const __bf16 hh = (__bf16)v;
+    const float r1 = v - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
+  }
+}
+template <int N> __device__ __forceinline__ void cp_settle12(f32x4c (&a)[12]) {
+  asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void cp_settle6(f32x4c (&a)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]) : "n"(N));
+}
+#define CP_XMFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, A), B, C, 0, 0, 0)
+
+// one dense layer: out[ot] = bias + sum_ip W[ot, ip] in[ip]; NP in pairs, HT out tiles
+template <int NP, int HT> __device__ __forceinline__ void cp_layer_split(CpRingS& ring, const float* bias_q, const CpBv& in, const CpAct& out) {
+  constexpr int STEPS = (HT / 4) * NP;
+  f32x4c a[2][12];  // images (t, part) of the step: a[.][3 t + part], part 0 = h, 1 = m, 2 = l
+  cp_for<12>([&](auto i) CP_ALWAYS_INLINE { a[0][i] = ring.template read<decltype(i)::value>(); });
+  cp_for<STEPS>([&](auto st_) CP_ALWAYS_INLINE {
+    constexpr int st = st_, otg = st / NP, ip = st % NP;
+    if constexpr (ip == 0) {
+      cp_for<4>([&](auto t) CP_ALWAYS_INLINE { out[otg * 4 + t] = *reinterpret_cast<const f32x4c*>(bias_q + (otg * 4 + t) * 16); });
+    }
+    if constexpr (st + 1 < STEPS) {
+      cp_for<12>([&](auto i) CP_ALWAYS_INLINE { a[(st + 1) & 1][i] = ring.template read<(st + 1) * 12 + decltype(i)::value>(); });
+      cp_settle12<12>(a[st & 1]);
+    } else {
+      cp_settle12<0>(a[st & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const cbf16x8 bh = in.h(ip), bm = in.m(ip), bl = in.l(ip);
+    // six partial products, smallest first, each over the four out tiles of the step
+    cp_for<4>([&](auto t) CP_ALWAYS_INLINE { CP_XMFMA(a[st & 1][3 * t + 2], bh, out[otg * 4 + t]); });
+    cp_for<4>([&](auto t) CP_ALWAYS_INLINE { CP_XMFMA(a[st & 1][3 * t + 0], bl, out[otg * 4 + t]); });
+    cp_for<4>([&](auto t) CP_ALWAYS_INLINE { CP_XMFMA(a[st & 1][3 * t + 1], bm, out[otg * 4 + t]); });
+    cp_for<4>([&](auto t) CP_ALWAYS_INLINE { CP_XMFMA(a[st & 1][3 * t + 1], bh, out[otg * 4 + t]); });
+    cp_for<4>([&](auto t) CP_ALWAYS_INLINE { CP_XMFMA(a[st & 1][3 * t + 0], bm, out[otg * 4 + t]); });
+    cp_for<4>([&](auto t) CP_ALWAYS_INLINE { CP_XMFMA(a[st & 1][3 * t + 0], bh, out[otg * 4 + t]); });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// ReLU + conversion of the HT out tiles into the next layer's B operands
+template <int HT> __device__ __forceinline__ void cp_convert(const CpAct& out, const CpBv& in) {
+  cp_for<HT / 2>([&](auto p_) CP_ALWAYS_INLINE {
+    constexpr int p = p_;
+    f32x4c lo = out[2 * p], hi = out[2 * p + 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lo[r] = lo[r] < 0.f ? 0.f : lo[r];  // NaN stays NaN, as torch.relu
+      hi[r] = hi[r] < 0.f ? 0.f : hi[r];
+    }
+    cp_split(lo, hi, in.h(p), in.m(p), in.l(p));
+  });
+}
+
+template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_kernel_split(CpArgs a) {
+  static_assert(HT % 4 == 0 && HT <= CP_T && NIT <= CP_IT && NIT % 2 == 0 && (12 * (NIT / 2) * (HT / 4)) % CP_CH == 0 && (12 * (HT / 2) * (HT / 4)) % CP_CH == 0 && (3 * (HT / 2)) % CP_CH == 0,
+                "every layer and every group of the last layer fills whole chunks");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & 15, q = lane >> 4;
+  float* bias_lds = cp_lds + CP_NR * CP_CH * 256;
+  int* amap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);
+  int* fmap_lds = amap_lds + CP_IT * 16;
+  int* lay_lds = fmap_lds + a.NG * 8;
+  float* xw = reinterpret_cast<float*>(lay_lds + 3 * CP_MAXL) + (size_t)wave * 16 * a.xs;
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < CP_MAXL; ++l) lay_lds[2 * CP_MAXL + l] = a.bias_off[l];
+  }
+  for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+  for (int i = tid; i < NIT * 16; i += 256) amap_lds[i] = a.amap[i];
+  for (int i = tid; i < a.NG * 8; i += 256) fmap_lds[i] = a.fmap[i];
+  CpRingS ring;
+  ring.lds = cp_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < CP_NR - 1; ++i) ring.issue();
+  ring.slot = CP_NR - 1;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)cp_lds);
+  ring.cur_off = ring.lds_off;
+  __syncthreads();
+
+  const int xs = a.xs;
+  float* xrow = xw + jl * xs;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * 64 + wave * 16;
+    const int64_t n = n0 + jl;
+    const bool live = n < a.N;
+    cp_stage_rows(a, xw, xs, n0, lane);
+
+    f32x4c out_lo[16], out_hi[16];
+    cbf16x8 bhl[8], bhh[8], bml[8], bmh[8], bll[8], blh[8];
+    const CpAct out{out_lo, out_hi};
+    const CpBv in{bhl, bhh, bml, bmh, bll, blh};
+    // first layer: B operands gathered from the row image through idx_a, converted pair by pair
+    cp_for<NIT / 2>([&](auto p_) CP_ALWAYS_INLINE {
+      constexpr int p = p_;
+      f32x4c v[2];
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int src = amap_lds[(2 * p + hlf) * 16 + 4 * q + r];
+          v[hlf][r] = src >= 0 ? xrow[src] : (src <= -2 ? xrow[a.D + (-2 - src)] : 0.f);
+        }
+      cp_split(v[0], v[1], in.h(p), in.m(p), in.l(p));
+    });
+    cp_layer_split<NIT / 2, HT>(ring, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL]) + 4 * q, in, out);
+    cp_convert<HT>(out, in);
+    for (int l = 1; l < a.L - 1; ++l) {
+      cp_layer_split<HT / 2, HT>(ring, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + l]) + 4 * q, in, out);
+      cp_convert<HT>(out, in);
+    }
+    // last layer + affine map: one group of 8 moved features = one out tile = HT / 2 blocks, two blocks per step on six accumulators
+    const float* bias_last = bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + a.L - 1]) + 4 * q;
+    float lacc = 0.f;
+    for (int g = 0; g < a.NG; ++g) {
+      const int f0 = fmap_lds[g * 8 + 2 * q], f1 = fmap_lds[g * 8 + 2 * q + 1];
+      const float x0 = xrow[f0 < 0 ? 0 : f0], x1 = xrow[f1 < 0 ? 0 : f1];
+      const f32x4c zero = {0.f, 0.f, 0.f, 0.f};
+      f32x4c cH[2] = {*reinterpret_cast<const f32x4c*>(bias_last + g * 16), zero}, cM[2] = {zero, zero}, cS[2] = {zero, zero};
+      f32x4c w[2][6];  // images of the step's two blocks: w[.][3 b + part]
+      constexpr int KS = HT / 4;  // steps per group
+      cp_for<6>([&](auto i) CP_ALWAYS_INLINE { w[0][i] = ring.template read<decltype(i)::value>(); });
+      cp_for<KS>([&](auto k_) CP_ALWAYS_INLINE {
+        constexpr int k = k_;
+        if constexpr (k + 1 < KS) {
+          cp_for<6>([&](auto i) CP_ALWAYS_INLINE { w[(k + 1) & 1][i] = ring.template read<(k + 1) * 6 + decltype(i)::value>(); });
+          cp_settle6<6>(w[k & 1]);
+        } else {
+          cp_settle6<0>(w[k & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cp_for<2>([&](auto b) CP_ALWAYS_INLINE { CP_XMFMA(w[k & 1][3 * b + 2], in.h(2 * k + b), cS[b]); });
+        cp_for<2>([&](auto b) CP_ALWAYS_INLINE { CP_XMFMA(w[k & 1][3 * b + 1], in.h(2 * k + b), cM[b]); });
+        cp_for<2>([&](auto b) CP_ALWAYS_INLINE { CP_XMFMA(w[k & 1][3 * b + 0], in.h(2 * k + b), cH[b]); });
+        cp_for<2>([&](auto b) CP_ALWAYS_INLINE { CP_XMFMA(w[k & 1][3 * b + 0], in.l(2 * k + b), cS[b]); });
+        cp_for<2>([&](auto b) CP_ALWAYS_INLINE { CP_XMFMA(w[k & 1][3 * b + 0], in.m(2 * k + b), cM[b]); });
+        cp_for<2>([&](auto b) CP_ALWAYS_INLINE { CP_XMFMA(w[k & 1][3 * b + 1], in.m(2 * k + b), cS[b]); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      const f32x4c p = ((cS[0] + cS[1]) + (cM[0] + cM[1])) + (cH[0] + cH[1]);  // (shift, scale) of slot 2 q, then of slot 2 q + 1
+      float y0, y1, l0, l1;
+      cp_affine(a, p[0], p[1], x0, y0, l0);
+      cp_affine(a, p[2], p[3], x1, y1, l1);
+      if (f0 >= 0) { xrow[f0] = y0; lacc += l0; }
+      if (f1 >= 0) { xrow[f1] = y1; lacc += l1; }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    cp_store_rows(a, xw, xs, n0, lane);
+    if (a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -630,6 +815,17 @@ static int cp_launch(int inverse, int64_t N, int D, int C, const void* x, int64_
   // that its stream has the matching layout (every layer and every triple of groups starts on a chunk boundary)
   bool same = act == 1 && nit == 8;
   for (int l = 0; l < n_layers - 1; ++l) same = same && tiles[l] == 32 && widths[l] == 512;
+  if (same && static_ok == 2) {  // the plan's stream is the operand-split one (coupling_plan.py: split_gather): bf16 images, (4 out tiles, in pair) steps
+    static bool attr3 = false;
+    if (!attr3) {
+      hipError_t e = hipFuncSetAttribute((const void*)coupling_kernel_split<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr3 = true;
+    }
+    hipLaunchKernelGGL((coupling_kernel_split<8, 32>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    return ZK_LAUNCH_CHECK();
+  }
+  if (static_ok == 2) return ZK_EINVAL;  // a split stream cannot be read by the f32 kernels
   if (same && static_ok) {
     static bool attr2 = false;
     if (!attr2) {
