@@ -344,7 +344,9 @@ int zk_ar_lds_bytes(int variant, int bias_floats);
  * Any fusable activation (the kernel checks `act` against the one it was generated for); uni_kind 0 / 1 / 2 / 4; hidden widths up to 512 (the generic zk_ar_forward stops at 256).  Results are
  * bit-identical to zk_ar_forward on the same plan (the tiles the per-tile stream drops hold zeros only). */
 /* Reads: launcher, rev, uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream, bias, bias_floats, featmap, n_layers, n_groups,
- * n_chunks, bound, slope. */
+ * n_chunks, bound, slope; bin_out + knots_out (both or neither): the DIAGNOSTIC twin of an operand-split kernel — same arithmetic as the
+ * product launch plus the bin index used and the knots searched, as zk_ar_forward_diag (the f32-instruction static kernels return
+ * hipErrorInvalidValue for it: they are bit-identical to zk_ar_forward, whose twin serves). */
 int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream);
 /* Conditioner-only launch of a generated static-shape kernel for the training forward (zuko_amd/train.py): phi [N, D * total] =
  * net(x) in module order (what the last MaskedLinear of zuko/nn.py:221-318 returns) and the hidden activations h_l [N, width_l]

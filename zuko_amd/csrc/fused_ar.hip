@@ -458,7 +458,8 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
   if (variant != 0) return ZK_EINVAL;  // reserved
 #endif
   if (part.static_fn) {  // a generated static-shape kernel: it derives its own tiling / LDS size from its Shape and re-checks the dimensions
-    if (inverse || part.sched || part.bin_out || part.knots_out) return ZK_EINVAL;
+    if (inverse || part.sched || ((part.bin_out != nullptr) != (part.knots_out != nullptr))) return ZK_EINVAL;
+    a.bin_out = part.bin_out; a.knots_out = part.knots_out;  // (diagnostic twin of an operand-split kernel; the f32 static kernels decline)
     a.l1rev = part.rev;
     for (int l = 0; l < 3; ++l) a.act_out[l] = part.act_out[l];
     a.phi_out = part.phi_out; a.ldphi = part.ldphi;
@@ -544,6 +545,7 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
   if (!ar_args_ok(args) || !args->launcher) return ZK_EINVAL;
   ArPartial part;
   part.static_fn = args->launcher; part.rev = args->rev;
+  part.bin_out = args->bin_out; part.knots_out = args->knots_out;  // both set: the kernel's diagnostic twin (operand-split kernels only)
   zk_ar_args_v1 p = *args;
   p.skip = nullptr;  // (act: checked by the kernel against the activation it was generated for)
   return ar_launch_v1(part, false, p, stream);

@@ -137,10 +137,13 @@ template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ voi
   }
 }
 
-// TRAIN: conditioner only — the hidden activations and phi are stored for the backward pass (zuko_amd/train.py)
-template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(64 * S::WAVES, 2) void arx_kernel(ArArgs a) {
-  typedef ArRingS<S::WAVES, S::CH> Ring;
-  static_assert((S::WAVES == 8 || S::WAVES == 4) && S::TMAX <= 16 && S::TMAX % 2 == 0, "operand-split kernels: widths <= 256, two wavefronts per SIMD");
+// TRAIN: conditioner only — the hidden activations and phi are stored for the backward pass (zuko_amd/train.py).
+// DIAG: the diagnostic twin of the product launch (same arithmetic, same instruction order up to two extra stores per feature): also
+// writes the bin index the spline USED and the search-axis knots it searched (bin_out [N, D], knots_out [N, D, NKNOT]), as
+// zk_ar_forward_diag does for the generic kernel — the parity bar on the bin index is asserted on the product path (tests/test_gpu_bins.py).
+template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __launch_bounds__(64 * S::WAVES, 2) void arx_kernel(ArArgs a) {
+  typedef ArRingS<S::WAVES, S::CH, S::NR> Ring;
+  static_assert((S::WAVES == 8 || S::WAVES == 4) && (S::NR == 2 || S::NR == 3) && S::TMAX <= 16 && S::TMAX % 2 == 0, "operand-split kernels: widths <= 256, two wavefronts per SIMD");
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL, WAVES = S::WAVES;
   constexpr int NG = S::NG;
   constexpr int NSTEP = S::GOFF[NG];  // (group, in pair) steps of the last layer, NT blocks each
@@ -153,12 +156,12 @@ template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(64 * S
   const int j = lane & 15, q = lane >> 4;
 
   Ring ring;
-  float* bias_lds = ars_lds + ARS_NR * S::CH * AR_TF;
+  float* bias_lds = ars_lds + S::NR * S::CH * AR_TF;
   ring.lds = ars_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
   ring.load_chunk = 0; ring.load_slot = 0;
 #pragma unroll
-  for (int i = 0; i < ARS_NR - 1; ++i) ring.issue();
-  ring.slot = ARS_NR - 1;
+  for (int i = 0; i < S::NR - 1; ++i) ring.issue();
+  ring.slot = S::NR - 1;
   ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)ars_lds);
   ring.cur_off = ring.lds_off;
 
@@ -283,6 +286,15 @@ template <class S, typename Uni, bool TRAIN> __global__ __launch_bounds__(64 * S
               yv = p[fi * TOTAL] + xin[fi]; lj = p[fi * TOTAL + 1];
 #pragma unroll
               for (int i = 2; i < TOTAL; ++i) lj += p[fi * TOTAL + i];
+            } else if constexpr (DIAG) {
+              int kb = 0;
+              float ks[Uni::NKNOT];
+              Uni::fwd(ld, fi * TOTAL, a, xin[fi], yv, lj, &kb, ks);
+              if (live) {
+                a.bin_out[n * S::D + f] = kb;
+#pragma unroll
+                for (int jj = 0; jj < Uni::NKNOT; ++jj) a.knots_out[(n * S::D + f) * Uni::NKNOT + jj] = ks[jj];
+              }
             } else
             Uni::fwd(ld, fi * TOTAL, a, xin[fi], yv, lj);
             if constexpr (XLDS) xr[f] = yv;
@@ -462,11 +474,14 @@ template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi
   const bool vec_ok = (S::D % 4 == 0) && (train || ((a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0)));
   if (S::XLDS != 0 && !vec_ok) return ZK_EINVAL;
   a.xlds = S::XLDS;
-  const int lds = (ARS_NR * S::CH * AR_TF + a.bias_floats + 1024 + 256 + (S::XLDS ? S::WAVES * 16 * a.xs : 0)) * (int)sizeof(float);
+  const int lds = (S::NR * S::CH * AR_TF + a.bias_floats + 1024 + 256 + (S::XLDS ? S::WAVES * 16 * a.xs : 0)) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
   const void* fn = nullptr;
+  if ((a.bin_out != nullptr) != (a.knots_out != nullptr) || (a.bin_out && train)) return ZK_EINVAL;
   if (train) {
     if constexpr (S::TRAIN_OK) fn = (const void*)arx_kernel<S, Uni, true>;
+  } else if (a.bin_out) {
+    fn = (const void*)arx_kernel<S, Uni, false, true>;
   } else {
     fn = (const void*)arx_kernel<S, Uni, false>;
   }

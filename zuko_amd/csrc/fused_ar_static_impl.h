@@ -69,7 +69,7 @@ template <class S> struct ArsPat {
   static constexpr int n_last_steps() { return S::GOFF[S::NG]; }
 };
 
-template <int WAVES, int CH = ARS_CH> struct ArRingS {
+template <int WAVES, int CH = ARS_CH, int NR = ARS_NR> struct ArRingS {
   static constexpr int PER = CH / WAVES;  // consecutive tiles a wave copies per chunk: one address, one M0 value, immediate offsets
   static constexpr int PIVOT = PER > 4 ? 4 : 0;  // (signed immediates -4096 .. +1024 around the wave's fifth tile reach six tiles)
   static_assert(PER * WAVES == CH && PER <= 6, "ring geometry");
@@ -88,14 +88,14 @@ template <int WAVES, int CH = ARS_CH> struct ArRingS {
     const int b0 = wave * PER + PIVOT;
     if (ARX_ABL != 1) dma<0>(stream + ((size_t)load_chunk * CH + b0) * AR_TF + lane * 4, lds + (load_slot * CH + b0) * AR_TF);
     load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
-    load_slot = (load_slot + 1 == ARS_NR) ? 0 : load_slot + 1;
+    load_slot = (load_slot + 1 == NR) ? 0 : load_slot + 1;
   }
   __device__ __forceinline__ void advance() {  // all waves, at the same (static) points of the pass
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((ARS_NR - 2) * PER) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NR - 2) * PER) : "memory");
     if (ARX_ABL != 4) __builtin_amdgcn_s_barrier();  // (not __syncthreads(): its fence is s_waitcnt vmcnt(0) and would drain the look-ahead DMAs)
     asm volatile("" ::: "memory");
     issue();
-    slot = (slot + 1 == ARS_NR) ? 0 : slot + 1;
+    slot = (slot + 1 == NR) ? 0 : slot + 1;
     cur_off = lds_off + (unsigned)(slot * CH * AR_TF * 4 + lane * 16);
   }
   // Position S inside the pass (static).  The read is issued from inline assembly and returns a RAW value: the compiler does
@@ -490,6 +490,7 @@ template <class S, typename Uni> static int ars_launch(const ArArgs* in, int abi
   ArArgs a = *in;
   if (a.D != S::D || a.DIN != S::DIN || a.L != S::NH + 1 || a.act != S::ACT || a.sched || a.NG != S::NG || a.n_chunks != S::NCHUNK) return ZK_EINVAL;
   if (a.l1rev && !S::HAS_ALT) return ZK_EINVAL;
+  if (a.bin_out || a.knots_out) return ZK_EINVAL;  // (no diagnostic instantiation: these kernels are bit-identical to the generic one, whose twin serves)
   if (train && (!S::TRAIN_OK || !a.phi_out)) return ZK_EINVAL;
   a.n_tiles = (a.N + 16 * S::WAVES - 1) / (16 * S::WAVES);
   a.xs = ((S::D + 3) / 4) * 4 + 4;

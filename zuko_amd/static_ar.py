@@ -127,7 +127,7 @@ def split_geometry() -> tuple:
         w, c = (int(v) for v in g.split("x"))
     except ValueError:
         w, c = 8, 24
-    return (w, c) if (w, c) in ((4, 16), (8, 24), (4, 24), (8, 48)) else (8, 24)
+    return (w, c) if (w, c) in ((4, 16), (8, 24), (8, 48)) else (8, 24)
 
 
 def split_tables(plan, uni_kind: int, act: int = 1):
@@ -211,9 +211,10 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     out = dict(t)
     for key in ("S_OTG", "S_IT", "S_MASK", "NS", "GOFF", "G_IT"):
         out.pop(key)
-    xlds = int(t["D"] % 4 == 0 and (3 * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * (2 if waves == 4 else 1) <= 160 * 1024)
+    nr = 2 if ch == 48 else 3  # (48-image chunks: two ring slots, half as many barriers)
+    xlds = int(t["D"] % 4 == 0 and (nr * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * (2 if waves == 4 else 1) <= 160 * 1024)
     out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
-                "WAVES": waves, "CH": ch, "XLDS": xlds})
+                "WAVES": waves, "CH": ch, "NR": nr, "XLDS": xlds})
     plan._split_cache = ((uni_kind, act, split_geometry()), (out, gathers))
     return out, gathers
 
@@ -228,7 +229,7 @@ def emit_split(t: dict) -> str:
         "namespace {",
         "struct Shape {",
         f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NG = {t['NG']}, NCHUNK = {t['NCHUNK']};",
-        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, ACT = {t['ACT']};",
+        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, NR = {t['NR']}, ACT = {t['ACT']};",
         f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = false, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
         _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
         _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
