@@ -93,16 +93,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
         jobs.append((path, obj, stamp, dig, flags))
 
     def compile_one(job):
+        import time
+
         path, obj, stamp, dig, flags = job
         cmd = [hipcc, *flags, "-c", path, "-o", obj]
         if verbose:
             print("[zuko_amd build]", " ".join(cmd), flush=True)
+        t0 = time.time()
         subprocess.run(cmd, check=True)
+        if verbose:
+            print(f"[zuko_amd build] {os.path.basename(path)}: {time.time() - t0:.0f} s", flush=True)
         with open(stamp, "w") as f:
             f.write(dig)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        # every translation unit at once (nine, the longest ~4 min on its own): the wall time is the slowest unit's; the long ones first
+        jobs.sort(key=lambda j: -os.path.getsize(j[0]))
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     out = lib_path()
     if jobs or not os.path.exists(out):
@@ -122,7 +129,7 @@ def prebuild_static(verbose: bool = True) -> None:
     """Static-shape instantiations of the fused autoregressive kernel for the BASELINE.json conditioners and a few common
     shapes (zuko_amd/static_ar.py: PREBUILT): generated + compiled into zuko_amd/lib/ars/, a no-op when they are current.
     Runs in a child process because it imports the package (which needs the library that was just linked)."""
-    code = "import sys; sys.path.insert(0, %r); import zuko_amd.static_ar as s; s.prebuild(verbose=%r)" % (os.path.dirname(HERE), bool(verbose))
+    code = "import sys; sys.path.insert(0, %r); import zuko_amd.static_ar as s; s.prebuild(verbose=%r, jobs=%d)" % (os.path.dirname(HERE), bool(verbose), max(4, os.cpu_count() or 4))
     subprocess.run([sys.executable, "-c", code], check=True)
 
 
