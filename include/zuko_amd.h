@@ -417,6 +417,30 @@ int zk_wgrad_f32(int64_t N, int out_features, int in_features, const void* g, in
 int zk_wgrad_bias_f32(int64_t N, int out_features, int in_features, const void* g, int64_t ldg, const void* h, int64_t ldh,
                       const int32_t* pairs, int npairs, float* partial, const uint8_t* mask, void* dw, int accumulate,
                       const uint8_t* cs_flag, float* cs_partial, void* db, const int32_t* rows, const int32_t* cols, void* stream);
+/* The same for up to four layers of one conditioner in two launches (the GEMMs of all layers, then all reductions): a layer with two or
+ * three live blocks is otherwise a launch that the GPU finishes faster than the host queues the next one.  Products run on the bf16 matrix
+ * instruction with three-way split f32 operands (six partial products, f32 accumulate: csrc/train.hip, wgrad_split_kernel).  dw / db are
+ * written (not accumulated); partial / cs_partial sized as for zk_wgrad_bias_f32; db, cs_flag, cs_partial all NULL = no bias gradient. */
+typedef struct zk_wgrad_layer_v1 {
+  uint32_t struct_size;    /* sizeof(zk_wgrad_layer_v1) */
+  int32_t out_features;
+  int32_t in_features;
+  int32_t npairs;          /* live 128 x 128 blocks */
+  int64_t ldg;
+  int64_t ldh;
+  const void* g;           /* [N, out_features] gradient of the layer's output */
+  const void* h;           /* [N, in_features] the layer's input */
+  const int32_t* pairs;    /* DEVICE [npairs][2] = (out block, in block) */
+  void* partial;           /* workspace, zk_wgrad_slices(N, npairs) * npairs * 128 * 128 floats */
+  const uint8_t* mask;     /* [out, in] in the operands' (sorted) order, or NULL */
+  void* dw;                /* [out, in], written through rows / cols */
+  const uint8_t* cs_flag;  /* DEVICE [npairs]: one designated pair per out block, or NULL */
+  void* cs_partial;
+  void* db;                /* [out], written through rows */
+  const int32_t* rows;     /* sorted row -> the module's row, or NULL */
+  const int32_t* cols;
+} zk_wgrad_layer_v1;
+int zk_wgrad_multi(int n_layers, const zk_wgrad_layer_v1* layers, int64_t N, void* stream);
 int zk_colsum_slices(int64_t N);
 int zk_colsum_f32(int64_t N, int C, const void* x, int64_t ld, float* workspace, void* out, int accumulate, void* stream);
 

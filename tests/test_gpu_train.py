@@ -235,3 +235,31 @@ def test_dgrad_chain_matches_the_layerwise_backward(dev, kind, monkeypatch):
         for p in net.parameters():
             p.div_(3.0)
     assert torch.allclose(xr.grad, gx0, rtol=1e-5, atol=1e-5 * gx0.abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["nsf", "maf"])
+def test_wgrad_multi_matches_the_per_layer_launches(dev, kind, monkeypatch):
+    """zk_wgrad_multi (the weight / bias gradients of all layers of a conditioner in two launches) against one zk_wgrad_bias_f32 per
+    layer: the same kernel body on the same slices, so every parameter gradient must be bit-identical; ragged batch."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(12)
+    flow = (F.NSF(64, 0, transforms=2, bins=8, hidden_features=[256] * 3) if kind == "nsf" else F.MAF(64, 0, transforms=2, hidden_features=[256] * 3)).to(dev)
+    net = flow.transform.transforms[1].hyper
+    N = 3000 + 11
+    x = torch.randn(N, 64, generator=torch.Generator().manual_seed(6)).to(dev)
+    gphi = torch.randn(N, net[-1].weight.shape[0], generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        xr = x.clone().requires_grad_()
+        (net(xr) * gphi).sum().backward()
+        return xr.grad.clone(), [p.grad.clone() for p in net.parameters()]
+
+    gx1, gp1 = run()
+    monkeypatch.setenv("ZUKO_AMD_NO_WGRAD_MULTI", "1")
+    gx0, gp0 = run()
+    assert torch.equal(gx1, gx0)
+    for a, b in zip(gp1, gp0):
+        assert torch.equal(a, b), (a - b).abs().max().item()

@@ -16,6 +16,8 @@
 #include "zk_common.h"
 #include <stdlib.h>
 
+#include "../../include/zuko_amd.h"
+
 namespace zk {
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -245,7 +247,13 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
   // conflict-free ds_read_b32: A[i][k] = Gs[k][o], B[k][j] = Hs[k][c] with 32 consecutive units per half-wave.
   __shared__ __attribute__((aligned(16))) float Gs[32][128 + 4];
   __shared__ __attribute__((aligned(16))) float Hs[32][128 + 4];
-  const int p = blockIdx.x % a.npairs, s = blockIdx.x / a.npairs;
+  // XCD-aware walk: workgroups go round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  XCD x takes a CONTIGUOUS range of the
+  // (slice, pair) work list, so the blocks that share a G tile (the in blocks of one out block) and an H tile (all out blocks of a slice) run
+  // on the same L2 at about the same time: G[N, OUT] and H[N, IN] then come from HBM about once instead of once per sharing block.
+  const int total = a.nslices * a.npairs, per_xcd = (total + 7) / 8;
+  const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (work >= total || (int)(blockIdx.x >> 3) >= per_xcd) return;
+  const int p = work % a.npairs, s = work / a.npairs;
   const int ob = a.pairs[2 * p], ib = a.pairs[2 * p + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -337,8 +345,15 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
 // writes the three 16-byte bf16 vectors straight into the operand images of v_mfma_f32_16x16x32_bf16 (lane = 16 * sample octet + unit,
 // 8 samples per lane) — no transposition in LDS, operands are plain ds_read_b128.  k tile = 32 samples; a wavefront owns 64 x 64 of the
 // block (4 x 4 tiles) and issues the six terms tile after tile, so no accumulator is touched twice in a row.
+#ifndef ZK_WG_ABL
+#define ZK_WG_ABL 0  // probe builds (wrong results): 1 no conversion, 2 no global loads, 3 no MFMA, 4 no LDS operand reads
+#endif
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void wsplit8(const float (&v)[8], wbf16x8& h, wbf16x8& m, wbf16x8& l) {
+  if (ZK_WG_ABL == 1) {
+    h = __builtin_bit_cast(wbf16x8, f32x4_t4{v[0], v[1], v[2], v[3]}); m = __builtin_bit_cast(wbf16x8, f32x4_t4{v[4], v[5], v[6], v[7]}); l = h;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const __bf16 hh = (__bf16)v[e];
@@ -348,10 +363,8 @@ __device__ __forceinline__ void wsplit8(const float (&v)[8], wbf16x8& h, wbf16x8
   }
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) uint4 Gs[8 * 3 * 64];  // [unit block of 16][part h, m, l][lane]: 24 KiB
-  __shared__ __attribute__((aligned(16))) uint4 Hs[8 * 3 * 64];
-  const int p = blockIdx.x % a.npairs, s = blockIdx.x / a.npairs;
+__device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, int work, uint4* Gs, uint4* Hs) {
+  const int p = work % a.npairs, s = work / a.npairs;
   const int ob = a.pairs[2 * p], ib = a.pairs[2 * p + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -377,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
       for (int e = 0; e < 8; ++e) {
         const int64_t n = n0 + (oc0 + 2 * t) * 8 + e;
         const bool in = n < n_end;
-        rg[t][e] = (in && g_ok) ? a.g[n * a.ldg + go] : 0.f;
-        rh[t][e] = (in && h_ok) ? a.h[n * a.ldh + hc] : 0.f;
+        rg[t][e] = (ZK_WG_ABL != 2 && in && g_ok) ? a.g[n * a.ldg + go] : (ZK_WG_ABL == 2 ? (float)n : 0.f);
+        rh[t][e] = (ZK_WG_ABL != 2 && in && h_ok) ? a.h[n * a.ldh + hc] : (ZK_WG_ABL == 2 ? (float)e : 0.f);
       }
   };
   const bool do_cs = a.cs_flag && a.cs_flag[p];
@@ -406,12 +419,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int part = 0; part < 3; ++part) {
-        A[i][part] = __builtin_bit_cast(wbf16x8, Gs[((wr * 4 + i) * 3 + part) * 64 + lane]);
-        B[i][part] = __builtin_bit_cast(wbf16x8, Hs[((wc * 4 + i) * 3 + part) * 64 + lane]);
+        A[i][part] = __builtin_bit_cast(wbf16x8, Gs[ZK_WG_ABL == 4 ? lane : ((wr * 4 + i) * 3 + part) * 64 + lane]);
+        B[i][part] = __builtin_bit_cast(wbf16x8, Hs[ZK_WG_ABL == 4 ? lane : ((wc * 4 + i) * 3 + part) * 64 + lane]);
       }
     // six partial products, smallest first: (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
 #define ZK_WTERM(PA, PB)                                                                                                            \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+      if (ZK_WG_ABL == 3) { asm volatile("" ::"v"(A[i][PA]), "v"(B[j][PB])); } else                                                  \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][PA], B[j][PB], acc[i][j], 0, 0, 0);
     ZK_WTERM(2, 0) ZK_WTERM(0, 2) ZK_WTERM(1, 1) ZK_WTERM(1, 0) ZK_WTERM(0, 1) ZK_WTERM(0, 0)
 #undef ZK_WTERM
@@ -435,13 +449,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
       for (int r = 0; r < 4; ++r) dst[(wr * 64 + i * 16 + 4 * (lane >> 4) + r) * 128 + wc * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
 }
 
+// XCD-aware walk: workgroups go round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  XCD x takes a CONTIGUOUS range of the
+// (slice, pair) work list, so the blocks that share a G tile (the in blocks of one out block) and an H tile (all out blocks of a slice) run
+// on the same L2 at about the same time.
+__device__ __forceinline__ int wgrad_work(int total) {
+  const int per_xcd = (total + 7) / 8;
+  const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  return work < total ? work : -1;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 Gs[8 * 3 * 64];  // [unit block of 16][part h, m, l][lane]: 24 KiB
+  __shared__ __attribute__((aligned(16))) uint4 Hs[8 * 3 * 64];
+  const int work = wgrad_work(a.nslices * a.npairs);
+  if (work < 0) return;
+  wgrad_split_body(a, work, Gs, Hs);
+}
+
+// The weight gradients of ALL layers of a conditioner in one launch (up to four: the layers' work lists follow each other; a layer with two
+// or three live blocks is otherwise a launch of its own that the GPU finishes faster than the host can queue the next one).
+struct WgradMulti {
+  int n;
+  int start[5];  // first work item of every layer, start[n] = total
+  WgradArgs a[4];
+};
+__global__ __launch_bounds__(256, 2) void wgrad_split_multi_kernel(WgradMulti m) {
+  __shared__ __attribute__((aligned(16))) uint4 Gs[8 * 3 * 64];
+  __shared__ __attribute__((aligned(16))) uint4 Hs[8 * 3 * 64];
+  const int work = wgrad_work(m.start[m.n]);
+  if (work < 0) return;
+  // (a chain of selects on the by-value argument block: indexing it with a run-time layer would spill the whole block to scratch)
+  WgradArgs a = m.a[0];
+  int base = 0;
+  if (m.n > 1 && work >= m.start[1]) { a = m.a[1]; base = m.start[1]; }
+  if (m.n > 2 && work >= m.start[2]) { a = m.a[2]; base = m.start[2]; }
+  if (m.n > 3 && work >= m.start[3]) { a = m.a[3]; base = m.start[3]; }
+  wgrad_split_body(a, work - base, Gs, Hs);
+}
+
 // dW[o, i] (+)= mask[o, i] * sum_s partial[s][p][...] in slice order (deterministic); 64 blocks of 256 elements per pair
 // rows / cols (optional): the gradient is computed on a row / column PERMUTED weight (zuko_amd/train.py: units sorted by dependency
 // count) but written where the module keeps it: element (o, c) goes to dw[rows[o], cols[c]] — no scatter pass afterwards
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int OUT, int IN, const int32_t* pairs, int npairs, int nslices, const float* partial,
-                                                           const uint8_t* mask, float* dw, int accumulate, const int32_t* rows, const int32_t* cols) {
-  const int p = blockIdx.x >> 6;
-  const int e = ((blockIdx.x & 63) << 8) + threadIdx.x;
+struct WredArgs {
+  int OUT, IN, npairs, nslices, accumulate;
+  const int32_t* pairs;
+  const float* partial;
+  const uint8_t* mask;
+  float* dw;
+  const int32_t *rows, *cols;
+  // bias gradient (optional): column sums of g from the same pass
+  const float* cs_partial;
+  float* db;
+  int cs_ld;
+};
+__device__ __forceinline__ void wgrad_reduce_body(int OUT, int IN, const int32_t* pairs, int npairs, int nslices, const float* partial, const uint8_t* mask, float* dw, int accumulate,
+                                                  const int32_t* rows, const int32_t* cols, int block) {
+  const int p = block >> 6;
+  const int e = ((block & 63) << 8) + threadIdx.x;
   const int ob = pairs[2 * p], ib = pairs[2 * p + 1];
   const int i = e >> 7, j = e & 127;
   const int o = ob * 128 + i, c = ib * 128 + j;
@@ -462,6 +526,49 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int OUT, int IN, cons
   if (mask && !mask[idx]) sum = 0.f;
   const size_t dst = (size_t)(rows ? rows[o] : o) * IN + (cols ? cols[c] : c);
   dw[dst] = accumulate ? dw[dst] + sum : sum;
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int OUT, int IN, const int32_t* pairs, int npairs, int nslices, const float* partial,
+                                                           const uint8_t* mask, float* dw, int accumulate, const int32_t* rows, const int32_t* cols) {
+  wgrad_reduce_body(OUT, IN, pairs, npairs, nslices, partial, mask, dw, accumulate, rows, cols, (int)blockIdx.x);
+}
+struct WredMulti {
+  int n;
+  int start[5];     // first reduce block (64 per live pair) of every layer
+  int cs_start[5];  // first column-sum block (256 columns each) of every layer, after all reduce blocks
+  WredArgs r[4];
+};
+// dW of every layer (+ the bias gradients) from the partial sums of wgrad_split_multi_kernel: one launch
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WredMulti m) {
+  const int b = (int)blockIdx.x;
+  if (b < m.start[m.n]) {
+    WredArgs r = m.r[0];
+    int base = 0;
+    if (m.n > 1 && b >= m.start[1]) { r = m.r[1]; base = m.start[1]; }
+    if (m.n > 2 && b >= m.start[2]) { r = m.r[2]; base = m.start[2]; }
+    if (m.n > 3 && b >= m.start[3]) { r = m.r[3]; base = m.start[3]; }
+    wgrad_reduce_body(r.OUT, r.IN, r.pairs, r.npairs, r.nslices, r.partial, r.mask, r.dw, r.accumulate, r.rows, r.cols, b - base);
+    return;
+  }
+  const int cb = b - m.start[m.n];
+  WredArgs r = m.r[0];
+  int base = 0;
+  if (m.n > 1 && cb >= m.cs_start[1]) { r = m.r[1]; base = m.cs_start[1]; }
+  if (m.n > 2 && cb >= m.cs_start[2]) { r = m.r[2]; base = m.cs_start[2]; }
+  if (m.n > 3 && cb >= m.cs_start[3]) { r = m.r[3]; base = m.cs_start[3]; }
+  if (!r.db) return;
+  const int c = (cb - base) * 256 + threadIdx.x;
+  if (c >= r.OUT) return;
+  float sum = 0.f;
+  int sl = 0;
+  for (; sl + 8 <= r.nslices; sl += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = r.cs_partial[(size_t)(sl + u) * r.cs_ld + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; sl < r.nslices; ++sl) sum += r.cs_partial[(size_t)sl * r.cs_ld + c];
+  r.db[r.rows ? r.rows[c] : c] = sum;
 }
 
 // column sums: out[c] = sum_n x[n, c] (bias gradients), two passes with a fixed reduction order
@@ -584,11 +691,11 @@ static int wgrad_launch(int64_t N, int out_features, int in_features, const void
   // (operand-split kernel unless ZUKO_AMD_EXACT_F32=1 asks for the f32 matrix instruction; k tiles of 32 samples need S % 32 == 0)
   static const bool exact = [] { const char* e = getenv("ZUKO_AMD_EXACT_F32"); return e && e[0] == '1'; }();
   if (exact) {
-    hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)(8 * ((a.nslices * npairs + 7) / 8))), dim3(256), 0, st, a);
   } else {
     a.S = (a.S + 31) / 32 * 32;
     a.nslices = (int)((N + a.S - 1) / a.S);
-    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)(a.nslices * npairs)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)(8 * ((a.nslices * npairs + 7) / 8))), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)npairs * 64), dim3(256), 0, st, out_features, in_features, pairs, npairs, a.nslices, (const float*)partial, mask,
                      (float*)dw, accumulate, rows, cols);
@@ -609,6 +716,48 @@ int zk_wgrad_bias_f32(int64_t N, int out_features, int in_features, const void* 
                       const int32_t* cols, void* stream) {
   if (!cs_flag || !cs_partial || !db) return ZK_EINVAL;
   return wgrad_launch(N, out_features, in_features, g, ldg, h, ldh, pairs, npairs, partial, mask, dw, accumulate, cs_flag, cs_partial, db, rows, cols, stream);
+}
+
+// zk_wgrad_bias_f32 for up to four layers in TWO launches (operand-split kernel; the reductions of all layers in one kernel).  `layers`:
+// HOST array of n descriptors (include/zuko_amd.h: zk_wgrad_layer_v1).  Every layer needs cs_flag / cs_partial / db (bias gradient) or none
+// of the three; dw / db are written, not accumulated.
+int zk_wgrad_multi(int n, const zk_wgrad_layer_v1* layers, int64_t N, void* stream) {
+  if (n < 1 || n > 4 || !layers) return ZK_EINVAL;
+  if (N <= 0) return 0;
+  WgradMulti m{};
+  WredMulti r{};
+  m.n = r.n = n;
+  int work = 0, red = 0, cs = 0;
+  // ONE slice length for all layers, so that every block of the launch runs equally long and the blocks fill a whole number of rounds:
+  // about zk_wgrad_slices' blocks-per-CU target over the live blocks of ALL layers (never more slices than a layer's own launch would use:
+  // the callers size `partial` for that)
+  int64_t pairs_total = 0;
+  for (int l = 0; l < n; ++l) pairs_total += layers[l].npairs > 0 ? layers[l].npairs : 0;
+  const int common = pairs_total > 0 ? zk_wgrad_slices(N, (int)pairs_total) : 1;
+  for (int l = 0; l < n; ++l) {
+    const zk_wgrad_layer_v1& d = layers[l];
+    if (d.struct_size != sizeof(zk_wgrad_layer_v1) || d.npairs <= 0 || !d.g || !d.h || !d.pairs || !d.partial || !d.dw) return ZK_EINVAL;
+    if ((d.db != nullptr) != (d.cs_flag != nullptr) || (d.db != nullptr) != (d.cs_partial != nullptr)) return ZK_EINVAL;
+    WgradArgs& a = m.a[l];
+    a.N = N; a.OUT = d.out_features; a.IN = d.in_features; a.g = (const float*)d.g; a.ldg = d.ldg; a.h = (const float*)d.h; a.ldh = d.ldh;
+    a.pairs = d.pairs; a.npairs = d.npairs; a.partial = (float*)d.partial;
+    a.cs_flag = d.cs_flag; a.cs_partial = (float*)d.cs_partial; a.cs_ld = (d.out_features + 127) / 128 * 128;
+    a.nslices = zk_wgrad_slices(N, d.npairs);
+    a.nslices = a.nslices < common ? a.nslices : common;
+    a.S = (((N + a.nslices - 1) / a.nslices) + 31) / 32 * 32;
+    a.nslices = (int)((N + a.S - 1) / a.S);
+    m.start[l] = work; work += a.nslices * a.npairs;
+    WredArgs& q = r.r[l];
+    q.OUT = a.OUT; q.IN = a.IN; q.npairs = a.npairs; q.nslices = a.nslices; q.accumulate = 0; q.pairs = a.pairs; q.partial = a.partial; q.mask = d.mask; q.dw = (float*)d.dw;
+    q.rows = d.rows; q.cols = d.cols; q.cs_partial = a.cs_partial; q.db = (float*)d.db; q.cs_ld = a.cs_ld;
+    r.start[l] = red; red += a.npairs * 64;
+    r.cs_start[l] = cs; cs += (a.OUT + 255) / 256;
+  }
+  m.start[n] = work; r.start[n] = red; r.cs_start[n] = cs;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_split_multi_kernel, dim3((unsigned)(8 * ((work + 7) / 8))), dim3(256), 0, st, m);
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)(red + cs)), dim3(256), 0, st, r);
+  return ZK_LAUNCH_CHECK();
 }
 
 // out[c] (+)= sum_n x[n, c];  workspace: >= zk_colsum_slices(N) * C floats

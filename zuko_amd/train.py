@@ -184,6 +184,40 @@ class SortedPlan:
         _C.check(err, "zk_wgrad_f32")
         return (dw, None) if want_bias else dw
 
+    def wgrad_multi(self, items):
+        """Weight and bias gradients of several layers in two launches (zk_wgrad_multi).  items: [(layer, g, h)] with every layer's
+        cs_flag present; returns {layer: (dW in the module's order, db in the module's order)}."""
+        import ctypes
+
+        lib = _C.lib()
+        cls = _C.STRUCTS["zk_wgrad_layer_v1"]
+        n = len(items)
+        N = items[0][1].shape[0]
+        dev = items[0][1].device
+        sizes_w = [self.shapes[l][0] * self.shapes[l][1] for l, _, _ in items]
+        sizes_b = [self.shapes[l][0] for l, _, _ in items]
+        ns = [max(1, lib.zk_wgrad_slices(N, self.pairs[l].shape[0])) for l, _, _ in items]
+        sizes_p = [ns[i] * self.pairs[l].shape[0] * 128 * 128 for i, (l, _, _) in enumerate(items)]
+        sizes_c = [ns[i] * (-(-self.shapes[l][0] // 128) * 128) for i, (l, _, _) in enumerate(items)]
+        flat = torch.zeros(sum(sizes_w) + sum(sizes_b), dtype=torch.float32, device=dev)  # (dW: only the live blocks are written)
+        work = torch.empty(sum(sizes_p) + sum(sizes_c), dtype=torch.float32, device=dev)
+        arr = (cls * n)()
+        out = {}
+        ow, ob, op, oc = 0, sum(sizes_w), 0, sum(sizes_p)
+        for i, (l, g, h) in enumerate(items):
+            out_f, in_f = self.shapes[l]
+            dw, db = flat[ow : ow + sizes_w[i]].view(out_f, in_f), flat[ob : ob + sizes_b[i]]
+            d = arr[i]
+            d.struct_size = ctypes.sizeof(cls)
+            d.out_features, d.in_features, d.npairs, d.ldg, d.ldh = out_f, in_f, self.pairs[l].shape[0], g.stride(0), h.stride(0)
+            for name, t in (("g", g), ("h", h), ("pairs", self.pairs[l]), ("partial", work[op:]), ("mask", self.mask_s[l]), ("dw", dw), ("cs_flag", self.cs_flag[l]),
+                            ("cs_partial", work[oc:]), ("db", db), ("rows", self.idx_b[l]), ("cols", self.cols_dev[l])):
+                setattr(d, name, None if t is None else t.data_ptr())
+            out[l] = (dw, db)
+            ow += sizes_w[i]; ob += sizes_b[i]; op += sizes_p[i]; oc += sizes_c[i]
+        _C.check(lib.zk_wgrad_multi(n, ctypes.cast(arr, ctypes.c_void_p), N, _stream()), "zk_wgrad_multi")
+        return out
+
     def colsum(self, g: Tensor) -> Tensor:
         lib = _C.lib()
         N, C = g.shape
@@ -407,6 +441,12 @@ class ConditionerFn(torch.autograd.Function):
     def _backward_chain(ctx, chain: "DgradChain", g: Tensor, hs, wts, grads: list):
         """Last layer as the layer-wise path (its K = out_features product is a plain GEMM), every other dgrad in one launch."""
         plan, n = ctx.plan, ctx.n
+        if chain.full and ConditionerFn._multi_ok(ctx):  # every dgrad in one launch, then every weight / bias gradient in two
+            gs, gx = chain.run(plan, wts[0], g, hs)
+            res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else g, hs[l]) for l in range(n)])
+            for l in range(n):
+                grads[2 * l], grads[2 * l + 1] = res[l]
+            return (None, None, gx if ctx.needs_input_grad[2] else None, *grads)
         ConditionerFn._param_grads(ctx, n - 1, g, hs[n - 1], grads)
         if chain.full:
             gs, gx = chain.run(plan, wts[0], g, hs)
@@ -417,6 +457,16 @@ class ConditionerFn(torch.autograd.Function):
         for l in range(n - 2, -1, -1):
             ConditionerFn._param_grads(ctx, l, gs[l], hs[l], grads)
         return (None, None, gx if ctx.needs_input_grad[2] else None, *grads)
+
+    @staticmethod
+    def _multi_ok(ctx) -> bool:
+        """All layers want dW and db, every layer's bias gradient can ride on its wgrad pass, the split kernels are in use."""
+        import os
+
+        plan, n = ctx.plan, ctx.n
+        return (n <= 4 and os.environ.get("ZUKO_AMD_EXACT_F32", "0") != "1" and os.environ.get("ZUKO_AMD_NO_WGRAD_MULTI", "0") != "1"
+                and all(ctx.needs_input_grad[3 + 2 * l] and ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l] and plan.cs_flag[l] is not None and plan.pairs[l].shape[0] > 0
+                        for l in range(n)))
 
 
 def plan_for(module, device: torch.device):
