@@ -361,6 +361,18 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
  * weight as three bf16 numbers h + m + l.  idx [n_blocks * 512] int32 (lane-major, 8 per lane, -1 = zero) into src, mask as
  * zk_gather_f32; dst receives three 1 KiB images per block. */
 int zk_gather_split_bf16(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n_blocks, void* dst, void* stream);
+/* Up to eight of the two gathers above in ONE launch (the streams and bias images of a conditioner are a dozen tiny gathers; training
+ * re-gathers them every step).  split != 0: zk_gather_split_bf16 with count = blocks; else zk_gather_f32 with count = elements. */
+typedef struct zk_gather_desc_v1 {
+  uint32_t struct_size;    /* sizeof(zk_gather_desc_v1) */
+  int32_t split;
+  int64_t count;
+  const void* src;
+  const uint8_t* mask;     /* or NULL */
+  const int32_t* idx;
+  void* dst;
+} zk_gather_desc_v1;
+int zk_gather_multi(int n, const zk_gather_desc_v1* descs, void* stream);
 
 /* ---- backward (vector-Jacobian products; fp32).  The reference has no backward code: autograd runs
  *      through the ATen ops of zuko/transforms.py:480-490,554-567 (spline), :436-446 (affine),

@@ -74,6 +74,19 @@ def args(struct: str, **fields):
     return a
 
 
+def gather_multi(items, stream) -> None:
+    """items: [(src, mask, idx, count, dst, split)] of tensors / None — zk_gather_multi in launches of up to eight gathers."""
+    cls = STRUCTS["zk_gather_desc_v1"]
+    items = [it for it in items if it[3] > 0]
+    for i0 in range(0, len(items), 8):
+        part = items[i0 : i0 + 8]
+        arr = (cls * len(part))()
+        for d, (src, mask, idx, count, dst, split) in zip(arr, part):
+            d.struct_size, d.split, d.count = ctypes.sizeof(cls), int(split), int(count)
+            d.src, d.mask, d.idx, d.dst = src.data_ptr(), (None if mask is None else mask.data_ptr()), idx.data_ptr(), dst.data_ptr()
+        check(lib().zk_gather_multi(len(part), ctypes.cast(arr, c_void_p), stream), "zk_gather_multi")
+
+
 _AR, _CP, _INC = POINTER(STRUCTS["zk_ar_args_v1"]), POINTER(STRUCTS["zk_coupling_args_v1"]), POINTER(STRUCTS["zk_ar_inc_args_v1"])
 
 # symbol -> argument types (return type is always int = hipError_t)
@@ -95,6 +108,7 @@ SIGNATURES = {
     "zk_sum_f64": [I, L, P, F, P, P, P],
     "zk_gather_f32": [P, P, P, L, P, P],
     "zk_gather_split_bf16": [P, P, P, L, P, P],
+    "zk_gather_multi": [I, P, P],
     "zk_univariate_backward": [I, L, L, I, F, F, P, P, P, P, I, P, P, P],
     "zk_diag_normal_backward": [L, L, P, P, P, P, P, P],
     "zk_act_backward": [L, P, P, I, P, P],

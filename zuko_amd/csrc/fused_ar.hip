@@ -381,6 +381,51 @@ __global__ __launch_bounds__(256) void gather_split_kernel(const float* __restri
   }
 }
 
+// Up to eight gathers (f32 elements or operand-split blocks) in one launch: the streams and bias images of a conditioner are a dozen tiny
+// gathers that the GPU finishes faster than the host queues them (training re-gathers every step).
+struct GatherMulti {
+  int n;
+  int start[9];  // first block of every gather, start[n] = total
+  struct One { const float* src; const uint8_t* mask; const int32_t* idx; int64_t count; void* dst; int split; } g[8];
+};
+__global__ __launch_bounds__(256) void gather_multi_kernel(GatherMulti m) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  const int b = (int)blockIdx.x;
+  GatherMulti::One g = m.g[0];
+  int base = 0;
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    if (k < m.n && b >= m.start[k]) { g = m.g[k]; base = m.start[k]; }
+  const int64_t i = (int64_t)(b - base) * 256 + threadIdx.x;
+  if (!g.split) {
+    if (i >= g.count) return;
+    const int32_t k = g.idx[i];
+    float v = 0.f;
+    if (k >= 0 && (!g.mask || g.mask[k])) v = g.src[k];
+    reinterpret_cast<float*>(g.dst)[i] = v;
+    return;
+  }
+  if (i >= g.count * 64) return;
+  const int4 k0 = *reinterpret_cast<const int4*>(g.idx + i * 8), k1 = *reinterpret_cast<const int4*>(g.idx + i * 8 + 4);
+  const int k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+  bf16x8 h, mm_, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = 0.f;
+    if (k[e] >= 0 && (!g.mask || g.mask[k[e]])) v = g.src[k[e]];
+    const __bf16 hh = (__bf16)v;
+    const float r1 = v - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    h[e] = hh; mm_[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
+  }
+  const int64_t blk = i >> 6;
+  const int lane = (int)(i & 63);
+  uint4* dst = reinterpret_cast<uint4*>(g.dst);
+  dst[(blk * 3 + 0) * 64 + lane] = __builtin_bit_cast(uint4, h);
+  dst[(blk * 3 + 1) * 64 + lane] = __builtin_bit_cast(uint4, mm_);
+  dst[(blk * 3 + 2) * 64 + lane] = __builtin_bit_cast(uint4, l);
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -402,6 +447,28 @@ int zk_gather_split_bf16(const void* src, const uint8_t* mask, const int32_t* id
   if (!src || !idx || !dst || ((uintptr_t)idx % 16) || ((uintptr_t)dst % 16)) return ZK_EINVAL;
   const int64_t n_lanes = n_blocks * 64, nb = (n_lanes + 255) / 256;
   hipLaunchKernelGGL(gather_split_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, (const float*)src, mask, idx, n_lanes, (uint4*)dst);
+  return ZK_LAUNCH_CHECK();
+}
+
+// Up to eight zk_gather_f32 / zk_gather_split_bf16 in one launch; `descs`: HOST array (include/zuko_amd.h: zk_gather_desc_v1).
+int zk_gather_multi(int n, const zk_gather_desc_v1* descs, void* stream) {
+  if (n < 1 || n > 8 || !descs) return ZK_EINVAL;
+  GatherMulti m{};
+  m.n = n;
+  int blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    const zk_gather_desc_v1& d = descs[k];
+    if (d.struct_size != sizeof(zk_gather_desc_v1) || d.count < 0 || (d.count > 0 && (!d.src || !d.idx || !d.dst))) return ZK_EINVAL;
+    if (d.split && (((uintptr_t)d.idx % 16) || ((uintptr_t)d.dst % 16))) return ZK_EINVAL;
+    m.g[k] = {(const float*)d.src, d.mask, d.idx, d.count, d.dst, d.split};
+    m.start[k] = blocks;
+    const int64_t threads = d.split ? d.count * 64 : d.count;
+    if (threads > (int64_t)0x7fffffff) return ZK_EINVAL;
+    blocks += (int)((threads + 255) / 256);
+  }
+  m.start[n] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m);
   return ZK_LAUNCH_CHECK();
 }
 

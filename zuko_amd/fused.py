@@ -480,27 +480,27 @@ class FusedAR:
         want_fine = self.static is not None and stamp != self._fine_stamp
         if not (want_generic or want_fine):
             return
-        lib = _C.lib()
+        items = []
         for l, m in enumerate(linears):
             w = m.weight.detach()
             if not w.is_contiguous():
                 w = w.contiguous()
             mask = m.mask.contiguous().view(torch.uint8)
             if want_generic:
-                dst = self.stream[self.plan.layer_block0[l] * 256 :]
-                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.gather[l]), self.gather[l].numel(), _ptr(dst), _stream()), "zk_gather_f32")
+                items.append((w, mask, self.gather[l], self.gather[l].numel(), self.stream[self.plan.layer_block0[l] * 256 :], 0))
             if want_fine:
                 fdst = self.fine_stream[self.fine_offsets[l] :]
                 if self.static[0].meta.get("split"):
-                    _C.check(lib.zk_gather_split_bf16(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel() // 512, _ptr(fdst), _stream()), "zk_gather_split_bf16")
+                    items.append((w, mask, self.fine_gather[l], self.fine_gather[l].numel() // 512, fdst, 1))
                 else:
-                    _C.check(lib.zk_gather_f32(_ptr(w), _ptr(mask), _ptr(self.fine_gather[l]), self.fine_gather[l].numel(), _ptr(fdst), _stream()), "zk_gather_f32")
+                    items.append((w, mask, self.fine_gather[l], self.fine_gather[l].numel(), fdst, 0))
             nb = self.bias_gather[l].numel()
             bdst = self.bias[self.plan.bias_off[l] :]
             if m.bias is None:
                 bdst[:nb].zero_()
             else:
-                _C.check(lib.zk_gather_f32(_ptr(m.bias.detach().contiguous()), None, _ptr(self.bias_gather[l]), nb, _ptr(bdst), _stream()), "zk_gather_f32")
+                items.append((m.bias.detach().contiguous(), None, self.bias_gather[l], nb, bdst, 0))
+        _C.gather_multi(items, _stream())  # (one launch per eight gathers: they are tiny, and training re-gathers every step)
         if want_generic:
             self._stamp = stamp
         if want_fine:

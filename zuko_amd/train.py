@@ -310,16 +310,14 @@ class DgradChain:
 
     def gather(self, plan: SortedPlan, lins) -> Tensor:
         """The kernel's weight stream from the module's CURRENT parameters (a fresh tensor: the forward saves it for its backward)."""
-        lib = _C.lib()
         stream = torch.empty((self.t["STREAM_IMAGES"] if self.full else self.t["NCHUNK"] * 24) * 256, dtype=torch.float32, device=self.device)
         n1 = len(self.idx)
+        items = []
         for c, idx in enumerate(self.idx):
             l = n1 - 1 - c
             w = lins[l].weight.detach().contiguous()
-            if self.full:
-                _C.check(lib.zk_gather_split_bf16(_ptr(w), _ptr(plan.mask_u8[l]), _ptr(idx), idx.numel() // 512, _ptr(stream[self.offsets[c] :]), _stream()), "zk_gather_split_bf16")
-            else:
-                _C.check(lib.zk_gather_f32(_ptr(w), _ptr(plan.mask_u8[l]), _ptr(idx), idx.numel(), _ptr(stream[self.offsets[c] :]), _stream()), "zk_gather_f32")
+            items.append((w, plan.mask_u8[l], idx, idx.numel() // 512 if self.full else idx.numel(), stream[self.offsets[c] :], 1 if self.full else 0))
+        _C.gather_multi(items, _stream())
         return stream
 
     def run(self, plan: SortedPlan, stream: Tensor, g_in: Tensor, hs):
