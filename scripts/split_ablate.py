@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from zuko_amd import static_ar as sa  # noqa: E402
 
-OUT = os.path.join(sa.ARS_DIR, "abl_" + "x".join(map(str, sa.split_geometry())))
+OUT = os.path.join(sa.ARS_DIR, "abl_" + "x".join(map(str, sa.split_geometry())) + os.environ.get("ABL_TAG", ""))
 NAMES = {0: "full kernel", 1: "no DMA into the ring", 2: "no MFMA", 3: "no spline arithmetic", 4: "no barrier at chunk boundaries", 5: "no LDS reads of the weights", 6: "no operand conversion"}
 
 
@@ -30,7 +30,7 @@ def build():
     with open(src, "w") as f:
         f.write(sa.emit_split(t))
     procs = []
-    for k in NAMES:
+    for k in (NAMES if os.environ.get("ABL_ONLY0", "0") != "1" else [0]):
         cmd = [sa._hipcc(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{sa.CSRC}", f"-DARX_ABL={k}", "-shared",
                "-no-hip-rt", src, f"-L{sa._torch_lib_dir()}", "-l:libamdhip64.so", "-o", os.path.join(OUT, f"arx_abl{k}.so")] + sys.argv[2:]
         procs.append(subprocess.Popen(cmd))
