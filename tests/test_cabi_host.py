@@ -120,3 +120,32 @@ def test_product_code_never_touches_the_oracle_or_a_cpu_fallback():
         ops.rqs_forward(torch.zeros(4, 2), torch.zeros(4, 2, 8), torch.zeros(4, 2, 8), torch.zeros(4, 2, 7))
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.linear(torch.zeros(4, 8), torch.zeros(3, 8))
+
+
+def test_ctypes_argument_blocks_match_the_c_compiler(tmp_path):
+    """zuko_amd/_C.py builds its ctypes.Structure classes by PARSING include/zuko_amd.h; their sizes and every field offset must be what a
+    C compiler makes of the same header (gcc: the header is plain C), for the versioned argument blocks and the descriptor arrays."""
+    import ctypes
+    import subprocess
+
+    import zuko_amd._C as C
+
+    names = sorted(C.STRUCTS)
+    assert {"zk_ar_args_v1", "zk_coupling_args_v1", "zk_ar_inc_args_v1", "zk_wgrad_layer_v1", "zk_gather_desc_v1"} <= set(names)
+    header = os.path.join(ROOT, "include", "zuko_amd.h")
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{header}"', "int main(void) {"]
+    for n in names:
+        lines.append(f'  printf("{n} %zu\\n", sizeof({n}));')
+        for f, _ in C.STRUCTS[n]._fields_:
+            lines.append(f'  printf("{n}.{f} %zu\\n", offsetof({n}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "sizes.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n in names:
+        cls = C.STRUCTS[n]
+        assert int(out[n]) == ctypes.sizeof(cls), n
+        for f, _ in cls._fields_:
+            assert int(out[f"{n}.{f}"]) == getattr(cls, f).offset, f"{n}.{f}"
