@@ -149,3 +149,30 @@ def test_ctypes_argument_blocks_match_the_c_compiler(tmp_path):
         assert int(out[n]) == ctypes.sizeof(cls), n
         for f, _ in cls._fields_:
             assert int(out[f"{n}.{f}"]) == getattr(cls, f).offset, f"{n}.{f}"
+
+
+def test_entry_points_reject_foreign_argument_blocks_without_touching_the_device():
+    """A block with the wrong struct_size / version (a caller built against another header) or an empty descriptor list is refused with
+    hipErrorInvalidValue before anything is launched — this runs on a box without a GPU."""
+    import zuko_amd._C as C
+
+    lib = C.lib()
+    EINVAL = 1
+    for struct, fns in (("zk_ar_args_v1", ["zk_ar_forward", "zk_ar_forward_static", "zk_ar_forward_train", "zk_ar_inverse_sweep", "zk_ar_dgrad_chain", "zk_ar_dgrad_full"]),
+                        ("zk_coupling_args_v1", ["zk_coupling_forward", "zk_coupling_inverse"]), ("zk_ar_inc_args_v1", ["zk_ar_inverse_incremental"])):
+        good = C.args(struct)
+        for fn in fns:
+            bad = C.args(struct)
+            bad.struct_size = good.struct_size - 8
+            assert getattr(lib, fn)(bad, None) == EINVAL, fn
+            bad = C.args(struct)
+            bad.version = 99
+            assert getattr(lib, fn)(bad, None) == EINVAL, fn
+    assert lib.zk_gather_multi(0, None, None) == EINVAL and lib.zk_gather_multi(9, None, None) == EINVAL
+    assert lib.zk_wgrad_multi(0, None, 16, None) == EINVAL and lib.zk_wgrad_multi(5, None, 16, None) == EINVAL
+    layer = (C.STRUCTS["zk_wgrad_layer_v1"] * 1)()
+    layer[0].struct_size = 4
+    assert lib.zk_wgrad_multi(1, ctypes.cast(layer, ctypes.c_void_p), 16, None) == EINVAL
+    desc = (C.STRUCTS["zk_gather_desc_v1"] * 1)()
+    desc[0].struct_size = 4
+    assert lib.zk_gather_multi(1, ctypes.cast(desc, ctypes.c_void_p), None) == EINVAL
