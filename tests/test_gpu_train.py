@@ -263,3 +263,35 @@ def test_wgrad_multi_matches_the_per_layer_launches(dev, kind, monkeypatch):
     assert torch.equal(gx1, gx0)
     for a, b in zip(gp1, gp0):
         assert torch.equal(a, b), (a - b).abs().max().item()
+
+
+def test_gather_multi_equals_the_single_gathers(dev):
+    """zk_gather_multi (up to eight f32 / operand-split gathers per launch) writes exactly what zk_gather_f32 / zk_gather_split_bf16 write,
+    including masked entries, -1 indices, an empty gather and a list longer than eight."""
+    from zuko_amd import _C
+    from zuko_amd.ops import _ptr, _stream
+
+    gen = torch.Generator().manual_seed(4)
+    lib = _C.lib()
+    items, want = [], []
+    for k in range(11):
+        n_src = 500 + 37 * k
+        src = torch.randn(n_src, generator=gen).to(dev)
+        mask = (torch.rand(n_src, generator=gen) < 0.7).to(torch.uint8).to(dev) if k % 3 else None
+        split = k % 2
+        count = 0 if k == 5 else (3 + k if split else 1000 + 13 * k)
+        n_idx = count * 512 if split else count
+        idx = torch.randint(-1, n_src, (max(n_idx, 1),), generator=gen, dtype=torch.int32).to(dev)
+        n_out = count * 3 * 256 if split else count
+        dst, ref = torch.full((max(n_out, 1),), 7.0, device=dev), torch.full((max(n_out, 1),), 7.0, device=dev)
+        if count:
+            if split:
+                _C.check(lib.zk_gather_split_bf16(_ptr(src), _ptr(mask), _ptr(idx), count, _ptr(ref), _stream()), "zk_gather_split_bf16")
+            else:
+                _C.check(lib.zk_gather_f32(_ptr(src), _ptr(mask), _ptr(idx), count, _ptr(ref), _stream()), "zk_gather_f32")
+        items.append((src, mask, idx, count, dst, split))
+        want.append(ref)
+    _C.gather_multi(items, _stream())
+    torch.cuda.synchronize()
+    for (src, mask, idx, count, dst, split), ref in zip(items, want):
+        assert torch.equal(dst.view(torch.int32), ref.view(torch.int32)), (count, split)
