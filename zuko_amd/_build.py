@@ -35,6 +35,8 @@ SOURCES = {
     "fused_coupling.hip": ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000"],
     "inc_inverse.hip": ["-ffp-contract=off"],
     "backward_poly.hip": ["-ffp-contract=off"],
+    "backward_bern.hip": ["-ffp-contract=off"],
+    "backward_bern_u.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"] + (["-DZK_INC_FAST_BUILD"] if os.environ.get("ZUKO_AMD_FAST_BUILD") == "1" else [])
 
