@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bin-report", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="default cfg2 run at N=1: do not append the cfg3 / cfg4 / cfg5 side measurements (each a short run of this script in a process of its own)")
+    ap.add_argument("--side-steps", type=int, default=0, help="timed steps of every side configuration (0 = a per-config default)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
                     help="cfg2 = the headline NSF workload (default, the only graded line); cfg3 = MAF(64,T=8,H=256x3); "
                          "cfg4 = RealNVP(256,T=16,H=512x3); cfg5 = NSF(1024,T=12,K=16,H=1024x3) in bf16 (use --batch-log2 19) — "
@@ -223,11 +226,17 @@ def cpu_baseline(flow_cpu, seconds: float):
             while time.perf_counter() < t_end or len(times) < least:
                 times.append(once(n))
             times.sort()
-            per_chunk[n] = (times[len(times) // 2], len(times))
-    rates = {n: n / med for n, (med, _) in per_chunk.items()}
+            per_chunk[n] = (times[len(times) // 2], len(times), times[0])
+    # `value` is the BEST credible CPU figure: the fastest single pass over all chunk sizes (and never below what the thread sweep saw
+    # at the chosen setting); the median of the same passes is printed next to it
+    medians = {n: n / med for n, (med, _, _) in per_chunk.items()}
+    rates = {n: n / fastest for n, (_, _, fastest) in per_chunk.items()}
+    rates[chunks[0]] = max(rates[chunks[0]], sweep.get(threads, 0.0))
     n_best = max(rates, key=rates.get)
     out = {
         "value": rates[n_best],
+        "value_is": "fastest single pass (best chunk size, fastest thread count of the sweep)",
+        "median_samples_per_s": medians[n_best],
         "unit": "samples/s",
         "cores": threads,
         "host_cpus": ncpu,
@@ -235,9 +244,10 @@ def cpu_baseline(flow_cpu, seconds: float):
         "pinned_bitwise": True,  # the port equals the live reference bit for bit (fixtures regenerated by tests/golden/make_golden.py)
         "thread_sweep_samples_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
         "chunk_sweep_samples_per_s": {f"2^{n.bit_length() - 1}": round(r, 1) for n, r in rates.items()},
+        "chunk_sweep_median_samples_per_s": {f"2^{n.bit_length() - 1}": round(r, 1) for n, r in medians.items()},
         "chunk_passes": {f"2^{n.bit_length() - 1}": per_chunk[n][1] for n in per_chunk},
         "extrapolated_seconds_for_2^20": (1 << 20) / rates[n_best],
-        "sample": f"median over {per_chunk[n_best][1]} passes of a 2^{n_best.bit_length() - 1}-row chunk (best of the 2^12 / 2^14 / 2^16 sweep) at the fastest thread count of the sweep, same model, same rows the GPU parity block uses",
+        "sample": f"fastest of {per_chunk[n_best][1]} passes of a 2^{n_best.bit_length() - 1}-row chunk (best of the 2^12 / 2^14 / 2^16 sweep) at the fastest thread count of the sweep, same model, same rows the GPU parity block uses",
         "cpu_model": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown"),
     }
     return out, {"x": xall, "spec": spec, "out": keep}
@@ -388,6 +398,136 @@ def bin_report(flow, flow_cpu, x, dev) -> dict:
 
 
 # --------------------------------------------------------------------------------------------------
+# side configurations (BASELINE.json configs[2..4]): parity block of a `--config cfgN` run, and the short runs the default
+# invocation appends to the headline line
+# --------------------------------------------------------------------------------------------------
+
+SIDE_RUNS = {  # config: (batch log2 = its per-GPU share, warm-up, timed steps)
+    "cfg3": (20, 3, 20),
+    "cfg4": (19, 2, 6),
+    "cfg5": (19, 1, 3),
+}
+
+
+def side_parity(config: str, flow, flow_cpu, dev) -> dict:
+    """cfg3 / cfg4 (fp32): a 2^12-row chunk through the GPU flow against the CPU oracle (the pinned restatement of the reference) on
+    the same rows — north_star's bar, log_prob within 1e-5 relative — with each side's distance from the float64 oracle next to it.
+    cfg5 (bf16): SURVEY 9.1's bar on the FULL flow at 64 rows — against the fp32 oracle on the same bf16-valued weights the HIP bf16
+    path must be no worse than the reference's own bf16 evaluation (the oracle run in torch.bfloat16) in mean / median / p99."""
+    import dataclasses
+
+    import torch
+
+    from oracle import zuko_oracle as O
+
+    ctor, kw, _, bf16 = CONFIGS[config]
+    D = kw["features"]
+    if not bf16:
+        kind = "coupling" if ctor in ("RealNVP", "NICE") else "ar"
+        uni = O.uni_rqs(kw["bins"]) if ctor == "NSF" else O.UNI_AFFINE
+        sd = {k: v for k, v in flow_cpu.state_dict().items() if v is not None}
+        spec = O.spec_from_state_dict(sd, kind, uni, D)
+        n = 1 << 12
+        xs = torch.randn(n, D, generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            z_o, l_o = O.flow_forward(spec, xs)
+            lp_o = O.diag_normal_log_prob(z_o, spec.loc, spec.scale) + l_o
+            dist = flow()
+            xg = xs.to(dev)
+            lp = dist.log_prob(xg).cpu()
+            z, ladj = dist.transform.call_and_ladj(xg)
+            z, ladj = z.cpu(), ladj.cpu()
+        rel = float(((lp - lp_o).abs() / lp_o.abs()).max())
+        rep = {"bar": "log_prob max relative error <= 1e-5 against the CPU oracle on the same rows (north_star)", "rows": n, "log_prob_max_rel": rel,
+               "z_max_abs": float((z - z_o).abs().max()), "ladj_max_abs": float((ladj - l_o).abs().max()), "ok": bool(rel <= 1e-5)}
+        try:
+            def f64(o):
+                if isinstance(o, torch.Tensor):
+                    return o.double() if o.is_floating_point() else o
+                if dataclasses.is_dataclass(o) and not isinstance(o, type):
+                    return type(o)(**{f.name: f64(getattr(o, f.name)) for f in dataclasses.fields(o)})
+                if isinstance(o, (list, tuple)):
+                    return type(o)(f64(v) for v in o)
+                return o
+
+            s64 = f64(spec)
+            with torch.no_grad():
+                z64, l64 = O.flow_forward(s64, xs.double())
+                lp64 = O.diag_normal_log_prob(z64, s64.loc, s64.scale) + l64
+            mx = lambda a, b: float((a.double() - b).abs().max())
+            rep["vs_float64_oracle"] = {
+                "z_max_abs": {"hip": mx(z, z64), "reference_fp32": mx(z_o, z64)},
+                "ladj_max_abs": {"hip": mx(ladj, l64), "reference_fp32": mx(l_o, l64)},
+                "log_prob_max_rel": {"hip": float(((lp.double() - lp64).abs() / lp64.abs()).max()), "reference_fp32": float(((lp_o.double() - lp64).abs() / lp64.abs()).max())},
+            }
+        except Exception as exc:
+            rep["vs_float64_oracle"] = {"error": repr(exc)}
+        return rep
+    # bf16
+    K, n = kw["bins"], 64
+    sdb = {k: v.detach().cpu() for k, v in flow.state_dict().items() if v is not None}
+    xs = torch.randn(n, D, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16)
+    with torch.no_grad():
+        spec_b = O.spec_from_state_dict(sdb, "ar", O.uni_rqs(K), D)
+        zb, lb = O.flow_forward(spec_b, xs)
+        lpb = O.flow_log_prob(spec_b, xs)
+        del spec_b
+        spec_32 = O.spec_from_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sdb.items()}, "ar", O.uni_rqs(K), D)
+        z32, l32 = O.flow_forward(spec_32, xs.float())
+        lp32 = O.flow_log_prob(spec_32, xs.float())
+        del spec_32, sdb
+        dist = flow()
+        lp = dist.log_prob(xs.to(dev)).cpu()
+        z, ladj = dist.transform.call_and_ladj(xs.to(dev))
+        z, ladj = z.float().cpu(), ladj.float().cpu()
+
+    def stats(e):
+        e = e.double().flatten()
+        return {"mean": float(e.mean()), "median": float(e.median()), "p99": float(torch.quantile(e, 0.99)), "max": float(e.max())}
+
+    rep = {"bar": "bf16 (SURVEY 9.1): |hip_bf16 - fp32 oracle| <= |reference's own bf16 evaluation - fp32 oracle| in mean, median and p99 of z, ladj and log_prob "
+                  "(max within 2x), same bf16-valued weights and rows", "rows": n, "ok": True}
+    for what, hip, ref, gold in (("z", z, zb.float(), z32), ("ladj", ladj, lb.float(), l32), ("log_prob", lp.float(), lpb.float(), lp32)):
+        e_hip, e_ref = stats((hip - gold).abs()), stats((ref - gold).abs())
+        good = e_hip["mean"] <= e_ref["mean"] and e_hip["median"] <= e_ref["median"] + 1e-12 and e_hip["p99"] <= e_ref["p99"] and e_hip["max"] <= 2.0 * e_ref["max"] + 1e-6
+        rep[what] = {"hip_bf16_abs_err": e_hip, "reference_bf16_abs_err": e_ref, "ok": bool(good)}
+        rep["ok"] = bool(rep["ok"] and good)
+    rep["log_prob_max_rel_vs_fp32_oracle"] = float(((lp.float() - lp32).abs() / lp32.abs()).max())
+    return rep
+
+
+def run_side_configs(args) -> dict:
+    """cfg3 / cfg4 / cfg5 for a few steps each, every one as `python bench.py --config cfgN ...` in a process of its own (own
+    allocator, own plans; a failure costs that entry only), AFTER the headline's timed region.  Returns {cfgN: condensed line}."""
+    out = {}
+    for cfg, (blog, warm, steps) in SIDE_RUNS.items():
+        steps = args.side_steps or steps
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--gpus", "1", "--batch-log2", str(blog), "--warmup", str(warm), "--steps", str(steps),
+               "--no-bin-report", "--no-side-configs"]
+        t0 = time.perf_counter()
+        try:
+            env = dict(os.environ)
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+            line = next((l for l in reversed(res.stdout.splitlines()) if l.startswith("{")), None)
+            if res.returncode != 0 or line is None:
+                out[cfg] = {"error": f"exit code {res.returncode}", "stderr_tail": res.stderr[-600:]}
+                continue
+            full = json.loads(line)
+            roof = full.get("roofline") or {}
+            out[cfg] = {
+                "workload": full["config"]["workload"],
+                "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"], "steps": full["steps"], "warmup": full["warmup"], "dtype": full["dtype"],
+                "batch_per_gpu": full["config"]["batch_per_gpu"],
+                "roofline": {k: roof.get(k) for k in ("kernel", "avg_launch_ms", "bound", "achieved", "peak", "unit", "frac", "instantiation", "note") if roof.get(k) is not None},
+                "parity": full.get("parity"),
+                "kernels": [{k: r.get(k) for k in ("kernel", "calls", "avg_ms", "frac") if r.get(k) is not None} for r in full.get("kernels", [])],
+                "wall_s": round(time.perf_counter() - t0, 1),
+            }
+        except Exception as exc:  # never let a side measurement break the headline line
+            out[cfg] = {"error": repr(exc)}
+    return out
 
 
 def model_flops(flow) -> dict:
@@ -466,8 +606,8 @@ def main() -> None:
     solo = None
     if dist is not None and hasattr(dist, "_zuko_form_group"):
         if rank == 0:  # the SAME per-GPU workload on rank 0 alone, before the group exists: what N-GPU weak scaling is measured against
-            k = min(args.steps, 20)
-            for _ in range(min(args.warmup, 5)):
+            k = args.steps  # same warm-up and step counts as the group run (a colder, shorter solo run would flatter the efficiency)
+            for _ in range(args.warmup):
                 step(collective=False)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -638,10 +778,23 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             out["cpu_baseline"], sample = cpu_baseline(flow_cpu, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline_median"] = value / out["cpu_baseline"]["median_samples_per_s"]
             try:
                 out["parity"] = parity_report(flow, x, sample, dev)
             except Exception as exc:
                 out["parity"] = {"error": repr(exc), "ok": False}
+        elif world == 1 and not args.no_cpu_baseline:
+            try:
+                del x
+                torch.cuda.empty_cache()
+                out["parity"] = side_parity(args.config, flow, flow_cpu, dev)
+            except Exception as exc:
+                out["parity"] = {"error": repr(exc), "ok": False}
+        if world == 1 and args.config == "cfg2" and args.batch_log2 == 20 and not args.no_side_configs and os.environ.get("ZUKO_BENCH_SINGLE_DEVICE") != "1":
+            # BASELINE.json configs[2..4] at their per-GPU share, a few steps each, after the headline's timed region
+            del flow, x
+            torch.cuda.empty_cache()
+            out["side_configs"] = run_side_configs(args)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -176,3 +176,26 @@ def test_entry_points_reject_foreign_argument_blocks_without_touching_the_device
     desc = (C.STRUCTS["zk_gather_desc_v1"] * 1)()
     desc[0].struct_size = 4
     assert lib.zk_gather_multi(1, ctypes.cast(desc, ctypes.c_void_p), None) == EINVAL
+
+
+def test_jit_build_failures_never_raise_into_the_callers_log_prob(tmp_path, monkeypatch):
+    """the first-use compile of a static-shape kernel writes .hip / .so / .json / lock files.  A directory that cannot be
+    written (read-only install, full disk) must make `_build_so` return None — the caller then stays on the generic kernel — not
+    raise OSError out of the user's call; ZUKO_AMD_CACHE_DIR redirects the JIT's output, the prebuilt kernels stay visible."""
+    from zuko_amd import static_ar
+
+    blocker = tmp_path / "not_a_directory"
+    blocker.write_text("x")
+    monkeypatch.setenv("ZUKO_AMD_CACHE_DIR", str(blocker))  # <file>/ars cannot be created: NotADirectoryError (an OSError)
+    assert static_ar._jit_dir() == os.path.join(str(blocker), "ars") and static_ar._dirs()[-1] == static_ar.ARS_DIR
+    assert static_ar._build_so("ars_unit_test_never_built", lambda: "int main() { return 0; }", {"so": "x"}, verbose=False) is None
+    # the scan still finds what was built ahead of time next to the package
+    static_ar._INDEX = None
+    idx = static_ar._scan()
+    assert idx and all(os.path.exists(os.path.join(m["dir"], m["so"])) for metas in idx.values() for m in metas)
+    static_ar._INDEX = None
+    # a writable cache directory takes the JIT's files (hipcc is present in the build container; skip the compile itself when it is not)
+    good = tmp_path / "cache"
+    monkeypatch.setenv("ZUKO_AMD_CACHE_DIR", str(good))
+    assert static_ar._jit_dir() == os.path.join(str(good), "ars")
+    assert static_ar._arch() == "gfx950"

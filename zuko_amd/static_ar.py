@@ -35,7 +35,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-ARS_DIR = os.path.join(HERE, "lib", "ars")
+ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
 ARS_ABI = 4  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 4: "zk::UniCircRqs8"}  # (16 bins: 12 accumulator tiles per group do not fit the double-buffered last layer)
 _HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
@@ -46,6 +46,86 @@ def _hipcc() -> str | None:
         if cand and os.path.exists(cand):
             return cand
     return None
+
+
+def _arch() -> str:
+    from . import _build
+
+    return _build.ARCH
+
+
+def _jit_dir() -> str:
+    """Where kernels compiled on first use go: ZUKO_AMD_CACHE_DIR when set (a read-only install of the package), else lib/ars."""
+    d = os.environ.get("ZUKO_AMD_CACHE_DIR")
+    return os.path.join(d, "ars") if d else ARS_DIR
+
+
+def _dirs() -> list[str]:
+    d = _jit_dir()
+    return [ARS_DIR] if d == ARS_DIR else [d, ARS_DIR]
+
+
+def _find(name: str) -> str | None:
+    for d in _dirs():
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            return path
+    return None
+
+
+_WARNED: set = set()
+
+
+def _warn_once(key: str, msg: str) -> None:
+    if key not in _WARNED:
+        _WARNED.add(key)
+        sys.stderr.write(f"[zuko_amd static_ar] {msg}\n")
+
+
+def _build_so(stem: str, source, meta: dict | None, verbose: bool, out_dir: str | None = None) -> str | None:
+    """Compile the one-kernel translation unit `source()` into <dir>/<stem>.so (+ <stem>.json when `meta` is given); a no-op when it
+    is there.  Returns the .so path, or None when there is no hipcc, the compile fails, or the directory cannot be written (read-only
+    install, full disk): the caller then stays on the generic / layer-wise kernels — a failed JIT must never fail the user's call."""
+    have = _find(stem + ".so")
+    if have is not None and (meta is None or os.path.exists(have[: -len(".so")] + ".json")):
+        return have
+    hipcc = _hipcc()
+    if hipcc is None:
+        return None
+    d = out_dir or _jit_dir()
+    try:
+        os.makedirs(d, exist_ok=True)
+        so = os.path.join(d, stem + ".so")
+        with open(os.path.join(d, f".lock_{stem}"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)  # (several ranks / test workers may want the same kernel at once)
+            if os.path.exists(so) and (meta is None or os.path.exists(os.path.join(d, stem + ".json"))):
+                return so
+            src = os.path.join(d, stem + ".hip")
+            with open(src, "w") as f:
+                f.write(source())
+            tmp = os.path.join(d, f".{stem}.so.{os.getpid()}")
+            cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", f"--offload-arch={_arch()}", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
+                   src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
+            if verbose:
+                print("[zuko_amd static_ar]", " ".join(cmd), flush=True)
+            elif out_dir is None:
+                _warn_once("jit", f"compiling a static-shape kernel for this conditioner on first use ({stem}, 10-25 s; ZUKO_AMD_JIT=0 disables, ZUKO_AMD_CACHE_DIR redirects)")
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(f"[zuko_amd static_ar] hipcc failed for {src}:\n{r.stdout[-2000:]}\n")
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
+                return None
+            os.replace(tmp, so)
+            if meta is not None:
+                with open(os.path.join(d, stem + ".json"), "w") as f:
+                    json.dump(meta, f)
+        return so
+    except OSError as exc:
+        _warn_once("oserror:" + d, f"cannot build kernels in {d} ({exc}); staying on the generic kernels (set ZUKO_AMD_CACHE_DIR to a writable directory)")
+        return None
 
 
 def _header_digest() -> str:
@@ -306,15 +386,20 @@ def _scan() -> dict:
     global _INDEX
     idx: dict = {}
     stamp = _header_digest()
-    if os.path.isdir(ARS_DIR):
-        for name in sorted(os.listdir(ARS_DIR)):
+    for d in _dirs():
+        try:
+            names = sorted(os.listdir(d)) if os.path.isdir(d) else []
+        except OSError:
+            names = []
+        for name in names:
             if name.endswith(".json"):
                 try:
-                    with open(os.path.join(ARS_DIR, name)) as f:
+                    with open(os.path.join(d, name)) as f:
                         meta = json.load(f)
                 except (OSError, ValueError):
                     continue
-                if meta.get("headers") == stamp and os.path.exists(os.path.join(ARS_DIR, meta["so"])):
+                if meta.get("headers") == stamp and os.path.exists(os.path.join(d, meta["so"])):
+                    meta["dir"] = d
                     idx.setdefault(meta["core"], []).append(meta)
     _INDEX = idx
     return idx
@@ -327,89 +412,39 @@ def _torch_lib_dir() -> str:
     return os.path.join(os.path.dirname(spec.origin), "lib")
 
 
-def compile_kernel(t: dict, alt: list | None, verbose: bool = False) -> dict | None:
-    """Build lib/ars/ars_<sig>.so for tables `t` (no-op when it is there and current); returns its meta or None (no hipcc / failure)."""
-    hipcc = _hipcc()
-    if hipcc is None:
-        return None
+def compile_kernel(t: dict, alt: list | None, verbose: bool = False, out_dir: str | None = None) -> dict | None:
+    """Build ars_<sig>.so for tables `t` (no-op when it is there and current); returns its meta or None (no hipcc / failure / read-only directory)."""
     core, l0 = _split(t)
     stamp = _header_digest()
     sig = _digest({"core": core, "l0": l0, "alt": alt, "headers": stamp})
-    os.makedirs(ARS_DIR, exist_ok=True)
-    so, meta_path = f"ars_{sig}.so", os.path.join(ARS_DIR, f"ars_{sig}.json")
-    meta = {"so": so, "core": _digest(core), "l0": l0, "alt": alt, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"], "WAVES": t["WAVES"],
+    meta = {"so": f"ars_{sig}.so", "core": _digest(core), "l0": l0, "alt": alt, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"], "WAVES": t["WAVES"],
             "TRAIN_OK": t["TRAIN_OK"], "XLDS": t["XLDS"]}
-    with open(os.path.join(ARS_DIR, f".lock_{sig}"), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)  # (several ranks / test workers may want the same kernel at once)
-        if os.path.exists(os.path.join(ARS_DIR, so)) and os.path.exists(meta_path):
-            return meta
-        src = os.path.join(ARS_DIR, f"ars_{sig}.hip")
-        with open(src, "w") as f:
-            f.write(emit(t, alt))
-        tmp = os.path.join(ARS_DIR, f".{so}.{os.getpid()}")
-        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
-               src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
-        if verbose:
-            print("[zuko_amd static_ar]", " ".join(cmd), flush=True)
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(f"[zuko_amd static_ar] hipcc failed for {src}:\n{r.stdout[-2000:]}\n")
-            try:
-                os.remove(tmp)
-            except OSError:
-                pass
-            return None
-        os.replace(tmp, os.path.join(ARS_DIR, so))
-        with open(meta_path, "w") as f:
-            json.dump(meta, f)
+    so = _build_so(f"ars_{sig}", lambda: emit(t, alt), meta, verbose, out_dir)
+    if so is None:
+        return None
     global _INDEX
     _INDEX = None
-    return meta
+    return dict(meta, dir=os.path.dirname(so))
 
 
-def compile_split(t: dict, verbose: bool = False) -> dict | None:
-    """Build lib/ars/arx_<sig>.so, the operand-split kernel of tables `t` (split_tables); returns its meta or None."""
-    hipcc = _hipcc()
-    if hipcc is None:
-        return None
+def compile_split(t: dict, verbose: bool = False, out_dir: str | None = None) -> dict | None:
+    """Build arx_<sig>.so, the operand-split kernel of tables `t` (split_tables); returns its meta or None."""
     stamp = _header_digest()
     sig = _digest({"split": t, "headers": stamp})
-    os.makedirs(ARS_DIR, exist_ok=True)
-    so, meta_path = f"arx_{sig}.so", os.path.join(ARS_DIR, f"arx_{sig}.json")
-    meta = {"so": so, "core": "x" + _digest(t), "split": 1, "l0": [], "alt": None, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"],
+    meta = {"so": f"arx_{sig}.so", "core": "x" + _digest(t), "split": 1, "l0": [], "alt": None, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"],
             "WAVES": t["WAVES"], "CH": t["CH"], "TRAIN_OK": t["TRAIN_OK"], "XLDS": t["XLDS"], "NCHUNK": t["NCHUNK"]}
-    with open(os.path.join(ARS_DIR, f".lock_{sig}"), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        if os.path.exists(os.path.join(ARS_DIR, so)) and os.path.exists(meta_path):
-            return meta
-        src = os.path.join(ARS_DIR, f"arx_{sig}.hip")
-        with open(src, "w") as f:
-            f.write(emit_split(t))
-        tmp = os.path.join(ARS_DIR, f".{so}.{os.getpid()}")
-        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
-               src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
-        if verbose:
-            print("[zuko_amd static_ar]", " ".join(cmd), flush=True)
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(f"[zuko_amd static_ar] hipcc failed for {src}:\n{r.stdout[-2000:]}\n")
-            try:
-                os.remove(tmp)
-            except OSError:
-                pass
-            return None
-        os.replace(tmp, os.path.join(ARS_DIR, so))
-        with open(meta_path, "w") as f:
-            json.dump(meta, f)
+    so = _build_so(f"arx_{sig}", lambda: emit_split(t), meta, verbose, out_dir)
+    if so is None:
+        return None
     global _INDEX
     _INDEX = None
-    return meta
+    return dict(meta, dir=os.path.dirname(so))
 
 
 def _load(meta: dict) -> StaticKernel:
     k = _LOADED.get(meta["so"])
     if k is None:
-        k = StaticKernel(os.path.join(ARS_DIR, meta["so"]), meta)
+        k = StaticKernel(os.path.join(meta.get("dir", ARS_DIR), meta["so"]), meta)
         _LOADED[meta["so"]] = k
     return k
 
@@ -434,6 +469,9 @@ def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
     if t is None:
         return None
     allow = rows is not None and rows >= jit_min_rows() and jit_enabled()
+    verbose = os.environ.get("ZUKO_AMD_JIT_VERBOSE", "0") == "1"
+    # (a compile runs OUTSIDE the module lock — the per-kernel file lock serialises ranks / threads that want the same kernel — so that
+    #  other threads' lookups do not wait 10-25 s behind it)
     if split_enabled():  # the operand-split kernel (6/16 of the f32 matrix time) when there is one or one may be built
         ts = split_tables(plan, uni_kind, act)
         if ts is not None:
@@ -442,9 +480,10 @@ def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
                 idx = _INDEX if _INDEX is not None else _scan()
                 for meta in idx.get(cdx, []):
                     return _load(meta), 0
-                if allow:
-                    meta = compile_split(ts[0], verbose=os.environ.get("ZUKO_AMD_JIT_VERBOSE", "0") == "1")
-                    if meta is not None:
+            if allow:
+                meta = compile_split(ts[0], verbose=verbose)
+                if meta is not None:
+                    with _LOCK:
                         return _load(meta), 0
     core, l0 = _split(t)
     cd = _digest(core)
@@ -455,9 +494,10 @@ def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
                 return _load(meta), 0
             if meta["alt"] is not None and meta["alt"] == l0:
                 return _load(meta), 1
-        if allow:
-            meta = compile_kernel(t, None, verbose=os.environ.get("ZUKO_AMD_JIT_VERBOSE", "0") == "1")
-            if meta is not None:
+    if allow:
+        meta = compile_kernel(t, None, verbose=verbose)
+        if meta is not None:
+            with _LOCK:
                 return _load(meta), 0
     return None
 
@@ -634,40 +674,29 @@ class ChainKernel:
 _CHAINS: dict[str, ChainKernel] = {}
 
 
-def chain_kernel(t: dict, allow_compile: bool, verbose: bool = False):
-    """The compiled dgrad-chain kernel for tables `t` (lib/ars/arsd_<sig>.so), built on demand when allowed; None otherwise."""
+def chain_kernel(t: dict, allow_compile: bool, verbose: bool = False, out_dir: str | None = None):
+    """The compiled dgrad-chain kernel for tables `t` (arsd_<sig>.so), built on demand when allowed; None otherwise."""
     stamp = _header_digest()
     sig = _digest({"t": t, "headers": stamp})
-    so = os.path.join(ARS_DIR, f"arsd_{sig}.so")
+    stem = f"arsd_{sig}"
     with _LOCK:
-        k = _CHAINS.get(so)
+        k = _CHAINS.get(stem)
         if k is not None:
             return k
-        if not os.path.exists(so):
-            hipcc = _hipcc()
-            if not allow_compile or hipcc is None:
+        so = _find(stem + ".so")
+        if so is None:
+            if not allow_compile:
                 return None
-            os.makedirs(ARS_DIR, exist_ok=True)
-            with open(os.path.join(ARS_DIR, f".lock_{sig}"), "w") as lock:
-                fcntl.flock(lock, fcntl.LOCK_EX)
-                if not os.path.exists(so):
-                    src = os.path.join(ARS_DIR, f"arsd_{sig}.hip")
-                    with open(src, "w") as f:
-                        f.write(emit_chain_split(t) if t.get("chain") == 2 else emit_chain(t))
-                    with open(os.path.join(ARS_DIR, f"arsd_{sig}.json"), "w") as f:
-                        json.dump({"so": f"arsd_{sig}.so", "headers": stamp, "core": "chain", "l0": [], "alt": None, "DIN": t.get("DIN", t.get("DIN0")), "DOUT": t["DOUT"], "HT": t["HT"]}, f)
-                    tmp = so + f".{os.getpid()}"
-                    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
-                           src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
-                    if verbose:
-                        print("[zuko_amd static_ar]", " ".join(cmd), flush=True)
-                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-                    if r.returncode != 0:
-                        sys.stderr.write(f"[zuko_amd static_ar] hipcc failed for {src}:\n{r.stdout[-2000:]}\n")
-                        return None
-                    os.replace(tmp, so)
-        k = ChainKernel(so)
-        _CHAINS[so] = k
+            meta = {"so": stem + ".so", "headers": stamp, "core": "chain", "l0": [], "alt": None, "DIN": t.get("DIN", t.get("DIN0")), "DOUT": t["DOUT"], "HT": t["HT"]}
+            so = _build_so(stem, lambda: emit_chain_split(t) if t.get("chain") == 2 else emit_chain(t), meta, verbose, out_dir)
+            if so is None:
+                return None
+        try:
+            k = ChainKernel(so)
+        except OSError as exc:
+            _warn_once("load:" + so, f"cannot load {so}: {exc}")
+            return None
+        _CHAINS[stem] = k
         return k
 
 
@@ -797,9 +826,9 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
         finally:
             del os.environ["ZUKO_AMD_SPLIT_GEOM"]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        metas = list(ex.map(lambda w: compile_kernel(w[0], w[1], verbose), work))
-        kerns = list(ex.map(lambda tg: chain_kernel(tg[0], True, verbose), chains))
-        xmetas = list(ex.map(lambda t: compile_split(t, verbose), splits))
+        metas = list(ex.map(lambda w: compile_kernel(w[0], w[1], verbose, ARS_DIR), work))
+        kerns = list(ex.map(lambda tg: chain_kernel(tg[0], True, verbose, ARS_DIR), chains))
+        xmetas = list(ex.map(lambda t: compile_split(t, verbose, ARS_DIR), splits))
     if any(m is None for m in metas + xmetas) or any(k is None for k in kerns):
         raise RuntimeError("zuko_amd.static_ar: a prebuilt static kernel failed to compile")
     return [m["so"] for m in metas + xmetas] + [os.path.basename(k.so) for k in kerns]

@@ -162,8 +162,9 @@ class SortedPlan:
 
     def wgrad(self, l: int, g: Tensor, h: Tensor, want_bias: bool = False):
         """Weight gradient dW_l [out, in] in the MODULE's unit order (zeros where the mask is false): computed on the sorted-domain
-        operands, written through the row / column permutations by the reduction kernel.  want_bias: returns (dW_l, dbs_l) with the
-        SORTED-domain bias gradient from the same pass over g (None when some 128-row out block has no live weight block)."""
+        operands, written through the row / column permutations by the reduction kernel.  want_bias: returns (dW_l, db_l) with the bias
+        gradient from the same pass over g, ALSO in the module's unit order (zk_wgrad_bias_f32 writes db[rows[o]]; assign it as it is —
+        None when some 128-row out block has no live weight block: the caller then takes the column-sum path)."""
         lib = _C.lib()
         out_f, in_f = self.shapes[l]
         N = g.shape[0]
@@ -365,11 +366,16 @@ def _dgrad_chain(plan: SortedPlan, lins, rows: int):
                     st = DgradChain(plan, kern, tg[0], tg[1], plan.device)
                     _CHAINS[plan] = st
                     return st
+                split_pending = tg is not None and not allow and static_ar.jit_enabled()  # a later, larger batch may compile the one-launch split chain
+            else:
+                split_pending = False
             tg = static_ar.chain_tables(plan.mask_s_cpu[: n - 1], plan.rows_cpu[: n - 1], plan.cols_cpu[: n - 1])
             if tg is not None:
                 kern = static_ar.chain_kernel(tg[0], allow_compile=allow)
                 if kern is not None:
                     st = DgradChain(plan, kern, tg[0], tg[1], plan.device)
+                    if split_pending:
+                        return st  # (the f32 chain serves this batch, but is NOT cached: re-probe, as FusedAR._acquire_static does)
                 else:
                     return None  # (not cached: a later, larger batch may be allowed to compile)
         _CHAINS[plan] = st
@@ -426,14 +432,14 @@ class ConditionerFn(torch.autograd.Function):
         plan = ctx.plan
         out_f = plan.shapes[l][0]
         want_b = ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
-        dbs = None
+        db = None  # module order
         if ctx.needs_input_grad[3 + 2 * l]:
-            grads[2 * l], dbs = plan.wgrad(l, g, h, want_bias=True) if want_b else (plan.wgrad(l, g, h), None)
+            grads[2 * l], db = plan.wgrad(l, g, h, want_bias=True) if want_b else (plan.wgrad(l, g, h), None)
         if want_b:
-            if dbs is None:  # (no pass over g to ride on: column sums in the sorted order, scattered to the module's)
-                dbs, srt = torch.empty(out_f, dtype=torch.float32, device=g.device), plan.colsum(g)
-                dbs[plan.idx_b64[l]] = srt
-            grads[2 * l + 1] = dbs
+            if db is None:  # (no pass over g to ride on: column sums in the sorted order, scattered to the module's)
+                db, srt = torch.empty(out_f, dtype=torch.float32, device=g.device), plan.colsum(g)
+                db[plan.idx_b64[l]] = srt
+            grads[2 * l + 1] = db
 
     @staticmethod
     def _backward_chain(ctx, chain: "DgradChain", g: Tensor, hs, wts, grads: list):
