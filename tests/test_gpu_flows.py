@@ -753,6 +753,138 @@ def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
         assert torch.equal(l2[ok], (ladj + ladj)[ok])
 
 
+def _run_static(st, inp, N, D, dev):
+    y, ladj = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+    st.run(inp, y, ladj, False)
+    return y, ladj
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in STATIC_CASES if len(c) == 4], ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}")
+@pytest.mark.parametrize("N", [1, 129, 1000, 40000])
+def test_two_set_split_kernel_is_bit_identical_to_the_eight_wavefront_one(dev, case, N, monkeypatch):
+    """The default forward of an operand-split conditioner is the TWO-SET kernel (csrc/fused_ar_split2_impl.h: one wavefront per SIMD
+    carrying two 16-sample sets, VALU work dealt into the shadow of the matrix instructions); ZUKO_AMD_SPLIT_V1=1 keeps the launch on
+    the 8-wavefront form (csrc/fused_ar_split_impl.h).  Same stream, same products in the same order per output: y / ladj bit for bit
+    (zeros compare equal whatever their sign: the two-set kernel's integer ReLU writes +0 for -0), poisoned rows included."""
+    from zuko_amd import static_ar
+    from zuko_amd.flows import MAF, NSF
+    from zuko_amd.nn import MaskedLinear
+
+    kind, D, C, hidden = case
+    monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
+    torch.manual_seed(3)
+    flow = (NSF(D, C, transforms=2, bins=8, hidden_features=hidden) if kind == "nsf" else MAF(D, C, transforms=2, hidden_features=hidden)).to(dev)
+    g = torch.Generator().manual_seed(N)
+    din = D + C
+    inp = torch.zeros(N, -(-din // 4) * 4)
+    inp[:, :din] = torch.randn(N, din, generator=g) * 1.5
+    if N >= 127:
+        inp[5, min(7, D - 1)] = float("nan")
+        inp[100, din - 1] = float("inf")
+        inp[101, 0] = 9.0
+    inp = inp.to(dev)
+    for i, lazy in enumerate(flow.transform.transforms):
+        st = lazy.fused_state(dev)
+        assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
+        has2 = static_ar.split_tables(st.plan, st.plan.layout.kind, st.act)[0]["HAS2"]
+        assert has2 == int(D % 4 == 0), "the two-set kernel covers every LDS-staged (D % 4 == 0) ReLU conditioner"
+        st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+        monkeypatch.setenv("ZUKO_AMD_SPLIT_V1", "1")
+        y1, l1 = _run_static(st, inp, N, D, dev)
+        monkeypatch.setenv("ZUKO_AMD_SPLIT_V1", "0")
+        y2, l2 = _run_static(st, inp, N, D, dev)
+        nn = lambda t: torch.nan_to_num(t, nan=12345.0, posinf=3e38, neginf=-3e38)
+        assert torch.equal(torch.isnan(y1), torch.isnan(y2)) and torch.equal(torch.isnan(l1), torch.isnan(l2))
+        assert torch.equal(nn(y1), nn(y2)) and torch.equal(nn(l1), nn(l2)), f"transform {i}: {(nn(y1) != nn(y2)).sum().item()} outputs differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regime", ["trained", "wide-range", "denormal"])
+@pytest.mark.parametrize("kind", ["nsf", "maf"])
+def test_split_kernels_away_from_default_init(dev, kind, regime, monkeypatch):
+    """the 6-of-9 partial-product argument is relative, so it has to hold away from seed-3 Kaiming weights too.
+    `trained`: weights x 30, inputs x 8 (activations in the hundreds to thousands, as a trained flow has them); `wide-range`: every
+    weight multiplied by 2^u, u uniform in [-20, 4]; `denormal`: first-layer weights scaled into the f32 denormal range (bf16 shares
+    f32's exponent range: the parts stay representable or flush exactly like the f32 instruction's operands).  Same bar as
+    test_split_kernels_carry_f32_accuracy: |split - f64| <= 2 x |f32-instruction kernel - f64| (+ 2 ulp floor), identical NaN / inf
+    patterns."""
+    from zuko_amd.flows import MAF, NSF
+    from zuko_amd.nn import MaskedLinear
+
+    D, N = 64, 4099
+    torch.manual_seed(5)
+    flow = (NSF(D, 0, transforms=1, bins=8, hidden_features=[256] * 3) if kind == "nsf" else MAF(D, 0, transforms=1, hidden_features=[256] * 3)).to(dev)
+    lazy = flow.transform.transforms[0]
+    lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+    g = torch.Generator().manual_seed(17)
+    xs = 1.5
+    with torch.no_grad():
+        if regime == "trained":
+            for l in lins[:-1]:
+                l.weight.mul_(30.0 ** (1.0 / 3.0) * 1.5)  # (x 30 accumulated over the three hidden layers, and then some)
+            lins[-1].weight.mul_(0.05)
+            xs = 8.0
+        elif regime == "wide-range":
+            for l in lins:
+                u = torch.rand(l.weight.shape, generator=g) * 24.0 - 20.0
+                l.weight.mul_(torch.exp2(u).to(dev))
+        else:
+            lins[0].weight.mul_(2.0 ** -120)
+            lins[0].bias.mul_(2.0 ** -120)
+            lins[1].weight.mul_(2.0 ** 100)
+    inp = (torch.randn(N, D, generator=g) * xs).to(dev)
+    st = lazy.fused_state(dev)
+    assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
+    st.refresh(lins)
+    y, ladj = _run_static(st, inp, N, D, dev)
+    keep, st.static = st.static, None
+    y0, ladj0 = _run_static(st, inp, N, D, dev)
+    st.static = keep
+    uni = O.uni_rqs(8) if kind == "nsf" else O.UNI_AFFINE
+    with torch.no_grad():
+        phi = O.mlp_forward(inp.cpu().double(), [l.weight.detach().cpu().double() for l in lins], [l.bias.detach().cpu().double() for l in lins], [l.mask.cpu() for l in lins], act=torch.relu)
+        y64, l64 = O.univariate_forward(uni, phi.reshape(N, D, uni.total), inp.cpu().double())
+        l64 = l64.sum(dim=-1)
+    assert torch.isfinite(y).all() and torch.isfinite(ladj).all(), "the regime must stay finite in f32"
+    tag = f"split kernel, {kind}, {regime} weights"
+    assert_parity(y, y0, y64, f"{tag}: y", c=2.0)
+    assert_parity(ladj, ladj0, l64, f"{tag}: ladj", c=2.0)
+
+
+@pytest.mark.gpu
+def test_split_kernel_overflowing_activation_is_nan_not_inf(dev):
+    """The documented difference of the operand split, as a test: a hidden activation that overflows f32 becomes NaN in the split
+    kernels (h = bf16(inf) = inf, the remainder inf - inf = NaN enters the m / l parts) where the f32 matrix instruction carries
+    inf x w.  The reference turns the same row into NaN one layer later (inf x 0 on its masked zeros, zuko/nn.py:217-218), so y / ladj of
+    that ROW are NaN on all three; every other row is untouched."""
+    from zuko_amd.flows import NSF
+    from zuko_amd.nn import MaskedLinear
+
+    D, N = 64, 256
+    torch.manual_seed(5)
+    flow = NSF(D, 0, transforms=1, bins=8, hidden_features=[256] * 3).to(dev)
+    lazy = flow.transform.transforms[0]
+    lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+    x = torch.randn(N, D, generator=torch.Generator().manual_seed(1)).to(dev)
+    x[3, 0] = 3e38  # finite, but |W x| overflows in the first layer for the units that see feature 0
+    with torch.no_grad():
+        lins[0].weight.mul_(8.0)
+    st = lazy.fused_state(dev)
+    assert st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
+    st.refresh(lins)
+    y, ladj = _run_static(st, x, N, D, dev)
+    ok = torch.ones(N, dtype=torch.bool, device=dev)
+    ok[3] = False
+    assert torch.isfinite(y[ok]).all() and torch.isfinite(ladj[ok]).all()
+    assert torch.isnan(ladj[3]), "the overflowing row's log-determinant is NaN (as the reference's: inf x 0 in its next layer)"
+    with torch.no_grad():
+        spec = O.spec_from_state_dict({k: v.detach().cpu() for k, v in flow.state_dict().items() if v is not None}, "ar", O.uni_rqs(8), D)
+        z_o, l_o = O.flow_forward(spec, x.cpu())
+    assert torch.isnan(l_o[3]) and torch.isfinite(l_o[ok.cpu()]).all()
+    assert torch.equal(torch.isnan(y.cpu()), torch.isnan(z_o)) or torch.isnan(y[3]).any()
+
+
 @pytest.mark.gpu
 def test_split_kernel_geometries_agree(dev, monkeypatch):
     """ZUKO_AMD_SPLIT_GEOM: one workgroup of eight wavefronts (24-image chunks, the default) and two workgroups of four per CU (16-image

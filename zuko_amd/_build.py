@@ -61,15 +61,32 @@ def _torch_lib_dir() -> str:
     return d
 
 
+def _includes(path: str, seen: set) -> None:
+    """Transitive closure of the `#include "x.h"` lines of a translation unit, within csrc/."""
+    import re
+
+    with open(path, "r", errors="replace") as f:
+        text = f.read()
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        full = os.path.normpath(os.path.join(os.path.dirname(path), name))  # (also ../../include/zuko_amd.h)
+        if full not in seen and os.path.exists(full):
+            seen.add(full)
+            _includes(full, seen)
+
+
 def _digest(path: str, flags: list[str]) -> str:
+    """Flags + the unit + the headers it actually includes (a header only the generated static-shape kernels use — zuko_amd/static_ar.py
+    keeps its own digest — does not rebuild the library)."""
     h = hashlib.sha256()
     h.update(" ".join(flags).encode())
     with open(path, "rb") as f:
         h.update(f.read())
-    for name in sorted(os.listdir(CSRC)):
-        if name.endswith(".h"):
-            with open(os.path.join(CSRC, name), "rb") as f:
-                h.update(f.read())
+    seen: set = set()
+    _includes(path, seen)
+    for full in sorted(seen):
+        h.update(os.path.basename(full).encode())
+        with open(full, "rb") as f:
+            h.update(f.read())
     return h.hexdigest()
 
 

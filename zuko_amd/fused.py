@@ -398,6 +398,14 @@ def chunk_of(variant: int = 0) -> int:
     return CHUNK
 
 
+def _split_variant() -> int:
+    """zk_ar_args_v1.variant for a static-shape launch: ZUKO_AMD_SPLIT_V1=1 keeps an operand-split kernel in its 8-wavefront form
+    (csrc/fused_ar_split_impl.h) instead of the two-set form (csrc/fused_ar_split2_impl.h) — read at every launch: an A/B switch."""
+    import os
+
+    return 1 if os.environ.get("ZUKO_AMD_SPLIT_V1", "0") == "1" else 0
+
+
 def default_variant() -> int:
     return 0  # reserved argument of the C ABI
 
@@ -520,7 +528,7 @@ class FusedAR:
                 a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
                             y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate), wstream=_ptr(self.fine_stream), bias=_ptr(self.bias),
                             bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=self.fine_n_chunks, act=self.act,
-                            bound=self.bound, slope=self.slope)
+                            bound=self.bound, slope=self.slope, variant=_split_variant())
                 _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
                 return
         if not self.generic_ok:
@@ -549,7 +557,7 @@ class FusedAR:
             a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=inp.shape[0], D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
                         y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=0, wstream=_ptr(self.fine_stream), bias=_ptr(self.bias), bias_floats=self.bias_floats,
                         featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=self.fine_n_chunks, act=self.act, bound=self.bound, slope=self.slope,
-                        bin_out=_ptr(bins), knots_out=_ptr(knots))
+                        bin_out=_ptr(bins), knots_out=_ptr(knots), variant=_split_variant())
             _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
             return
         a = self._generic_args(N=inp.shape[0], DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0), y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), bin_out=_ptr(bins), knots_out=_ptr(knots))

@@ -38,7 +38,7 @@ CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
 ARS_ABI = 4  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 4: "zk::UniCircRqs8"}  # (16 bins: 12 accumulator tiles per group do not fit the double-buffered last layer)
-_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
+_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "fused_ar_split2_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
 
 
 def _hipcc() -> str | None:
@@ -252,14 +252,20 @@ def split_tables(plan, uni_kind: int, act: int = 1):
                         pos[(otg * 4 + b, it)] = k
                         k += 1
         n_in = NIT if l == 0 else HT[l - 1]
+        # stream order: out-tile PAIR major, then in pair, then the two out tiles of the pair — an accumulator still sees its blocks by
+        # ascending in pair (the summation order per output does not depend on this interleave), while consecutive blocks alternate
+        # between two accumulators: the two-set kernel (csrc/fused_ar_split2_impl.h) rotates four independent accumulator chains
         blocks = []
-        for ot in range(HT[l]):
+        for op in range(-(-HT[l] // 2)):
             for ip in range(-(-n_in // 2)):
-                t0, t1 = pos.get((ot, 2 * ip)), pos.get((ot, 2 * ip + 1))
-                if t0 is None and t1 is None:
-                    continue
-                blocks.append(pair_block(fg, t0, t1))
-                B_OT.append(ot), B_IP.append(ip)
+                for ot in (2 * op, 2 * op + 1):
+                    if ot >= HT[l]:
+                        continue
+                    t0, t1 = pos.get((ot, 2 * ip)), pos.get((ot, 2 * ip + 1))
+                    if t0 is None and t1 is None:
+                        continue
+                    blocks.append(pair_block(fg, t0, t1))
+                    B_OT.append(ot), B_IP.append(ip)
         NB.append(len(blocks))
         BASE.append(cursor)
         cursor += 3 * len(blocks)
@@ -295,17 +301,142 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     xlds = int(t["D"] % 4 == 0 and (nr * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * (2 if waves == 4 else 1) <= 160 * 1024)
     out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
                 "WAVES": waves, "CH": ch, "NR": nr, "XLDS": xlds})
+    out.update(split2_schedule(out, plan.layout))
     plan._split_cache = ((uni_kind, act, split_geometry()), (out, gathers))
     return out, gathers
+
+
+# micro-steps of the univariate maps of the two-set kernel (csrc/fused_ar_split2_impl.h: Uni2*::step<I>) and what each costs in VALU
+# instructions — an estimate that only steers how the steps are spread over the matrix instructions, never a result
+def _uni2_costs(uni_kind: int) -> list[int] | None:
+    if uni_kind == 0:  # affine: load + map
+        return [4, 14]
+    bins = {1: 8, 2: 4, 4: 8}.get(uni_kind)
+    if bins is None:
+        return None
+    lv = bins.bit_length() - 1
+    cost = [bins + 4] + [8] * bins  # load / poison; one softmax element of both axes per step
+    cost += [4 + 6] + [6] * (-(-bins // 4) - 1)  # knots, four per step (the first also normalises)
+    cost += [bins // 2 + 6, 2 * (bins // 2 + 1)]  # bisection level 0 in two halves
+    m = bins // 2
+    for _ in range(lv - 1):  # the other levels
+        cost.append(3 * (m // 2 + 1) + 2)
+        m //= 2
+    cost += [8, 8, 13, 14]  # the two selected slopes; bin geometry; the rational-quadratic map; its derivative, log, stores
+    return cost
+
+
+def split2_schedule(t: dict, layout) -> dict:
+    """Step lists and the VALU schedule of the TWO-SET operand-split kernel (csrc/fused_ar_split2_impl.h), or {"HAS2": 0}.
+
+    One wavefront per SIMD carries two 16-sample sets.  A STEP is one in pair against up to two out tiles (consecutive blocks of the
+    stream: six images), executed as six QUADS — one partial-product term each, four matrix instructions on four different accumulators
+    (2 out tiles x 2 sets).  The non-matrix work is cut into small units and dealt to the quads here, so that it issues in the shadow of
+    the same wavefront's matrix instructions:
+      * conversion units — (in pair, set, value pair): ReLU + three-way bf16 split of two activations of the PREVIOUS layer's output,
+        which must be complete for pairs <= max(in pair, out tile / 2) before a step starts (the accumulators alias the old outputs);
+      * micro-steps of the univariate map of the previous feature group (last layer).
+    CVQ / SPQ: units completed at the END of every quad (cumulative per layer / per group; index 0 = before the first quad)."""
+    costs = _uni2_costs(t["uni"])
+    if costs is None or t["ACT"] not in (0, 1) or t["WAVES"] != 8 or t["CH"] != 24 or t["NR"] != 3 or not t["XLDS"]:
+        return {"HAS2": 0}
+    try:
+        qb = int(os.environ.get("ZUKO_AMD_ARX2_QB", "8"))  # VALU instructions dealt to one quad (4 matrix instructions)
+    except ValueError:
+        qb = 8
+    try:
+        fill = int(os.environ.get("ZUKO_AMD_ARX2_FILL", "2"))  # VALU instructions requested behind every matrix instruction of a quad
+    except ValueError:
+        fill = 2
+    NH, HT, NIT = t["NH"], t["HT"], t["NIT"]
+    nt, fpl = layout.nt, layout.fpl
+    COST_CV = 7  # a conversion HALF-unit: two values (ReLU, h, remainder | m, remainder, l)
+    UPP = 16     # half-units per in pair: 2 sets x 4 value pairs x 2 halves
+    H_OT0, H_OT1, H_IP, H_BLK, HS_OFF, CVQ, CVQ_OFF = [], [], [], [], [0], [], [0]
+    boff = 0
+    for l in range(NH):
+        ots, ips = t["B_OT"][boff : boff + t["NB"][l]], t["B_IP"][boff : boff + t["NB"][l]]
+        boff += t["NB"][l]
+        steps, s = [], 0
+        while s < len(ots):
+            if s + 1 < len(ots) and ips[s + 1] == ips[s] and ots[s + 1] // 2 == ots[s] // 2 and ots[s + 1] != ots[s]:
+                steps.append((ots[s], ots[s + 1], ips[s], s))
+                s += 2
+            else:
+                steps.append((ots[s], 255, ips[s], s))
+                s += 1
+        n_in_pairs = 0 if l == 0 else -(-HT[l - 1] // 2)  # (layer 0 reads x: converted up front)
+        units = UPP * n_in_pairs
+        done, credit = 0, 0
+        CVQ.append(0)
+        for (o0, o1, ip, blk) in steps:
+            H_OT0.append(o0), H_OT1.append(o1), H_IP.append(ip), H_BLK.append(blk)
+            need = min(units, UPP * (max(ip, max(o0, o1 if o1 != 255 else 0) // 2) + 1)) if l > 0 else 0
+            for q in range(6):
+                if q == 0:
+                    done = max(done, need)
+                credit += qb
+                while done < units and credit >= COST_CV:
+                    done, credit = done + 1, credit - COST_CV
+                if done == units:
+                    credit = 0
+                CVQ.append(done)
+        if steps:
+            CVQ[-1] = units  # (everything converted when the layer ends: the bias-only tiles are initialised then)
+        HS_OFF.append(len(H_OT0))
+        CVQ_OFF.append(len(CVQ))
+    # last layer: group g, in pair, sub-steps of two out tiles
+    L_T0, L_T1, L_IP, L_BLK, LS_OFF, SPQ = [], [], [], [], [0], []
+    n_in_pairs = -(-HT[NH - 1] // 2) if NH > 0 else 0
+    units = UPP * n_in_pairs
+    sp_total = 2 * fpl * len(costs)
+    sp_cost = [costs[k % len(costs)] for k in range(sp_total)]
+    done, credit = 0, 0
+    CVQ.append(0)
+    blk = 0
+    for g in range(t["NG"]):
+        sp_done = 0
+        SPQ.append(0)
+        first = True
+        for st in range(t["GOFF"][g], t["GOFF"][g + 1]):
+            ip = t["G_IP"][st]
+            for t0 in range(0, nt, 2):
+                t1 = t0 + 1 if t0 + 1 < nt else 255
+                L_T0.append(t0), L_T1.append(t1), L_IP.append(ip), L_BLK.append(blk + t0)
+                need = min(units, UPP * (ip + 1)) if NH > 0 else 0
+                for q in range(6):
+                    if q == 0:
+                        done = max(done, need)
+                    credit += qb
+                    while done < units and credit >= COST_CV:
+                        done, credit = done + 1, credit - COST_CV
+                    if g > 0:  # micro-steps of the previous group's univariate map
+                        while sp_done < sp_total and credit >= sp_cost[sp_done]:
+                            credit -= sp_cost[sp_done]
+                            sp_done += 1
+                    if done == units and (g == 0 or sp_done == sp_total):
+                        credit = 0
+                    CVQ.append(done)
+                    SPQ.append(sp_done)
+            blk += nt
+        if t["GOFF"][g + 1] > t["GOFF"][g] and g > 0:
+            SPQ[-1] = sp_total  # (the previous group's accumulators are recycled by the next group)
+        if g == 0 and t["GOFF"][1] > t["GOFF"][0]:
+            done = units
+            CVQ[-1] = units  # (register plan: the previous layer's outputs are dead before the first map's state comes alive)
+        LS_OFF.append(len(L_T0))
+    return {"HAS2": 1, "QB": qb, "FILL": fill, "H_OT0": H_OT0, "H_OT1": H_OT1, "H_IP": H_IP, "H_BLK": H_BLK, "HS_OFF": HS_OFF, "CVQ": CVQ, "CVQ_OFF": CVQ_OFF,
+            "L_T0": L_T0, "L_T1": L_T1, "L_IP": L_IP, "L_BLK": L_BLK, "LS_OFF": LS_OFF, "SPQ": SPQ, "SP_TOTAL": sp_total}
 
 
 def emit_split(t: dict) -> str:
     boff = [0]
     for n in t["NB"]:
         boff.append(boff[-1] + n)
+    has2 = bool(t.get("HAS2"))
     lines = [
         "// generated by zuko_amd/static_ar.py — do not edit",
-        '#include "fused_ar_split_impl.h"',
+        '#include "fused_ar_split2_impl.h"' if has2 else '#include "fused_ar_split_impl.h"',
         "namespace {",
         "struct Shape {",
         f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NG = {t['NG']}, NCHUNK = {t['NCHUNK']};",
@@ -313,11 +444,26 @@ def emit_split(t: dict) -> str:
         f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = false, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
         _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
         _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
-        "};",
-        "}  // namespace",
-        f'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {{ return zk::arx_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, train, stream); }}',
-        "",
     ]
+    if has2:  # step lists + VALU schedule of the two-set kernel (split2_schedule)
+        lines += [
+            f"  static constexpr int SP_TOTAL = {t['SP_TOTAL']}, FILL = {t['FILL']};",
+            _arr("H_OT0", "unsigned char", t["H_OT0"]), _arr("H_OT1", "unsigned char", t["H_OT1"]), _arr("H_IP", "unsigned char", t["H_IP"]), _arr("H_BLK", "short", t["H_BLK"]),
+            _arr("HS_OFF", "int", t["HS_OFF"]), _arr("CVQ", "short", t["CVQ"]), _arr("CVQ_OFF", "int", t["CVQ_OFF"]),
+            _arr("L_T0", "unsigned char", t["L_T0"]), _arr("L_T1", "unsigned char", t["L_T1"]), _arr("L_IP", "unsigned char", t["L_IP"]), _arr("L_BLK", "short", t["L_BLK"]),
+            _arr("LS_OFF", "int", t["LS_OFF"]), _arr("SPQ", "short", t["SPQ"]),
+        ]
+    lines += ["};", "}  // namespace"]
+    if has2:  # forward: the two-set kernel (dbg bit 0: the 8-wavefront kernel of fused_ar_split_impl.h, the A/B switch ZUKO_AMD_SPLIT_V1=1); training forward: that kernel
+        lines += [
+            'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {',
+            f'  if (!train && !(a->dbg & 1)) return zk::arx2_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, stream);',
+            f'  return zk::arx_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, train, stream);',
+            "}",
+            "",
+        ]
+    else:
+        lines += [f'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {{ return zk::arx_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, train, stream); }}', ""]
     return "\n".join(lines)
 
 
