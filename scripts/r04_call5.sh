@@ -1,0 +1,3 @@
+mkdir -p gpurun_out/r04
+ZUKO_AMD_CACHE_DIR=/root/repo/variants/8x2xARX2_TRACE ZUKO_AMD_JIT=0 python scripts/arx2_trace.py > gpurun_out/r04/arx2_trace.json 2> gpurun_out/r04/arx2_trace.err
+tail -3 gpurun_out/r04/arx2_trace.err; head -c 3000 gpurun_out/r04/arx2_trace.json

@@ -369,11 +369,13 @@ def test_split_kernel_tables_describe_the_plan(cfg):
         got = np.full(D * total, np.nan)
         blk = 0
         bias_last = plan.bias_gather[NH].reshape(-1, nt, 16)
-        for g in range(t["NG"]):
+        assert sorted(t["G_ORD"]) == list(range(t["NG"]))
+        for gi in range(t["NG"]):  # stream position gi holds feature group g
+            g = t["G_ORD"][gi]
             acc = np.zeros((nt, 16))
             for b in range(nt):
                 acc[b] = np.where(bias_last[g, b] >= 0, Bv[NH][np.maximum(bias_last[g, b], 0)], 0.0)
-            for st in range(t["GOFF"][g], t["GOFF"][g + 1]):
+            for st in range(t["GOFF"][gi], t["GOFF"][gi + 1]):
                 ip = t["G_IP"][st]
                 for b in range(nt):
                     for lane in range(64):

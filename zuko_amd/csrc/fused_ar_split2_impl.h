@@ -18,21 +18,44 @@
 //     (sched_group_barrier), which is where VALU work is free (scripts/probes/coexec_probe.hip: two VALU instructions per matrix
 //     instruction of the SAME wavefront cost nothing).
 //
-// Register plan per set: in[TMAX / 2] (bf16 h, m, l of the layer's input: 96) + out[TMAX] (f32 accumulators: 64); the next layer's input
-// is converted from `out` in place while the next layer already runs: before a step (out tile ot, in pair ip) starts, the units of
-// pairs <= max(ip, ot / 2) are done (the new accumulator of tile ot overwrites the old output of tile ot).  Last layer: when a group's
-// accumulators are complete they become the parameter registers of its maps, and the next group accumulates while those are evaluated.
+// Register plan per set: in[NSLOT] (bf16 h, m, l parts of a layer's input pairs: 12 registers each) + out[2 NOS] (f32 accumulators of
+// NOS = 3 out pairs).  A hidden layer walks its out pairs from the last to the first; with the units sorted by dependency count out
+// pair P reads in pairs <= P, so when P is complete in pair P is dead, and P's conversion — the next layer's in pair P — is written over
+// it (slots dealt by split2_schedule) while out pair P - 1 is being multiplied.  The next layer, and the last layer's feature groups,
+// read the pairs in the order they were finished.  Last layer: when a group's accumulators are complete they become the parameter
+// registers of its maps, and the next group accumulates while those are evaluated.
 #pragma once
 #include "fused_ar_split_impl.h"
 
 namespace zk {
 
+// Raw LDS accesses.  While an LDS-DMA (global_load_lds) is in flight the compiler orders EVERY LDS access it knows about behind
+// `s_waitcnt vmcnt(0)` (the DMA might write the same bytes) — which drains the weight ring's look-ahead, one to two thousand cycles each
+// time.  The ring, the row image and the bias image are disjoint, so the accesses inside the pass are issued from inline assembly: a
+// read returns a RAW value, usable only behind a covering `s_waitcnt lgkmcnt` that names it (ArRingS::read has the idiom); a write
+// needs nothing — the LDS operations of a wavefront execute in order, so a later read of the same word sees it.
+template <int OFF> __device__ __forceinline__ void arx2_raw_read(f32x4& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
+__device__ __forceinline__ float arx2_raw_read1(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ float arx2_raw_read1i(unsigned addr) {  // (one base register + an immediate: nothing per-group for the compiler to hoist and spill)
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void arx2_raw_write1(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void arx2_settle1(float& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+__device__ __forceinline__ void arx2_tie(int& v) { asm volatile("" : "+v"(v)); }  // orders the uses of a raw value behind the wait in front of this statement
+
 // ---- univariate maps as sequences of micro-steps -------------------------------------------------------------------------------------
 // State lives in registers between the quads that carry the steps.  `p(i)` is a reference to parameter i of the feature (an accumulator
 // register).  Every step sequence evaluates exactly what Uni::fwd of zk_ar_common.h evaluates, operation by operation.
 struct Uni2Io {
-  float* xr;      // the wave's row image in LDS (row of this lane's sample): x is read from it, y written to it
+  unsigned xr;    // LDS byte address of the row image of this lane's sample: x is read from it, y written to it (raw accesses)
   int f;          // feature id (< 0: padding slot)
+  int spare;      // index of a word of the row image no feature owns (the rows are padded to D + 4 words)
   float poison;   // NaN when the sample has a non-finite input, else 0
   int64_t n;      // sample (diagnostic stores)
   bool live;
@@ -44,16 +67,15 @@ struct Uni2Affine {
   struct State { float x; };
   template <int I, bool DIAG, class P, class A> static __device__ __forceinline__ void step(State& st, const P& p, const A& a, const Uni2Io& io, float& lacc) {
     if constexpr (I == 0) {
-      st.x = io.xr[io.f < 0 ? 0 : io.f];
+      st.x = arx2_raw_read1(io.xr + 4u * (unsigned)(io.f < 0 ? 0 : io.f));
       p(0) += io.poison;
       p(1) += io.poison;
     } else {
-      if (io.f >= 0) {
-        float y, lj;
-        affine_fwd<float, MathFast>(p(0), p(1), a.ls, st.x, y, lj);
-        io.xr[io.f] = y;
-        lacc += lj;
-      }
+      arx2_settle1(st.x);
+      float y, lj;  // (no branch: see Uni2Rqs)
+      affine_fwd<float, MathFast>(p(0), p(1), a.ls, st.x, y, lj);
+      arx2_raw_write1(io.xr + 4u * (unsigned)(io.f >= 0 ? io.f : io.spare), y);
+      lacc += io.f >= 0 ? lj : 0.f;
     }
   }
 };
@@ -79,8 +101,7 @@ template <int K, bool CIRC> struct Uni2Rqs {
   template <int I, bool DIAG, class P, class A> static __device__ __forceinline__ void step(State& st, const P& p, const A& a, const Uni2Io& io, float& lacc) {
     const RqsLeanConst& c = a.lc;
     if constexpr (I == 0) {
-      const float x = io.xr[io.f < 0 ? 0 : io.f];
-      st.v = CIRC ? Base::shift(x, a.bound) : x;
+      st.v = arx2_raw_read1(io.xr + 4u * (unsigned)(io.f < 0 ? 0 : io.f));  // (raw: settled by the first knot step, long after)
 #pragma unroll
       for (int j = 0; j < K; ++j) p(j) += io.poison;  // (UniRqs::poison<false>: the search-axis parameters)
       st.acc = f32x2_t{0.f, 0.f};
@@ -94,16 +115,21 @@ template <int K, bool CIRC> struct Uni2Rqs {
     } else if constexpr (I < S_BIS) {
       constexpr int q = I - S_KNOT;
       if constexpr (q == 0) {
+        arx2_settle1(st.v);
+        if constexpr (CIRC) st.v = Base::shift(st.v, a.bound);
         st.scale = f32x2_t{__builtin_amdgcn_rcpf(st.acc.x), __builtin_amdgcn_rcpf(st.acc.y)} * (2.f * c.bound);
         st.kx[0] = -c.bound; st.ky[0] = -c.bound;
         st.kr[0] = 0.f; st.kr[K] = 0.f;
       }
       const f32x2_t negB = {-c.bound, -c.bound};
 #pragma unroll
-      for (int j = 4 * q; j < 4 * q + 4 && j < K; ++j) {
-        const f32x2_t kn = __builtin_elementwise_fma(st.cum[j], st.scale, negB);
-        st.kx[j + 1] = kn.x; st.ky[j + 1] = kn.y;
-        if (j >= 1) st.kr[j] = p(2 * K + j - 1);
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * q + jj;  // (a compile-time constant after unrolling: the state must stay in registers)
+        if (j < K) {
+          const f32x2_t kn = __builtin_elementwise_fma(st.cum[j], st.scale, negB);
+          st.kx[j + 1] = kn.x; st.ky[j + 1] = kn.y;
+          if (j >= 1) st.kr[j] = p(2 * K + j - 1);
+        }
       }
     } else if constexpr (I == S_BIS) {  // bisection, level 0, first half: flags, the compare, the search axis
       if constexpr (DIAG) {
@@ -161,10 +187,13 @@ template <int K, bool CIRC> struct Uni2Rqs {
       const float sr = s * st.rden;
       const float jac = (sr * sr) * jn;
       const float lj = st.m * (__builtin_amdgcn_logf(jac) * c.il2e);
-      if (io.f >= 0) {
-        io.xr[io.f] = st.out;
-        lacc += lj;
-        if constexpr (DIAG) {
+      // NO branch around the result: everything above is used only here, and a conditional block would make the compiler sink the whole
+      // map into it (one lump of ~330 VALU instructions behind the last step instead of micro-steps between the matrix instructions).
+      // A padding slot (f < 0) writes the row's spare word and adds zero.
+      arx2_raw_write1(io.xr + 4u * (unsigned)(io.f >= 0 ? io.f : io.spare), st.out);
+      lacc += io.f >= 0 ? lj : 0.f;
+      if constexpr (DIAG) {
+        if (io.f >= 0) {
           if (io.live) {
             a.bin_out[io.n * a.D + io.f] = st.inside ? st.bin : (st.above ? K : -1);
 #pragma unroll
@@ -210,22 +239,8 @@ template <int ACT, int E2, int HALF> __device__ __forceinline__ void arx2_conver
   }
 }
 
-// raw LDS read (usable only behind a covering s_waitcnt: see ArRingS::read)
-template <int OFF> __device__ __forceinline__ void arx2_raw_read(f32x4& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
 
 template <class S> struct Arx2Pat {
-  static constexpr bool first_of_tile(int l, int st, int which) {  // is this step the first of layer l that accumulates into its out tile `which`?
-    const int base = S::HS_OFF[l];
-    const int ot = which == 0 ? S::H_OT0[base + st] : S::H_OT1[base + st];
-    for (int i = 0; i < st; ++i)
-      if (S::H_OT0[base + i] == ot || S::H_OT1[base + i] == ot) return false;
-    return true;
-  }
-  static constexpr bool tile_has_steps(int l, int t) {
-    for (int i = S::HS_OFF[l]; i < S::HS_OFF[l + 1]; ++i)
-      if (S::H_OT0[i] == t || S::H_OT1[i] == t) return true;
-    return false;
-  }
   static constexpr int n_hidden_steps() { return S::HS_OFF[S::NH]; }
   static constexpr int n_steps() { return S::HS_OFF[S::NH] + S::LS_OFF[S::NG]; }
   static constexpr int layer_of(int gs) {  // hidden layer of global step gs (< n_hidden_steps())
@@ -243,13 +258,11 @@ template <class S> struct Arx2Pat {
     if (gs < n_hidden_steps()) return S::BASE[layer_of(gs)] + 3 * S::H_BLK[gs];
     return S::LAST_BASE + 3 * S::L_BLK[gs - n_hidden_steps()];
   }
-  // bias tile a hidden step has to start an accumulator from (slot 0 / 1), or -1: looked up one step ahead
+  // bias tile a hidden step has to start accumulator `which` of its out pair from, or -1: the pair's first step initialises both
   static constexpr int bias_tile(int gs, int which) {
-    if (gs >= n_hidden_steps()) return -1;
-    const int l = layer_of(gs), st = gs - S::HS_OFF[l];
-    const int ot = which == 0 ? S::H_OT0[gs] : S::H_OT1[gs];
-    if (ot == 255) return -1;
-    return first_of_tile(l, st, which) ? ot : -1;
+    if (gs >= n_hidden_steps() || !S::H_INIT[gs]) return -1;
+    const int l = layer_of(gs), t = 2 * (S::H_OT0[gs] / 2) + which;
+    return t < S::HT[l] ? t : -1;
   }
 };
 
@@ -282,10 +295,9 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
   typedef ArRingS<4, S::CH, S::NR> Ring;
   typedef typename Uni2Of<Uni>::type U2;
   typedef Arx2Pat<S> P2;
-  static_assert(S::NH >= 1 && S::CH == 24 && S::NR == 3 && S::TMAX <= 16 && S::TMAX % 2 == 0 && S::XLDS && (S::ACT == 0 || S::ACT == 1), "two-set operand-split kernel: widths <= 256, LDS-staged rows");
+  static_assert(S::NH >= 1 && S::CH == 24 && S::NR == 3 && S::NOS == 3 && S::XLDS && (S::ACT == 0 || S::ACT == 1), "two-set operand-split kernel: widths <= 256, LDS-staged rows");
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   constexpr int NG = S::NG, NH = S::NH;
-  constexpr bool FID_REGS = NG * FPL <= 32;
   constexpr int DT = (S::D + 15) / 16;
   constexpr int SPT = 2 * FPL * U2::NSTEP;  // micro-steps of one group's univariate maps: (set, feature slot, step)
   static_assert(SPT == S::SP_TOTAL, "schedule tables were dealt for another step sequence");
@@ -309,23 +321,21 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
   float* xrow_lds[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) xrow_lds[s] = reinterpret_cast<float*>(fmap_lds + 1024 + 256) + (wave * 32 + s * 16 + j) * a.xs;
+  const unsigned bias_off = ring.lds_off + (unsigned)((S::NR * S::CH * AR_TF + 4 * q) * 4);                       // this lane's quad of a bias tile; + tile offsets as immediates
+  const unsigned fmap_off = ring.lds_off + (unsigned)((S::NR * S::CH * AR_TF + a.bias_floats + q * FPL) * 4);  // this lane's slots of group 0; + group offsets as immediates
+  unsigned xrow_off[2];  // (LDS byte addresses of the same rows, for the raw accesses inside the pass)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) xrow_off[s] = ring.lds_off + (unsigned)((S::NR * S::CH * AR_TF + a.bias_floats + 1024 + 256 + (wave * 32 + s * 16 + j) * a.xs) * 4);
   for (int i = tid; i < NG * 4 * FPL; i += 256) fmap_lds[i] = a.featmap[i];
   __syncthreads();
   const float* bias_last = bias_lds + NH * S::BIAS_STRIDE;
-  int fids[FID_REGS ? NG * FPL : 1];
-  if constexpr (FID_REGS) {
-#pragma unroll
-    for (int i = 0; i < NG; ++i)
-#pragma unroll
-      for (int fi = 0; fi < FPL; ++fi) fids[i * FPL + fi] = fmap_lds[(i * 4 + q) * FPL + fi];
-  }
-
-  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  int pass_no = 0;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, ++pass_no) {
     int64_t n[2];
     bool live[2];
     float poison[2] = {0.f, 0.f};
-    ArxB in[2][S::TMAX / 2];
-    f32x4 out[2][S::TMAX];
+    ArxB in[2][S::NSLOT];
+    f32x4 out[2][2 * S::NOS];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       n[s] = tile * 128 + wave * 32 + s * 16 + j;
@@ -351,8 +361,7 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
 #pragma unroll
       for (int it = 0; it < DT; ++it)
         if ((it + 1) * 16 <= S::D || it * 16 + 4 * q < S::D) *reinterpret_cast<f32x4*>(xrow_lds[s] + it * 16 + 4 * q) = xin[it];
-#pragma unroll
-      for (int p = 0; p < (S::NIT + 1) / 2; ++p) arx_split(xin[2 * p], xin[2 * p + 1], in[s][p]);
+      ars_for<(S::NIT + 1) / 2>([&](auto p_) ARS_ALWAYS_INLINE { arx_split(xin[2 * decltype(p_)::value], xin[2 * decltype(p_)::value + 1], in[s][S::X_SLOT[decltype(p_)::value]]); });
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -360,30 +369,32 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
     f32x4 w[2][6];   // the six images of a step, double-buffered (raw until settled)
     f32x4 bpre[2];   // bias tiles the NEXT step starts accumulators from, requested one step ahead (raw until settled)
     float cvrem[2];  // remainders v - h of the conversion unit whose second half is still to come
-    // conversion units [LO, HI) of the input of a layer whose predecessor has PT out tiles
-    auto convert = [&](auto lo_, auto hi_, auto pt_) ARS_ALWAYS_INLINE {
-      constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value, PT = decltype(pt_)::value;
+    // conversion half-units [LO, HI) of the pass-wide sequence: unit u belongs to the out pair at completion position u / 16 (tables CP_*:
+    // its accumulator slot, the in slot it becomes, whether it has a second tile), set (u / 8) % 2, value pair (u / 2) % 4, half u % 2
+    auto convert = [&](auto lo_, auto hi_) ARS_ALWAYS_INLINE {
+      constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      if (ARX_ABL == 7) return;
       ars_for<HI - LO>([&](auto i_) ARS_ALWAYS_INLINE {
-        constexpr int u = LO + decltype(i_)::value, p = u / 16, s = (u / 8) % 2, e2 = (u / 2) % 4, half = u % 2;
-        if constexpr (2 * p + 1 < PT) arx2_convert<S::ACT, e2, half>(out[s][2 * p], out[s][2 * p + 1], in[s][p], cvrem);
-        else arx2_convert<S::ACT, e2, half>(out[s][2 * p], zero, in[s][p], cvrem);
+        constexpr int u = LO + decltype(i_)::value, gp = u / 16, s = (u / 8) % 2, e2 = (u / 2) % 4, half = u % 2;
+        constexpr int os = S::CP_OS[gp], is = S::CP_IS[gp];
+        if constexpr (S::CP_T1[gp] != 255) arx2_convert<S::ACT, e2, half>(out[s][2 * os], out[s][2 * os + 1], in[s][is], cvrem);
+        else arx2_convert<S::ACT, e2, half>(out[s][2 * os], zero, in[s][is], cvrem);
       });
     };
     // COUNT images of global step GS starting with image FIRST
     auto fetch = [&](auto gs_, auto first_, auto count_) ARS_ALWAYS_INLINE {
       constexpr int GS = decltype(gs_)::value, FIRST = decltype(first_)::value, COUNT = decltype(count_)::value;
-      ars_for<COUNT>([&](auto i_) ARS_ALWAYS_INLINE { w[GS & 1][FIRST + decltype(i_)::value] = ring.template read<P2::step_pos(GS) + FIRST + decltype(i_)::value>(); });
+      ars_for<COUNT>([&](auto i_) ARS_ALWAYS_INLINE { w[GS & 1][FIRST + decltype(i_)::value] = ring.template read_acc<P2::step_pos(GS) + FIRST + decltype(i_)::value>(); });
     };
     // bias tiles of global step GS (hidden layers): raw LDS reads
     auto fetch_bias = [&](auto gs_) ARS_ALWAYS_INLINE {
       constexpr int GS = decltype(gs_)::value;
       if constexpr (GS < P2::n_hidden_steps()) {
         constexpr int L = P2::layer_of(GS);
-        const unsigned base = ring.lds_off + (unsigned)((S::NR * S::CH * AR_TF + L * S::BIAS_STRIDE + 4 * q) * 4);
         ars_for<2>([&](auto w_) ARS_ALWAYS_INLINE {
           constexpr int T = P2::bias_tile(GS, decltype(w_)::value);
-          if constexpr (T >= 0) arx2_raw_read<T * 64>(bpre[decltype(w_)::value], base);
+          if constexpr (T >= 0) arx2_raw_read<(L * S::BIAS_STRIDE + T * 16) * 4>(bpre[decltype(w_)::value], bias_off);
         });
       }
     };
@@ -396,8 +407,14 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
     auto run_step = [&](auto gs_, auto&& quad_extra, f32x4& c00, f32x4& c10, f32x4& c01, f32x4& c11, const ArxB& b0, const ArxB& b1) ARS_ALWAYS_INLINE {
       constexpr int GS = decltype(gs_)::value, BUF = GS & 1, NI = P2::step_images(GS);
       constexpr bool TWO = NI == 6;
-      if constexpr (TWO) ars_settle<0>(w[BUF][0], w[BUF][1], w[BUF][2], w[BUF][3], w[BUF][4], w[BUF][5]);
-      else ars_settle<0>(w[BUF][0], w[BUF][1], w[BUF][2]);
+#ifdef ARX2_TRACE  // probe build (scripts/arx2_trace.py): shader clock at the start of every step of workgroup 0 / wavefront 0, first two passes
+      if (a.bin_out && blockIdx.x == 0 && wave == 0 && pass_no < 2) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (lane == 0) a.bin_out[pass_no * (NSTEPS + 1) + GS] = (int)(unsigned)now;
+      }
+#endif
+      if constexpr (TWO) ars_settle_acc<0>(w[BUF][0], w[BUF][1], w[BUF][2], w[BUF][3], w[BUF][4], w[BUF][5]);
+      else ars_settle_acc<0>(w[BUF][0], w[BUF][1], w[BUF][2]);
       asm volatile("" : "+v"(bpre[0]), "+v"(bpre[1]));  // (settled by the same wait: LDS operations complete in order)
       __builtin_amdgcn_sched_barrier(0);
       ars_for<6>([&](auto k_) ARS_ALWAYS_INLINE {
@@ -421,60 +438,46 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
       });
     };
 
-    // ---- hidden layers ---------------------------------------------------------------------------------------------
-    ars_for<NH>([&](auto l_) ARS_ALWAYS_INLINE {
-      constexpr int L = decltype(l_)::value, HTL = S::HT[L], NS = S::HS_OFF[L + 1] - S::HS_OFF[L];
-      constexpr int PT = L == 0 ? 0 : S::HT[L == 0 ? 0 : L - 1];
-      ars_for<NS>([&](auto st_) ARS_ALWAYS_INLINE {
-        constexpr int ST = decltype(st_)::value, GS = S::HS_OFF[L] + ST;
-        constexpr int OT0 = S::H_OT0[GS], OT1 = S::H_OT1[GS], IP = S::H_IP[GS];
-        constexpr bool TWO = OT1 != 255;
-        run_step(
-            std::integral_constant<int, GS>{},
-            [&](auto k_) ARS_ALWAYS_INLINE {
-              constexpr int KT = decltype(k_)::value, QI = S::CVQ_OFF[L] + 6 * ST + KT;
-              convert(std::integral_constant<int, S::CVQ[QI]>{}, std::integral_constant<int, S::CVQ[QI + 1]>{}, std::integral_constant<int, PT>{});
-              if constexpr (KT == 0) {  // the accumulators start at the bias (after the units that still read the old outputs)
-                if constexpr (P2::bias_tile(GS, 0) >= 0) {
-                  out[0][OT0] = bpre[0];
-                  out[1][OT0] = bpre[0];
-                }
-                if constexpr (P2::bias_tile(GS, 1) >= 0) {
-                  out[0][OT1] = bpre[1];
-                  out[1][OT1] = bpre[1];
-                }
+    // ---- hidden layers: out pairs from the last to the first ----------------------------------------------------------------------------
+    ars_for<NSTEPS_H>([&](auto gs_) ARS_ALWAYS_INLINE {
+      constexpr int GS = decltype(gs_)::value;
+      constexpr int OT0 = S::H_OT0[GS], OT1 = S::H_OT1[GS], OS = S::H_OS[GS];
+      constexpr bool TWO = OT1 != 255;
+      run_step(
+          std::integral_constant<int, GS>{},
+          [&](auto k_) ARS_ALWAYS_INLINE {
+            constexpr int KT = decltype(k_)::value, QI = 6 * GS + KT;
+            convert(std::integral_constant<int, S::CVQ[QI]>{}, std::integral_constant<int, S::CVQ[QI + 1]>{});
+            if constexpr (KT == 0) {  // a pair's first step: both accumulators start at the bias (after the units that still read the slot's previous tenant)
+              if constexpr (P2::bias_tile(GS, 0) >= 0) {
+                out[0][2 * OS] = bpre[0];
+                out[1][2 * OS] = bpre[0];
               }
-            },
-            out[0][OT0], out[1][OT0], out[0][TWO ? OT1 : OT0], out[1][TWO ? OT1 : OT0], in[0][IP], in[1][IP]);
-      });
-      // units that depend on nothing: bias only (initialised last: their registers held the previous layer's outputs)
-      const float* bias_q = bias_lds + L * S::BIAS_STRIDE + 4 * q;
-      ars_for<HTL>([&](auto t_) ARS_ALWAYS_INLINE {
-        constexpr int t = decltype(t_)::value;
-        if constexpr (!P2::tile_has_steps(L, t)) {
-          out[0][t] = *reinterpret_cast<const f32x4*>(bias_q + t * 16);
-          out[1][t] = out[0][t];
-        }
-      });
-      if constexpr (NS == 0 && L > 0) convert(std::integral_constant<int, 0>{}, std::integral_constant<int, 16 * ((PT + 1) / 2)>{}, std::integral_constant<int, PT>{});
+              if constexpr (P2::bias_tile(GS, 1) >= 0) {
+                out[0][2 * OS + 1] = bpre[1];
+                out[1][2 * OS + 1] = bpre[1];
+              }
+            }
+          },
+          out[0][2 * OS + (OT0 & 1)], out[1][2 * OS + (OT0 & 1)], out[0][2 * OS + ((TWO ? OT1 : OT0) & 1)], out[1][2 * OS + ((TWO ? OT1 : OT0) & 1)], in[0][S::H_IP[GS]], in[1][S::H_IP[GS]]);
     });
 
     // ---- last layer + univariate maps: group g + 1 accumulates while the maps of group g are evaluated ------------------------------
     float lacc[2] = {0.f, 0.f};
     f32x4 acc[2][NT];       // [set][tile] of the group that accumulates
     float par[2][4 * NT];   // parameters of the group whose maps are being evaluated (the previous group's accumulators)
+    int fnext[FPL], fpar[FPL];  // feature ids of this lane's slots in the accumulating group / in the group whose maps are evaluated
     typename U2::State ust;
-    constexpr int PTL = S::HT[NH - 1];
     // micro-steps [LO, HI) of group G
     auto spline = [&](auto g_, auto lo_, auto hi_) ARS_ALWAYS_INLINE {
-      constexpr int G = decltype(g_)::value, LO = decltype(lo_)::value, HI = decltype(hi_)::value;
+      constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
+      if (ARX_ABL == 8) return;
       ars_for<HI - LO>([&](auto i_) ARS_ALWAYS_INLINE {
         constexpr int u = LO + decltype(i_)::value, s = u / (FPL * U2::NSTEP), fi = (u / U2::NSTEP) % FPL, k = u % U2::NSTEP;
         Uni2Io io;
-        io.xr = xrow_lds[s];
-        if constexpr (FID_REGS) io.f = fids[G * FPL + fi];
-        else io.f = fmap_lds[(G * 4 + q) * FPL + fi];
-        io.poison = poison[s]; io.n = n[s]; io.live = live[s];
+        io.xr = xrow_off[s];
+        io.f = fpar[fi];
+        io.poison = poison[s]; io.n = n[s]; io.live = live[s]; io.spare = S::D;
         auto p = [&](int i) ARS_ALWAYS_INLINE -> float& { return par[s][fi * TOTAL + i]; };
         U2::template step<k, DIAG>(ust, p, a, io, lacc[s]);
       });
@@ -486,34 +489,38 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
 #pragma unroll
           for (int r = 0; r < 4; ++r) par[s][4 * decltype(t)::value + r] = acc[s][t][r];
         });
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) fpar[fi] = fnext[fi];
     };
-    ars_for<NG>([&](auto g_) ARS_ALWAYS_INLINE {
-      constexpr int G = decltype(g_)::value, NS = S::LS_OFF[G + 1] - S::LS_OFF[G];
-      constexpr int SPQ0 = G + 6 * S::LS_OFF[G];  // this group's slice of SPQ (one leading entry per group)
-      {
-        const float* bg = bias_last + (G * NT) * 16 + 4 * q;
-        ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE {
-          acc[0][t] = *reinterpret_cast<const f32x4*>(bg + t * 16);
-          acc[1][t] = acc[0][t];
-        });
+    ars_for<NG>([&](auto g_) ARS_ALWAYS_INLINE {  // stream position GI holds feature group G (the last group first)
+      constexpr int GI = decltype(g_)::value, G = S::G_ORD[GI], GPREV = S::G_ORD[GI > 0 ? GI - 1 : 0], NS = S::LS_OFF[GI + 1] - S::LS_OFF[GI];
+      constexpr int SPQ0 = GI + 6 * S::LS_OFF[GI];  // this group's slice of SPQ (one leading entry per group)
+      {  // the accumulators start at the bias (raw reads, their own wait: once per group)
+        ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE { arx2_raw_read<(NH * S::BIAS_STRIDE + (G * NT + decltype(t)::value) * 16) * 4>(acc[0][t], bias_off); });
+        ars_for<FPL>([&](auto fi) ARS_ALWAYS_INLINE { fnext[fi] = __builtin_bit_cast(int, arx2_raw_read1i<(G * 4 * FPL + decltype(fi)::value) * 4>(fmap_off)); });
+        if constexpr (NT == 6) ars_settle<0>(acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[0][4], acc[0][5]);
+        else if constexpr (NT == 3) ars_settle<0>(acc[0][0], acc[0][1], acc[0][2]);
+        else ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE { ars_settle<0>(acc[0][t]); });
+        ars_for<FPL>([&](auto fi) ARS_ALWAYS_INLINE { arx2_tie(fnext[fi]); });  // (covered by the same wait: LDS operations complete in order)
+        ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE { acc[1][t] = acc[0][t]; });
       }
-      if constexpr (NS == 0 && G > 0) spline(std::integral_constant<int, (G > 0 ? G - 1 : 0)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, SPT>{});
+      if constexpr (NS == 0 && GI > 0) spline(std::integral_constant<int, GPREV>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, SPT>{});
       ars_for<NS>([&](auto st_) ARS_ALWAYS_INLINE {
-        constexpr int ST = decltype(st_)::value, LS = S::LS_OFF[G] + ST, GS = NSTEPS_H + LS;
+        constexpr int ST = decltype(st_)::value, LS = S::LS_OFF[GI] + ST, GS = NSTEPS_H + LS;
         constexpr int T0 = S::L_T0[LS], T1 = S::L_T1[LS], IP = S::L_IP[LS];
         constexpr bool TWO = T1 != 255;
         run_step(
             std::integral_constant<int, GS>{},
             [&](auto k_) ARS_ALWAYS_INLINE {
-              constexpr int KT = decltype(k_)::value, QI = S::CVQ_OFF[NH] + 6 * LS + KT, SI = SPQ0 + 6 * ST + KT;
-              convert(std::integral_constant<int, S::CVQ[QI]>{}, std::integral_constant<int, S::CVQ[QI + 1]>{}, std::integral_constant<int, PTL>{});
-              if constexpr (G > 0) spline(std::integral_constant<int, (G > 0 ? G - 1 : 0)>{}, std::integral_constant<int, S::SPQ[SI]>{}, std::integral_constant<int, S::SPQ[SI + 1]>{});
+              constexpr int KT = decltype(k_)::value, QI = 6 * GS + KT, SI = SPQ0 + 6 * ST + KT;
+              convert(std::integral_constant<int, S::CVQ[QI]>{}, std::integral_constant<int, S::CVQ[QI + 1]>{});
+              if constexpr (GI > 0) spline(std::integral_constant<int, GPREV>{}, std::integral_constant<int, S::SPQ[SI]>{}, std::integral_constant<int, S::SPQ[SI + 1]>{});
             },
             acc[0][T0], acc[1][T0], acc[0][TWO ? T1 : T0], acc[1][TWO ? T1 : T0], in[0][IP], in[1][IP]);
       });
       hand_over();
     });
-    if constexpr (NG > 0) spline(std::integral_constant<int, (NG > 0 ? NG - 1 : 0)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, SPT>{});
+    if constexpr (NG > 0) spline(std::integral_constant<int, S::G_ORD[NG > 0 ? NG - 1 : 0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, SPT>{});
 
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -532,6 +539,12 @@ template <class S, typename Uni, bool DIAG> __global__ __launch_bounds__(256, 1)
         if (live[s] && q == 0) a.ladj[n[s]] = a.accumulate ? a.ladj[n[s]] + l : l;
       }
     }
+#ifdef ARX2_TRACE
+    if (a.bin_out && blockIdx.x == 0 && wave == 0 && pass_no < 2) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (lane == 0) a.bin_out[pass_no * (NSTEPS + 1) + NSTEPS] = (int)(unsigned)now;
+    }
+#endif
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();  // the next pass overwrites the row image
   }
@@ -549,7 +562,11 @@ template <class S, typename Uni> static int arx2_launch(const ArArgs* in, int ab
   const int lds = (S::NR * S::CH * AR_TF + a.bias_floats + 1024 + 256 + 128 * a.xs) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
   if ((a.bin_out != nullptr) != (a.knots_out != nullptr)) return ZK_EINVAL;
+#if defined(ARX2_TRACE) || defined(ARX2_ONLY)  // probe builds: the product instantiation only (bin_out, if given, receives the trace)
+  const void* fn = (const void*)arx2_kernel<S, Uni, false>;
+#else
   const void* fn = a.bin_out ? (const void*)arx2_kernel<S, Uni, true> : (const void*)arx2_kernel<S, Uni, false>;
+#endif
   hipError_t e = hipSuccess;
   {
     static std::mutex mu;

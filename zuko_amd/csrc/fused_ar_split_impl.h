@@ -22,7 +22,7 @@
 //
 //   Shape::NB[l], BOFF[l], B_OT, B_IP   blocks of hidden layer l in stream order (out-tile pair, in pair, out tile): out tile, in pair
 //   Shape::BASE[l], LAST_BASE           stream position (in images) where each layer starts
-//   Shape::GOFF[g], G_IP                last layer: kept in pairs of every feature group (each with Uni::NT blocks)
+//   Shape::GOFF[i], G_IP, G_ORD[i]      last layer: kept in pairs of the feature group at stream position i (each with Uni::NT blocks), and which group that is
 #pragma once
 #include "fused_ar_static_impl.h"
 
@@ -232,7 +232,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
       ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[0][p] = ring.template read<S::LAST_BASE + decltype(p)::value>(); });
     }
     ars_for<NG>([&](auto g_) ARS_ALWAYS_INLINE {
-      constexpr int g = g_, ST0 = S::GOFF[g], GN = S::GOFF[g + 1] - S::GOFF[g];
+      constexpr int gi = g_, g = S::G_ORD[gi], ST0 = S::GOFF[gi], GN = S::GOFF[gi + 1] - S::GOFF[gi];  // (stream order: the last feature group first)
       int fid[FPL];
       float xin[FPL];
 #pragma unroll

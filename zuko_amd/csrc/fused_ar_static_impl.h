@@ -114,6 +114,15 @@ template <int WAVES, int CH = ARS_CH, int NR = ARS_NR> struct ArRingS {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(cur_off), "n"((S % CH) * AR_TF * 4));
     return v;
   }
+  // the same read into an ACCUMULATION register (two-set kernel: the images are matrix-instruction operands only; keeping them out of
+  // the 256 architected VGPRs is what lets the univariate maps' state live there without spills — and a spill reload is a vector-memory
+  // load, whose wait drains the ring's look-ahead DMAs)
+  template <int S> __device__ __forceinline__ f32x4 read_acc() {
+    if constexpr (S % CH == 0) advance();
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(cur_off), "n"((S % CH) * AR_TF * 4));
+    return v;
+  }
 };
 
 template <int N> __device__ __forceinline__ void ars_settle(f32x4& a0) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a0) : "n"(N)); }
@@ -125,6 +134,10 @@ template <int N> __device__ __forceinline__ void ars_settle(f32x4& a0, f32x4& a1
 }
 template <int N> __device__ __forceinline__ void ars_settle(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ars_settle_acc(f32x4& a0, f32x4& a1, f32x4& a2) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+a"(a0), "+a"(a1), "+a"(a2) : "n"(N)); }
+template <int N> __device__ __forceinline__ void ars_settle_acc(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3), "+a"(a4), "+a"(a5) : "n"(N));
 }
 template <int N, int NT> __device__ __forceinline__ void ars_settle_tiles(f32x4 (&w)[NT]) {
   if constexpr (NT == 1) ars_settle<N>(w[0]);

@@ -105,6 +105,7 @@ def _build_so(stem: str, source, meta: dict | None, verbose: bool, out_dir: str 
                 f.write(source())
             tmp = os.path.join(d, f".{stem}.so.{os.getpid()}")
             cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", f"--offload-arch={_arch()}", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{CSRC}", "-shared", "-no-hip-rt",
+                   *os.environ.get("ZUKO_AMD_STATIC_CXXFLAGS", "").split(),  # (probe / ablation builds into a ZUKO_AMD_CACHE_DIR of their own: NOT part of the kernel's signature)
                    src, f"-L{_torch_lib_dir()}", "-l:libamdhip64.so", "-o", tmp]
             if verbose:
                 print("[zuko_amd static_ar]", " ".join(cmd), flush=True)
@@ -252,12 +253,13 @@ def split_tables(plan, uni_kind: int, act: int = 1):
                         pos[(otg * 4 + b, it)] = k
                         k += 1
         n_in = NIT if l == 0 else HT[l - 1]
-        # stream order: out-tile PAIR major, then in pair, then the two out tiles of the pair — an accumulator still sees its blocks by
-        # ascending in pair (the summation order per output does not depend on this interleave), while consecutive blocks alternate
-        # between two accumulators: the two-set kernel (csrc/fused_ar_split2_impl.h) rotates four independent accumulator chains
+        # stream order: out-tile PAIR major (DESCENDING), then in pair (DESCENDING: a layer reads its in pairs in the order the layer
+        # before finished them; every kernel that walks this stream sums an output in this order), then the two out tiles of the pair —
+        # consecutive blocks alternate between two accumulators: the two-set kernel (csrc/fused_ar_split2_impl.h) rotates four independent accumulator chains, and converts a
+        # finished out pair into the next layer's operand over the in pair that has just died (split2_schedule)
         blocks = []
-        for op in range(-(-HT[l] // 2)):
-            for ip in range(-(-n_in // 2)):
+        for op in reversed(range(-(-HT[l] // 2))):
+            for ip in reversed(range(-(-n_in // 2))):
                 for ot in (2 * op, 2 * op + 1):
                     if ot >= HT[l]:
                         continue
@@ -273,17 +275,23 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     # last layer: group g, kept in-tile it, tile t of the group  ->  group g, kept in-pair ip, tile t
     nt = plan.layout.nt
     fg = plan.fine_gather[NH].reshape(-1, 64, 4)
-    G_IP, GOFFP, blocks, k = [], [0], [], 0
+    # Stream order: feature groups from the LAST (the one with the most inputs) to the first, in pairs descending inside a group — the
+    # hidden layers finish their out pairs from the last to the first, so the last layer reads them in the order they were converted
+    # (G_ORD[i] = group at position i; GOFF / G_IP follow the positions).
+    G_IP, GOFFP, G_ORD, blocks = [], [0], [], []
+    tile0 = [0]
     for g in range(t["NG"]):
+        tile0.append(tile0[-1] + (t["GOFF"][g + 1] - t["GOFF"][g]) * nt)
+    for g in reversed(range(t["NG"])):
         its = t["G_IT"][t["GOFF"][g] : t["GOFF"][g + 1]]
-        at = {it: k + i * nt for i, it in enumerate(its)}
-        k += len(its) * nt
-        for ip in sorted({it // 2 for it in its}):
+        at = {it: tile0[g] + i * nt for i, it in enumerate(its)}
+        for ip in sorted({it // 2 for it in its}, reverse=True):
             for b in range(nt):
                 t0, t1 = at.get(2 * ip), at.get(2 * ip + 1)
                 blocks.append(pair_block(fg, None if t0 is None else t0 + b, None if t1 is None else t1 + b))
             G_IP.append(ip)
         GOFFP.append(len(G_IP))
+        G_ORD.append(g)
     last_base = cursor
     cursor += 3 * len(blocks)
     # The stream is ceil(images / ch) chunks long: every chunk's first image belongs to a real block (the kernel moves the ring on when
@@ -299,7 +307,7 @@ def split_tables(plan, uni_kind: int, act: int = 1):
         out.pop(key)
     nr = 2 if ch == 48 else 3  # (48-image chunks: two ring slots, half as many barriers)
     xlds = int(t["D"] % 4 == 0 and (nr * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * (2 if waves == 4 else 1) <= 160 * 1024)
-    out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
+    out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "G_ORD": G_ORD, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
                 "WAVES": waves, "CH": ch, "NR": nr, "XLDS": xlds})
     out.update(split2_schedule(out, plan.layout))
     plan._split_cache = ((uni_kind, act, split_geometry()), (out, gathers))
@@ -327,35 +335,43 @@ def _uni2_costs(uni_kind: int) -> list[int] | None:
 
 
 def split2_schedule(t: dict, layout) -> dict:
-    """Step lists and the VALU schedule of the TWO-SET operand-split kernel (csrc/fused_ar_split2_impl.h), or {"HAS2": 0}.
+    """Step lists, register slots and the VALU schedule of the TWO-SET operand-split kernel (csrc/fused_ar_split2_impl.h), or {"HAS2": 0}.
 
-    One wavefront per SIMD carries two 16-sample sets.  A STEP is one in pair against up to two out tiles (consecutive blocks of the
-    stream: six images), executed as six QUADS — one partial-product term each, four matrix instructions on four different accumulators
-    (2 out tiles x 2 sets).  The non-matrix work is cut into small units and dealt to the quads here, so that it issues in the shadow of
-    the same wavefront's matrix instructions:
-      * conversion units — (in pair, set, value pair): ReLU + three-way bf16 split of two activations of the PREVIOUS layer's output,
-        which must be complete for pairs <= max(in pair, out tile / 2) before a step starts (the accumulators alias the old outputs);
+    One wavefront per SIMD carries two 16-sample sets.  A STEP is one in pair against the (up to) two out tiles of an out PAIR
+    (consecutive blocks of the stream: six images), executed as six QUADS — one partial-product term each, four matrix instructions on
+    four different accumulators (2 out tiles x 2 sets).  A hidden layer walks its out pairs in DESCENDING order (the stream is laid out
+    that way, split_tables): with the units sorted by dependency count out pair P reads in pairs <= P, so when P is complete in pair P is
+    dead and P's ReLU + three-way bf16 split — the next layer's in pair P — is written over it, while out pair P - 1 is already being
+    multiplied.  The accumulators are a pool of three out pairs.  All non-matrix work is cut into small units and dealt to the quads:
+      * conversion HALF-units (pair in completion order, set, value pair, half): available when their pair is complete; due before the
+        first step that reads the pair, and before the accumulator slot is handed to the third pair after it;
       * micro-steps of the univariate map of the previous feature group (last layer).
-    CVQ / SPQ: units completed at the END of every quad (cumulative per layer / per group; index 0 = before the first quad)."""
+    CVQ (one global sequence over the pass) / SPQ (per group): units completed at the END of every quad; index 0 = before the first."""
     costs = _uni2_costs(t["uni"])
     if costs is None or t["ACT"] not in (0, 1) or t["WAVES"] != 8 or t["CH"] != 24 or t["NR"] != 3 or not t["XLDS"]:
         return {"HAS2": 0}
-    try:
-        qb = int(os.environ.get("ZUKO_AMD_ARX2_QB", "8"))  # VALU instructions dealt to one quad (4 matrix instructions)
-    except ValueError:
-        qb = 8
-    try:
-        fill = int(os.environ.get("ZUKO_AMD_ARX2_FILL", "2"))  # VALU instructions requested behind every matrix instruction of a quad
-    except ValueError:
-        fill = 2
+
+    def env_int(name, default):
+        try:
+            return int(os.environ.get(name, str(default)))
+        except ValueError:
+            return default
+
+    qb = env_int("ZUKO_AMD_ARX2_QB", 8)      # VALU instructions dealt to one quad (4 matrix instructions)
+    fill = env_int("ZUKO_AMD_ARX2_FILL", 2)  # VALU instructions requested behind every matrix instruction of a quad
     NH, HT, NIT = t["NH"], t["HT"], t["NIT"]
     nt, fpl = layout.nt, layout.fpl
-    COST_CV = 7  # a conversion HALF-unit: two values (ReLU, h, remainder | m, remainder, l)
-    UPP = 16     # half-units per in pair: 2 sets x 4 value pairs x 2 halves
-    H_OT0, H_OT1, H_IP, H_BLK, HS_OFF, CVQ, CVQ_OFF = [], [], [], [], [0], [], [0]
+    COST_CV, UPP, NOS = 7, 16, 3  # cost of a half-unit; half-units per pair (2 sets x 4 value pairs x 2 halves); out-pair slots
+    # ---- hidden layers: steps in stream order, pairs in processing order (pairs without a block first: bias only) -------------------
+    H_OT0, H_OT1, H_IP, H_BLK, H_OS, H_INIT, HS_OFF = [], [], [], [], [], [], [0]
+    CP_OS, CP_IS, CP_T0, CP_T1, CP_L = [], [], [], [], []  # per pair in completion order: accumulator slot, destination in slot, its tiles (255: none), layer
+    in_slot = [{p: p for p in range(-(-NIT // 2))}]        # per layer: in pair -> register slot
+    events = []   # program order: ("begin", gp) / ("quad",) x 6 per step preceded by ("step", reads_pair_gp or None) / ("complete", gp)
+    pair_gp = [{}]  # per boundary: out pair -> global pair position
     boff = 0
+    gpos = 0
     for l in range(NH):
-        ots, ips = t["B_OT"][boff : boff + t["NB"][l]], t["B_IP"][boff : boff + t["NB"][l]]
+        ots, ips = list(t["B_OT"][boff : boff + t["NB"][l]]), list(t["B_IP"][boff : boff + t["NB"][l]])
         boff += t["NB"][l]
         steps, s = [], 0
         while s < len(ots):
@@ -365,68 +381,125 @@ def split2_schedule(t: dict, layout) -> dict:
             else:
                 steps.append((ots[s], 255, ips[s], s))
                 s += 1
-        n_in_pairs = 0 if l == 0 else -(-HT[l - 1] // 2)  # (layer 0 reads x: converted up front)
-        units = UPP * n_in_pairs
-        done, credit = 0, 0
-        CVQ.append(0)
-        for (o0, o1, ip, blk) in steps:
-            H_OT0.append(o0), H_OT1.append(o1), H_IP.append(ip), H_BLK.append(blk)
-            need = min(units, UPP * (max(ip, max(o0, o1 if o1 != 255 else 0) // 2) + 1)) if l > 0 else 0
-            for q in range(6):
-                if q == 0:
-                    done = max(done, need)
-                credit += qb
-                while done < units and credit >= COST_CV:
-                    done, credit = done + 1, credit - COST_CV
-                if done == units:
-                    credit = 0
-                CVQ.append(done)
-        if steps:
-            CVQ[-1] = units  # (everything converted when the layer ends: the bias-only tiles are initialised then)
+        npairs = -(-HT[l] // 2)
+        order = []  # pairs with steps, in stream order
+        for (o0, _, _, _) in steps:
+            if o0 // 2 not in order:
+                order.append(o0 // 2)
+        for i in range(1, len(steps)):  # the steps of a pair are contiguous
+            assert steps[i][0] // 2 == steps[i - 1][0] // 2 or steps[i][0] // 2 not in [x[0] // 2 for x in steps[: i - 1]]
+        bias_only = [p for p in range(npairs) if p not in order]
+        if bias_only:  # an out pair without a single weight block (units that depend on nothing): left to the 8-wavefront kernel
+            return {"HAS2": 0}
+        # the last step index that reads every in pair
+        cur = in_slot[l]
+        last_read = {p: -1 for p in cur}
+        for i, (_, _, ip, _) in enumerate(steps):
+            last_read[ip] = i
+        last_step_of = {}
+        for i, (o0, _, _, _) in enumerate(steps):
+            last_step_of[o0 // 2] = i
+        nxt, taken = {}, set()
+        gp_of = {}
+
+        def place(P, after_step):
+            busy = {cur[p] for p in cur if last_read[p] > after_step} | taken
+            want = cur.get(P)
+            slot = want if (want is not None and want not in busy) else min(x for x in range(64) if x not in busy)
+            nxt[P] = slot
+            taken.add(slot)
+
+        for P in order:
+            place(P, last_step_of[P])
+        in_slot.append(nxt)
+        for P in order:
+            gp_of[P] = gpos
+            CP_OS.append(gpos % NOS), CP_IS.append(nxt[P]), CP_T0.append(2 * P), CP_T1.append(2 * P + 1 if 2 * P + 1 < HT[l] else 255), CP_L.append(l)
+            gpos += 1
+        pair_gp.append(gp_of)
+        for i, (o0, o1, ip, blk) in enumerate(steps):
+            P = o0 // 2
+            first = i == 0 or steps[i - 1][0] // 2 != P
+            H_OT0.append(o0), H_OT1.append(o1), H_IP.append(cur[ip]), H_BLK.append(blk), H_OS.append(gp_of[P] % NOS), H_INIT.append(int(first))
+            if first:
+                events.append(("begin", gp_of[P]))
+            events.append(("step", pair_gp[l].get(ip)))  # (layer 0 reads x: no conversion units)
+            events += [("quad",)] * 6
+            if i == last_step_of[P]:
+                events.append(("complete", gp_of[P]))
         HS_OFF.append(len(H_OT0))
-        CVQ_OFF.append(len(CVQ))
-    # last layer: group g, in pair, sub-steps of two out tiles
-    L_T0, L_T1, L_IP, L_BLK, LS_OFF, SPQ = [], [], [], [], [0], []
-    n_in_pairs = -(-HT[NH - 1] // 2) if NH > 0 else 0
-    units = UPP * n_in_pairs
-    sp_total = 2 * fpl * len(costs)
-    sp_cost = [costs[k % len(costs)] for k in range(sp_total)]
-    done, credit = 0, 0
-    CVQ.append(0)
+    # ---- last layer: group g, in pair, sub-steps of two out tiles ---------------------------------------------------------------------
+    L_T0, L_T1, L_IP, L_BLK, LS_OFF = [], [], [], [], [0]
+    cur = in_slot[NH]
     blk = 0
-    for g in range(t["NG"]):
-        sp_done = 0
-        SPQ.append(0)
-        first = True
+    for g in range(t["NG"]):  # (positions in stream order: group G_ORD[g])
+        events.append(("group", g))
         for st in range(t["GOFF"][g], t["GOFF"][g + 1]):
             ip = t["G_IP"][st]
             for t0 in range(0, nt, 2):
-                t1 = t0 + 1 if t0 + 1 < nt else 255
-                L_T0.append(t0), L_T1.append(t1), L_IP.append(ip), L_BLK.append(blk + t0)
-                need = min(units, UPP * (ip + 1)) if NH > 0 else 0
-                for q in range(6):
-                    if q == 0:
-                        done = max(done, need)
-                    credit += qb
-                    while done < units and credit >= COST_CV:
-                        done, credit = done + 1, credit - COST_CV
-                    if g > 0:  # micro-steps of the previous group's univariate map
-                        while sp_done < sp_total and credit >= sp_cost[sp_done]:
-                            credit -= sp_cost[sp_done]
-                            sp_done += 1
-                    if done == units and (g == 0 or sp_done == sp_total):
-                        credit = 0
-                    CVQ.append(done)
-                    SPQ.append(sp_done)
+                L_T0.append(t0), L_T1.append(t0 + 1 if t0 + 1 < nt else 255), L_IP.append(cur[ip]), L_BLK.append(blk + t0)
+                events.append(("step", pair_gp[NH].get(ip)))
+                events += [("quad",)] * 6
             blk += nt
-        if t["GOFF"][g + 1] > t["GOFF"][g] and g > 0:
-            SPQ[-1] = sp_total  # (the previous group's accumulators are recycled by the next group)
-        if g == 0 and t["GOFF"][1] > t["GOFF"][0]:
-            done = units
-            CVQ[-1] = units  # (register plan: the previous layer's outputs are dead before the first map's state comes alive)
+        events.append(("group_end", g))
         LS_OFF.append(len(L_T0))
-    return {"HAS2": 1, "QB": qb, "FILL": fill, "H_OT0": H_OT0, "H_OT1": H_OT1, "H_IP": H_IP, "H_BLK": H_BLK, "HS_OFF": HS_OFF, "CVQ": CVQ, "CVQ_OFF": CVQ_OFF,
-            "L_T0": L_T0, "L_T1": L_T1, "L_IP": L_IP, "L_BLK": L_BLK, "LS_OFF": LS_OFF, "SPQ": SPQ, "SP_TOTAL": sp_total}
+    # ---- deal the units: every unit gets the quad in whose region it is issued ------------------------------------------------------
+    # First the quad index of every event; then conversion units are spread from their pair's completion on, one every `stride` quads
+    # (never slower than their deadline allows), and the micro-steps of a group's maps evenly over the quads of the next group.
+    sp_total = 2 * fpl * len(costs)
+    nq = sum(1 for e in events if e[0] == "quad")
+    n_pairs = len(CP_OS)
+    release, deadline = [None] * n_pairs, [nq] * n_pairs  # (in quads: issued in a quad q with release <= q < deadline)
+    q = 0
+    groups = []  # (first quad, quads) per group position
+    for ev in events:
+        if ev[0] == "quad":
+            q += 1
+        elif ev[0] == "complete":
+            release[ev[1]] = q
+        elif ev[0] == "begin" and ev[1] - NOS >= 0:
+            deadline[ev[1] - NOS] = min(deadline[ev[1] - NOS], q)
+        elif ev[0] == "step" and ev[1] is not None:
+            deadline[ev[1]] = min(deadline[ev[1]], q)
+        elif ev[0] == "group":
+            groups.append([q, 0])
+        elif ev[0] == "group_end":
+            groups[-1][1] = q - groups[-1][0]
+    stride = max(1, env_int("ZUKO_AMD_ARX2_CVSTRIDE", 2))
+    target = []
+    for gp in range(n_pairs):
+        r, d = release[gp], deadline[gp]
+        if d >= nq and not any(ev[0] == "step" and ev[1] == gp for ev in events):
+            d = r  # a pair nothing reads (cannot happen with a masked conditioner's blocks): its units are never issued
+        win = max(1, d - r)
+        step = min(float(stride), win / float(UPP))
+        target += [min(d - 1, r + int(j * step)) for j in range(UPP)]
+    for u in range(len(target) - 2, -1, -1):  # units are issued in order
+        target[u] = min(target[u], target[u + 1])
+    for gp in range(n_pairs):
+        assert all(target[gp * UPP + j] >= release[gp] - (1 if release[gp] == deadline[gp] else 0) for j in range(UPP)) or release[gp] >= deadline[gp], "conversion deadlines cannot be met"
+    CVQ = [0] * (nq + 1)
+    for tq in target:
+        CVQ[max(0, tq) + 1] += 1
+    for i in range(1, nq + 1):
+        CVQ[i] += CVQ[i - 1]
+    SPQ = []
+    for gi, (q0, n) in enumerate(groups):
+        SPQ.append(0)
+        if gi == 0 or n == 0:
+            SPQ += [0] * n
+            continue
+        cnt = [0] * n
+        for k in range(sp_total):
+            cnt[min(n - 1, (k * n) // sp_total)] += 1
+        acc_ = 0
+        for c in cnt:
+            acc_ += c
+            SPQ.append(acc_)
+    NSLOT = 1 + max(max(d.values()) for d in in_slot if d)
+    return {"HAS2": 1, "QB": qb, "FILL": fill, "NSLOT": NSLOT, "NOS": NOS, "H_OT0": H_OT0, "H_OT1": H_OT1, "H_IP": H_IP, "H_BLK": H_BLK, "H_OS": H_OS, "H_INIT": H_INIT, "HS_OFF": HS_OFF,
+            "CP_OS": CP_OS, "CP_IS": CP_IS, "CP_T0": CP_T0, "CP_T1": CP_T1, "CP_L": CP_L, "X_SLOT": [in_slot[0][p] for p in sorted(in_slot[0])],
+            "CVQ": CVQ, "L_T0": L_T0, "L_T1": L_T1, "L_IP": L_IP, "L_BLK": L_BLK, "LS_OFF": LS_OFF, "SPQ": SPQ, "SP_TOTAL": sp_total}
 
 
 def emit_split(t: dict) -> str:
@@ -443,13 +516,15 @@ def emit_split(t: dict) -> str:
         f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, NR = {t['NR']}, ACT = {t['ACT']};",
         f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = false, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
         _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
-        _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
+        _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]), _arr("G_ORD", "unsigned char", t["G_ORD"]),
     ]
     if has2:  # step lists + VALU schedule of the two-set kernel (split2_schedule)
         lines += [
-            f"  static constexpr int SP_TOTAL = {t['SP_TOTAL']}, FILL = {t['FILL']};",
+            f"  static constexpr int SP_TOTAL = {t['SP_TOTAL']}, FILL = {t['FILL']}, NSLOT = {t['NSLOT']}, NOS = {t['NOS']};",
             _arr("H_OT0", "unsigned char", t["H_OT0"]), _arr("H_OT1", "unsigned char", t["H_OT1"]), _arr("H_IP", "unsigned char", t["H_IP"]), _arr("H_BLK", "short", t["H_BLK"]),
-            _arr("HS_OFF", "int", t["HS_OFF"]), _arr("CVQ", "short", t["CVQ"]), _arr("CVQ_OFF", "int", t["CVQ_OFF"]),
+            _arr("H_OS", "unsigned char", t["H_OS"]), _arr("H_INIT", "unsigned char", t["H_INIT"]), _arr("HS_OFF", "int", t["HS_OFF"]), _arr("CVQ", "short", t["CVQ"]),
+            _arr("CP_OS", "unsigned char", t["CP_OS"]), _arr("CP_IS", "unsigned char", t["CP_IS"]), _arr("CP_T0", "unsigned char", t["CP_T0"]), _arr("CP_T1", "unsigned char", t["CP_T1"]),
+            _arr("X_SLOT", "unsigned char", t["X_SLOT"]),
             _arr("L_T0", "unsigned char", t["L_T0"]), _arr("L_T1", "unsigned char", t["L_T1"]), _arr("L_IP", "unsigned char", t["L_IP"]), _arr("L_BLK", "short", t["L_BLK"]),
             _arr("LS_OFF", "int", t["LS_OFF"]), _arr("SPQ", "short", t["SPQ"]),
         ]
@@ -458,7 +533,11 @@ def emit_split(t: dict) -> str:
         lines += [
             'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {',
             f'  if (!train && !(a->dbg & 1)) return zk::arx2_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, stream);',
+            "#if defined(ARX2_TRACE) || defined(ARX2_ONLY)  // probe builds (ZUKO_AMD_STATIC_CXXFLAGS): the two-set kernel alone, a third of the compile time",
+            "  return 1;",
+            "#else",
             f'  return zk::arx_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, train, stream);',
+            "#endif",
             "}",
             "",
         ]
