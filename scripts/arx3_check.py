@@ -1,8 +1,9 @@
 #!/usr/bin/env python
-"""Two-set operand-split kernel (csrc/fused_ar_split2_impl.h) against its 8-wavefront form (csrc/fused_ar_split_impl.h) on the GPU:
-bit-identity of y / ladj on several conditioners and batch shapes, then launch times of both at the headline batch.
+"""32-sample operand-split kernel (csrc/fused_ar_split3_impl.h) against the 8-wavefront one (csrc/fused_ar_split_impl.h) on the GPU:
+agreement of y / ladj on several conditioners and batch shapes (same formulation, another summation order inside the matrix
+instruction: a few f32 ulps), identical NaN patterns, then launch times of both at the headline batch.
 
-    python scripts/arx2_check.py [--time-only] [--label NAME]       (ZUKO_AMD_ARX2_QB / _FILL / ZUKO_AMD_CACHE_DIR select a variant build)
+    python scripts/arx3_check.py [--time-only] [--label NAME]       (ZUKO_AMD_ARX2_FILL / ZUKO_AMD_CACHE_DIR select a variant build)
 """
 import argparse
 import json
@@ -32,8 +33,14 @@ def both(flow, x, c=None):
     return out
 
 
-def same(a, b):
-    return bool(torch.equal(torch.nan_to_num(a, nan=12345.0, posinf=2e30, neginf=-2e30), torch.nan_to_num(b, nan=12345.0, posinf=2e30, neginf=-2e30)))
+def close(a, b):
+    """(identical NaN / inf pattern, max |a - b| over the finite part, its scale)"""
+    fa, fb = torch.isfinite(a), torch.isfinite(b)
+    pattern = bool(torch.equal(fa, fb) and torch.equal(torch.isnan(a), torch.isnan(b)))
+    ok = fa & fb
+    if not ok.any():
+        return pattern, 0.0, 1.0
+    return pattern, float((a[ok] - b[ok]).abs().max()), float(b[ok].abs().max())
 
 
 def identity_checks():
@@ -49,7 +56,7 @@ def identity_checks():
         torch.manual_seed(3)
         flow = make().to(dev)
         st = flow.transform.transforms[0].fused_state(dev)
-        split = bool(st is not None and st.static is not None and st.static[0].meta.get("split"))
+        v3 = bool(st is not None and getattr(st, "static3", None) is not None)
         for N in (1, 100, 128, 4133, 1 << 16):
             g = torch.Generator().manual_seed(N)
             x = (1.5 * torch.randn(N, D, generator=g)).to(dev)
@@ -59,10 +66,11 @@ def identity_checks():
                 x[11, D - 1] = float("inf")
                 x[13, 0] = 7.5
             (z1, l1), (z2, l2) = both(flow, x, c)
-            good = same(z1, z2) and same(l1, l2)
+            pz, ez, sz = close(z2, z1)
+            pl, el, sl = close(l2, l1)
+            good = pz and pl and ez <= 2e-5 * max(sz, 1.0) and el <= 1e-4 * max(sl, 1.0)
             ok &= good
-            nd = int((torch.nan_to_num(z1, nan=1.0) != torch.nan_to_num(z2, nan=1.0)).sum())
-            print(f"{name:24s} N={N:6d} split={split} bit-identical={good}" + ("" if good else f"  differing y: {nd}, max |dy| {float((z1 - z2).abs().nan_to_num().max()):.3e}, max |dladj| {float((l1 - l2).abs().nan_to_num().max()):.3e}"), flush=True)
+            print(f"{name:24s} N={N:6d} v3={v3} patterns={pz and pl} max|dy|={ez:.2e} (scale {sz:.1f}) max|dladj|={el:.2e} (scale {sl:.1f}) {'ok' if good else 'MISMATCH'}", flush=True)
     return ok
 
 
@@ -86,11 +94,11 @@ def timing(label):
                     prof, _C.PROFILE = _C.PROFILE, None
             except RuntimeError:  # (probe builds hold the two-set kernel only)
                 _C.PROFILE = None
-                res[f"{name}_{'v1_8wave' if v1 == '1' else 'v2_twoset'}_ms"] = None
+                res[f"{name}_{'v1_8wave' if v1 == '1' else 'v3_32sample'}_ms"] = None
                 continue
             ts = [a.elapsed_time(b) for a, b, _ in prof.get("zk_ar_forward_static", [])]
             ts.sort()
-            res[f"{name}_{'v1_8wave' if v1 == '1' else 'v2_twoset'}_ms"] = {"median": ts[len(ts) // 2], "min": ts[0], "calls": len(ts)} if ts else None
+            res[f"{name}_{'v1_8wave' if v1 == '1' else 'v3_32sample'}_ms"] = {"median": ts[len(ts) // 2], "min": ts[0], "calls": len(ts)} if ts else None
         os.environ["ZUKO_AMD_SPLIT_V1"] = "0"
         del flow, x
     print(json.dumps(res), flush=True)
@@ -105,6 +113,6 @@ if __name__ == "__main__":
     good = True
     if not args.time_only:
         good = identity_checks()
-        print("ALL BIT-IDENTICAL" if good else "MISMATCH", flush=True)
+        print("ALL CLOSE" if good else "MISMATCH", flush=True)
     timing(args.label)
     sys.exit(0 if good else 1)

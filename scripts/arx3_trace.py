@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-step shader-clock trace of the two-set split kernel (a -DARX2_TRACE build selected through ZUKO_AMD_CACHE_DIR):
+"""Per-step shader-clock trace of the 32-sample split kernel (a -DARX3_TRACE build selected through ZUKO_AMD_CACHE_DIR):
 prints the cycles of every step of workgroup 0 / wavefront 0 in its first two passes, summed per layer / feature group."""
 import json
 import os
@@ -21,12 +21,13 @@ lazy = flow.transform.transforms[0]
 st = lazy.fused_state(dev)
 assert st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split")
 st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
-t = static_ar.split_tables(st.plan, st.plan.layout.kind, st.act)[0]
-N = 1 << 20
+t = st.t3
+assert st.static3 is not None
+N = 1 << 17  # (four passes per workgroup; the knots buffer must be real: without a trace build the diagnostic kernel writes it)
 x = torch.randn(N, 64, generator=torch.Generator().manual_seed(1)).to(dev)
 y, ladj = torch.empty_like(x), torch.empty(N, device=dev)
 bins = torch.zeros(N, 64, dtype=torch.int32, device=dev)
-knots = torch.zeros(16, device=dev)
+knots = torch.zeros(N, 64, 9, device=dev)
 for _ in range(3):
     st.run_diag(x, y, ladj, bins, knots)
 torch.cuda.synchronize()
@@ -38,8 +39,8 @@ for p in range(2):
     d = np.diff(ts) & 0xFFFFFFFF
     hs, ls = t["HS_OFF"], t["LS_OFF"]
     layers = [int(d[hs[l] : hs[l + 1]].sum()) for l in range(t["NH"])]
-    groups = [int(d[hs[-1] + ls[g] : hs[-1] + ls[g + 1]].sum()) for g in range(t["NG"])]
+    groups = [int(d[hs[-1] + ls[g] : hs[-1] + ls[g + 1]].sum()) for g in range(t["NG3"])]
     out[f"pass{p}"] = {"total": int(d.sum()), "hidden_layers": layers, "hidden_steps": [hs[l + 1] - hs[l] for l in range(t["NH"])],
-                       "groups": groups, "group_steps": [ls[g + 1] - ls[g] for g in range(t["NG"])],
+                       "groups": groups, "group_steps": [ls[g + 1] - ls[g] for g in range(t["NG3"])],
                        "per_step": d.tolist()}
 print(json.dumps(out))
