@@ -176,7 +176,7 @@ typedef struct zk_ar_args_v1 {
   int32_t n_sched;         /* partial sweeps: entries of sched */
   int32_t g0;              /* partial sweeps: last-layer groups [g0, g1) */
   int32_t g1;
-  int32_t variant;         /* 0; zk_ar_forward_static: bit 0 selects the 8-wavefront form of an operand-split kernel instead of its two-set form (A/B) */
+  int32_t reserved;        /* 0 */
   int64_t N;               /* rows */
   int64_t ldx;             /* row stride of x (elements, multiple of 4) */
   int64_t ldy;             /* row stride of y (forward) / of y_in (inverse sweeps) */

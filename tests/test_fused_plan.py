@@ -369,13 +369,11 @@ def test_split_kernel_tables_describe_the_plan(cfg):
         got = np.full(D * total, np.nan)
         blk = 0
         bias_last = plan.bias_gather[NH].reshape(-1, nt, 16)
-        assert sorted(t["G_ORD"]) == list(range(t["NG"]))
-        for gi in range(t["NG"]):  # stream position gi holds feature group g
-            g = t["G_ORD"][gi]
+        for g in range(t["NG"]):
             acc = np.zeros((nt, 16))
             for b in range(nt):
                 acc[b] = np.where(bias_last[g, b] >= 0, Bv[NH][np.maximum(bias_last[g, b], 0)], 0.0)
-            for st in range(t["GOFF"][gi], t["GOFF"][gi + 1]):
+            for st in range(t["GOFF"][g], t["GOFF"][g + 1]):
                 ip = t["G_IP"][st]
                 for b in range(nt):
                     for lane in range(64):
@@ -433,129 +431,3 @@ def test_coupling_split_stream_is_the_f32_stream_regrouped():
     l2 = list(t2.hyper)[0::2]
     p2 = cp.build_coupling_plan([tuple(l.weight.shape) for l in l2], t2.mask.nonzero().squeeze(-1).numpy(), (~t2.mask).nonzero().squeeze(-1).numpy(), 12, 2)
     assert p2.split_gather is None
-
-
-@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("rqs", 32, 0, (256, 256), 8), ("rqs", 20, 3, (100, 72), 8),
-                                 ("affine", 16, 0, (128, 128), 0)])
-def test_split3_tables_walked_register_by_register(cfg):
-    """The 32-sample operand-split kernel (csrc/fused_ar_split3_impl.h) is straight-line code over static_ar.split3_tables: steps of one
-    in half-tile against an out pair, accumulator / operand register SLOTS that are recycled while the pass runs, conversion half-units
-    and univariate micro-steps dealt to the duos.  Walked here exactly as the kernel walks them — one sample, both lane halves, every
-    register slot modelled, a step's product applied with its LAST duo (so a conversion unit scheduled before its pair is complete, or
-    an operand slot overwritten while still read, gives wrong numbers) — the parameters must be the masked MLP's, both feature orders."""
-    from zuko_amd import static_ar
-
-    kind, D, C, hidden, bins = cfg
-    rng = np.random.default_rng(5)
-    for plan, lay, lins in static_ar._plans_for(kind, D, C, hidden, bins):
-        r = static_ar.split3_tables(plan, lay.kind, 1)
-        assert r is not None
-        t, gathers, bias_last, fmap = r
-        NH, NOS, NT3, TP, FPL3, NG3 = t["NH"], t["NOS"], t["NT3"], t["TP"], t["FPL3"], t["NG3"]
-        total = lay.total
-        W = [l.weight.detach().numpy().astype(np.float64) * l.mask.numpy() for l in lins]
-        Bv = [l.bias.detach().numpy().astype(np.float64) for l in lins]
-        x = rng.standard_normal(plan.din)
-        h = x.copy()
-        for l in range(NH + 1):
-            h = W[l] @ h + Bv[l]
-            if l < NH:
-                h = np.maximum(h, 0.0)
-        ref = h.reshape(D, total)
-        images = []
-        for l in range(NH + 1):
-            idx = gathers[l].reshape(-1, 64, 8)
-            flat = W[l].reshape(-1)
-            images.append(np.where(idx >= 0, flat[np.maximum(idx, 0)], 0.0))
-        assert 3 * sum(len(g) // 512 for g in gathers) >= t["NCHUNK"] * t["CH"] and t["STREAM_IMAGES"] >= t["NCHUNK"] * t["CH"]
-        # registers: in slots [slot][lane half][k-slot], accumulator tiles [tile][lane half][register]
-        in_regs = np.full((t["NSLOT"], 2, 8), np.nan)
-        out_regs = np.full((2 * NOS, 2, 16), np.nan)
-        slot_unit = lambda kg, i: 8 * (i // 4) + 4 * kg + i % 4  # unit of the half-tile in k-slot (kg, i)
-        for H in range(t["NIH0"]):
-            for kg in range(2):
-                for i in range(8):
-                    c = 16 * H + slot_unit(kg, i)
-                    in_regs[t["X_SLOT"][H], kg, i] = x[c] if c < plan.din else 0.0
-        row_of = lambda hb, v: 8 * (v // 4) + 4 * hb + v % 4  # tile row held by (lane half, register)
-
-        def product(img, acc, breg):  # acc[hb][v] += sum over k-slots of A[(row, kg)][i] * B[kg][i]
-            for hb in range(2):
-                for v in range(16):
-                    m = row_of(hb, v)
-                    acc[hb, v] += sum(float(np.dot(img[m + 32 * kg], breg[kg])) for kg in range(2))
-
-        def convert(lo, hi):
-            for u in range(lo, hi):
-                gp, tt, vp, half = u // 32, (u // 16) % 2, (u // 2) % 8, u % 2
-                if half == 0:
-                    continue  # (h and the remainder: nothing visible until the second half writes m and l)
-                dst = t["CP_IS"][4 * gp + 2 * tt + vp // 4]
-                if dst == 255:
-                    continue
-                for v in (2 * vp, 2 * vp + 1):
-                    in_regs[dst, :, v % 8] = np.maximum(out_regs[2 * t["CP_OS"][gp] + tt, :, v], 0.0)
-
-        hs = t["HS_OFF"]
-        for gs in range(hs[-1]):
-            l = next(i for i in range(NH) if gs < hs[i + 1])
-            T0, T1, OS = t["H_T0"][gs], t["H_T1"][gs], t["H_OS"][gs]
-            if t["H_INIT"][gs]:
-                for w_ in range(2):
-                    T = 2 * (T0 // 2) + w_
-                    if T < t["HT32"][l]:
-                        bimg = np.where(plan.bias_gather[l] >= 0, Bv[l][np.maximum(plan.bias_gather[l], 0)], 0.0)
-                        for hb in range(2):
-                            for v in range(16):
-                                out_regs[2 * OS + w_, hb, v] = bimg[32 * T + row_of(hb, v)] if 32 * T + row_of(hb, v) < len(bimg) else 0.0
-            breg = in_regs[t["H_IN"][gs]].copy()
-            for kt in range(6):
-                qi = 6 * gs + kt
-                convert(t["CVQ"][qi], t["CVQ"][qi + 1])
-                if kt == 5:
-                    blk = t["H_BLK"][gs]
-                    product(images[l][blk], out_regs[2 * OS + (T0 & 1)], breg)
-                    if T1 != 255:
-                        product(images[l][blk + 1], out_regs[2 * OS + (T1 & 1)], breg)
-            assert not np.isnan(breg).any(), f"step {gs} reads an operand slot nobody has written"
-        # last layer
-        got = np.full((D, total), np.nan)
-        ls = t["LS_OFF"]
-        for gi in range(NG3):
-            g = t["G_ORD"][gi]
-            acc = np.zeros((NT3, 2, 16))
-            bl = bias_last.reshape(NG3, NT3, 32)[g]
-            for tt in range(NT3):
-                for hb in range(2):
-                    for v in range(16):
-                        r_ = bl[tt, row_of(hb, v)]
-                        acc[tt, hb, v] = Bv[NH][r_] if r_ >= 0 else 0.0
-            for st in range(ls[gi], ls[gi + 1]):
-                gs = hs[-1] + st
-                breg = in_regs[t["L_IN"][st]].copy()
-                for kt in range(6):
-                    qi = 6 * gs + kt
-                    convert(t["CVQ"][qi], t["CVQ"][qi + 1])
-                    if kt == 5:
-                        blk = t["L_BLK"][st]
-                        product(images[NH][blk], acc[t["L_T0"][st]], breg)
-                        if t["L_T1"][st] != 255:
-                            product(images[NH][blk + 1], acc[t["L_T1"][st]], breg)
-                assert not np.isnan(breg).any()
-            fm = fmap.reshape(NG3, 2, FPL3)[g]
-            for hb in range(2):
-                par = np.concatenate([acc[tt, hb] for tt in range(NT3)])  # the lane half's 16 NT3 parameters
-                for fi in range(FPL3):
-                    if fm[hb, fi] >= 0:
-                        got[fm[hb, fi]] = par[fi * TP : fi * TP + total]
-        assert t["CVQ"][-1] == 32 * len(t["CP_OS"]) or t["CVQ"][-1] % 32 == 0
-        assert not np.isnan(got).any()
-        scale = np.abs(ref).max()
-        assert np.abs(got - ref).max() <= 1e-9 * scale, (np.abs(got - ref).max(), scale)
-        # the maps' micro-steps: every group but the first in stream order gets all of them, in order, inside the next group's duos
-        sp, k = t["SPQ"], 0
-        for gi in range(NG3):
-            n = 6 * (ls[gi + 1] - ls[gi])
-            seg = sp[k : k + n + 1]
-            k += n + 1
-            assert seg[0] == 0 and all(b >= a for a, b in zip(seg, seg[1:])) and seg[-1] == (0 if gi == 0 or n == 0 else t["SP_TOTAL"])

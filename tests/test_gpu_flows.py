@@ -760,46 +760,6 @@ def _run_static(st, inp, N, D, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [c for c in STATIC_CASES if len(c) == 4], ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}")
-@pytest.mark.parametrize("N", [1, 129, 1000, 40000])
-def test_two_set_split_kernel_is_bit_identical_to_the_eight_wavefront_one(dev, case, N, monkeypatch):
-    """The default forward of an operand-split conditioner is the TWO-SET kernel (csrc/fused_ar_split2_impl.h: one wavefront per SIMD
-    carrying two 16-sample sets, VALU work dealt into the shadow of the matrix instructions); ZUKO_AMD_SPLIT_V1=1 keeps the launch on
-    the 8-wavefront form (csrc/fused_ar_split_impl.h).  Same stream, same products in the same order per output: y / ladj bit for bit
-    (zeros compare equal whatever their sign: the two-set kernel's integer ReLU writes +0 for -0), poisoned rows included."""
-    from zuko_amd import static_ar
-    from zuko_amd.flows import MAF, NSF
-    from zuko_amd.nn import MaskedLinear
-
-    kind, D, C, hidden = case
-    monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
-    torch.manual_seed(3)
-    flow = (NSF(D, C, transforms=2, bins=8, hidden_features=hidden) if kind == "nsf" else MAF(D, C, transforms=2, hidden_features=hidden)).to(dev)
-    g = torch.Generator().manual_seed(N)
-    din = D + C
-    inp = torch.zeros(N, -(-din // 4) * 4)
-    inp[:, :din] = torch.randn(N, din, generator=g) * 1.5
-    if N >= 127:
-        inp[5, min(7, D - 1)] = float("nan")
-        inp[100, din - 1] = float("inf")
-        inp[101, 0] = 9.0
-    inp = inp.to(dev)
-    for i, lazy in enumerate(flow.transform.transforms):
-        st = lazy.fused_state(dev)
-        assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
-        has2 = static_ar.split_tables(st.plan, st.plan.layout.kind, st.act)[0]["HAS2"]
-        assert has2 == int(D % 4 == 0), "the two-set kernel covers every LDS-staged (D % 4 == 0) ReLU conditioner"
-        st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
-        monkeypatch.setenv("ZUKO_AMD_SPLIT_V1", "1")
-        y1, l1 = _run_static(st, inp, N, D, dev)
-        monkeypatch.setenv("ZUKO_AMD_SPLIT_V1", "0")
-        y2, l2 = _run_static(st, inp, N, D, dev)
-        nn = lambda t: torch.nan_to_num(t, nan=12345.0, posinf=3e38, neginf=-3e38)
-        assert torch.equal(torch.isnan(y1), torch.isnan(y2)) and torch.equal(torch.isnan(l1), torch.isnan(l2))
-        assert torch.equal(nn(y1), nn(y2)) and torch.equal(nn(l1), nn(l2)), f"transform {i}: {(nn(y1) != nn(y2)).sum().item()} outputs differ"
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("regime", ["trained", "wide-range", "denormal"])
 @pytest.mark.parametrize("kind", ["nsf", "maf"])
 def test_split_kernels_away_from_default_init(dev, kind, regime, monkeypatch):

@@ -484,7 +484,6 @@ int zk_ar_lds_bytes(int variant, int bias_floats) { return (ar_base_lds_floats(b
 struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and the prefix of the network they depend on
   const void* static_fn = nullptr;  // launcher of a generated static-shape kernel: the launch goes there after the argument checks
   int rev = 0;                      // ... with the alternative first-layer pattern (descending feature order)
-  int static_variant = 0;           // ... bit 0: an operand-split kernel in its 8-wavefront form (csrc/fused_ar_split_impl.h) instead of the two-set form
   float* act_out[3] = {nullptr, nullptr, nullptr};  // ... conditioner-only (training) instantiation: hidden activations and phi
   float* phi_out = nullptr;
   int64_t ldphi = 0;
@@ -529,7 +528,6 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
     if (inverse || part.sched || ((part.bin_out != nullptr) != (part.knots_out != nullptr))) return ZK_EINVAL;
     a.bin_out = part.bin_out; a.knots_out = part.knots_out;  // (diagnostic twin of an operand-split kernel; the f32 static kernels decline)
     a.l1rev = part.rev;
-    a.dbg = part.static_variant;  // bit 0: the 8-wavefront form of an operand-split kernel instead of its two-set form (A/B measurements, bit-identity tests)
     for (int l = 0; l < 3; ++l) a.act_out[l] = part.act_out[l];
     a.phi_out = part.phi_out; a.ldphi = part.ldphi;
     return ((ars_launch_fn)part.static_fn)(&a, ARS_ABI, (int)sizeof(ArArgs), part.phi_out != nullptr, stream);
@@ -614,7 +612,6 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
   if (!ar_args_ok(args) || !args->launcher) return ZK_EINVAL;
   ArPartial part;
   part.static_fn = args->launcher; part.rev = args->rev;
-  part.static_variant = args->variant & 1;
   part.bin_out = args->bin_out; part.knots_out = args->knots_out;  // both set: the kernel's diagnostic twin (operand-split kernels only)
   zk_ar_args_v1 p = *args;
   p.skip = nullptr;  // (act: checked by the kernel against the activation it was generated for)

@@ -20,9 +20,9 @@
 // registers of the two tiles, converted once per layer: no shuffle, no LDS round trip between layers.  The ring, the chunking and
 // the raw-read / counted-wait idiom are those of fused_ar_static_impl.h (one block = three consecutive images).
 //
-//   Shape::NB[l], BOFF[l], B_OT, B_IP   blocks of hidden layer l in stream order (out-tile pair, in pair, out tile): out tile, in pair
+//   Shape::NB[l], BOFF[l], B_OT, B_IP   blocks of hidden layer l in stream order (sorted by out tile): out tile, in pair
 //   Shape::BASE[l], LAST_BASE           stream position (in images) where each layer starts
-//   Shape::GOFF[i], G_IP, G_ORD[i]      last layer: kept in pairs of the feature group at stream position i (each with Uni::NT blocks), and which group that is
+//   Shape::GOFF[g], G_IP                last layer: kept in pairs of every feature group (each with Uni::NT blocks)
 #pragma once
 #include "fused_ar_static_impl.h"
 
@@ -75,11 +75,6 @@ template <class S> struct ArxPat {
       if (ot(l, s) == t) return true;
     return false;
   }
-  static constexpr bool first_of_tile(int l, int s) {  // (the stream interleaves the two out tiles of a pair: zuko_amd/static_ar.py:split_tables)
-    for (int i = 0; i < s; ++i)
-      if (ot(l, i) == ot(l, s)) return false;
-    return true;
-  }
 };
 
 // one hidden layer: out = W in + bias over the blocks of the generated pattern
@@ -95,7 +90,7 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arx_hidden
     ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[0][p] = ring.template read<BASE + decltype(p)::value>(); });
     ars_for<NB>([&](auto s_) ARS_ALWAYS_INLINE {
       constexpr int s = s_, ot = P::ot(L, s), ip = P::ip(L, s);
-      if constexpr (P::first_of_tile(L, s)) out[ot] = *reinterpret_cast<const f32x4*>(bias_q + ot * 16);  // accumulators start at the bias
+      if constexpr (s == 0 || P::ot(L, s - 1) != ot) out[ot] = *reinterpret_cast<const f32x4*>(bias_q + ot * 16);  // accumulators start at the bias
       if constexpr (s + 1 < NB) {
         ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[(s + 1) & 1][p] = ring.template read<BASE + 3 * (s + 1) + decltype(p)::value>(); });
         ars_settle<3>(a[s & 1][0], a[s & 1][1], a[s & 1][2]);  // this block's images are in; only the next block's may be outstanding
@@ -232,7 +227,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
       ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[0][p] = ring.template read<S::LAST_BASE + decltype(p)::value>(); });
     }
     ars_for<NG>([&](auto g_) ARS_ALWAYS_INLINE {
-      constexpr int gi = g_, g = S::G_ORD[gi], ST0 = S::GOFF[gi], GN = S::GOFF[gi + 1] - S::GOFF[gi];  // (stream order: the last feature group first)
+      constexpr int g = g_, ST0 = S::GOFF[g], GN = S::GOFF[g + 1] - S::GOFF[g];
       int fid[FPL];
       float xin[FPL];
 #pragma unroll

@@ -114,43 +114,6 @@ template <int WAVES, int CH = ARS_CH, int NR = ARS_NR> struct ArRingS {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(cur_off), "n"((S % CH) * AR_TF * 4));
     return v;
   }
-  // advance() with the DMAs of the refill dealt out one at a time (32-sample kernel: a DMA costs its wavefront ~50 cycles of issue, six in
-  // a row leave the matrix pipe idle; one behind a matrix instruction hides in its shadow): sync() waits, passes the barrier and moves
-  // to the next slot; piece<I>() issues DMA I of the refill of the slot that has just been freed — all PER pieces before the next sync()
-  const float* pend_g;
-  float* pend_l;
-  __device__ __forceinline__ void sync() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NR - 2) * PER) : "memory");
-    if (ARX_ABL != 4) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const int b0 = wave * PER + PIVOT;
-    pend_g = stream + ((size_t)load_chunk * CH + b0) * AR_TF + lane * 4;
-    pend_l = lds + (load_slot * CH + b0) * AR_TF;
-    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
-    load_slot = (load_slot + 1 == NR) ? 0 : load_slot + 1;
-    slot = (slot + 1 == NR) ? 0 : slot + 1;
-    cur_off = lds_off + (unsigned)(slot * CH * AR_TF * 4 + lane * 16);
-  }
-  template <int I> __device__ __forceinline__ void piece() {
-    static_assert(I >= 0 && I < PER, "ring piece");
-    if (ARX_ABL != 1)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pend_g, (__attribute__((address_space(3))) void*)pend_l, 16, (I - PIVOT) * AR_TF * 4, 0);
-  }
-  template <int S> __device__ __forceinline__ f32x4 read_acc_nodma() {  // read_acc whose refill is issued by the caller (sync() here, piece<I>() later)
-    if constexpr (S % CH == 0) sync();
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(cur_off), "n"((S % CH) * AR_TF * 4));
-    return v;
-  }
-  // the same read into an ACCUMULATION register (two-set kernel: the images are matrix-instruction operands only; keeping them out of
-  // the 256 architected VGPRs is what lets the univariate maps' state live there without spills — and a spill reload is a vector-memory
-  // load, whose wait drains the ring's look-ahead DMAs)
-  template <int S> __device__ __forceinline__ f32x4 read_acc() {
-    if constexpr (S % CH == 0) advance();
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(cur_off), "n"((S % CH) * AR_TF * 4));
-    return v;
-  }
 };
 
 template <int N> __device__ __forceinline__ void ars_settle(f32x4& a0) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a0) : "n"(N)); }
@@ -162,10 +125,6 @@ template <int N> __device__ __forceinline__ void ars_settle(f32x4& a0, f32x4& a1
 }
 template <int N> __device__ __forceinline__ void ars_settle(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "n"(N));
-}
-template <int N> __device__ __forceinline__ void ars_settle_acc(f32x4& a0, f32x4& a1, f32x4& a2) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+a"(a0), "+a"(a1), "+a"(a2) : "n"(N)); }
-template <int N> __device__ __forceinline__ void ars_settle_acc(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5) {
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3), "+a"(a4), "+a"(a5) : "n"(N));
 }
 template <int N, int NT> __device__ __forceinline__ void ars_settle_tiles(f32x4 (&w)[NT]) {
   if constexpr (NT == 1) ars_settle<N>(w[0]);

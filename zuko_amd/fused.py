@@ -398,14 +398,6 @@ def chunk_of(variant: int = 0) -> int:
     return CHUNK
 
 
-def _split_variant() -> int:
-    """ZUKO_AMD_SPLIT_V1=1 keeps an operand-split launch on the 8-wavefront kernel (csrc/fused_ar_split_impl.h) instead of the 32-sample
-    kernel (csrc/fused_ar_split3_impl.h) — read at every launch: an A/B switch."""
-    import os
-
-    return 1 if os.environ.get("ZUKO_AMD_SPLIT_V1", "0") == "1" else 0
-
-
 def default_variant() -> int:
     return 0  # reserved argument of the C ABI
 
@@ -434,9 +426,6 @@ class FusedAR:
         self._static_tried_rows = -1
         self.fine_gather = self.fine_stream = self.fine_offsets = None
         self.fine_n_chunks = 0
-        self.static3 = None         # the 32-sample operand-split kernel (csrc/fused_ar_split3_impl.h): the default forward when there is one
-        self.t3 = self.gather3 = self.stream3 = self.offsets3 = self.bias3 = self.bias3_gather = self.featmap3 = None
-        self._stamp3 = None
         self._acquire_static(None)  # kernels already on disk (prebuilt or compiled earlier) are used whatever the batch size
 
     @property
@@ -470,18 +459,6 @@ class FusedAR:
                 stream_images = self.fine_n_chunks * 24
             self.fine_stream = torch.zeros(stream_images * 256, dtype=torch.float32, device=self.device)
             self._fine_stamp = None
-        if self.static is not None and self.static[0].meta.get("split") and self.static3 is None:
-            k3 = static_ar.lookup3(self.plan, self.plan.layout.kind, self.act, rows)
-            if k3 is not None:
-                t3, gathers, bias_last, fmap = static_ar.split3_tables(self.plan, self.plan.layout.kind, self.act)
-                self.static3, self.t3 = k3, t3
-                self.gather3 = [torch.from_numpy(g).to(self.device) for g in gathers]
-                self.offsets3 = [b * 256 for b in t3["BASE"]] + [t3["LAST_BASE"] * 256]
-                self.stream3 = torch.zeros(t3["STREAM_IMAGES"] * 256, dtype=torch.float32, device=self.device)
-                self.bias3 = torch.zeros(t3["BIAS_FLOATS"], dtype=torch.float32, device=self.device)
-                self.bias3_gather = torch.from_numpy(np.ascontiguousarray(bias_last)).to(self.device)
-                self.featmap3 = torch.from_numpy(np.ascontiguousarray(fmap)).to(self.device)
-                self._stamp3 = None
 
     def ready(self, rows: int) -> bool:
         """Whether run() can be served: always for plans the generic kernel covers; for wider ones only with a static-shape kernel
@@ -501,8 +478,7 @@ class FusedAR:
         stamp = _param_stamp(linears)
         want_generic = self.generic_ok and not (fine_only and self.static is not None) and stamp != self._stamp
         want_fine = self.static is not None and stamp != self._fine_stamp
-        want3 = self.static3 is not None and not fine_only and stamp != self._stamp3
-        if not (want_generic or want_fine or want3):
+        if not (want_generic or want_fine):
             return
         items = []
         for l, m in enumerate(linears):
@@ -518,17 +494,6 @@ class FusedAR:
                     items.append((w, mask, self.fine_gather[l], self.fine_gather[l].numel() // 512, fdst, 1))
                 else:
                     items.append((w, mask, self.fine_gather[l], self.fine_gather[l].numel(), fdst, 0))
-            if want3:
-                items.append((w, mask, self.gather3[l], self.gather3[l].numel() // 512, self.stream3[self.offsets3[l] :], 1))
-                last = l + 1 == len(linears)
-                g3 = self.bias3_gather if last else self.bias_gather[l]
-                b3 = self.bias3[self.plan.bias_off[l] :]
-                if m.bias is None:
-                    b3[: g3.numel()].zero_()
-                else:
-                    items.append((m.bias.detach().contiguous(), None, g3, g3.numel(), b3, 0))
-            if not (want_generic or want_fine):
-                continue
             nb = self.bias_gather[l].numel()
             bdst = self.bias[self.plan.bias_off[l] :]
             if m.bias is None:
@@ -540,8 +505,6 @@ class FusedAR:
             self._stamp = stamp
         if want_fine:
             self._fine_stamp = stamp
-        if want3:
-            self._stamp3 = stamp
 
     def run(self, inp: Tensor, y: Tensor, ladj: Tensor | None, accumulate: bool) -> None:
         """inp [N, DINP] (cat(x, c), zero-padded to a multiple of 4 columns), y [N, D], ladj [N]."""
@@ -550,14 +513,6 @@ class FusedAR:
 
         p = self.plan
         N = inp.shape[0]
-        if self.static3 is not None and not _split_variant() and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0:
-            t3 = self.t3
-            a = _C.args("zk_ar_args_v1", launcher=self.static3.launcher, rev=0, uni_kind=p.layout.kind, N=N, D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
-                        y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate), wstream=_ptr(self.stream3), bias=_ptr(self.bias3),
-                        bias_floats=t3["BIAS_FLOATS"], featmap=_ptr(self.featmap3), n_layers=p.n_layers, n_groups=t3["NG3"], n_chunks=t3["NCHUNK"], act=self.act,
-                        bound=self.bound, slope=self.slope)
-            _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
-            return
         if self.static is not None:
             kern, rev = self.static
             # (a static-shape kernel that stages rows through LDS needs them 16-byte addressable; the generic kernel has an instantiation for the other case)
@@ -588,15 +543,6 @@ class FusedAR:
         from .ops import _ptr, _stream
 
         p = self.plan
-        if self.static3 is not None and not _split_variant() and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0:
-            # the product launch is the 32-sample operand-split kernel: its own diagnostic instantiation
-            t3 = self.t3
-            a = _C.args("zk_ar_args_v1", launcher=self.static3.launcher, rev=0, uni_kind=p.layout.kind, N=inp.shape[0], D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
-                        y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=0, wstream=_ptr(self.stream3), bias=_ptr(self.bias3), bias_floats=t3["BIAS_FLOATS"],
-                        featmap=_ptr(self.featmap3), n_layers=p.n_layers, n_groups=t3["NG3"], n_chunks=t3["NCHUNK"], act=self.act, bound=self.bound, slope=self.slope,
-                        bin_out=_ptr(bins), knots_out=_ptr(knots))
-            _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
-            return
         if self.static is not None and self.static[0].meta.get("split") and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0:
             # the product launch is an operand-split kernel: its own diagnostic instantiation (the generic kernel differs from it by rounding)
             kern, rev = self.static

@@ -38,7 +38,7 @@ CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
 ARS_ABI = 4  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 4: "zk::UniCircRqs8"}  # (16 bins: 12 accumulator tiles per group do not fit the double-buffered last layer)
-_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "fused_ar_split3_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
+_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
 
 
 def _hipcc() -> str | None:
@@ -253,20 +253,14 @@ def split_tables(plan, uni_kind: int, act: int = 1):
                         pos[(otg * 4 + b, it)] = k
                         k += 1
         n_in = NIT if l == 0 else HT[l - 1]
-        # stream order: out-tile PAIR major (DESCENDING), then in pair (DESCENDING: a layer reads its in pairs in the order the layer
-        # before finished them; every kernel that walks this stream sums an output in this order), then the two out tiles of the pair —
-        # consecutive blocks alternate between two accumulators (the 32-sample kernel, csrc/fused_ar_split3_impl.h, lays its own stream out the same way: split3_tables)
         blocks = []
-        for op in reversed(range(-(-HT[l] // 2))):
-            for ip in reversed(range(-(-n_in // 2))):
-                for ot in (2 * op, 2 * op + 1):
-                    if ot >= HT[l]:
-                        continue
-                    t0, t1 = pos.get((ot, 2 * ip)), pos.get((ot, 2 * ip + 1))
-                    if t0 is None and t1 is None:
-                        continue
-                    blocks.append(pair_block(fg, t0, t1))
-                    B_OT.append(ot), B_IP.append(ip)
+        for ot in range(HT[l]):
+            for ip in range(-(-n_in // 2)):
+                t0, t1 = pos.get((ot, 2 * ip)), pos.get((ot, 2 * ip + 1))
+                if t0 is None and t1 is None:
+                    continue
+                blocks.append(pair_block(fg, t0, t1))
+                B_OT.append(ot), B_IP.append(ip)
         NB.append(len(blocks))
         BASE.append(cursor)
         cursor += 3 * len(blocks)
@@ -274,23 +268,17 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     # last layer: group g, kept in-tile it, tile t of the group  ->  group g, kept in-pair ip, tile t
     nt = plan.layout.nt
     fg = plan.fine_gather[NH].reshape(-1, 64, 4)
-    # Stream order: feature groups from the LAST (the one with the most inputs) to the first, in pairs descending inside a group — the
-    # hidden layers finish their out pairs from the last to the first, so the last layer reads them in the order they were converted
-    # (G_ORD[i] = group at position i; GOFF / G_IP follow the positions).
-    G_IP, GOFFP, G_ORD, blocks = [], [0], [], []
-    tile0 = [0]
+    G_IP, GOFFP, blocks, k = [], [0], [], 0
     for g in range(t["NG"]):
-        tile0.append(tile0[-1] + (t["GOFF"][g + 1] - t["GOFF"][g]) * nt)
-    for g in reversed(range(t["NG"])):
         its = t["G_IT"][t["GOFF"][g] : t["GOFF"][g + 1]]
-        at = {it: tile0[g] + i * nt for i, it in enumerate(its)}
-        for ip in sorted({it // 2 for it in its}, reverse=True):
+        at = {it: k + i * nt for i, it in enumerate(its)}
+        k += len(its) * nt
+        for ip in sorted({it // 2 for it in its}):
             for b in range(nt):
                 t0, t1 = at.get(2 * ip), at.get(2 * ip + 1)
                 blocks.append(pair_block(fg, None if t0 is None else t0 + b, None if t1 is None else t1 + b))
             G_IP.append(ip)
         GOFFP.append(len(G_IP))
-        G_ORD.append(g)
     last_base = cursor
     cursor += 3 * len(blocks)
     # The stream is ceil(images / ch) chunks long: every chunk's first image belongs to a real block (the kernel moves the ring on when
@@ -306,368 +294,10 @@ def split_tables(plan, uni_kind: int, act: int = 1):
         out.pop(key)
     nr = 2 if ch == 48 else 3  # (48-image chunks: two ring slots, half as many barriers)
     xlds = int(t["D"] % 4 == 0 and (nr * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * (2 if waves == 4 else 1) <= 160 * 1024)
-    out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "G_ORD": G_ORD, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
+    out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
                 "WAVES": waves, "CH": ch, "NR": nr, "XLDS": xlds})
     plan._split_cache = ((uni_kind, act, split_geometry()), (out, gathers))
     return out, gathers
-
-
-# micro-steps of the univariate maps of the 32-sample kernel (csrc/fused_ar_split3_impl.h: Uni2*::step<I>) and what each costs in VALU
-# instructions — an estimate that only steers how the steps are spread over the matrix instructions, never a result
-def _uni2_costs(uni_kind: int) -> list[int] | None:
-    if uni_kind == 0:  # affine: load + map
-        return [4, 14]
-    bins = {1: 8, 2: 4, 4: 8}.get(uni_kind)
-    if bins is None:
-        return None
-    lv = bins.bit_length() - 1
-    cost = [bins + 4] + [8] * bins  # load / poison; one softmax element of both axes per step
-    cost += [4 + 6] + [6] * (-(-bins // 4) - 1)  # knots, four per step (the first also normalises)
-    cost += [bins // 2 + 6, 2 * (bins // 2 + 1)]  # bisection level 0 in two halves
-    m = bins // 2
-    for _ in range(lv - 1):  # the other levels
-        cost.append(3 * (m // 2 + 1) + 2)
-        m //= 2
-    cost += [8, 8, 13, 14]  # the two selected slopes; bin geometry; the rational-quadratic map; its derivative, log, stores
-    return cost
-
-
-# --------------------------------------------------------------------------------------------------------------------
-# the 32-sample form of the operand-split kernel (csrc/fused_ar_split3_impl.h): v_mfma_f32_32x32x16_bf16, one wavefront per SIMD
-# --------------------------------------------------------------------------------------------------------------------
-
-# per univariate kind: padded parameters per feature, 32-row tiles per feature group, features per group
-_UNI3 = {0: (2, 1, 16), 1: (24, 3, 4), 2: (12, 3, 8), 4: (24, 3, 4)}
-
-
-def split3_enabled() -> bool:
-    return os.environ.get("ZUKO_AMD_SPLIT_V1", "0") != "1"
-
-
-def split3_tables(plan, uni_kind: int, act: int = 1):
-    """Tables + gathers of the 32-SAMPLE operand-split kernel (csrc/fused_ar_split3_impl.h), or None.
-
-    Measured on the MI355X (scripts/probes/mfma32_probe.hip): one wavefront issues v_mfma_f32_16x16x32_bf16 at 61 % of the bf16 peak at
-    best — which is where the 8-wavefront kernel sits — but v_mfma_f32_32x32x16_bf16 at 85 %, with four to five other instructions
-    behind each for free.  So here a wavefront carries 32 samples (the N dimension of the 32 x 32 form) through the layers, one
-    wavefront per SIMD (512 registers).  A stream BLOCK is 32 out units x 16 in units (an out TILE against an in HALF-TILE) as three
-    1 KiB bf16 images (h, m, l): lane (m = lane % 32, kg = lane / 32) holds W[out 32 T + m][in 16 H + 8 (i / 4) + 4 kg + i % 4],
-    i = 0..7 — the k-slot order in which a lane (sample, lane / 32) of the accumulator tile holds its 16 units (rows 8 g + 4 (lane / 32)
-    + r), so that a layer's result becomes the next layer's B operand by an in-register conversion, as in the 16-sample kernels.
-    A STEP = one in half-tile against the (up to) two out tiles of an out PAIR; out pairs DESCENDING, half-tiles descending inside a
-    pair, feature groups of the last layer from the last to the first (see split2_schedule for why); finished pairs are converted over
-    the in half-tiles that have just died.  Last layer: groups of FG features whose TP-padded parameters fill NT3 tiles, a lane
-    (sample, half) ending up with all parameters of FG / 2 features.
-    Returns (tables, gathers, bias_last, fmap): gathers[l] int32 [blocks_l * 512] into W_l.flatten() (-1 = zero); bias_last int32
-    [groups * NT3 * 32] into the last bias; fmap int32 [groups * 2 * FG / 2] feature ids (-1 = padding)."""
-    t1 = tables(plan, uni_kind, act)
-    if t1 is None or t1["WAVES"] != 8 or uni_kind not in _UNI3 or act not in (0, 1) or not t1["XLDS"]:
-        return None
-    costs = _uni2_costs(uni_kind)
-    if costs is None:
-        return None
-    cached = getattr(plan, "_split3_cache", None)
-    key = (uni_kind, act, os.environ.get("ZUKO_AMD_ARX2_FILL", ""), os.environ.get("ZUKO_AMD_ARX2_CVSTRIDE", ""), os.environ.get("ZUKO_AMD_STATIC_CXXFLAGS", ""))
-    if cached is not None and cached[0] == key:
-        return cached[1]
-
-    def env_int(name, default):
-        try:
-            return int(os.environ.get(name, str(default)))
-        except ValueError:
-            return default
-
-    fill = env_int("ZUKO_AMD_ARX2_FILL", 4)
-    NH, widths, din = t1["NH"], list(plan.widths), plan.din
-    total = plan.layout.total
-    TP, NT3, FG = _UNI3[uni_kind]
-    FPL3 = FG // 2
-    tm = plan.fine_tilemask
-    n_otg = tm.shape[1]
-    lane = np.arange(64)
-    lm, lkg = lane % 32, lane // 32
-    slot_unit = 8 * (np.arange(8) // 4)[None, :] + 4 * lkg[:, None] + (np.arange(8) % 4)[None, :]  # [64, 8]: unit of the half-tile in k-slot (lane, i)
-
-    def image(rows32, cols16, in_width):
-        r = rows32[lm][:, None]
-        c = cols16[slot_unit]
-        idx = r * in_width + c
-        idx[(r < 0) | (c < 0)] = -1
-        return idx.reshape(-1)
-
-    def padded(a, mult):
-        n = -(-len(a) // mult) * mult
-        return np.concatenate([np.asarray(a, dtype=np.int64), -np.ones(n - len(a), dtype=np.int64)])
-
-    perms = [padded(np.asarray(plan.bias_gather[l][: -(-widths[l] // 16) * 16], dtype=np.int64), 32) for l in range(NH)]
-    cols = padded(np.arange(din), 16)
-    NOS, UPP = 3, 32
-    gathers, BASE = [], []
-    H_T0, H_T1, H_IN, H_BLK, H_OS, H_INIT, HS_OFF = [], [], [], [], [], [], [0]
-    CP_OS, CP_IS, CP_T0, CP_T1, CP_L = [], [], [], [], []
-    in_slot = [{h: h for h in range(len(cols) // 16)}]
-    pair_gp = [{}]
-    events = []
-    gpos = cursor = 0
-    HT32 = []
-    for l in range(NH):
-        rows = perms[l]
-        n_t, n_h = len(rows) // 32, len(cols) // 16
-        HT32.append(n_t)
-        in_width = din if l == 0 else widths[l - 1]
-
-        def kept(T, H):
-            for ot in (2 * T, 2 * T + 1):
-                if ot // 4 < n_otg and H < tm.shape[2] and (int(tm[l, ot // 4, H]) >> (ot % 4)) & 1:
-                    return True
-            return False
-
-        steps, blocks = [], []
-        for P in reversed(range(-(-n_t // 2))):
-            for H in reversed(range(n_h)):
-                ts = [T for T in (2 * P, 2 * P + 1) if T < n_t and kept(T, H)]
-                if not ts:
-                    continue
-                steps.append((ts[0], ts[1] if len(ts) > 1 else 255, H, len(blocks)))
-                for T in ts:
-                    blocks.append(image(rows[32 * T : 32 * T + 32], cols[16 * H : 16 * H + 16], in_width))
-        order = []
-        for (T0, _, _, _) in steps:
-            if T0 // 2 not in order:
-                order.append(T0 // 2)
-        if sorted(order) != list(range(-(-n_t // 2))):
-            return None  # an out pair without a single block (units that depend on nothing): left to the 8-wavefront kernel
-        cur = in_slot[l]
-        last_read = {h: -1 for h in cur}
-        last_step_of = {}
-        for i, (T0, _, H, _) in enumerate(steps):
-            last_read[H] = i
-            last_step_of[T0 // 2] = i
-        nxt, taken, gp_of = {}, set(), {}
-        n_next = -(-widths[l] // 16)  # half-tiles the next layer reads
-        for P in order:
-            busy = {cur[h] for h in cur if last_read[h] > last_step_of[P]} | taken
-            for k in range(4):
-                hn = 4 * P + k
-                if hn >= n_next:
-                    continue
-                want = cur.get(hn)
-                slot = want if (want is not None and want not in busy) else min(x for x in range(64) if x not in busy)
-                nxt[hn] = slot
-                taken.add(slot)
-                busy.add(slot)
-        in_slot.append(nxt)
-        for P in order:
-            gp_of[P] = gpos
-            CP_OS.append(gpos % NOS), CP_T0.append(2 * P), CP_T1.append(2 * P + 1 if 2 * P + 1 < n_t else 255), CP_L.append(l)
-            CP_IS += [nxt.get(4 * P + k, 255) for k in range(4)]
-            gpos += 1
-        pair_gp.append(gp_of)
-        for i, (T0, T1, H, blk) in enumerate(steps):
-            P = T0 // 2
-            first = i == 0 or steps[i - 1][0] // 2 != P
-            H_T0.append(T0), H_T1.append(T1), H_IN.append(cur[H]), H_BLK.append(blk), H_OS.append(gp_of[P] % NOS), H_INIT.append(int(first))
-            if first:
-                events.append(("begin", gp_of[P]))
-            events.append(("step", None if l == 0 else pair_gp[l].get(H // 4)))
-            events += [("quad",)] * 6
-            if i == last_step_of[P]:
-                events.append(("complete", gp_of[P]))
-        HS_OFF.append(len(H_T0))
-        gathers.append(np.concatenate(blocks).astype(np.int32) if blocks else np.zeros(0, np.int32))
-        BASE.append(cursor)
-        cursor += 3 * len(blocks)
-        cols = rows if len(rows) % 16 == 0 else padded(rows, 16)
-        cols = padded(np.asarray(plan.bias_gather[l][: -(-widths[l] // 16) * 16], dtype=np.int64), 16)
-    # ---- last layer ------------------------------------------------------------------------------------------------------------
-    per_old = 4 * plan.layout.fpl
-    feat_sorted = [int(f) for f in plan.featmap]  # groups of per_old slots, -1 = padding
-    n_old = plan.n_groups
-    old_per_new = max(1, FG // per_old)
-    NG3 = -(-n_old // old_per_new)
-    fmap = -np.ones((NG3, 2, FPL3), dtype=np.int32)
-    bias_last = -np.ones((NG3, NT3, 32), dtype=np.int32)
-    need = []
-    n_h = len(cols) // 16
-    for g in range(NG3):
-        feats = []
-        bits = 0
-        for og in range(g * old_per_new, min(n_old, (g + 1) * old_per_new)):
-            feats += feat_sorted[og * per_old : (og + 1) * per_old]
-            bits |= int(plan.skip[NH * n_otg + og])
-        feats += [-1] * (FG - len(feats))
-        for hb in range(2):
-            for fi in range(FPL3):
-                fmap[g, hb, fi] = feats[hb * FPL3 + fi]
-        need.append([H for H in range(n_h) if bits >> H & 1])
-    last_rows = -np.ones((NG3, NT3, 32), dtype=np.int64)
-    for g in range(NG3):
-        for t in range(NT3):
-            for i in range(32):
-                hb, v = (i // 4) % 2, 4 * (i // 8) + i % 4
-                pidx = 16 * t + v
-                fi, j = divmod(pidx, TP)
-                if fi < FPL3 and j < total and fmap[g, hb, fi] >= 0:
-                    last_rows[g, t, i] = int(fmap[g, hb, fi]) * total + j
-        bias_last[g] = last_rows[g]
-    L_T0, L_T1, L_IN, L_BLK, LS_OFF, G_ORD = [], [], [], [], [0], []
-    blocks = []
-    cur = in_slot[NH]
-    in_width = widths[NH - 1]
-    for g in reversed(range(NG3)):
-        events.append(("group", g))
-        for H in reversed(need[g]):
-            for t0 in range(0, NT3, 2):
-                t1_ = t0 + 1 if t0 + 1 < NT3 else 255
-                L_T0.append(t0), L_T1.append(t1_), L_IN.append(cur[H]), L_BLK.append(len(blocks))
-                for tt in (t0, t1_):
-                    if tt != 255:
-                        blocks.append(image(last_rows[g, tt], cols[16 * H : 16 * H + 16], in_width))
-                events.append(("step", pair_gp[NH].get(H // 4)))
-                events += [("quad",)] * 6
-        events.append(("group_end", g))
-        LS_OFF.append(len(L_T0))
-        G_ORD.append(g)
-    last_base = cursor
-    cursor += 3 * len(blocks)
-    ch = 24
-    n_chunks = -(-cursor // ch)
-    pad_blocks = -(-(n_chunks * ch - cursor) // 3)
-    gathers.append(np.concatenate(blocks + [-np.ones(512, dtype=np.int64)] * pad_blocks).astype(np.int32))
-    stream_images = max(n_chunks * ch, cursor + 3 * pad_blocks)
-    # ---- deal the conversion half-units and the maps' micro-steps to the quads (as split2_schedule) ------------------------------------
-    sp_total = FPL3 * len(costs)
-    nq = sum(1 for e in events if e[0] == "quad")
-    n_pairs = len(CP_OS)
-    release, deadline = [None] * n_pairs, [nq] * n_pairs
-    q = 0
-    groups = []
-    step_starts = []
-    for ev in events:
-        if ev[0] == "quad":
-            q += 1
-        elif ev[0] == "complete":
-            release[ev[1]] = q
-        elif ev[0] == "begin" and ev[1] - NOS >= 0:  # the slot's bias is requested one step ahead: the previous tenant is gone a step earlier
-            deadline[ev[1] - NOS] = min(deadline[ev[1] - NOS], max(0, q - 6))
-        elif ev[0] == "step":
-            if ev[1] is not None:
-                deadline[ev[1]] = min(deadline[ev[1]], q)
-        elif ev[0] == "group":
-            groups.append([q, 0])
-        elif ev[0] == "group_end":
-            groups[-1][1] = q - groups[-1][0]
-    stride = max(1, env_int("ZUKO_AMD_ARX2_CVSTRIDE", 3))  # at most one half-unit every `stride` duos (a duo hides ~10 instructions behind its two matrix instructions)
-    target = []
-    end_prev = 0.0
-    for gp in range(n_pairs):  # one pair after the other, each as slowly as its deadline (and `stride`) allows
-        start = max(float(release[gp]), end_prev)
-        step = max(0.0, min(float(stride), 0.9 * (deadline[gp] - start) / float(UPP)))
-        target += [int(start + j * step) for j in range(UPP)]
-        end_prev = start + UPP * step
-    # units are issued in order: a pair starts when the pair before it is through (pushed later), unless its deadline says otherwise (pulled earlier)
-    for u in range(1, len(target)):
-        target[u] = max(target[u], target[u - 1])
-    for u in range(len(target)):
-        target[u] = max(0, min(target[u], deadline[u // UPP] - 1))
-    for u in range(len(target) - 2, -1, -1):
-        target[u] = min(target[u], target[u + 1])
-    CVQ = [0] * (nq + 1)
-    for tq in target:
-        CVQ[tq + 1] += 1
-    for i in range(1, nq + 1):
-        CVQ[i] += CVQ[i - 1]
-    for gp in range(n_pairs):  # (a unit issued in quad tq reads accumulators that are complete when quad tq starts)
-        if any(target[gp * UPP + j] < release[gp] for j in range(UPP)):
-            return None
-    SPQ = []
-    for gi, (q0, n) in enumerate(groups):
-        SPQ.append(0)
-        if gi == 0 or n == 0:
-            SPQ += [0] * n
-            continue
-        cnt = [0] * n
-        for k in range(sp_total):
-            cnt[min(n - 1, (k * n) // sp_total)] += 1
-        a_ = 0
-        for c in cnt:
-            a_ += c
-            SPQ.append(a_)
-    NSLOT = 1 + max(max(d.values()) for d in in_slot if d)
-    D = plan.features
-    xs = ((D + 3) // 4) * 4 + 4
-    bias_floats = plan.bias_off[NH] + NG3 * NT3 * 32
-    lds = (3 * 24 * 256 + bias_floats + NG3 * 2 * FPL3 + 128 * xs) * 4
-    if lds > 160 * 1024 or NSLOT * 12 > 216 or max(HT32) > 8:
-        return None
-    t = {"v3": 1, "uni": int(uni_kind), "ACT": int(act), "D": int(D), "DIN": int(t1["DIN"]), "NIH0": len(in_slot[0]), "NH": int(NH), "HT32": HT32, "NSLOT": NSLOT, "NOS": NOS,
-         "NG3": NG3, "NT3": NT3, "TP": TP, "FPL3": FPL3, "BIAS_STRIDE": int(t1["BIAS_STRIDE"]), "BIAS_LAST": int(plan.bias_off[NH]), "BIAS_FLOATS": int(bias_floats),
-         "H_T0": H_T0, "H_T1": H_T1, "H_IN": H_IN, "H_BLK": H_BLK, "H_OS": H_OS, "H_INIT": H_INIT, "HS_OFF": HS_OFF,
-         "CP_OS": CP_OS, "CP_IS": CP_IS, "CP_T0": CP_T0, "CP_T1": CP_T1, "X_SLOT": [in_slot[0][h] for h in sorted(in_slot[0])],
-         "L_T0": L_T0, "L_T1": L_T1, "L_IN": L_IN, "L_BLK": L_BLK, "LS_OFF": LS_OFF, "G_ORD": G_ORD, "CVQ": CVQ, "SPQ": SPQ, "SP_TOTAL": sp_total,
-         "BASE": BASE, "LAST_BASE": last_base, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images, "FILL": fill, "CH": ch, "NR": 3}
-    if os.environ.get("ZUKO_AMD_STATIC_CXXFLAGS"):  # probe / ablation builds get a signature of their own (same variable at build and at run time)
-        t["probe"] = os.environ["ZUKO_AMD_STATIC_CXXFLAGS"]
-    out = (t, gathers, bias_last.reshape(-1), fmap.reshape(-1))
-    plan._split3_cache = (key, out)
-    return out
-
-
-def emit_split3(t: dict) -> str:
-    lines = [
-        "// generated by zuko_amd/static_ar.py — do not edit",
-        '#include "fused_ar_split3_impl.h"',
-        "namespace {",
-        "struct Shape {",
-        f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIH0 = {t['NIH0']}, NH = {t['NH']}, NSLOT = {t['NSLOT']}, NOS = {t['NOS']}, NG3 = {t['NG3']}, NT3 = {t['NT3']}, TP = {t['TP']}, FPL3 = {t['FPL3']};",
-        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, BIAS_LAST = {t['BIAS_LAST']}, BIAS_FLOATS = {t['BIAS_FLOATS']}, LAST_BASE = {t['LAST_BASE']}, NCHUNK = {t['NCHUNK']};",
-        f"  static constexpr int CH = {t['CH']}, NR = {t['NR']}, ACT = {t['ACT']}, SP_TOTAL = {t['SP_TOTAL']}, FILL = {t['FILL']};",
-        _arr("HT32", "int", t["HT32"]), _arr("BASE", "int", t["BASE"]), _arr("HS_OFF", "int", t["HS_OFF"]), _arr("LS_OFF", "int", t["LS_OFF"]),
-        _arr("H_T0", "unsigned char", t["H_T0"]), _arr("H_T1", "unsigned char", t["H_T1"]), _arr("H_IN", "unsigned char", t["H_IN"]), _arr("H_BLK", "short", t["H_BLK"]),
-        _arr("H_OS", "unsigned char", t["H_OS"]), _arr("H_INIT", "unsigned char", t["H_INIT"]),
-        _arr("CP_OS", "unsigned char", t["CP_OS"]), _arr("CP_IS", "unsigned char", t["CP_IS"]), _arr("X_SLOT", "unsigned char", t["X_SLOT"]),
-        _arr("L_T0", "unsigned char", t["L_T0"]), _arr("L_T1", "unsigned char", t["L_T1"]), _arr("L_IN", "unsigned char", t["L_IN"]), _arr("L_BLK", "short", t["L_BLK"]),
-        _arr("G_ORD", "unsigned char", t["G_ORD"]), _arr("CVQ", "short", t["CVQ"]), _arr("SPQ", "short", t["SPQ"]),
-        "};",
-        "}  // namespace",
-        f'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {{ return train ? ZK_EINVAL : zk::arx3_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, stream); }}',
-        "",
-    ]
-    return "\n".join(lines)
-
-
-def compile_split3(t: dict, verbose: bool = False, out_dir: str | None = None) -> dict | None:
-    """Build ary_<sig>.so, the 32-sample operand-split kernel of tables `t` (split3_tables); returns its meta or None."""
-    stamp = _header_digest()
-    sig = _digest({"split3": t, "headers": stamp})
-    meta = {"so": f"ary_{sig}.so", "core": "y" + _digest(t), "split": 1, "v3": 1, "l0": [], "alt": None, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"],
-            "NCHUNK": t["NCHUNK"], "XLDS": 1}
-    so = _build_so(f"ary_{sig}", lambda: emit_split3(t), meta, verbose, out_dir)
-    if so is None:
-        return None
-    global _INDEX
-    _INDEX = None
-    return dict(meta, dir=os.path.dirname(so))
-
-
-def lookup3(plan, uni_kind: int, act: int, rows: int | None = None):
-    """The 32-sample operand-split kernel of this plan (StaticKernel) or None: found on disk, or compiled when `rows` reaches the JIT threshold."""
-    if os.environ.get("ZUKO_AMD_NO_STATIC_AR", "0") == "1" or not split_enabled():
-        return None
-    ts = split3_tables(plan, uni_kind, act)
-    if ts is None:
-        return None
-    cd = "y" + _digest(ts[0])
-    with _LOCK:
-        idx = _INDEX if _INDEX is not None else _scan()
-        for meta in idx.get(cd, []):
-            return _load(meta)
-    if rows is not None and rows >= jit_min_rows() and jit_enabled():
-        meta = compile_split3(ts[0], verbose=os.environ.get("ZUKO_AMD_JIT_VERBOSE", "0") == "1")
-        if meta is not None:
-            with _LOCK:
-                return _load(meta)
-    return None
 
 
 def emit_split(t: dict) -> str:
@@ -683,7 +313,7 @@ def emit_split(t: dict) -> str:
         f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, NR = {t['NR']}, ACT = {t['ACT']};",
         f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = false, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
         _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
-        _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]), _arr("G_ORD", "unsigned char", t["G_ORD"]),
+        _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
         "};",
         "}  // namespace",
         f'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {{ return zk::arx_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, train, stream); }}',
@@ -1157,7 +787,7 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
                     os.remove(os.path.join(ARS_DIR, name))
                 except OSError:
                     pass
-    work, chains, splits, splits3 = [], [], [], []
+    work, chains, splits = [], [], []
     for entry in PREBUILT:
         kind, features, context, hidden, bins = entry[:5]
         import torch
@@ -1175,9 +805,6 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
             ts = split_tables(pl, layout.kind, act)
             if ts is not None and not any(x == ts[0] for x in splits):
                 splits.append(ts[0])
-            t3 = split3_tables(pl, layout.kind, act)
-            if t3 is not None and not any(x == t3[0] for x in splits3):
-                splits3.append(t3[0])
         ta, td = tables(pa, layout.kind, act), tables(pd, layout.kind, act)
         if ta is None or td is None:
             raise RuntimeError(f"zuko_amd.static_ar: no static kernel for the prebuilt shape {entry}")
@@ -1203,7 +830,6 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
         metas = list(ex.map(lambda w: compile_kernel(w[0], w[1], verbose, ARS_DIR), work))
         kerns = list(ex.map(lambda tg: chain_kernel(tg[0], True, verbose, ARS_DIR), chains))
         xmetas = list(ex.map(lambda t: compile_split(t, verbose, ARS_DIR), splits))
-        xmetas += list(ex.map(lambda t: compile_split3(t, verbose, ARS_DIR), splits3))
     if any(m is None for m in metas + xmetas) or any(k is None for k in kerns):
         raise RuntimeError("zuko_amd.static_ar: a prebuilt static kernel failed to compile")
     return [m["so"] for m in metas + xmetas] + [os.path.basename(k.so) for k in kerns]
