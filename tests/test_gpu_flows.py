@@ -1018,3 +1018,42 @@ def test_composed_flow_accumulates_ladj_inside_the_kernels(dev, kind):
     assert torch.equal(torch.isnan(total), torch.isnan(ref)) and torch.equal(total[ok], ref[ok])
     assert torch.equal(torch.nan_to_num(z), torch.nan_to_num(v))
     assert all(hasattr(t, "call_and_accumulate_ladj") for t in tr.transforms if type(t).__name__.startswith("Fused")) or True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [129, 40000])
+def test_sixteen_bin_spline_runs_on_a_split_kernel(dev, N, monkeypatch):
+    """NSF(bins=16) (zuko/flows/spline.py:48-62 with bins=16): the twelve accumulator tiles of a feature group do not fit the f32-instruction
+    static template, but the operand-split template holds them — the conditioner gets a generated split kernel (prebuilt for the headline
+    shape) instead of staying on the generic f32 kernel.  Same bar as the other split kernels: as close to float64 as the generic f32
+    kernel is (C = 2), identical NaN pattern on poisoned rows."""
+    from zuko_amd.flows import NSF
+    from zuko_amd.nn import MaskedLinear
+
+    D = 64
+    monkeypatch.setenv("ZUKO_AMD_JIT", "0")  # the prebuilt kernel, not a compile on the box
+    torch.manual_seed(3)
+    flow = NSF(D, 0, transforms=2, bins=16, hidden_features=[256] * 3).to(dev)
+    g = torch.Generator().manual_seed(N)
+    inp = torch.randn(N, D, generator=g) * 1.5
+    inp[5, 7] = float("nan")
+    inp[100, D - 1] = float("inf")
+    inp[101, 0] = 9.0
+    x_cpu = inp.clone()
+    inp = inp.to(dev)
+    for i, lazy in enumerate(flow.transform.transforms):
+        st = lazy.fused_state(dev)
+        assert st is not None and st.ready(N) and st.static is not None and st.static[0].meta.get("split") == 1 and st.static[0].meta["uni"] == 3
+        lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+        st.refresh(lins)
+        y, ladj = _run_static(st, inp, N, D, dev)
+        keep, st.static = st.static, None
+        y0, ladj0 = _run_static(st, inp, N, D, dev)
+        st.static = keep
+        uni = O.uni_rqs(16)
+        with torch.no_grad():
+            phi = O.mlp_forward(x_cpu.double(), [l.weight.detach().cpu().double() for l in lins], [l.bias.detach().cpu().double() for l in lins], [l.mask.cpu() for l in lins], act=torch.relu)
+            y64, l64 = O.univariate_forward(uni, phi.reshape(N, D, uni.total), x_cpu.double())
+            l64 = l64.sum(dim=-1)
+        assert_parity(y, y0, y64, f"16-bin split kernel N={N} transform {i}: y", c=2.0)
+        assert_parity(ladj, ladj0, l64, f"16-bin split kernel N={N} transform {i}: ladj", c=2.0)

@@ -37,7 +37,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
 ARS_ABI = 4  # == ARS_ABI of csrc/zk_ar_common.h
-UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 4: "zk::UniCircRqs8"}  # (16 bins: 12 accumulator tiles per group do not fit the double-buffered last layer)
+UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 3: "zk::UniRqs16", 4: "zk::UniCircRqs8"}
+# 16 bins: the twelve accumulator tiles of a feature group do not fit the f32-instruction template's double-buffered last layer (it would
+# spill), but the operand-split template holds them (255 VGPRs, no scratch): that kind exists as a split kernel only, forward only
+SPLIT_ONLY_KINDS = {3}
 _HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
 
 
@@ -190,7 +193,7 @@ def tables(plan, uni_kind: int, act: int = 1) -> dict | None:
         "uni": int(uni_kind), "ACT": int(act), "D": int(D), "DIN": int(din4), "NIT": int(NIT), "NH": int(NH), "HT": HT, "TMAX": int(TMAX), "NG": int(plan.n_groups),
         "NCHUNK": int(plan.fine_n_chunks), "BIAS_STRIDE": int(plan.max_width), "NS": NS, "S_OTG": S_OTG, "S_IT": S_IT, "S_MASK": S_MASK,
         "BASE": [int(b) for b in plan.fine_layer_block0[:NH]], "LAST_BASE": int(plan.fine_layer_block0[NH]), "GOFF": GOFF, "G_IT": G_IT,
-        "WAVES": waves, "XLDS": xlds, "TRAIN_OK": int(act == 1 and NH <= 3 and waves == 8 and all(w % 16 == 0 for w in widths)),
+        "WAVES": waves, "XLDS": xlds, "TRAIN_OK": int(act == 1 and NH <= 3 and waves == 8 and all(w % 16 == 0 for w in widths) and uni_kind not in SPLIT_ONLY_KINDS),
     }
 
 
@@ -486,6 +489,8 @@ def lookup(plan, uni_kind: int, act: int, rows: int | None = None):
                 if meta is not None:
                     with _LOCK:
                         return _load(meta), 0
+    if uni_kind in SPLIT_ONLY_KINDS:
+        return None
     core, l0 = _split(t)
     cd = _digest(core)
     with _LOCK:
@@ -720,6 +725,7 @@ PREBUILT = [
     ("rqs", 24, 8, (384, 512, 320), 8),
     ("rqs", 16, 2, (64, 64), 8, "ELU"),
     ("affine", 12, 0, (48, 32), 0, "Tanh"),
+    ("rqs", 64, 0, (256, 256, 256), 16),   # NSF(bins=16): operand-split kernel only (SPLIT_ONLY_KINDS)
 ]
 
 
@@ -796,7 +802,7 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
 
         act = _act_code(getattr(torch.nn, entry[5])()) if len(entry) > 5 else 1
         (pa, layout, lins_a), (pd, _, lins_d) = _plans_for(kind, features, context, hidden, bins)
-        if act == 1:  # the training backward of the same conditioners (one kernel per feature order)
+        if act == 1 and layout.kind not in SPLIT_ONLY_KINDS:  # the training backward of the same conditioners (one kernel per feature order)
             for lins in (lins_a, lins_d):
                 for tg in (chain_tables_for(lins), chain_tables_for(lins, full=True)):
                     if tg is not None and not any(c[0] == tg[0] for c in chains):
@@ -805,6 +811,8 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
             ts = split_tables(pl, layout.kind, act)
             if ts is not None and not any(x == ts[0] for x in splits):
                 splits.append(ts[0])
+        if layout.kind in SPLIT_ONLY_KINDS:
+            continue  # (no f32-instruction kernel, no training chain for this kind)
         ta, td = tables(pa, layout.kind, act), tables(pd, layout.kind, act)
         if ta is None or td is None:
             raise RuntimeError(f"zuko_amd.static_ar: no static kernel for the prebuilt shape {entry}")
