@@ -8,14 +8,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bin-report"
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bin-report --no-side-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 tail -2 $OUT/trace.log
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 head -12 $OUT/kernel_stats.csv
 pmc() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bin-report > $OUT/pmc_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bin-report --no-side-configs > $OUT/pmc_$name.log 2>&1
   find $OUT/pmc_$name -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$name.csv \;
   python $ROOT/scripts/summarize_pmc.py $OUT/pmc_$name.csv | tee $OUT/pmc_$name.summary.txt
 }

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""profiles/<tag>/traffic.json (+ the summaries it is made of) from gpurun_out/prof_<tag>/ (scripts/gpu_profile.sh): HBM bytes per launch of
+the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes (gfx950 read-side correction of MI355X_MICROARCH.md: x 2), matrix-pipe and wave
+counters, kernel-trace average.        python scripts/make_traffic_json.py r04"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+KERNEL = "arx_kernel"  # dominant kernel: zk::arx_kernel<Shape, UniRqs<8, false>, false, false>
+
+
+def counters(name):
+    out = {}
+    path = os.path.join(src, f"pmc_{name}.summary.txt")
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        parts = line.split()
+        if len(parts) >= 4 and KERNEL in line:  # summarize_pmc.py cuts names: the bench workload launches this one arx instantiation only
+            out[parts[-4]] = float(parts[-1].split("=")[1])
+    shutil.copy(path, os.path.join(dst, f"pmc_{name}.txt"))
+    return out
+
+
+c = {}
+for n in ("fetch", "write", "sq", "lds", "act", "ifetch"):
+    c.update(counters(n))
+stats = {}
+ks = os.path.join(src, "kernel_stats.csv")
+if os.path.exists(ks):
+    shutil.copy(ks, os.path.join(dst, "kernel_trace_stats.csv"))
+    for row in csv.DictReader(open(ks)):
+        if KERNEL in row["Name"] and "UniRqs<8, false>, false, false" in row["Name"]:
+            stats = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6, "min_ms": float(row["MinNs"]) / 1e6}
+B, D = 1 << 20, 64
+alg = B * (2 * D * 4 + 4)
+out = {
+    "kernel": "zk::arx_kernel<Shape, zk::UniRqs<8, false>, false, false> (generated operand-split static-shape instantiation of zk_ar_forward)",
+    "workload": "NSF(64, T=8, K=8, H=[256]*3) log_prob, batch 2^20, one transform per launch",
+    "source": f"rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1` (scripts/gpu_profile.sh {tag}), mean per dispatch; raw rows in pmc_*.txt",
+    "FETCH_SIZE_KiB": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB": c.get("WRITE_SIZE"),
+    "correction": "gfx950 FETCH_SIZE counts 128-B requests at 64 B for 16 B/lane streams (MI355X_MICROARCH.md, HBM section): read side x2; WRITE_SIZE taken as is",
+    "hbm_bytes_per_launch": None if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c else int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+    "algorithmic_bytes_per_launch": alg,
+    "kernel_trace": stats,
+}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+    g = c.get("GRBM_GUI_ACTIVE")
+    cyc = None if not g else g / 8.0  # summed over the 8 XCDs
+    out["mfma"] = {"SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_INSTS_MFMA": c.get("SQ_INSTS_MFMA"), "SQ_VALU_MFMA_COEXEC_CYCLES": c.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
+                   "busy_cycles_per_simd": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, "launch_cycles": cyc,
+                   "busy_frac": None if not cyc else c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc,
+                   "coexec_share_of_busy": None if not c.get("SQ_VALU_MFMA_COEXEC_CYCLES") else c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"],
+                   "note": "16 busy cycles per v_mfma_f32_16x16x32_bf16; the instruction form issues at 26 nominal cycles per instruction at best (profiles/r04/mfma32_probe.txt): a busy fraction of 0.62 IS that ceiling"}
+out["waves"] = {k: c[k] for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_IFETCH") if k in c}
+out["lds"] = {k: c[k] for k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS") if k in c}
+json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "kernel_trace")}), out.get("mfma", {}).get("busy_frac"))
