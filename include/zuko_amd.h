@@ -224,7 +224,8 @@ int zk_ar_forward_diag(const zk_ar_args_v1* args, void* stream);
 int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream);
 /* The same chain from the gradient of the packed parameters: x [N, DIN = features * total] (row stride ldx) = d loss / d phi, and the
  * dgrad of the LAST linear layer is part of the launch (its K = features * total input is streamed from global memory, each element read
- * once).  h1 .. h_{n-1} (read) / gh1 .. gh_{n-1} (written) cover all hidden layers; y [N, D] = gradient w.r.t. the conditioner's input.
+ * once).  h1 .. h_{n-1} (read) / gh1 .. gh_{n-1} (written) cover all hidden layers; y [N, D] = gradient w.r.t. the conditioner's input
+ * (accumulate != 0: ADDED to what y holds — the univariate map's own d/dx term of an autoregressive transform).
  * `launcher` = zk_ars_dgrad_launch of an operand-split chain kernel (zuko_amd/static_ar.py: chain_split_tables; the products run on the
  * bf16 matrix instruction with every f32 operand split three ways, as zk_gather_split_bf16 describes). */
 int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream);
@@ -352,7 +353,9 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream);
  * net(x) in module order (what the last MaskedLinear of zuko/nn.py:221-318 returns) and the hidden activations h_l [N, width_l]
  * (n_layers - 1 <= 3 of them; h2 / h3 may be NULL beyond that) with the units in the stream's dependency-sorted order, which the
  * mask-aware dgrad / wgrad kernels consume.  Same launcher, per-tile stream, bias image, feature map and chunk count as
- * zk_ar_forward_static; the univariate map is not evaluated. */
+ * zk_ar_forward_static.  y == NULL: the univariate map is not evaluated; y != NULL (operand-split kernels): the same launch also writes
+ * y [N, D] and ladj [N] as zk_ar_forward_static does (reads y, ldy, ladj, accumulate, bound, slope as well), so that a training step
+ * reads phi back only in its backward pass. */
 int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */

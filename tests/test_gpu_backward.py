@@ -266,3 +266,46 @@ def test_bf16_module_trains(dev):
     bf.zero_grad()
     bf(c[:8].to(torch.bfloat16)).rsample().float().square().sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in bf.parameters())
+
+
+def _graph_nodes(fn, seen=None):
+    seen = set() if seen is None else seen
+    if fn is None or fn in seen:
+        return seen
+    seen.add(fn)
+    for nxt, _ in fn.next_functions:
+        _graph_nodes(nxt, seen)
+    return seen
+
+
+@pytest.mark.parametrize("name", ["nsf_cfg2", "maf_cfg3"])
+def test_training_step_is_one_autograd_node_per_transform(dev, name, monkeypatch):
+    """The headline flows train through zuko_amd/train.py:AutoregressiveFn — conditioner, univariate map and log|det J| of a transform as
+    ONE node (forward one launch, phi read back only by the backward) — and get the gradients of the two-node path
+    (ZUKO_AMD_NO_FUSED_AR_TRAIN=1: ConditionerFn + UnivariatePackedFn) to rounding."""
+    flow, entry = build_flow(name)
+    flow = flow.to(dev)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(777, entry[1]["features"], generator=gen).to(dev)
+
+    def step(x_req):
+        flow.zero_grad()
+        xg = x.clone().requires_grad_(x_req)
+        loss = -flow().log_prob(xg).mean()
+        names = {type(f).__name__ for f in _graph_nodes(loss.grad_fn)}
+        loss.backward()
+        return loss.item(), names, {k: p.grad.clone() for k, p in flow.named_parameters()}, xg.grad
+
+    loss_f, names_f, grads_f, gx_f = step(True)
+    assert "AutoregressiveFnBackward" in names_f and "ConditionerFnBackward" not in names_f and "UnivariatePackedFnBackward" not in names_f, names_f
+    loss_n, names_n, grads_n, _ = step(False)  # (x without gradient: the usual training step)
+    assert "AutoregressiveFnBackward" in names_n
+    monkeypatch.setenv("ZUKO_AMD_NO_FUSED_AR_TRAIN", "1")
+    loss_u, names_u, grads_u, gx_u = step(True)
+    assert "AutoregressiveFnBackward" not in names_u and "ConditionerFnBackward" in names_u
+    assert abs(loss_f - loss_u) < 1e-5 * max(1.0, abs(loss_u)) and abs(loss_n - loss_u) < 1e-5 * max(1.0, abs(loss_u))
+    for k, g in grads_u.items():
+        scale = g.abs().max().clamp_min(1e-6)
+        assert ((grads_f[k] - g).abs().max() / scale).item() < 2e-5, k
+        assert ((grads_n[k] - g).abs().max() / scale).item() < 2e-5, k
+    assert ((gx_f - gx_u).abs().max() / gx_u.abs().max()).item() < 2e-5

@@ -618,8 +618,9 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
   return ar_launch_v1(part, false, p, stream);
 }
 
-// Conditioner-only (training) launch of a generated static-shape kernel: phi [N, D * total] = net(x) in module order plus the hidden
-// activations h_l [N, width_l] (up to three; units in the stream's sorted order), for the backward pass of zuko_amd/train.py.
+// Training launch of a generated static-shape kernel: phi [N, D * total] = net(x) in module order plus the hidden activations
+// h_l [N, width_l] (up to three; units in the stream's sorted order), for the backward pass of zuko_amd/train.py.  With y != NULL (operand-split
+// kernels only) the same launch also yields y [N, D] and ladj [N] as zk_ar_forward_static does (bound, slope, accumulate are read then).
 int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
   if (!ar_args_ok(args) || !args->launcher || !args->phi || !args->h1) return ZK_EINVAL;
   const int n_layers = args->n_layers;
@@ -629,7 +630,10 @@ int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
   part.static_fn = args->launcher; part.rev = args->rev;
   part.act_out[0] = (float*)args->h1; part.act_out[1] = (float*)args->h2; part.act_out[2] = (float*)args->h3; part.phi_out = (float*)args->phi; part.ldphi = args->ldphi;
   zk_ar_args_v1 p = *args;
-  p.act = 1; p.skip = nullptr; p.y = nullptr; p.ldy = 0; p.ladj = nullptr; p.accumulate = 0; p.bound = 1.0; p.slope = 1e-3;
+  p.act = 1; p.skip = nullptr;
+  if (!p.y) {  // conditioner only
+    p.ldy = 0; p.ladj = nullptr; p.accumulate = 0; p.bound = 1.0; p.slope = 1e-3;
+  }
   return ar_launch_v1(part, false, p, stream);
 }
 
@@ -671,7 +675,7 @@ int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream) {
   ArArgs a{};
   a.x = (const float*)args->x; a.ldx = args->ldx; a.N = args->N; a.D = args->D; a.DIN = args->DIN; a.L = n; a.n_chunks = args->n_chunks;
   a.stream = (const float*)args->wstream;
-  a.phi_out = (float*)args->y; a.ldphi = args->ldy;
+  a.phi_out = (float*)args->y; a.ldphi = args->ldy; a.accumulate = args->accumulate;
   for (int c = 0; c + 1 < n; ++c) {  // chain layer c gates with (and yields the gradient of) hidden layer n - 1 - c (1-based)
     a.gate[c] = (const float*)hs[n - 2 - c];
     a.act_out[c] = (float*)gs[n - 2 - c];

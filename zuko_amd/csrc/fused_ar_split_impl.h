@@ -137,7 +137,7 @@ template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ voi
   }
 }
 
-// TRAIN: conditioner only — the hidden activations and phi are stored for the backward pass (zuko_amd/train.py).
+// TRAIN: the hidden activations and phi are stored for the backward pass (zuko_amd/train.py); y / ladj only when a.y is given.
 // DIAG: the diagnostic twin of the product launch (same arithmetic, same instruction order up to two extra stores per feature): also
 // writes the bin index the spline USED and the search-axis knots it searched (bin_out [N, D], knots_out [N, D, NKNOT]), as
 // zk_ar_forward_diag does for the generic kernel — the parity bar on the bin index is asserted on the product path (tests/test_gpu_bins.py).
@@ -148,7 +148,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
   constexpr int NG = S::NG;
   constexpr int NSTEP = S::GOFF[NG];  // (group, in pair) steps of the last layer, NT blocks each
   constexpr bool XLDS = S::XLDS;
-  constexpr bool FID_REGS = NG * FPL <= 32;
+  constexpr bool FID_REGS = NG * FPL <= 32 && !TRAIN;  // (the training instantiation holds phi for its stores as well: the feature ids stay in LDS there)
   constexpr int DT = (S::D + 15) / 16;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -179,6 +179,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
       for (int fi = 0; fi < FPL; ++fi) fids[i * FPL + fi] = fmap_lds[(i * 4 + q) * FPL + fi];
   }
 
+  const bool uni_on = !TRAIN || a.y != nullptr;  // (training launch: y, ladj beside phi and the activations when the caller passes y)
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n = tile * (16 * WAVES) + wave * 16 + j;
     const bool live = n < a.N;
@@ -273,7 +274,8 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
             for (int i = 0; i < TOTAL; ++i) dst[i] = p[fi * TOTAL + i] + poison;
           }
         }
-      } else {
+      }
+      if (uni_on) {
 #pragma unroll
         for (int fi = 0; fi < FPL; ++fi) Uni::template poison<false>(p, fi * TOTAL, poison);
         auto ld = [&](int i) { return p[i]; };
@@ -304,16 +306,16 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
         }
       }
     });
-    if constexpr (XLDS && !TRAIN) {
+    if constexpr (XLDS) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      if (live) {
+      if (live && uni_on) {
 #pragma unroll
         for (int it = 0; it < DT; ++it)
           if ((it + 1) * 16 <= S::D || it * 16 + 4 * q < S::D) *reinterpret_cast<f32x4*>(a.y + n * a.ldy + it * 16 + 4 * q) = *reinterpret_cast<const f32x4*>(xr + it * 16 + 4 * q);
       }
     }
-    if (!TRAIN && a.ladj) {
+    if (uni_on && a.ladj) {
       lacc += __shfl_xor(lacc, 16, 64);
       lacc += __shfl_xor(lacc, 32, 64);
       if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
@@ -402,10 +404,13 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arxd_stack
 #pragma unroll
       for (int p = 0; p < (HTL + 1) / 2; ++p) arx_split(out[2 * p], 2 * p + 1 < HTL ? out[2 * p + 1] : zero, in[p]);
       arxd_stack<S, L + 1, Ring>(ring, zero_q, q, in, out, a, n, nc, live);
-    } else if (live) {  // gradient w.r.t. the conditioner's input: module column order, DOUT columns
+    } else if (live) {  // gradient w.r.t. the conditioner's input: module column order, DOUT columns (accumulate: added to what the buffer holds)
 #pragma unroll
       for (int t = 0; t < HTL; ++t)
-        if ((t + 1) * 16 <= S::DOUT || t * 16 + 4 * q < S::DOUT) *reinterpret_cast<f32x4*>(a.phi_out + n * a.ldphi + t * 16 + 4 * q) = out[t];
+        if ((t + 1) * 16 <= S::DOUT || t * 16 + 4 * q < S::DOUT) {
+          f32x4* dst = reinterpret_cast<f32x4*>(a.phi_out + n * a.ldphi + t * 16 + 4 * q);
+          *dst = a.accumulate ? *dst + out[t] : out[t];
+        }
     }
   }
 }
@@ -471,7 +476,7 @@ template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi
   if (train && (!S::TRAIN_OK || !a.phi_out)) return ZK_EINVAL;
   a.n_tiles = (a.N + 16 * S::WAVES - 1) / (16 * S::WAVES);
   a.xs = ((S::D + 3) / 4) * 4 + 4;
-  const bool vec_ok = (S::D % 4 == 0) && (train || ((a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0)));
+  const bool vec_ok = (S::D % 4 == 0) && ((train && !a.y) || ((a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0)));
   if (S::XLDS != 0 && !vec_ok) return ZK_EINVAL;
   a.xlds = S::XLDS;
   const int lds = (S::NR * S::CH * AR_TF + a.bias_floats + 1024 + 256 + (S::XLDS ? S::WAVES * 16 * a.xs : 0)) * (int)sizeof(float);

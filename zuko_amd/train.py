@@ -279,21 +279,26 @@ def _fused_forward_state(plan: "SortedPlan", lins, device):
     return st or None
 
 
-def _fused_forward(st, x: Tensor, out_features: int):
+def _fused_forward(st, x: Tensor, out_features: int, uni=None):
     """([h_1, ...] sorted-domain hidden activations, phi) from one launch of zk_ar_forward_train (a static-shape kernel of
-    zuko_amd/static_ar.py in its conditioner-only instantiation)."""
+    zuko_amd/static_ar.py in its training instantiation).  uni = (bound, slope) (operand-split kernels): the launch also evaluates the
+    univariate map, and (hs, phi, y, ladj) is returned."""
     p = st.plan
     N = x.shape[0]
     hs = [torch.empty((N, w), dtype=torch.float32, device=x.device) for w in p.widths]
     phi = torch.empty((N, out_features), dtype=torch.float32, device=x.device)
     kern, rev = st.static
     hp = [_ptr(h) for h in hs] + [None] * (3 - len(hs))
+    extra = {}
+    if uni is not None:
+        y, ladj = torch.empty((N, p.features), dtype=torch.float32, device=x.device), torch.empty(N, dtype=torch.float32, device=x.device)
+        extra = dict(y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), bound=float(uni[0]), slope=float(uni[1]))
     a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
                 phi=_ptr(phi), ldphi=out_features, wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap), n_layers=p.n_layers,
-                n_groups=p.n_groups, n_chunks=st.fine_n_chunks, act=1)
+                n_groups=p.n_groups, n_chunks=st.fine_n_chunks, act=1, **extra)
     err = _C.lib().zk_ar_forward_train(a, _stream())
     _C.check(err, "zk_ar_forward_train")
-    return hs, phi
+    return (hs, phi) if uni is None else (hs, phi, y, ladj)
 
 
 class DgradChain:
@@ -321,19 +326,21 @@ class DgradChain:
         _C.gather_multi(items, _stream())
         return stream
 
-    def run(self, plan: SortedPlan, stream: Tensor, g_in: Tensor, hs):
+    def run(self, plan: SortedPlan, stream: Tensor, g_in: Tensor, hs, gx_add: Tensor | None = None):
         """g_in: gradient of the packed parameters [N, out_features] (full) or of the last hidden layer's pre-activations [N, width];
-        hs = [x, h_1, ..] as saved by the forward.  Returns ([g_1, .., g_{n-1}] gradients of the hidden pre-activations, gx)."""
+        hs = [x, h_1, ..] as saved by the forward.  Returns ([g_1, .., g_{n-1}] gradients of the hidden pre-activations, gx).
+        gx_add (full chains): a [N, in] contiguous tensor the input gradient is ADDED to in place (and which is returned as gx)."""
         n = len(plan.shapes)
         N = g_in.shape[0]
         dev = g_in.device
         n_out = n - 1 if self.full else n - 2
         gs = [torch.empty((N, plan.shapes[l][0]), dtype=torch.float32, device=dev) for l in range(n_out)]
-        gx = torch.empty((N, plan.shapes[0][1]), dtype=torch.float32, device=dev)
+        gx = torch.empty((N, plan.shapes[0][1]), dtype=torch.float32, device=dev) if gx_add is None else gx_add
         hp = [_ptr(hs[1 + l]) for l in range(n_out)] + [None] * 3
         gp = [_ptr(g) for g in gs] + [None] * 3
         a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, N=N, D=plan.shapes[0][1], DIN=g_in.shape[1], x=_ptr(g_in), ldx=g_in.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
-                    gh1=gp[0], gh2=gp[1], gh3=gp[2], y=_ptr(gx), ldy=gx.stride(0), wstream=_ptr(stream), n_layers=n, n_chunks=self.t["NCHUNK"], act=1)
+                    gh1=gp[0], gh2=gp[1], gh3=gp[2], y=_ptr(gx), ldy=gx.stride(0), wstream=_ptr(stream), n_layers=n, n_chunks=self.t["NCHUNK"], act=1,
+                    accumulate=int(gx_add is not None and self.full))
         if self.full:
             _C.check(_C.lib().zk_ar_dgrad_full(a, _stream()), "zk_ar_dgrad_full")
             return gs, gx
@@ -471,6 +478,80 @@ class ConditionerFn(torch.autograd.Function):
         return (n <= 4 and os.environ.get("ZUKO_AMD_EXACT_F32", "0") != "1" and os.environ.get("ZUKO_AMD_NO_WGRAD_MULTI", "0") != "1"
                 and all(ctx.needs_input_grad[3 + 2 * l] and ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l] and plan.cs_flag[l] is not None and plan.pairs[l].shape[0] > 0
                         for l in range(n)))
+
+
+class AutoregressiveFn(torch.autograd.Function):
+    """(y, ladj) = univariate(net(x)).call_and_ladj(x) of one unconditional masked autoregressive transform
+    (zuko/flows/autoregressive.py:207-218 + zuko/transforms.py:966-992) as ONE autograd node: the forward is one launch (conditioner,
+    univariate map and the feature sum of log|dy/dx|; phi and the hidden activations are kept for the backward), the backward is the
+    univariate adjoint, one launch of the dgrad chain — which adds its input gradient to the adjoint's direct d/dx term — and the
+    two launches of the weight / bias gradients.  uni = (kind, bound, slope, sizes): kind 0 affine / 1 spline, sizes = widths of the
+    packed pieces.  Inputs after `x`: weight_0, bias_0, weight_1, ... (all trainable, see autoregressive())."""
+
+    @staticmethod
+    def forward(ctx, plan: SortedPlan, lins, st, chain, uni, x: Tensor, *params):
+        n = len(lins)
+        st.refresh(lins, fine_only=True)
+        stream = chain.gather(plan, lins)
+        acts, phi, y, ladj = _fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]))
+        ctx.plan, ctx.n, ctx.chain, ctx.uni = plan, n, chain, uni
+        ctx.save_for_backward(x, *acts, phi, stream)
+        return y, ladj
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, gl):
+        from .autograd import _adj_any
+
+        plan, n, chain = ctx.plan, ctx.n, ctx.chain
+        kind, bound, slope, sizes = ctx.uni
+        saved = ctx.saved_tensors
+        hs, phi, stream = saved[:n], saved[n], saved[n + 1]
+        x = hs[0]
+        N, D = x.shape
+        gy = torch.zeros_like(x) if gy is None else gy.contiguous()
+        gl = torch.zeros(N, dtype=torch.float32, device=x.device) if gl is None else gl.contiguous()
+        gx, gphi = _adj_any((kind, bound, slope, sizes, ()), x, phi.view(N, D, -1), gy, gl, True)
+        gphi = gphi.view(N, -1)
+        gs, gx = chain.run(plan, stream, gphi, hs, gx_add=gx)
+        res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else gphi, hs[l]) for l in range(n)])
+        grads = []
+        for l in range(n):
+            grads += list(res[l])
+        return (None, None, None, None, None, gx if ctx.needs_input_grad[5] else None, *grads)
+
+
+def autoregressive(module, uni, x: Tensor):
+    """(y, ladj) of an unconditional masked autoregressive transform under autograd through AutoregressiveFn, or None when this
+    conditioner / batch is not covered (then the caller composes ConditionerFn and the univariate map's own autograd node):
+    a masked ReLU (linear, activation)* stack with an operand-split static-shape kernel and its one-launch dgrad chain, every
+    weight and bias trainable, x [N, D] fp32 with 16-byte aligned rows.  ZUKO_AMD_NO_FUSED_AR_TRAIN=1 switches it off."""
+    import os
+
+    if os.environ.get("ZUKO_AMD_NO_FUSED_AR_TRAIN", "0") == "1" or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0):
+        return None
+    plan, lins = plan_for(module, x.device)
+    if plan is None or plan.act != 1 or x.shape[1] != plan.shapes[0][1] or sum(uni[3]) * x.shape[1] != plan.shapes[-1][0]:
+        return None
+    n = len(lins)
+    if not all(l.bias is not None and l.weight.requires_grad and l.bias.requires_grad and plan.cs_flag[i] is not None and plan.pairs[i].shape[0] > 0 for i, l in enumerate(lins)):
+        return None
+    if os.environ.get("ZUKO_AMD_EXACT_F32", "0") == "1" or os.environ.get("ZUKO_AMD_NO_WGRAD_MULTI", "0") == "1":
+        return None
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+        if x.stride(0) % 4 != 0:
+            return None
+    st = _fused_forward_state(plan, lins, x.device)
+    if st is None or not st.static[0].meta.get("split") or st.plan.layout.kind != uni[0]:
+        return None
+    chain = _dgrad_chain(plan, lins, x.shape[0]) if n >= 2 else None
+    if chain is None or not chain.full:
+        return None
+    params = []
+    for l in lins:
+        params += [l.weight, l.bias]
+    return AutoregressiveFn.apply(plan, lins, st, chain, uni, x, *params)
 
 
 def plan_for(module, device: torch.device):
