@@ -229,6 +229,17 @@ int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream);
  * `launcher` = zk_ars_dgrad_launch of an operand-split chain kernel (zuko_amd/static_ar.py: chain_split_tables; the products run on the
  * bf16 matrix instruction with every f32 operand split three ways, as zk_gather_split_bf16 describes). */
 int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream);
+/* The whole backward of ONE unconditional autoregressive transform y, ladj = univariate(net(x)).call_and_ladj(x) up to the weight
+ * gradients (what autograd derives from zuko/flows/autoregressive.py:207-218, zuko/transforms.py:436-446 / :480-490, :554-567 and
+ * zuko/nn.py:217-218), in one launch of a generated kernel (`launcher` = zk_ars_dgrad_launch of zuko_amd/static_ar.py:
+ * chain_split_tables(packed=...)):
+ *   reads   x [N, D] (ldx), phi [N, D * total] (ldphi: the forward's, zk_ar_forward_train), y_in = d loss / dy [N, D] (row stride ldo),
+ *           ladj = d loss / d ladj [N] (READ here), h1 .. h_{n-1} (the forward's hidden activations), wstream / n_chunks (the kernel's
+ *           stream of transposed weights), featmap / n_groups (the forward plan's), uni_kind (0 affine, 1 spline with 8 bins), bound, slope;
+ *   writes  x_out = d loss / d phi [N, D * total] (row stride ldphi; for the weight gradients), gh1 .. gh_{n-1}, y = d loss / dx [N, D]
+ *           (row stride ldy, a multiple of 4; accumulate != 0: added to what y holds) — the chain's input gradient plus the univariate
+ *           map's own d/dx term. */
+int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream);
 /* One sweep of AutoregressiveTransform._inverse (zuko/transforms.py:994-1000, the body of its loop):
  *     x_out = univariate(*unpack(MaskedMLP(x_cond))).inv(y)
  * x (= x_cond) [N, DIN] as for zk_ar_forward (features first, context after), y_in [N, D] (row stride ldy) the values to

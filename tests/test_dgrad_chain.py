@@ -99,20 +99,51 @@ def test_split_chain_tables_reproduce_the_whole_dgrad(cfg):
     """static_ar.chain_split_tables (the operand-split chain over ALL layers, csrc/fused_ar_split_impl.h: arxd_kernel) walked on the CPU:
     blocks of (out tile, in pair) as three bf16 images, six partial products per block, layer 0 in-pair major with its list of live
     pairs — must give d loss / d (hidden pre-activations) and d loss / d x of the masked ReLU network to f32 accuracy."""
+    _walk_split_chain(cfg, packed=False)
+
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("affine", 16, 0, (128, 128), 0), ("rqs", 8, 0, (48,), 8)])
+def test_packed_chain_tables_reproduce_the_whole_dgrad(cfg):
+    """The tables of the one-launch backward (chain_split_tables(packed=...), arxb_kernel): the first chain layer contracts over the FORWARD
+    kernel's packed order of phi (zuko_amd/fused.py: build_plan — unit 16 (g NT + t) + i of the stream = parameter 4 t + i % 4 of the features
+    of lane i / 4 in group g), in which a lane owns its features' parameters; PB lists the first block of every pair of packed tiles."""
+    _walk_split_chain(cfg, packed=True)
+
+
+def _walk_split_chain(cfg, packed):
     rng = np.random.default_rng(5)
-    for _, _, lins in static_ar._plans_for(*cfg):
+    for plan, layout, lins in static_ar._plans_for(*cfg):
         n = len(lins)
         sp = SortedPlan(lins, 1, torch.device("cpu"))
-        tg = static_ar.chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu)
+        pk = {"uni": layout.kind, "featmap": plan.featmap, "nt": layout.nt, "fpl": layout.fpl, "total": layout.total} if packed else None
+        tg = static_ar.chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu, packed=pk)
         assert tg is not None
         t, gathers = tg
-        assert t["NH"] == n and t["DIN0"] == lins[-1].weight.shape[0] and t["DOUT"] == lins[0].weight.shape[1]
+        dphi = lins[-1].weight.shape[0]
+        if packed:
+            # packed unit -> module row, as the forward plan lays the last layer's rows out (fused.py: build_plan)
+            ng = len(plan.featmap) // (4 * layout.fpl)
+            mod_row = -np.ones(ng * layout.nt * 16, dtype=np.int64)
+            for g in range(ng):
+                for tt in range(layout.nt):
+                    for i in range(16):
+                        fi, k = divmod(4 * tt + (i & 3), layout.total)
+                        if fi < layout.fpl:
+                            f = plan.featmap[g * 4 * layout.fpl + (i >> 2) * layout.fpl + fi]
+                            if f >= 0:
+                                mod_row[(g * layout.nt + tt) * 16 + i] = f * layout.total + k
+            assert t["chain"] == 3 and t["NG"] == ng and t["DIN0"] == len(mod_row) and sorted(mod_row[mod_row >= 0]) == list(range(dphi))
+            ips_ = np.asarray(t["B_IP"][: t["NB"][0]])
+            assert t["PB"] == [int((ips_ < pp).sum()) for pp in range(t["DIN0"] // 32 + 1)] and t["PB"][-1] == t["NB"][0]
+        else:
+            assert t["DIN0"] == dphi
+        assert t["NH"] == n and t["DOUT"] == lins[0].weight.shape[1]
         assert t["BASE"] == [3 * sum(t["NB"][:c]) for c in range(n)] and t["NCHUNK"] == -(-3 * sum(t["NB"]) // t["CH"])
         assert sorted(set(t["B_IP"][: t["NB"][0]])) == t["P0"] and len(t["P0"]) == t["NP0"]
         ips = t["B_IP"][: t["NB"][0]]
         assert all(ips[i] <= ips[i + 1] for i in range(len(ips) - 1)), "layer 0 is in-pair major"
         W = [(l.weight.detach().numpy() * l.mask.numpy()).astype(np.float32) for l in lins]
-        g_phi = rng.standard_normal(t["DIN0"]).astype(np.float32)
+        g_phi = rng.standard_normal(dphi).astype(np.float32)
         gates = [(rng.random(lins[l].weight.shape[0]) > 0.4).astype(np.float64) for l in range(n - 1)]  # module order, per hidden layer
         # reference (module order)
         ref, g = [], g_phi.astype(np.float64)
@@ -123,7 +154,7 @@ def test_split_chain_tables_reproduce_the_whole_dgrad(cfg):
             ref.append(g)
         # the kernel's walk (sorted unit order)
         vec = np.zeros(max(t["DIN0"], t["TMAX"] * 16) + 32, dtype=np.float32)
-        vec[: t["DIN0"]] = g_phi  # (the last layer's rows are in module order: rows[n-1] is the identity)
+        vec[: t["DIN0"]] = np.where(mod_row >= 0, g_phi[np.maximum(mod_row, 0)], 0.0) if packed else g_phi  # (unpacked: the last layer's rows are in module order)
         boff = 0
         for c in range(n):
             l = n - 1 - c

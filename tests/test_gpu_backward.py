@@ -281,7 +281,8 @@ def _graph_nodes(fn, seen=None):
 @pytest.mark.parametrize("name", ["nsf_cfg2", "maf_cfg3"])
 def test_training_step_is_one_autograd_node_per_transform(dev, name, monkeypatch):
     """The headline flows train through zuko_amd/train.py:AutoregressiveFn — conditioner, univariate map and log|det J| of a transform as
-    ONE node (forward one launch, phi read back only by the backward) — and get the gradients of the two-node path
+    ONE node (forward one launch; backward one launch up to the weight gradients: univariate adjoint inside the dgrad chain's first layer) —
+    and get the gradients of the same node with the stand-alone adjoint kernel (ZUKO_AMD_NO_FUSED_AR_BACKWARD=1) and of the two-node path
     (ZUKO_AMD_NO_FUSED_AR_TRAIN=1: ConditionerFn + UnivariatePackedFn) to rounding."""
     flow, entry = build_flow(name)
     flow = flow.to(dev)
@@ -300,6 +301,16 @@ def test_training_step_is_one_autograd_node_per_transform(dev, name, monkeypatch
     assert "AutoregressiveFnBackward" in names_f and "ConditionerFnBackward" not in names_f and "UnivariatePackedFnBackward" not in names_f, names_f
     loss_n, names_n, grads_n, _ = step(False)  # (x without gradient: the usual training step)
     assert "AutoregressiveFnBackward" in names_n
+    from zuko_amd import train
+
+    fused_backwards = [bk for bk in train._BACKWARDS.values() if bk]
+    assert fused_backwards and all(bk.fused for bk in fused_backwards), "the backward of every transform is ONE launch (zk_ar_backward_full)"
+    monkeypatch.setenv("ZUKO_AMD_NO_FUSED_AR_BACKWARD", "1")  # the same node with the stand-alone adjoint kernel + dgrad chain
+    loss_b, names_b, grads_b, gx_b = step(True)
+    assert "AutoregressiveFnBackward" in names_b and abs(loss_b - loss_f) < 1e-6 * max(1.0, abs(loss_f))
+    for k, g in grads_b.items():
+        assert ((grads_f[k] - g).abs().max() / g.abs().max().clamp_min(1e-6)).item() < 2e-5, k
+    assert ((gx_f - gx_b).abs().max() / gx_b.abs().max()).item() < 2e-5
     monkeypatch.setenv("ZUKO_AMD_NO_FUSED_AR_TRAIN", "1")
     loss_u, names_u, grads_u, gx_u = step(True)
     assert "AutoregressiveFnBackward" not in names_u and "ConditionerFnBackward" in names_u
@@ -308,4 +319,34 @@ def test_training_step_is_one_autograd_node_per_transform(dev, name, monkeypatch
         scale = g.abs().max().clamp_min(1e-6)
         assert ((grads_f[k] - g).abs().max() / scale).item() < 2e-5, k
         assert ((grads_n[k] - g).abs().max() / scale).item() < 2e-5, k
+    assert ((gx_f - gx_u).abs().max() / gx_u.abs().max()).item() < 2e-5
+
+
+def test_one_launch_backward_without_staged_rows(dev, monkeypatch):
+    """MAF(12): the second feature group of the affine layout (8 features per group) is half empty, so the one-launch backward moves phi / g_phi
+    lane by lane instead of as staged 16-byte pieces (Shape::STG = false) — same gradients as the two-node path."""
+    from zuko_amd import train
+    from zuko_amd.flows import MAF
+
+    torch.manual_seed(11)
+    flow = MAF(12, 0, transforms=2, hidden_features=[64, 64]).to(dev)
+    x = torch.randn(300, 12, device=dev)
+
+    def step():
+        flow.zero_grad()
+        xg = x.clone().requires_grad_()
+        loss = -flow().log_prob(xg).mean()
+        names = {type(f).__name__ for f in _graph_nodes(loss.grad_fn)}
+        loss.backward()
+        return loss.item(), names, {k: p.grad.clone() for k, p in flow.named_parameters()}, xg.grad
+
+    loss_f, names_f, grads_f, gx_f = step()
+    assert "AutoregressiveFnBackward" in names_f
+    bks = [bk for bk in train._BACKWARDS.values() if bk and bk.t["DOUT"] == 12]
+    assert bks and all(bk.fused and bk.t["STG"] == 0 for bk in bks)
+    monkeypatch.setenv("ZUKO_AMD_NO_FUSED_AR_TRAIN", "1")
+    loss_u, names_u, grads_u, gx_u = step()
+    assert "AutoregressiveFnBackward" not in names_u and abs(loss_f - loss_u) < 1e-5 * max(1.0, abs(loss_u))
+    for k, g in grads_u.items():
+        assert ((grads_f[k] - g).abs().max() / g.abs().max().clamp_min(1e-6)).item() < 2e-5, k
     assert ((gx_f - gx_u).abs().max() / gx_u.abs().max()).item() < 2e-5

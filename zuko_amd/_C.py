@@ -126,6 +126,7 @@ SIGNATURES = {
     "zk_ar_forward_train": [_AR, P],
     "zk_ar_dgrad_chain": [_AR, P],
     "zk_ar_dgrad_full": [_AR, P],
+    "zk_ar_backward_full": [_AR, P],
     "zk_wgrad_multi": [I, P, L, P],
     "zk_ar_forward": [_AR, P],
     "zk_ar_forward_diag": [_AR, P],

@@ -13,40 +13,9 @@
 // are sparse: only the two knots of the active bin receive gradient).
 // Data movement mirrors the forward kernel: a wave owns 64 consecutive elements, phi comes in and
 // g_phi goes out through a wave-private LDS image with 16-byte global accesses.
-#include "zk_univariate.h"
+#include "zk_univariate_bwd.h"
 
 namespace zk {
-
-struct Dual7 {
-  float v;
-  float d[7];
-};
-__device__ __forceinline__ Dual7 dconst(float c) { Dual7 r; r.v = c;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) r.d[i] = 0.f; return r; }
-__device__ __forceinline__ Dual7 dvar(float c, int i) { Dual7 r = dconst(c); r.d[i] = 1.f; return r; }
-__device__ __forceinline__ Dual7 operator+(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v + b.v;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-__device__ __forceinline__ Dual7 operator-(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v - b.v;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-__device__ __forceinline__ Dual7 operator*(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v * b.v;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-// (reciprocals, exponentials and logarithms of the adjoint use the hardware approximations — v_rcp / v_exp / v_log, ~1 ulp — like the
-//  forward's rqs_lean: with IEEE division and ocml expf the kernel was VALU-bound at 2.6 TB/s; gradients are compared at 2e-4)
-__device__ __forceinline__ Dual7 operator/(const Dual7& a, const Dual7& b) { Dual7 r; const float ib = __builtin_amdgcn_rcpf(b.v); r.v = a.v * ib;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
-__device__ __forceinline__ Dual7 dlog(const Dual7& a) { Dual7 r; r.v = __logf(a.v); const float ia = __builtin_amdgcn_rcpf(a.v);
-#pragma unroll
-  for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * ia; return r; }
-
-__device__ __forceinline__ float softclip_grad(float v, float c_abs) {  // d/dv [ v / (1 + |v| / c) ]
-  const float t = 1.f + fabsf(v) * __builtin_amdgcn_rcpf(c_abs);
-  return __builtin_amdgcn_rcpf(t * t);
-}
 
 struct BwdArgs {
   int64_t N, D;
@@ -60,87 +29,6 @@ struct BwdArgs {
   float bound, ls;
   int64_t iters;
 };
-
-// gv[0..6] = gy * dy/d(.) + gl * dladj/d(.) for (.) = x, x0, x1, y0, y1, d0, d1 of the active bin (zuko/transforms.py:554-567),
-// in 7-wide forward-mode dual numbers
-__device__ __forceinline__ void rqs_local_vjp(float x, float x0, float x1, float y0, float y1, float d0, float d1, float gyv, float glv, float (&gv)[7]) {
-  const Dual7 X = dvar(x, 0), X0 = dvar(x0, 1), X1 = dvar(x1, 2), Y0 = dvar(y0, 3), Y1 = dvar(y1, 4), D0 = dvar(d0, 5), D1 = dvar(d1, 6);
-  const Dual7 one = dconst(1.f), two = dconst(2.f);
-  const Dual7 w = X1 - X0, h = Y1 - Y0;
-  const Dual7 s = h / w;
-  const Dual7 z = (X - X0) / w;
-  const Dual7 omz = one - z;
-  const Dual7 zz = z * omz;
-  const Dual7 den = s + (D0 + D1 - two * s) * zz;
-  const Dual7 num = s * z * z + D0 * zz;
-  const Dual7 y = Y0 + h * num / den;
-  const Dual7 jac = s * s * (two * s * zz + D0 * omz * omz + D1 * z * z) / (den * den);
-  const Dual7 lad = dlog(jac);
-#pragma unroll
-  for (int i = 0; i < 7; ++i) gv[i] = gyv * y.d[i] + glv * lad.d[i];
-}
-
-template <int K> __device__ __forceinline__ void rqs_backward_element(const float* p, float x, float gyv, float glv, float bound, float ls, float& gxv, float* g) {
-  typedef MathFast M;
-  constexpr int TOTAL = 3 * K - 1;
-  float kx[K + 1], ky[K + 1], kd[K + 1], pw[K], ph[K];
-  // forward recompute, keeping the softmax probabilities
-  auto axis = [&](int off, float (&knot)[K + 1], float (&prob)[K]) {
-    float v[K], m;
-#pragma unroll
-    for (int j = 0; j < K; ++j) { v[j] = softclip2<float, M>(p[off + j], ls); m = (j == 0) ? v[0] : fmaxf(m, v[j]); }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < K; ++j) { v[j] = __expf(v[j] - m); s += v[j]; }
-    const float r = __builtin_amdgcn_rcpf(s);
-    float cum = 0.f;
-    knot[0] = -bound;
-#pragma unroll
-    for (int j = 0; j < K; ++j) { prob[j] = v[j] * r; cum += prob[j]; knot[j + 1] = bound * (2.f * cum - 1.f); }
-  };
-  axis(0, kx, pw);
-  axis(K, ky, ph);
-  rqs_slopes<float, K, M>([&](int j) { return p[2 * K + j]; }, ls, kd);
-  bool inside;
-  float x0, x1, y0, y1, d0, d1;
-  const int k = rqs_locate<float, K>(kx, kx, ky, kd, x, inside, x0, x1, y0, y1, d0, d1);
-#pragma unroll
-  for (int i = 0; i < TOTAL; ++i) g[i] = 0.f;
-  if (!inside) { gxv = gyv; return; }  // identity outside [-B, B]: y = x, ladj = 0, no parameter gradient
-  float gv[7];
-  rqs_local_vjp(x, x0, x1, y0, y1, d0, d1, gyv, glv, gv);
-  gxv = gv[0];
-  // knots -> softmax probabilities: kx_j = B (2 sum_{i<j} p_i - 1): only knots k and k+1 carry gradient
-  const float twoB = 2.f * bound;
-  float gpw[K], gph[K], dotw = 0.f, doth = 0.f;
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    gpw[i] = twoB * ((i < k ? gv[1] : 0.f) + (i <= k ? gv[2] : 0.f));
-    gph[i] = twoB * ((i < k ? gv[3] : 0.f) + (i <= k ? gv[4] : 0.f));
-    dotw += pw[i] * gpw[i];
-    doth += ph[i] * gph[i];
-  }
-  const float cw = fabsf(ls) * 0.5f, cd = fabsf(ls);
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    g[i] = pw[i] * (gpw[i] - dotw) * softclip_grad(p[i], cw);
-    g[K + i] = ph[i] * (gph[i] - doth) * softclip_grad(p[K + i], cw);
-  }
-  // slopes: kd_j = exp(softclip(ud_{j-1})), j = 1..K-1 (ends are the constant 1)
-#pragma unroll
-  for (int j = 1; j < K; ++j) {
-    const float gk = (j == k ? gv[5] : 0.f) + (j == k + 1 ? gv[6] : 0.f);
-    g[2 * K + j - 1] = gk * kd[j] * softclip_grad(p[2 * K + j - 1], cd);
-  }
-}
-
-__device__ __forceinline__ void affine_backward_element(const float* p, float x, float gyv, float glv, float ls, float& gxv, float* g) {
-  const float lsc = softclip<float>(p[1], ls);
-  const float e = expf(lsc);
-  gxv = gyv * e;
-  g[0] = gyv;                                                       // shift
-  g[1] = (gyv * x * e + glv) * softclip_grad(p[1], fabsf(ls));      // unconstrained log-scale
-}
 
 extern __shared__ __attribute__((aligned(16))) float bw_lds[];
 

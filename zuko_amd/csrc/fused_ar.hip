@@ -683,6 +683,31 @@ int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream) {
   return ((ars_dgrad_fn)args->launcher)(&a, ARS_ABI, (int)sizeof(ArArgs), stream);
 }
 
+// The whole backward of one unconditional autoregressive transform up to the weight gradients, in one launch of a generated kernel
+// (zuko_amd/static_ar.py: chain_split_tables(packed=...), csrc/fused_ar_split_impl.h: arxb_kernel): from (gy, gl) = d loss / d (y, ladj)
+// the univariate adjoint gives d loss / d phi — written to x_out for the weight gradients — and the map's own d/dx term; the dgrad chain
+// runs from there through every linear layer (gh1 .. = gradients of the hidden pre-activations); y = d loss / dx = chain + direct term.
+int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream) {
+  if (!ar_args_ok(args) || !args->launcher || !args->x || !args->y || !args->wstream || !args->phi || !args->x_out || !args->y_in || !args->ladj || !args->featmap) return ZK_EINVAL;
+  const int n = args->n_layers;
+  if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff || args->uni_kind < 0 || args->uni_kind > 1 || args->DIN != args->D) return ZK_EINVAL;
+  if (args->N == 0) return 0;
+  const void* hs[3] = {args->h1, args->h2, args->h3};
+  void* gs[3] = {args->gh1, args->gh2, args->gh3};
+  ArArgs a{};
+  a.x = (const float*)args->x; a.ldx = args->ldx; a.N = args->N; a.D = args->D; a.DIN = args->DIN; a.L = n; a.NG = args->n_groups; a.n_chunks = args->n_chunks;
+  a.stream = (const float*)args->wstream; a.featmap = args->featmap;
+  a.phi_out = (float*)args->y; a.ldphi = args->ldy; a.accumulate = args->accumulate;
+  a.gy = (const float*)args->y_in; a.ldgy = args->ldo; a.gl = (const float*)args->ladj;
+  a.phi_in = (const float*)args->phi; a.gphi_out = (float*)args->x_out; a.ldpin = args->ldphi;
+  a.bound = (float)args->bound; a.ls = (float)log(args->slope);
+  for (int c = 0; c + 1 < n; ++c) {
+    a.gate[c] = (const float*)hs[n - 2 - c];
+    a.act_out[c] = (float*)gs[n - 2 - c];
+  }
+  return ((ars_dgrad_fn)args->launcher)(&a, ARS_ABI, (int)sizeof(ArArgs), stream);
+}
+
 // One sweep of the autoregressive inverse (zuko/transforms.py:997-998): x_out = univariate(conditioner(x_cond)).inv(y).
 // x_out may alias x_cond (a wave reads its rows of x_cond completely before it writes them).
 int zk_ar_inverse_sweep(const zk_ar_args_v1* args, void* stream) {

@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AR_TF 256 /* floats per tile image */
 #define AR_WAVES 8
 #define AR_T 16   /* activation tiles (256 units) */
-#define ARS_ABI 4 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
+#define ARS_ABI 5 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
 
 struct ArArgs {
   int64_t N;
@@ -43,6 +43,14 @@ struct ArArgs {
   int64_t ldphi;
   // static-shape dgrad chain (ars_dgrad_kernel): saved activations h_l [N, width_l] whose sign gates the gradient of layer l
   const float* gate[3];
+  // fused backward of an autoregressive transform (arxb_kernel): x / featmap as for the forward; the forward's phi and the gradient
+  // of phi it writes for the weight gradients [N, D * total] (row stride ldpin); gy [N, D] (row stride ldgy), gl [N]; the input gradient
+  // goes to phi_out (row stride ldphi) as in the dgrad chain
+  const float* phi_in;
+  float* gphi_out;
+  int64_t ldpin;
+  const float* gy; int64_t ldgy;
+  const float* gl;
 };
 
 __device__ __forceinline__ float act_f32(float v, int act) {

@@ -36,12 +36,12 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
-ARS_ABI = 4  # == ARS_ABI of csrc/zk_ar_common.h
+ARS_ABI = 5  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 3: "zk::UniRqs16", 4: "zk::UniCircRqs8"}
 # 16 bins: the twelve accumulator tiles of a feature group do not fit the f32-instruction template's double-buffered last layer (it would
 # spill), but the operand-split template holds them (255 VGPRs, no scratch): that kind exists as a split kernel only, forward only
 SPLIT_ONLY_KINDS = {3}
-_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_common.h")
+_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_univariate_bwd.h", "zk_common.h")
 
 
 def _hipcc() -> str | None:
@@ -569,12 +569,17 @@ def chain_tables(masks_sorted: list, rows: list, cols: list):
     return t, gathers
 
 
-def chain_split_tables(masks_sorted: list, rows: list, cols: list):
+def chain_split_tables(masks_sorted: list, rows: list, cols: list, packed: dict | None = None):
     """Tables + gather indices of the operand-split dgrad chain over ALL n linear layers (csrc/fused_ar_split_impl.h: arxd_kernel), from the
     gradient of the packed parameters down to the conditioner's input.  Arguments as chain_tables, but for every layer l = 0 .. n-1.
     Chain layer c multiplies by the transpose of layer l = n-1-c; a block is (out tile = 16 sorted INPUT units of layer l, in pair = 32
     sorted OUTPUT units of layer l) as three bf16 images (split_tables).  Layer 0 is walked in-pair major (its input g_phi is streamed
-    from global memory), the others out-tile major.  Returns (tables, gathers) or None."""
+    from global memory), the others out-tile major.  Returns (tables, gathers) or None.
+
+    packed = {"uni": kind, "featmap": int array [NG * 4 * FPL], "nt", "fpl", "total"} (the forward plan's grouping of the features,
+    zuko_amd/fused.py: build_plan): the tables of arxb_kernel instead — the whole backward of the transform in one launch.  Its first layer
+    runs over the FORWARD kernel's packed order of phi (unit 16 (g NT + t) + 4 q + r = parameter 4 t + r of the features of lane q in group
+    g), in which a lane owns the parameters of its own features and computes their gradient itself."""
     n = len(masks_sorted)
     if n < 2 or n > 4:
         return None
@@ -582,6 +587,22 @@ def chain_split_tables(masks_sorted: list, rows: list, cols: list):
     din, dphi = masks_sorted[0].shape[1], masks_sorted[-1].shape[0]
     if any(w % 16 or w > 256 for w in hidden) or din % 4 or din > 256 or dphi % 4:
         return None
+    masks_sorted, rows = list(masks_sorted), list(rows)
+    if packed is not None:
+        fm, nt, fpl, total = np.asarray(packed["featmap"]), int(packed["nt"]), int(packed["fpl"]), int(packed["total"])
+        ng = len(fm) // (4 * fpl)
+        if ng * 4 * fpl != len(fm) or (ng * nt) % 2 or (nt % 2 and ng % 2) or fpl * total > 4 * nt or dphi != din * total or rows[-1] is None:
+            return None
+        u = np.arange(ng * nt * 16)
+        g_, t_, q_, r_ = u // (16 * nt), (u // 16) % nt, (u % 16) // 4, u % 4
+        fi_, k_ = np.divmod(4 * t_ + r_, total)
+        f_ = np.where(fi_ < fpl, fm[(g_ * 4 + q_) * fpl + np.minimum(fi_, fpl - 1)], -1)
+        mod_row = np.where(f_ >= 0, f_ * total + k_, -1)                                       # packed unit -> row of the last linear layer (module order)
+        if sorted(mod_row[mod_row >= 0].tolist()) != list(range(dphi)) or not np.array_equal(np.asarray(rows[-1]), np.arange(dphi)):
+            return None
+        M_last = np.asarray(masks_sorted[-1], dtype=bool)
+        masks_sorted[-1] = np.where((mod_row >= 0)[:, None], M_last[np.maximum(mod_row, 0)], False)
+        rows[-1] = mod_row
     ch = 24
     lane = np.arange(64)
     li, lq = lane % 16, lane // 16
@@ -598,8 +619,9 @@ def chain_split_tables(masks_sorted: list, rows: list, cols: list):
             a_ = ot * 16 + li[:, None]                                                        # sorted input unit of layer l
             e = np.arange(8)[None, :]
             b_ = (2 * ip + e // 4) * 16 + (4 * lq)[:, None] + e % 4                            # sorted output unit of layer l
-            ok = (a_ < in_l) & (b_ < out_l)
-            return np.where(ok, np.asarray(rows[l])[np.minimum(b_, out_l - 1)] * in_l + np.asarray(cols[l])[np.minimum(a_, in_l - 1)], -1)
+            row = np.asarray(rows[l])[np.minimum(b_, out_l - 1)]
+            ok = (a_ < in_l) & (b_ < out_l) & (row >= 0)
+            return np.where(ok, row * in_l + np.asarray(cols[l])[np.minimum(a_, in_l - 1)], -1)
 
         def live(ot, ip):
             return bool(M[ip * 32 : ip * 32 + 32, ot * 16 : ot * 16 + 16].any())
@@ -621,10 +643,19 @@ def chain_split_tables(masks_sorted: list, rows: list, cols: list):
     n_chunks = -(-cursor // ch)
     pad = -(-(n_chunks * ch - cursor) // 3)
     blocks_of[-1] = blocks_of[-1] + [-np.ones((64, 8), dtype=np.int64)] * pad
-    t = {"chain": 2, "DIN0": int(dphi), "DOUT": int(din), "NH": n, "HT": HT, "TMAX": int(2 * -(-max(HT) // 2)), "NB": NB, "BASE": BASE, "B_OT": B_OT, "B_IP": B_IP, "NP0": len(P0), "P0": P0,
-         "NCHUNK": n_chunks, "STREAM_IMAGES": max(n_chunks * ch, cursor + 3 * pad), "WAVES": 8, "CH": ch}
+    t = {"chain": 2, "DIN0": int(masks_sorted[-1].shape[0]), "DOUT": int(din), "NH": n, "HT": HT, "TMAX": int(2 * -(-max(HT) // 2)), "NB": NB, "BASE": BASE, "B_OT": B_OT, "B_IP": B_IP,
+         "NP0": len(P0), "P0": P0, "NCHUNK": n_chunks, "STREAM_IMAGES": max(n_chunks * ch, cursor + 3 * pad), "WAVES": 8, "CH": ch}
     if t["TMAX"] > 16:
         return None
+    if packed is not None:  # first block of every packed pair (layer 0 is in-pair major: the blocks of a pair are consecutive)
+        n_pairs = t["DIN0"] // 32
+        ips = np.asarray(B_IP[: NB[0]])
+        # groups of 4 * fpl CONSECUTIVE features whose parameters start a multiple of 16 bytes into the row can move as 16-byte pieces
+        grp = fm.reshape(ng, 4 * fpl)
+        gb = grp.min(axis=1)
+        stg = bool((grp >= 0).all() and all(sorted(r.tolist()) == list(range(int(b), int(b) + 4 * fpl)) for r, b in zip(grp, gb)) and ((gb * total) % 4 == 0).all()
+                   and (4 * fpl * total) % 4 == 0 and os.environ.get("ZUKO_AMD_ARXB_STAGED", "1") != "0")
+        t.update({"chain": 3, "uni": int(packed["uni"]), "NG": ng, "PB": [int((ips < pp).sum()) for pp in range(n_pairs + 1)], "STG": int(stg), "GB": [int(max(b, 0)) for b in gb]})
     return t, [np.stack(b).astype(np.int32).reshape(-1) for b in blocks_of]
 
 
@@ -640,9 +671,16 @@ def emit_chain_split(t: dict) -> str:
         f"  static constexpr int DIN0 = {t['DIN0']}, DOUT = {t['DOUT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NCHUNK = {t['NCHUNK']}, WAVES = 8, CH = {t['CH']}, NP0 = {t['NP0']}, ACT = 1;",
         _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]), _arr("P0", "unsigned char", t["P0"]),
         _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]),
+    ]
+    if t.get("chain") == 3:  # the whole backward of the transform (arxb_kernel)
+        lines += [f"  static constexpr int NG = {t['NG']};", f"  static constexpr bool STG = {'true' if t['STG'] else 'false'};", _arr("PB", "int", t["PB"]), _arr("GB", "int", t["GB"])]
+        launch = f"zk::arxb_launch<Shape, {UNI_TYPES[t['uni']]}>"
+    else:
+        launch = "zk::arxd_launch<Shape>"
+    lines += [
         "};",
         "}  // namespace",
-        'extern "C" int zk_ars_dgrad_launch(const zk::ArArgs* a, int abi, int args_bytes, void* stream) { return zk::arxd_launch<Shape>(a, abi, args_bytes, stream); }',
+        f'extern "C" int zk_ars_dgrad_launch(const zk::ArArgs* a, int abi, int args_bytes, void* stream) {{ return {launch}(a, abi, args_bytes, stream); }}',
         "",
     ]
     return "\n".join(lines)
@@ -694,7 +732,7 @@ def chain_kernel(t: dict, allow_compile: bool, verbose: bool = False, out_dir: s
             if not allow_compile:
                 return None
             meta = {"so": stem + ".so", "headers": stamp, "core": "chain", "l0": [], "alt": None, "DIN": t.get("DIN", t.get("DIN0")), "DOUT": t["DOUT"], "HT": t["HT"]}
-            so = _build_so(stem, lambda: emit_chain_split(t) if t.get("chain") == 2 else emit_chain(t), meta, verbose, out_dir)
+            so = _build_so(stem, lambda: emit_chain_split(t) if t.get("chain") in (2, 3) else emit_chain(t), meta, verbose, out_dir)
             if so is None:
                 return None
         try:
@@ -726,6 +764,7 @@ PREBUILT = [
     ("rqs", 16, 2, (64, 64), 8, "ELU"),
     ("affine", 12, 0, (48, 32), 0, "Tanh"),
     ("rqs", 64, 0, (256, 256, 256), 16),   # NSF(bins=16): operand-split kernel only (SPLIT_ONLY_KINDS)
+    ("affine", 12, 0, (64, 64), 0),        # training: a last feature group that is not full (the one-launch backward without staged rows)
 ]
 
 
@@ -753,8 +792,9 @@ def _plans_for(kind: str, features: int, context: int, hidden, bins: int, activa
     return out
 
 
-def chain_tables_for(lins, full: bool = False):
-    """chain_tables (full: chain_split_tables) of a masked ReLU conditioner given its linear layers (through zuko_amd/train.py:SortedPlan), or None."""
+def chain_tables_for(lins, full: bool = False, packed: dict | None = None):
+    """chain_tables (full: chain_split_tables, with `packed` the whole-backward tables) of a masked ReLU conditioner given its linear layers
+    (through zuko_amd/train.py:SortedPlan), or None."""
     import torch
 
     from .train import SortedPlan
@@ -764,7 +804,7 @@ def chain_tables_for(lins, full: bool = False):
     if n < 2 or n > 4 or any(m is None for m in sp.mask_s_cpu):
         return None
     if full:
-        return chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu) if sp.shapes[-1][0] % 4 == 0 else None
+        return chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu, packed=packed) if sp.shapes[-1][0] % 4 == 0 else None
     return chain_tables(sp.mask_s_cpu[: n - 1], sp.rows_cpu[: n - 1], sp.cols_cpu[: n - 1])
 
 
@@ -803,8 +843,11 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
         act = _act_code(getattr(torch.nn, entry[5])()) if len(entry) > 5 else 1
         (pa, layout, lins_a), (pd, _, lins_d) = _plans_for(kind, features, context, hidden, bins)
         if act == 1 and layout.kind not in SPLIT_ONLY_KINDS:  # the training backward of the same conditioners (one kernel per feature order)
-            for lins in (lins_a, lins_d):
-                for tg in (chain_tables_for(lins), chain_tables_for(lins, full=True)):
+            for lins, pl in ((lins_a, pa), (lins_d, pd)):
+                cands = [chain_tables_for(lins), chain_tables_for(lins, full=True)]
+                if context == 0 and layout.kind in (0, 1) and layout.total in (2, 23) and pl is not None:  # what zuko_amd/train.py:autoregressive() covers
+                    cands.append(chain_tables_for(lins, full=True, packed={"uni": layout.kind, "featmap": pl.featmap, "nt": layout.nt, "fpl": layout.fpl, "total": layout.total}))
+                for tg in cands:
                     if tg is not None and not any(c[0] == tg[0] for c in chains):
                         chains.append(tg)
         for pl in (pa, pd):

@@ -309,7 +309,8 @@ class DgradChain:
 
     def __init__(self, plan: SortedPlan, kernel, tables: dict, gathers, device) -> None:
         self.kernel, self.t = kernel, tables
-        self.full = tables.get("chain") == 2
+        self.full = tables.get("chain") in (2, 3)
+        self.fused = tables.get("chain") == 3  # the transform's whole backward (univariate adjoint + chain): run_backward
         self.idx = [torch.from_numpy(g).to(device) for g in gathers]
         self.offsets = [b * 256 for b in tables["BASE"]]
         self.device = device
@@ -348,7 +349,51 @@ class DgradChain:
         return gs + [g_in], gx
 
 
+    def run_backward(self, plan: SortedPlan, stream: Tensor, st, uni, x: Tensor, phi: Tensor, gy: Tensor, gl: Tensor, hs):
+        """Fused chains: (g_phi [N, out_features], [g_1, ..], gx) from d loss / d (y, ladj) in one launch (zk_ar_backward_full); st = the
+        forward's FusedAR (feature grouping), uni = (kind, bound, slope, ..)."""
+        n = len(plan.shapes)
+        N = x.shape[0]
+        dev = x.device
+        gs = [torch.empty((N, plan.shapes[l][0]), dtype=torch.float32, device=dev) for l in range(n - 1)]
+        gx = torch.empty((N, plan.shapes[0][1]), dtype=torch.float32, device=dev)
+        gphi = torch.empty_like(phi)
+        hp = [_ptr(hs[1 + l]) for l in range(n - 1)] + [None] * 3
+        gp = [_ptr(g) for g in gs] + [None] * 3
+        a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, uni_kind=uni[0], N=N, D=x.shape[1], DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
+                    gh1=gp[0], gh2=gp[1], gh3=gp[2], y=_ptr(gx), ldy=gx.stride(0), y_in=_ptr(gy), ldo=gy.stride(0), ladj=_ptr(gl), phi=_ptr(phi), x_out=_ptr(gphi), ldphi=phi.stride(0),
+                    wstream=_ptr(stream), featmap=_ptr(st.featmap), n_layers=n, n_groups=st.plan.n_groups, n_chunks=self.t["NCHUNK"], act=1, bound=float(uni[1]), slope=float(uni[2]))
+        _C.check(_C.lib().zk_ar_backward_full(a, _stream()), "zk_ar_backward_full")
+        return gphi, gs, gx
+
+
 _CHAINS = weakref.WeakKeyDictionary()  # SortedPlan -> DgradChain or False
+_BACKWARDS = weakref.WeakKeyDictionary()  # SortedPlan -> DgradChain (fused) or False
+
+
+def _backward_kernel(plan: SortedPlan, st, rows: int):
+    """The one-launch backward of the transform (DgradChain with .fused) for the forward state `st`, or None (kernel not built and compiling
+    not allowed for this batch, ZUKO_AMD_NO_FUSED_AR_BACKWARD=1)."""
+    import os
+
+    if os.environ.get("ZUKO_AMD_NO_FUSED_AR_BACKWARD", "0") == "1":
+        return None
+    bk = _BACKWARDS.get(plan)
+    if bk is None:
+        from . import static_ar
+
+        lay = st.plan.layout
+        tg = static_ar.chain_split_tables(plan.mask_s_cpu, plan.rows_cpu, plan.cols_cpu,
+                                          packed={"uni": lay.kind, "featmap": st.plan.featmap, "nt": lay.nt, "fpl": lay.fpl, "total": lay.total})
+        if tg is None:
+            _BACKWARDS[plan] = False
+            return None
+        kern = static_ar.chain_kernel(tg[0], allow_compile=static_ar.jit_enabled() and rows >= static_ar.jit_min_rows())
+        if kern is None:
+            return None  # (not cached: a later, larger batch may be allowed to compile)
+        bk = DgradChain(plan, kern, tg[0], tg[1], plan.device)
+        _BACKWARDS[plan] = bk
+    return bk or None
 
 
 def _dgrad_chain(plan: SortedPlan, lins, rows: int):
@@ -494,7 +539,7 @@ class AutoregressiveFn(torch.autograd.Function):
         st.refresh(lins, fine_only=True)
         stream = chain.gather(plan, lins)
         acts, phi, y, ladj = _fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]))
-        ctx.plan, ctx.n, ctx.chain, ctx.uni = plan, n, chain, uni
+        ctx.plan, ctx.n, ctx.chain, ctx.uni, ctx.st = plan, n, chain, uni, st
         ctx.save_for_backward(x, *acts, phi, stream)
         return y, ladj
 
@@ -511,9 +556,12 @@ class AutoregressiveFn(torch.autograd.Function):
         N, D = x.shape
         gy = torch.zeros_like(x) if gy is None else gy.contiguous()
         gl = torch.zeros(N, dtype=torch.float32, device=x.device) if gl is None else gl.contiguous()
-        gx, gphi = _adj_any((kind, bound, slope, sizes, ()), x, phi.view(N, D, -1), gy, gl, True)
-        gphi = gphi.view(N, -1)
-        gs, gx = chain.run(plan, stream, gphi, hs, gx_add=gx)
+        if chain.fused:
+            gphi, gs, gx = chain.run_backward(plan, stream, ctx.st, ctx.uni, x, phi, gy, gl, hs)
+        else:
+            gx, gphi = _adj_any((kind, bound, slope, sizes, ()), x, phi.view(N, D, -1), gy, gl, True)
+            gphi = gphi.view(N, -1)
+            gs, gx = chain.run(plan, stream, gphi, hs, gx_add=gx)
         res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else gphi, hs[l]) for l in range(n)])
         grads = []
         for l in range(n):
@@ -545,7 +593,9 @@ def autoregressive(module, uni, x: Tensor):
     st = _fused_forward_state(plan, lins, x.device)
     if st is None or not st.static[0].meta.get("split") or st.plan.layout.kind != uni[0]:
         return None
-    chain = _dgrad_chain(plan, lins, x.shape[0]) if n >= 2 else None
+    chain = _backward_kernel(plan, st, x.shape[0]) if n >= 2 else None  # the whole backward in one launch, else adjoint kernel + dgrad chain
+    if chain is None:
+        chain = _dgrad_chain(plan, lins, x.shape[0]) if n >= 2 else None
     if chain is None or not chain.full:
         return None
     params = []
