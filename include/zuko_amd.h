@@ -205,6 +205,8 @@ typedef struct zk_ar_args_v1 {
   void* gh1;               /* dgrad chain: gradient of hidden layer l's pre-activations [N, width_l] (outputs; the last one is the input x) */
   void* gh2;
   void* gh3;
+  int32_t phi_packed;      /* training launches (zk_ar_forward_train; zk_ar_backward_full always): phi / its gradient in the kernels' packed order, see there */
+  int32_t pad_;
 } zk_ar_args_v1;
 
 /* y, ladj of one layer on the generic tile-skipping kernel.  Reads: uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream,
@@ -233,10 +235,11 @@ int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream);
  * gradients (what autograd derives from zuko/flows/autoregressive.py:207-218, zuko/transforms.py:436-446 / :480-490, :554-567 and
  * zuko/nn.py:217-218), in one launch of a generated kernel (`launcher` = zk_ars_dgrad_launch of zuko_amd/static_ar.py:
  * chain_split_tables(packed=...)):
- *   reads   x [N, D] (ldx), phi [N, D * total] (ldphi: the forward's, zk_ar_forward_train), y_in = d loss / dy [N, D] (row stride ldo),
+ *   reads   x [N, D] (ldx), phi [N, n_groups * NT * 16] (ldphi) in the PACKED order of zk_ar_forward_train(phi_packed = 1), y_in = d loss / dy [N, D] (row stride ldo),
  *           ladj = d loss / d ladj [N] (READ here), h1 .. h_{n-1} (the forward's hidden activations), wstream / n_chunks (the kernel's
  *           stream of transposed weights), featmap / n_groups (the forward plan's), uni_kind (0 affine, 1 spline with 8 bins), bound, slope;
- *   writes  x_out = d loss / d phi [N, D * total] (row stride ldphi; for the weight gradients), gh1 .. gh_{n-1}, y = d loss / dx [N, D]
+ *   writes  x_out = d loss / d phi in the same packed order (row stride ldphi; padding slots zero; for the weight gradients, whose row table maps
+ *           packed slots to rows of the last linear layer), gh1 .. gh_{n-1}, y = d loss / dx [N, D]
  *           (row stride ldy, a multiple of 4; accumulate != 0: added to what y holds) — the chain's input gradient plus the univariate
  *           map's own d/dx term. */
 int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream);
@@ -366,7 +369,9 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream);
  * mask-aware dgrad / wgrad kernels consume.  Same launcher, per-tile stream, bias image, feature map and chunk count as
  * zk_ar_forward_static.  y == NULL: the univariate map is not evaluated; y != NULL (operand-split kernels): the same launch also writes
  * y [N, D] and ladj [N] as zk_ar_forward_static does (reads y, ldy, ladj, accumulate, bound, slope as well), so that a training step
- * reads phi back only in its backward pass. */
+ * reads phi back only in its backward pass.  phi_packed != 0: phi is written in the kernel's PACKED order — row n (stride ldphi >=
+ * n_groups * NT * 16) holds at (g NT + t) 16 + 4 q + r parameter 4 t + r of the features that lane q of group g owns (NT = tiles per
+ * group, zuko_amd/fused.py: UniLayout; parameters of one feature consecutive, featmap gives the features) — which zk_ar_backward_full reads. */
 int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream);
 /* dst[i] = idx[i] < 0 ? 0 : (mask && !mask[idx[i]] ? 0 : src[idx[i]]) — builds the weight stream
  * (mask * W gathered into tile images) and the bias image; fp32, n elements. */

@@ -19,14 +19,15 @@ for name, make, uni in (("NSF", lambda: NSF(64, 0, transforms=1, bins=8, hidden_
     st = train._fused_forward_state(plan, lins, dev)
     x = torch.randn(N, 64, device=dev)
     st.refresh(lins, fine_only=True)
-    acts, phi, y, ladj = train._fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]))
-    hs = [x, *acts]
-    gy, gl = torch.randn(N, 64, device=dev), torch.randn(N, device=dev)
     bk = train._backward_kernel(plan, st, N)
     ch = train._dgrad_chain(plan, lins, N)
+    acts, phi, y, ladj = train._fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]))
+    phi_packed = train._fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]), packed_width=bk.packed.width)[1]
+    hs = [x, *acts]
+    gy, gl = torch.randn(N, 64, device=dev), torch.randn(N, device=dev)
 
     def fused():
-        return bk.run_backward(plan, bk.gather(plan, lins), st, uni, x, phi, gy, gl, hs)
+        return bk.run_backward(plan, bk.gather(plan, lins), st, uni, x, phi_packed, gy, gl, hs)
 
     def two():
         gx, gphi = _adj_any((uni[0], uni[1], uni[2], uni[3], ()), x, phi.view(N, 64, -1), gy, gl, True)

@@ -132,7 +132,7 @@ def _walk_split_chain(cfg, packed):
                             f = plan.featmap[g * 4 * layout.fpl + (i >> 2) * layout.fpl + fi]
                             if f >= 0:
                                 mod_row[(g * layout.nt + tt) * 16 + i] = f * layout.total + k
-            assert t["chain"] == 3 and t["NG"] == ng and t["DIN0"] == len(mod_row) and sorted(mod_row[mod_row >= 0]) == list(range(dphi))
+            assert t["chain"] == 3 and t["MODROW"] == mod_row.tolist() and t["NG"] == ng and t["DIN0"] == len(mod_row) and sorted(mod_row[mod_row >= 0]) == list(range(dphi))
             ips_ = np.asarray(t["B_IP"][: t["NB"][0]])
             assert t["PB"] == [int((ips_ < pp).sum()) for pp in range(t["DIN0"] // 32 + 1)] and t["PB"][-1] == t["NB"][0]
         else:

@@ -322,9 +322,9 @@ def test_training_step_is_one_autograd_node_per_transform(dev, name, monkeypatch
     assert ((gx_f - gx_u).abs().max() / gx_u.abs().max()).item() < 2e-5
 
 
-def test_one_launch_backward_without_staged_rows(dev, monkeypatch):
-    """MAF(12): the second feature group of the affine layout (8 features per group) is half empty, so the one-launch backward moves phi / g_phi
-    lane by lane instead of as staged 16-byte pieces (Shape::STG = false) — same gradients as the two-node path."""
+def test_one_launch_backward_with_padding_slots(dev, monkeypatch):
+    """MAF(12): the second feature group of the affine layout (8 features per group) is half empty — the packed phi / g_phi rows carry padding
+    slots that the weight gradient's row table skips — same gradients as the two-node path."""
     from zuko_amd import train
     from zuko_amd.flows import MAF
 
@@ -343,7 +343,7 @@ def test_one_launch_backward_without_staged_rows(dev, monkeypatch):
     loss_f, names_f, grads_f, gx_f = step()
     assert "AutoregressiveFnBackward" in names_f
     bks = [bk for bk in train._BACKWARDS.values() if bk and bk.t["DOUT"] == 12]
-    assert bks and all(bk.fused and bk.t["STG"] == 0 for bk in bks)
+    assert bks and all(bk.fused and bk.packed.width == 32 and int((bk.packed.rows < 0).sum()) == 8 for bk in bks)
     monkeypatch.setenv("ZUKO_AMD_NO_FUSED_AR_TRAIN", "1")
     loss_u, names_u, grads_u, gx_u = step()
     assert "AutoregressiveFnBackward" not in names_u and abs(loss_f - loss_u) < 1e-5 * max(1.0, abs(loss_u))

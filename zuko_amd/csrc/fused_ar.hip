@@ -487,6 +487,7 @@ struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and th
   float* act_out[3] = {nullptr, nullptr, nullptr};  // ... conditioner-only (training) instantiation: hidden activations and phi
   float* phi_out = nullptr;
   int64_t ldphi = 0;
+  int phi_packed = 0;
   int32_t* bin_out = nullptr;  // diagnostic launch (forward, spline maps): bin index + search knots
   float* knots_out = nullptr;
   const int* sched = nullptr;
@@ -529,7 +530,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
     a.bin_out = part.bin_out; a.knots_out = part.knots_out;  // (diagnostic twin of an operand-split kernel; the f32 static kernels decline)
     a.l1rev = part.rev;
     for (int l = 0; l < 3; ++l) a.act_out[l] = part.act_out[l];
-    a.phi_out = part.phi_out; a.ldphi = part.ldphi;
+    a.phi_out = part.phi_out; a.ldphi = part.ldphi; a.phi_packed = part.phi_packed;
     return ((ars_launch_fn)part.static_fn)(&a, ARS_ABI, (int)sizeof(ArArgs), part.phi_out != nullptr, stream);
   }
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
@@ -629,6 +630,7 @@ int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
   ArPartial part;
   part.static_fn = args->launcher; part.rev = args->rev;
   part.act_out[0] = (float*)args->h1; part.act_out[1] = (float*)args->h2; part.act_out[2] = (float*)args->h3; part.phi_out = (float*)args->phi; part.ldphi = args->ldphi;
+  part.phi_packed = args->phi_packed;
   zk_ar_args_v1 p = *args;
   p.act = 1; p.skip = nullptr;
   if (!p.y) {  // conditioner only
@@ -699,7 +701,7 @@ int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream) {
   a.stream = (const float*)args->wstream; a.featmap = args->featmap;
   a.phi_out = (float*)args->y; a.ldphi = args->ldy; a.accumulate = args->accumulate;
   a.gy = (const float*)args->y_in; a.ldgy = args->ldo; a.gl = (const float*)args->ladj;
-  a.phi_in = (const float*)args->phi; a.gphi_out = (float*)args->x_out; a.ldpin = args->ldphi;
+  a.phi_in = (const float*)args->phi; a.gphi_out = (float*)args->x_out; a.ldpin = args->ldphi; a.phi_packed = 1;
   a.bound = (float)args->bound; a.ls = (float)log(args->slope);
   for (int c = 0; c + 1 < n; ++c) {
     a.gate[c] = (const float*)hs[n - 2 - c];

@@ -266,13 +266,22 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
         for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r];
       });
       if constexpr (TRAIN) {
+        if (a.phi_packed) {  // the accumulators as they are: 16 bytes per lane and tile (zk_ar_common.h: ArArgs::phi_packed)
+          if (live) {
+            float* dst = a.phi_out + n * a.ldphi + (g * NT) * 16 + 4 * q;
+            ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE {
+              *reinterpret_cast<f32x4*>(dst + decltype(t)::value * 16) = f32x4{p[4 * t] + poison, p[4 * t + 1] + poison, p[4 * t + 2] + poison, p[4 * t + 3] + poison};
+            });
+          }
+        } else {
 #pragma unroll
-        for (int fi = 0; fi < FPL; ++fi) {
-          const int f = fid[fi];
-          if (f >= 0 && live) {
-            float* dst = a.phi_out + n * a.ldphi + f * TOTAL;
+          for (int fi = 0; fi < FPL; ++fi) {
+            const int f = fid[fi];
+            if (f >= 0 && live) {
+              float* dst = a.phi_out + n * a.ldphi + f * TOTAL;
 #pragma unroll
-            for (int i = 0; i < TOTAL; ++i) dst[i] = p[fi * TOTAL + i] + poison;
+              for (int i = 0; i < TOTAL; ++i) dst[i] = p[fi * TOTAL + i] + poison;
+            }
           }
         }
       }
@@ -451,11 +460,12 @@ template <class S> __global__ __launch_bounds__(512, 2) void arxd_kernel(ArArgs 
 // (gy, gl) -> g_phi (univariate adjoint, zk_univariate_bwd.h) -> dgrad chain -> gx, in ONE launch: the chain's first layer is walked in
 // the FORWARD kernel's packed order of phi — K tile (g, t) = parameters 4 t .. 4 t + 3 of the 4 * FPL features of group g, so that lane
 // (sample j, q) holds exactly its own features' parameters, as the forward's accumulators did — and every lane computes the adjoint of
-// its own features from phi, x, gy, gl: the results ARE its B operand of the group's in pairs (no shuffle, no LDS), and they are written
-// out once for the weight gradients.  g_phi is never read back by this launch; the stand-alone adjoint kernel and its pass over phi /
-// g_phi are gone.  The map's direct d/dx term waits in a wave-private LDS row and is added to the chain's input gradient at the end.
+// its own features from phi, x, gy, gl: the results ARE its B operand of the group's in pairs (no shuffle, no LDS).  phi arrives and
+// g_phi leaves in that same packed order (ArArgs::phi_packed: the training forward stores its accumulators as they are, the weight
+// gradients read the packed gradient through a row table), 16 bytes per lane and tile — lane-wise dword accesses to module-order rows
+// (23 per feature, each instruction scattering 64 dwords over 16 rows) cost this kernel a third of its time (profiles/r04).  The map's
+// direct d/dx term waits in a wave-private LDS row and is added to the chain's input gradient at the end.
 //   Shape::NG, PB[]     feature groups; first block (of layer 0, in-pair major) of every packed pair, PB[NG * NT / 2] = NB[0]
-//   Shape::STG, GB[]    rows are staged through LDS (see arxb_first); first feature of every group
 template <typename Uni, typename A> __device__ __forceinline__ void arxb_adjoint(const float* p, const A& a, float x, float gy, float gl, float& gx, float* g) {
   if constexpr (Uni::TOTAL == 2) affine_backward_element(p, x, gy, gl, a.ls, gx, g);
   else rqs_backward_element<(Uni::TOTAL + 1) / 3>(p, x, gy, gl, a.bound, a.ls, gx, g);
@@ -464,144 +474,68 @@ template <typename Uni, typename A> __device__ __forceinline__ void arxb_adjoint
 #ifndef ARXB_ABL
 #define ARXB_ABL 0  // timing ablations (wrong results; scripts/build_chain_variant.py): 1 no g_phi stores, 2 no phi loads, 3 neither, 4 no adjoint arithmetic
 #endif
-// Staged rows (Shape::STG: every feature group is 4 * FPL consecutive features starting at GB[g], a multiple of 4 floats into the row): phi
-// comes in and g_phi goes out as 16-byte pieces of the group's contiguous GW = 4 * FPL * TOTAL floats of each of the wave's 16 rows,
-// through a wave-private LDS tile that turns "piece" order into "lane owns its features' parameters" order and back.  (Lane-wise dword
-// accesses — 23 per feature, each instruction scattering 64 dwords over 16 rows — cost the kernel a third of its time: profiles/r04.)
 template <class S, typename Uni, class Ring>
-__device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const int* fmap_lds, float* xr, float* stg, int q, int j, int lane, int64_t n0, int64_t n, int64_t nc, bool live,
-                                           f32x4 (&out)[S::TMAX]) {
+__device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const int* fmap_lds, float* xr, int q, int64_t n, int64_t nc, bool live, f32x4 (&out)[S::TMAX]) {
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   constexpr int SG = (NT % 2) ? 2 : 1;  // groups per step: a step ends on a pair boundary
   constexpr int NSTEP = S::NG / SG, PPS = SG * NT / 2, NF = SG * FPL;
   constexpr int NB = S::NB[0], BASE = S::BASE[0], HTL = S::HT[0];
-  constexpr bool STG = S::STG;
-  constexpr int GW = 4 * FPL * TOTAL, NPC = 16 * GW / 4, NIT = (NPC + 63) / 64;
-  static_assert(S::NG % SG == 0 && FPL * TOTAL <= 4 * NT && GW % 4 == 0, "packed order: whole pairs per step");
+  static_assert(S::NG % SG == 0 && FPL * TOTAL <= 4 * NT, "packed order: whole pairs per step");
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < HTL; ++t) out[t] = zero;
   const float glv = a.gl[nc];
-  const float* phirow = a.phi_in + nc * a.ldpin;
+  const float* phirow = a.phi_in + nc * a.ldpin + 4 * q;  // packed rows: tile (g, t) of this lane = 4 floats at (g NT + t) 16 + 4 q
+  float* gphirow = a.gphi_out + n * a.ldpin + 4 * q;
   const float* xrow = a.x + nc * a.ldx;
   const float* gyrow = a.gy + nc * a.ldgy;
-  float ph[NF * TOTAL], xv[NF], gyv[NF];
+  f32x4 ph4[SG * NT];
+  float xv[NF], gyv[NF];
   int fid[NF];
-  // pieces: piece pi = 64 it + lane of a group tile is floats 4 pi .. 4 pi + 3 of the staging tile = row pi / (GW / 4), columns 4 (pi % (GW / 4)) ..
-  f32x4 pf[STG ? SG * NIT : 1];
-  int poff[STG ? NIT : 1];  // element offset of the piece from the tile's first row (rows beyond N: the last row, never stored)
-  bool pst[STG ? NIT : 1];
-  if constexpr (STG) {
+  auto fetch = [&](int s) ARS_ALWAYS_INLINE {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int pi = it * 64 + lane, row = pi / (GW / 4), c4 = pi % (GW / 4);
-      const bool ok = pi < NPC;
-      const int64_t last = a.N - 1 - n0;
-      poff[it] = (int)((row < last ? row : last) * a.ldpin) + 4 * c4;
-      pst[it] = ok && row <= last;
-      if (!ok) poff[it] = 0;
-    }
-  }
-  const float* phit = a.phi_in + n0 * a.ldpin;
-  float* gphit = a.gphi_out + n0 * a.ldpin;
-  auto fetch_small = [&](int s) ARS_ALWAYS_INLINE {
+    for (int t = 0; t < SG * NT; ++t)
+      ph4[t] = (ARXB_ABL == 2 || ARXB_ABL == 3) ? f32x4{0.01f, 0.02f, 0.03f, 0.04f} : *reinterpret_cast<const f32x4*>(phirow + (s * SG * NT + t) * 16);
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       const int f = fmap_lds[((s * SG + i / FPL) * 4 + q) * FPL + i % FPL];
       const int fc = f < 0 ? 0 : f;
       fid[i] = f;
-      if constexpr (!STG) {
-#pragma unroll
-        for (int k = 0; k < TOTAL; ++k) ph[i * TOTAL + k] = (ARXB_ABL == 2 || ARXB_ABL == 3) ? 0.01f * (float)(k + fc) : phirow[fc * TOTAL + k];
-      }
       xv[i] = xrow[fc];
       gyv[i] = gyrow[fc];
     }
   };
-  auto fetch_pieces = [&](auto s_) ARS_ALWAYS_INLINE {
-    constexpr int s = decltype(s_)::value;
-    if constexpr (STG) {
-      ars_for<SG>([&](auto gg_) ARS_ALWAYS_INLINE {
-        constexpr int gg = gg_, gb = S::GB[s * SG + gg] * TOTAL;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) pf[gg * NIT + it] = (ARXB_ABL == 2 || ARXB_ABL == 3) ? f32x4{0.01f, 0.02f, 0.03f, 0.04f} : *reinterpret_cast<const f32x4*>(phit + gb + poff[it]);
-      });
-    }
-  };
-  fetch_small(0);
-  fetch_pieces(std::integral_constant<int, 0>{});
+  fetch(0);
   f32x4 w[2][3];
   if constexpr (NB > 0) {
     ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[0][p] = ring.template read<BASE + decltype(p)::value>(); });
   }
   ars_for<NSTEP>([&](auto s_) ARS_ALWAYS_INLINE {
     constexpr int s = s_;
-    if constexpr (STG) {  // this step's pieces -> staging tile -> every lane's own parameters
-      ars_for<SG>([&](auto gg_) ARS_ALWAYS_INLINE {
-        constexpr int gg = gg_, gbf = S::GB[s * SG + gg];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (it * 64 + lane < NPC) *reinterpret_cast<f32x4*>(stg + 4 * (it * 64 + lane)) = pf[gg * NIT + it];
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int fi = 0; fi < FPL; ++fi) {
-          const int f = fid[gg * FPL + fi];
-          const float* src = stg + j * GW + ((f < 0 ? gbf : f) - gbf) * TOTAL;
-#pragma unroll
-          for (int k = 0; k < TOTAL; ++k) ph[(gg * FPL + fi) * TOTAL + k] = src[k];
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-      });
-      if constexpr (s + 1 < NSTEP) fetch_pieces(std::integral_constant<int, s + 1>{});  // (arrive during this step's adjoint and matrix work)
-    }
     float gq[SG * NT * 4];
 #pragma unroll
     for (int i = 0; i < SG * NT * 4; ++i) gq[i] = 0.f;
-    ars_for<SG>([&](auto gg_) ARS_ALWAYS_INLINE {
-      constexpr int gg = gg_, gbf = S::GB[s * SG + gg];
 #pragma unroll
-      for (int fi = 0; fi < FPL; ++fi) {
-        const int i = gg * FPL + fi;
-        const int f = fid[i];
-        float g[TOTAL], gxv;
-        if (ARXB_ABL == 4) {
-          gxv = xv[i] + gyv[i];
+    for (int i = 0; i < NF; ++i) {
+      const int f = fid[i];
+      float ph[TOTAL], g[TOTAL], gxv;
 #pragma unroll
-          for (int k = 0; k < TOTAL; ++k) g[k] = ph[i * TOTAL + k] + glv;
-        } else
-        arxb_adjoint<Uni>(&ph[i * TOTAL], a, xv[i], gyv[i], glv, gxv, g);
-        if (f >= 0) {
-          xr[f] = gxv;
-          if constexpr (STG) {
-            float* dst = stg + j * GW + (f - gbf) * TOTAL;
+      for (int k = 0; k < TOTAL; ++k) ph[k] = ph4[(i / FPL) * NT + ((i % FPL) * TOTAL + k) / 4][((i % FPL) * TOTAL + k) % 4];
+      if (ARXB_ABL == 4) {
+        gxv = xv[i] + gyv[i];
 #pragma unroll
-            for (int k = 0; k < TOTAL; ++k) dst[k] = g[k];
-          } else if (live && ARXB_ABL != 1 && ARXB_ABL != 3) {
-            float* dst = a.gphi_out + n * a.ldpin + f * TOTAL;
+        for (int k = 0; k < TOTAL; ++k) g[k] = ph[k] + glv;
+      } else
+      arxb_adjoint<Uni>(ph, a, xv[i], gyv[i], glv, gxv, g);
+      if (f >= 0) xr[f] = gxv;
 #pragma unroll
-            for (int k = 0; k < TOTAL; ++k) dst[k] = g[k];
-          }
-        }
+      for (int k = 0; k < TOTAL; ++k) gq[(i / FPL) * NT * 4 + (i % FPL) * TOTAL + k] = f >= 0 ? g[k] : 0.f;
+    }
+    if (live && ARXB_ABL != 1 && ARXB_ABL != 3) {  // the gradient in the same packed order (padding slots zero), for the weight gradients
 #pragma unroll
-        for (int k = 0; k < TOTAL; ++k) gq[gg * NT * 4 + fi * TOTAL + k] = f >= 0 ? g[k] : 0.f;
-      }
-      if constexpr (STG) {  // the group's gradient tile leaves as 16-byte pieces
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          if (it * 64 + lane < NPC) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + 4 * (it * 64 + lane));
-            if (pst[it] && ARXB_ABL != 1 && ARXB_ABL != 3) *reinterpret_cast<f32x4*>(gphit + gbf * TOTAL + poff[it]) = v;
-          }
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-      }
-    });
-    if constexpr (s + 1 < NSTEP) fetch_small(s + 1);  // (x, gy and — unstaged — phi of this step are consumed: the next step's arrive during this step's matrix work)
+      for (int t = 0; t < SG * NT; ++t) *reinterpret_cast<f32x4*>(gphirow + (s * SG * NT + t) * 16) = f32x4{gq[4 * t], gq[4 * t + 1], gq[4 * t + 2], gq[4 * t + 3]};
+    }
+    if constexpr (s + 1 < NSTEP) fetch(s + 1);  // (phi of this step is consumed: the next step's arrives during this step's matrix work)
     ars_for<PPS>([&](auto pl_) ARS_ALWAYS_INLINE {
       constexpr int pl = pl_, pp = s * PPS + pl, B0 = S::PB[pp], B1 = S::PB[pp + 1];
       if constexpr (B1 > B0) {
@@ -643,8 +577,6 @@ template <class S, typename Uni> __global__ __launch_bounds__(512, 2) void arxb_
   float* zero_lds = ars_lds + ARS_NR * S::CH * AR_TF;
   int* fmap_lds = reinterpret_cast<int*>(zero_lds + S::TMAX * 16 + 16);
   float* xr = reinterpret_cast<float*>(fmap_lds + NFMAP) + (wave * 16 + j) * a.xs;
-  constexpr int GW = 4 * Uni::FPL * Uni::TOTAL;
-  float* stg = reinterpret_cast<float*>(fmap_lds + NFMAP) + 8 * 16 * a.xs + wave * 16 * GW;  // (Shape::STG) 16 rows x one group's parameters
   for (int i = tid; i < S::TMAX * 16 + 16; i += 512) zero_lds[i] = 0.f;
   for (int i = tid; i < S::NG * 4 * Uni::FPL; i += 512) fmap_lds[i] = a.featmap[i];
   __syncthreads();
@@ -654,7 +586,7 @@ template <class S, typename Uni> __global__ __launch_bounds__(512, 2) void arxb_
     const int64_t nc = live ? n : a.N - 1;
     ArxB in[S::TMAX / 2];
     f32x4 out[S::TMAX];
-    arxb_first<S, Uni>(ring, a, fmap_lds, xr, stg, q, j, lane, tile * 128 + wave * 16, n, nc, live, out);
+    arxb_first<S, Uni>(ring, a, fmap_lds, xr, q, n, nc, live, out);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     arxd_stack<S, 0, Ring>(ring, zero_lds + 4 * q, q, in, out, a, n, nc, live, xr + 4 * q);
@@ -668,15 +600,15 @@ template <class S, typename Uni> static int arxb_launch(const ArArgs* in, int ab
   if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;
   ArArgs a = *in;
   if (a.DIN != S::DOUT || a.D != S::DOUT || a.L != S::NH || a.NG != S::NG || a.n_chunks != S::NCHUNK || !a.x || !a.phi_out || !a.phi_in || !a.gphi_out || !a.gy || !a.gl || !a.featmap ||
-      a.ldx % 4 || a.ldphi % 4 || a.ldpin < (int64_t)S::DOUT * Uni::TOTAL || ((uintptr_t)a.x % 16) || ((uintptr_t)a.phi_out % 16))
+      a.ldx % 4 || a.ldphi % 4 || a.ldpin < (int64_t)S::NG * Uni::NT * 16 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.phi_out % 16))
     return ZK_EINVAL;
   for (int l = 0; l + 1 < S::NH; ++l)
     if (!a.gate[l] || !a.act_out[l] || ((uintptr_t)a.gate[l] % 16) || ((uintptr_t)a.act_out[l] % 16)) return ZK_EINVAL;
   a.n_tiles = (a.N + 127) / 128;
   a.xs = ((S::DOUT + 3) / 4) * 4 + 4;
   constexpr int NFMAP = ((S::NG * 4 * Uni::FPL + 3) / 4) * 4;
-  const int lds = (ARS_NR * S::CH * AR_TF + S::TMAX * 16 + 16 + NFMAP + 8 * 16 * a.xs + (S::STG ? 8 * 16 * 4 * Uni::FPL * Uni::TOTAL : 0)) * (int)sizeof(float);
-  if (lds > 160 * 1024 || (S::STG && (a.ldpin % 4 || ((uintptr_t)a.phi_in % 16) || ((uintptr_t)a.gphi_out % 16)))) return ZK_EINVAL;
+  const int lds = (ARS_NR * S::CH * AR_TF + S::TMAX * 16 + 16 + NFMAP + 8 * 16 * a.xs) * (int)sizeof(float);
+  if (lds > 160 * 1024 || a.ldpin % 4 || ((uintptr_t)a.phi_in % 16) || ((uintptr_t)a.gphi_out % 16)) return ZK_EINVAL;
   const void* fn = (const void*)arxb_kernel<S, Uni>;
   static bool granted = false;
   if (!granted) {
@@ -719,7 +651,7 @@ template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi
   if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;  // kernel built against another version of the library
   ArArgs a = *in;
   if (a.D != S::D || a.DIN != S::DIN || a.L != S::NH + 1 || a.act != S::ACT || a.sched || a.NG != S::NG || a.n_chunks != S::NCHUNK || a.l1rev) return ZK_EINVAL;
-  if (train && (!S::TRAIN_OK || !a.phi_out)) return ZK_EINVAL;
+  if (train && (!S::TRAIN_OK || !a.phi_out || (a.phi_packed && (a.ldphi % 4 || a.ldphi < (int64_t)S::NG * Uni::NT * 16 || ((uintptr_t)a.phi_out % 16))))) return ZK_EINVAL;
   a.n_tiles = (a.N + 16 * S::WAVES - 1) / (16 * S::WAVES);
   a.xs = ((S::D + 3) / 4) * 4 + 4;
   const bool vec_ok = (S::D % 4 == 0) && ((train && !a.y) || ((a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0)));

@@ -524,6 +524,7 @@ __device__ __forceinline__ void wgrad_reduce_body(int OUT, int IN, const int32_t
   for (; s < nslices; ++s) sum += src[(size_t)s * stride];
   const size_t idx = (size_t)o * IN + c;
   if (mask && !mask[idx]) sum = 0.f;
+  if (rows && rows[o] < 0) return;  // (a padding slot of a packed gradient: no row of the weight behind it)
   const size_t dst = (size_t)(rows ? rows[o] : o) * IN + (cols ? cols[c] : c);
   dw[dst] = accumulate ? dw[dst] + sum : sum;
 }
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WredMulti m) {
     for (int u = 0; u < 8; ++u) sum += v[u];
   }
   for (; sl < r.nslices; ++sl) sum += r.cs_partial[(size_t)sl * r.cs_ld + c];
+  if (r.rows && r.rows[c] < 0) return;
   r.db[r.rows ? r.rows[c] : c] = sum;
 }
 

@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AR_TF 256 /* floats per tile image */
 #define AR_WAVES 8
 #define AR_T 16   /* activation tiles (256 units) */
-#define ARS_ABI 5 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
+#define ARS_ABI 6 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
 
 struct ArArgs {
   int64_t N;
@@ -51,6 +51,10 @@ struct ArArgs {
   int64_t ldpin;
   const float* gy; int64_t ldgy;
   const float* gl;
+  // training launches: phi (and its gradient) in the kernels' PACKED order instead of the module's — row n holds, for group g and tile t,
+  // 16 floats at (g NT + t) 16: parameter 4 t + r of the features of lane q = 0..3 at 4 q + r (row stride >= NG * NT * 16), which is
+  // how a lane holds them in registers: 16-byte accesses, no regrouping (zuko_amd/train.py keeps such a phi to itself)
+  int phi_packed;
 };
 
 __device__ __forceinline__ float act_f32(float v, int act) {

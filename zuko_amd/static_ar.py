@@ -36,7 +36,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
-ARS_ABI = 5  # == ARS_ABI of csrc/zk_ar_common.h
+ARS_ABI = 6  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 3: "zk::UniRqs16", 4: "zk::UniCircRqs8"}
 # 16 bins: the twelve accumulator tiles of a feature group do not fit the f32-instruction template's double-buffered last layer (it would
 # spill), but the operand-split template holds them (255 VGPRs, no scratch): that kind exists as a split kernel only, forward only
@@ -579,7 +579,8 @@ def chain_split_tables(masks_sorted: list, rows: list, cols: list, packed: dict 
     packed = {"uni": kind, "featmap": int array [NG * 4 * FPL], "nt", "fpl", "total"} (the forward plan's grouping of the features,
     zuko_amd/fused.py: build_plan): the tables of arxb_kernel instead — the whole backward of the transform in one launch.  Its first layer
     runs over the FORWARD kernel's packed order of phi (unit 16 (g NT + t) + 4 q + r = parameter 4 t + r of the features of lane q in group
-    g), in which a lane owns the parameters of its own features and computes their gradient itself."""
+    g), in which a lane owns the parameters of its own features and computes their gradient itself; MODROW maps a packed unit to its row of
+    the last linear layer (-1: padding slot)."""
     n = len(masks_sorted)
     if n < 2 or n > 4:
         return None
@@ -650,12 +651,7 @@ def chain_split_tables(masks_sorted: list, rows: list, cols: list, packed: dict 
     if packed is not None:  # first block of every packed pair (layer 0 is in-pair major: the blocks of a pair are consecutive)
         n_pairs = t["DIN0"] // 32
         ips = np.asarray(B_IP[: NB[0]])
-        # groups of 4 * fpl CONSECUTIVE features whose parameters start a multiple of 16 bytes into the row can move as 16-byte pieces
-        grp = fm.reshape(ng, 4 * fpl)
-        gb = grp.min(axis=1)
-        stg = bool((grp >= 0).all() and all(sorted(r.tolist()) == list(range(int(b), int(b) + 4 * fpl)) for r, b in zip(grp, gb)) and ((gb * total) % 4 == 0).all()
-                   and (4 * fpl * total) % 4 == 0 and os.environ.get("ZUKO_AMD_ARXB_STAGED", "1") != "0")
-        t.update({"chain": 3, "uni": int(packed["uni"]), "NG": ng, "PB": [int((ips < pp).sum()) for pp in range(n_pairs + 1)], "STG": int(stg), "GB": [int(max(b, 0)) for b in gb]})
+        t.update({"chain": 3, "uni": int(packed["uni"]), "NG": ng, "NT": nt, "PB": [int((ips < pp).sum()) for pp in range(n_pairs + 1)], "MODROW": [int(r) for r in mod_row]})
     return t, [np.stack(b).astype(np.int32).reshape(-1) for b in blocks_of]
 
 
@@ -673,7 +669,7 @@ def emit_chain_split(t: dict) -> str:
         _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]),
     ]
     if t.get("chain") == 3:  # the whole backward of the transform (arxb_kernel)
-        lines += [f"  static constexpr int NG = {t['NG']};", f"  static constexpr bool STG = {'true' if t['STG'] else 'false'};", _arr("PB", "int", t["PB"]), _arr("GB", "int", t["GB"])]
+        lines += [f"  static constexpr int NG = {t['NG']};", _arr("PB", "int", t["PB"])]
         launch = f"zk::arxb_launch<Shape, {UNI_TYPES[t['uni']]}>"
     else:
         launch = "zk::arxd_launch<Shape>"
@@ -764,7 +760,7 @@ PREBUILT = [
     ("rqs", 16, 2, (64, 64), 8, "ELU"),
     ("affine", 12, 0, (48, 32), 0, "Tanh"),
     ("rqs", 64, 0, (256, 256, 256), 16),   # NSF(bins=16): operand-split kernel only (SPLIT_ONLY_KINDS)
-    ("affine", 12, 0, (64, 64), 0),        # training: a last feature group that is not full (the one-launch backward without staged rows)
+    ("affine", 12, 0, (64, 64), 0),        # training: a last feature group that is not full (padding slots in the packed phi / g_phi rows)
 ]
 
 

@@ -185,9 +185,10 @@ class SortedPlan:
         _C.check(err, "zk_wgrad_f32")
         return (dw, None) if want_bias else dw
 
-    def wgrad_multi(self, items):
+    def wgrad_multi(self, items, packed_last=None):
         """Weight and bias gradients of several layers in two launches (zk_wgrad_multi).  items: [(layer, g, h)] with every layer's
-        cs_flag present; returns {layer: (dW in the module's order, db in the module's order)}."""
+        cs_flag present; returns {layer: (dW in the module's order, db in the module's order)}.  packed_last (PackedRows): the LAST layer's g
+        has its columns in the fused kernels' packed order (padding slots included) — the row tables of that order are used for it."""
         import ctypes
 
         lib = _C.lib()
@@ -195,11 +196,19 @@ class SortedPlan:
         n = len(items)
         N = items[0][1].shape[0]
         dev = items[0][1].device
+        last = len(self.shapes) - 1
+
+        def side(l):  # (width of g, live pairs, sorted-domain mask, column-sum flags, row table)
+            if packed_last is not None and l == last:
+                return packed_last.width, packed_last.pairs, packed_last.mask_s, packed_last.cs_flag, packed_last.rows
+            return self.shapes[l][0], self.pairs[l], self.mask_s[l], self.cs_flag[l], self.idx_b[l]
+
+        sides = [side(l) for l, _, _ in items]
         sizes_w = [self.shapes[l][0] * self.shapes[l][1] for l, _, _ in items]
         sizes_b = [self.shapes[l][0] for l, _, _ in items]
-        ns = [max(1, lib.zk_wgrad_slices(N, self.pairs[l].shape[0])) for l, _, _ in items]
-        sizes_p = [ns[i] * self.pairs[l].shape[0] * 128 * 128 for i, (l, _, _) in enumerate(items)]
-        sizes_c = [ns[i] * (-(-self.shapes[l][0] // 128) * 128) for i, (l, _, _) in enumerate(items)]
+        ns = [max(1, lib.zk_wgrad_slices(N, sd[1].shape[0])) for sd in sides]
+        sizes_p = [ns[i] * sd[1].shape[0] * 128 * 128 for i, sd in enumerate(sides)]
+        sizes_c = [ns[i] * (-(-sd[0] // 128) * 128) for i, sd in enumerate(sides)]
         flat = torch.zeros(sum(sizes_w) + sum(sizes_b), dtype=torch.float32, device=dev)  # (dW: only the live blocks are written)
         work = torch.empty(sum(sizes_p) + sum(sizes_c), dtype=torch.float32, device=dev)
         arr = (cls * n)()
@@ -207,12 +216,13 @@ class SortedPlan:
         ow, ob, op, oc = 0, sum(sizes_w), 0, sum(sizes_p)
         for i, (l, g, h) in enumerate(items):
             out_f, in_f = self.shapes[l]
+            width, pairs, mask_s, cs_flag, rows = sides[i]
             dw, db = flat[ow : ow + sizes_w[i]].view(out_f, in_f), flat[ob : ob + sizes_b[i]]
             d = arr[i]
             d.struct_size = ctypes.sizeof(cls)
-            d.out_features, d.in_features, d.npairs, d.ldg, d.ldh = out_f, in_f, self.pairs[l].shape[0], g.stride(0), h.stride(0)
-            for name, t in (("g", g), ("h", h), ("pairs", self.pairs[l]), ("partial", work[op:]), ("mask", self.mask_s[l]), ("dw", dw), ("cs_flag", self.cs_flag[l]),
-                            ("cs_partial", work[oc:]), ("db", db), ("rows", self.idx_b[l]), ("cols", self.cols_dev[l])):
+            d.out_features, d.in_features, d.npairs, d.ldg, d.ldh = width, in_f, pairs.shape[0], g.stride(0), h.stride(0)
+            for name, t in (("g", g), ("h", h), ("pairs", pairs), ("partial", work[op:]), ("mask", mask_s), ("dw", dw), ("cs_flag", cs_flag),
+                            ("cs_partial", work[oc:]), ("db", db), ("rows", rows), ("cols", self.cols_dev[l])):
                 setattr(d, name, None if t is None else t.data_ptr())
             out[l] = (dw, db)
             ow += sizes_w[i]; ob += sizes_b[i]; op += sizes_p[i]; oc += sizes_c[i]
@@ -226,6 +236,37 @@ class SortedPlan:
         out = torch.empty(C, dtype=torch.float32, device=g.device)
         _C.check(lib.zk_colsum_f32(N, C, _ptr(g), g.stride(0), _ptr(ws), _ptr(out), 0, _stream()), "zk_colsum_f32")
         return out
+
+
+class PackedRows:
+    """Output-side tables of the LAST layer's weight gradient when g_phi comes in the fused kernels' packed order (csrc/zk_ar_common.h:
+    ArArgs::phi_packed): column u of g is row mod_row[u] of the weight (-1: a padding slot, always zero, no destination)."""
+
+    def __init__(self, plan: SortedPlan, mod_row, device) -> None:
+        import numpy as np
+
+        last = len(plan.shapes) - 1
+        out_f, in_f = plan.shapes[last]
+        mod_row = np.asarray(mod_row, dtype=np.int64)
+        self.width = int(mod_row.shape[0])
+        ms_mod = plan.mask_s_cpu[last]  # [out (module order: the last layer's rows are not sorted), in (sorted)]
+        ms = np.where((mod_row >= 0)[:, None], ms_mod[np.maximum(mod_row, 0)], False)
+        ob, ib = -(-self.width // 128), -(-in_f // 128)
+        pad = np.zeros((ob * 128, ib * 128), dtype=bool)
+        pad[: self.width, :in_f] = ms
+        live = torch.from_numpy(pad.reshape(ob, 128, ib, 128).any(axis=3).any(axis=1))
+        pr = live.nonzero().to(torch.int32).contiguous()
+        flag = torch.zeros(pr.shape[0], dtype=torch.uint8)
+        seen = set()
+        for k in range(pr.shape[0]):
+            o = int(pr[k, 0])
+            if o not in seen:
+                seen.add(o)
+                flag[k] = 1
+        self.ok = len(seen) == ob and pr.shape[0] > 0
+        self.pairs, self.cs_flag = pr.to(device), flag.to(device)
+        self.mask_s = torch.from_numpy(ms.astype(np.uint8)).contiguous().to(device)
+        self.rows = torch.from_numpy(mod_row.astype(np.int32)).to(device)
 
 
 _FUSED_TRAIN = weakref.WeakKeyDictionary()  # SortedPlan -> FusedAR (static-shape kernel) or False
@@ -279,14 +320,14 @@ def _fused_forward_state(plan: "SortedPlan", lins, device):
     return st or None
 
 
-def _fused_forward(st, x: Tensor, out_features: int, uni=None):
+def _fused_forward(st, x: Tensor, out_features: int, uni=None, packed_width: int = 0):
     """([h_1, ...] sorted-domain hidden activations, phi) from one launch of zk_ar_forward_train (a static-shape kernel of
     zuko_amd/static_ar.py in its training instantiation).  uni = (bound, slope) (operand-split kernels): the launch also evaluates the
-    univariate map, and (hs, phi, y, ladj) is returned."""
+    univariate map, and (hs, phi, y, ladj) is returned.  packed_width: phi [N, packed_width] in the kernels' packed order instead."""
     p = st.plan
     N = x.shape[0]
     hs = [torch.empty((N, w), dtype=torch.float32, device=x.device) for w in p.widths]
-    phi = torch.empty((N, out_features), dtype=torch.float32, device=x.device)
+    phi = torch.empty((N, packed_width or out_features), dtype=torch.float32, device=x.device)
     kern, rev = st.static
     hp = [_ptr(h) for h in hs] + [None] * (3 - len(hs))
     extra = {}
@@ -294,8 +335,8 @@ def _fused_forward(st, x: Tensor, out_features: int, uni=None):
         y, ladj = torch.empty((N, p.features), dtype=torch.float32, device=x.device), torch.empty(N, dtype=torch.float32, device=x.device)
         extra = dict(y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), bound=float(uni[0]), slope=float(uni[1]))
     a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
-                phi=_ptr(phi), ldphi=out_features, wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap), n_layers=p.n_layers,
-                n_groups=p.n_groups, n_chunks=st.fine_n_chunks, act=1, **extra)
+                phi=_ptr(phi), ldphi=phi.stride(0), phi_packed=int(packed_width > 0), wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap),
+                n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=st.fine_n_chunks, act=1, **extra)
     err = _C.lib().zk_ar_forward_train(a, _stream())
     _C.check(err, "zk_ar_forward_train")
     return (hs, phi) if uni is None else (hs, phi, y, ladj)
@@ -311,6 +352,7 @@ class DgradChain:
         self.kernel, self.t = kernel, tables
         self.full = tables.get("chain") in (2, 3)
         self.fused = tables.get("chain") == 3  # the transform's whole backward (univariate adjoint + chain): run_backward
+        self.packed = PackedRows(plan, tables["MODROW"], device) if self.fused else None  # phi / g_phi travel in the packed order then
         self.idx = [torch.from_numpy(g).to(device) for g in gathers]
         self.offsets = [b * 256 for b in tables["BASE"]]
         self.device = device
@@ -350,8 +392,8 @@ class DgradChain:
 
 
     def run_backward(self, plan: SortedPlan, stream: Tensor, st, uni, x: Tensor, phi: Tensor, gy: Tensor, gl: Tensor, hs):
-        """Fused chains: (g_phi [N, out_features], [g_1, ..], gx) from d loss / d (y, ladj) in one launch (zk_ar_backward_full); st = the
-        forward's FusedAR (feature grouping), uni = (kind, bound, slope, ..)."""
+        """Fused chains: (g_phi [N, packed width] in the packed order of phi, [g_1, ..], gx) from d loss / d (y, ladj) in one launch
+        (zk_ar_backward_full); phi: the forward's, packed; st = the forward's FusedAR (feature grouping), uni = (kind, bound, slope, ..)."""
         n = len(plan.shapes)
         N = x.shape[0]
         dev = x.device
@@ -392,6 +434,8 @@ def _backward_kernel(plan: SortedPlan, st, rows: int):
         if kern is None:
             return None  # (not cached: a later, larger batch may be allowed to compile)
         bk = DgradChain(plan, kern, tg[0], tg[1], plan.device)
+        if not bk.packed.ok:  # (some 128-column block of the packed gradient without a live weight block: the bias gradient could not ride on the weight pass)
+            bk = False
         _BACKWARDS[plan] = bk
     return bk or None
 
@@ -538,7 +582,7 @@ class AutoregressiveFn(torch.autograd.Function):
         n = len(lins)
         st.refresh(lins, fine_only=True)
         stream = chain.gather(plan, lins)
-        acts, phi, y, ladj = _fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]))
+        acts, phi, y, ladj = _fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]), packed_width=chain.packed.width if chain.fused else 0)
         ctx.plan, ctx.n, ctx.chain, ctx.uni, ctx.st = plan, n, chain, uni, st
         ctx.save_for_backward(x, *acts, phi, stream)
         return y, ladj
@@ -562,7 +606,7 @@ class AutoregressiveFn(torch.autograd.Function):
             gx, gphi = _adj_any((kind, bound, slope, sizes, ()), x, phi.view(N, D, -1), gy, gl, True)
             gphi = gphi.view(N, -1)
             gs, gx = chain.run(plan, stream, gphi, hs, gx_add=gx)
-        res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else gphi, hs[l]) for l in range(n)])
+        res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else gphi, hs[l]) for l in range(n)], packed_last=chain.packed if chain.fused else None)
         grads = []
         for l in range(n):
             grads += list(res[l])
