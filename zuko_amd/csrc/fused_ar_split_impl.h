@@ -344,6 +344,12 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
 //   Shape::DIN0, NP0, P0[]        width of g_phi, in pairs of layer 0 that have blocks, and which pairs these are (in stream order)
 //   Shape::NB[l], BOFF, B_OT, B_IP, BASE   blocks per chain layer (layer 0: in-pair major; others: out-tile major)
 //   Shape::HT[l]                  out tiles of chain layer l (= tiles of the hidden layer whose gradient it yields); DOUT: conditioner inputs
+#ifndef ARXB_AHEAD
+#define ARXB_AHEAD 1  // steps of look-ahead of the first layer's inputs (phi, x, gy) in registers
+#endif
+#ifndef ARXB_ABL
+#define ARXB_ABL 0  // timing ablations of the backward kernels (wrong results; scripts/build_chain_variant.py): 1 no g_phi stores, 2 no phi loads, 3 neither, 4 no adjoint arithmetic, 5 no g_h stores, 6 no gate loads, 7 = 5 + 6, 8 = 3 + 7
+#endif
 template <class S> struct ArxdPat {
   static constexpr int pair_index(int s) {  // position in P0 of the pair block s of layer 0 belongs to
     int n = 0;
@@ -402,11 +408,11 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arxd_stack
       const float* grow = a.gate[L] + nc * (HTL * 16) + 4 * q;
 #pragma unroll
       for (int t = 0; t < HTL; ++t) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(grow + t * 16);
+        const f32x4 h = (ARXB_ABL == 6 || ARXB_ABL == 7 || ARXB_ABL == 8) ? f32x4{1.f, -1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(grow + t * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[t][r] = out[t][r] * (h[r] > 0.f ? 1.f : 0.f);  // (a product, as autograd's: NaN gradients stay NaN)
       }
-      if (live) {
+      if (live && ARXB_ABL != 5 && ARXB_ABL != 7 && ARXB_ABL != 8) {
 #pragma unroll
         for (int t = 0; t < HTL; ++t) *reinterpret_cast<f32x4*>(a.act_out[L] + n * (HTL * 16) + t * 16 + 4 * q) = out[t];
       }
@@ -471,9 +477,6 @@ template <typename Uni, typename A> __device__ __forceinline__ void arxb_adjoint
   else rqs_backward_element<(Uni::TOTAL + 1) / 3>(p, x, gy, gl, a.bound, a.ls, gx, g);
 }
 
-#ifndef ARXB_ABL
-#define ARXB_ABL 0  // timing ablations (wrong results; scripts/build_chain_variant.py): 1 no g_phi stores, 2 no phi loads, 3 neither, 4 no adjoint arithmetic
-#endif
 template <class S, typename Uni, class Ring>
 __device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const int* fmap_lds, float* xr, int q, int64_t n, int64_t nc, bool live, f32x4 (&out)[S::TMAX]) {
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
@@ -489,53 +492,57 @@ __device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const in
   float* gphirow = a.gphi_out + n * a.ldpin + 4 * q;
   const float* xrow = a.x + nc * a.ldx;
   const float* gyrow = a.gy + nc * a.ldgy;
-  f32x4 ph4[SG * NT];
-  float xv[NF], gyv[NF];
-  int fid[NF];
-  auto fetch = [&](int s) ARS_ALWAYS_INLINE {
+  // ARXB_AHEAD steps of look-ahead in registers (buffer = step % ARXB_AHEAD): the loads of step s + ARXB_AHEAD are issued when step s's values are consumed
+  f32x4 ph4[ARXB_AHEAD][SG * NT];
+  float xv[ARXB_AHEAD][NF], gyv[ARXB_AHEAD][NF];
+  int fid[ARXB_AHEAD][NF];
+  auto fetch = [&](auto s_) ARS_ALWAYS_INLINE {
+    constexpr int s = decltype(s_)::value, bf = s % ARXB_AHEAD;
 #pragma unroll
     for (int t = 0; t < SG * NT; ++t)
-      ph4[t] = (ARXB_ABL == 2 || ARXB_ABL == 3) ? f32x4{0.01f, 0.02f, 0.03f, 0.04f} : *reinterpret_cast<const f32x4*>(phirow + (s * SG * NT + t) * 16);
+      ph4[bf][t] = (ARXB_ABL == 2 || ARXB_ABL == 3 || ARXB_ABL == 8) ? f32x4{0.01f, 0.02f, 0.03f, 0.04f} : *reinterpret_cast<const f32x4*>(phirow + (s * SG * NT + t) * 16);
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       const int f = fmap_lds[((s * SG + i / FPL) * 4 + q) * FPL + i % FPL];
       const int fc = f < 0 ? 0 : f;
-      fid[i] = f;
-      xv[i] = xrow[fc];
-      gyv[i] = gyrow[fc];
+      fid[bf][i] = f;
+      xv[bf][i] = xrow[fc];
+      gyv[bf][i] = gyrow[fc];
     }
   };
-  fetch(0);
+  ars_for<(ARXB_AHEAD < NSTEP ? ARXB_AHEAD : NSTEP)>([&](auto s_) ARS_ALWAYS_INLINE { fetch(s_); });
   f32x4 w[2][3];
   if constexpr (NB > 0) {
     ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[0][p] = ring.template read<BASE + decltype(p)::value>(); });
   }
   ars_for<NSTEP>([&](auto s_) ARS_ALWAYS_INLINE {
-    constexpr int s = s_;
+    constexpr int s = s_, bf = s % ARXB_AHEAD;
     float gq[SG * NT * 4];
 #pragma unroll
     for (int i = 0; i < SG * NT * 4; ++i) gq[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
-      const int f = fid[i];
+      const int f = fid[bf][i];
       float ph[TOTAL], g[TOTAL], gxv;
 #pragma unroll
-      for (int k = 0; k < TOTAL; ++k) ph[k] = ph4[(i / FPL) * NT + ((i % FPL) * TOTAL + k) / 4][((i % FPL) * TOTAL + k) % 4];
+      for (int k = 0; k < TOTAL; ++k) ph[k] = ph4[bf][(i / FPL) * NT + ((i % FPL) * TOTAL + k) / 4][((i % FPL) * TOTAL + k) % 4];
       if (ARXB_ABL == 4) {
-        gxv = xv[i] + gyv[i];
+        gxv = xv[bf][i] + gyv[bf][i];
 #pragma unroll
         for (int k = 0; k < TOTAL; ++k) g[k] = ph[k] + glv;
       } else
-      arxb_adjoint<Uni>(ph, a, xv[i], gyv[i], glv, gxv, g);
+      arxb_adjoint<Uni>(ph, a, xv[bf][i], gyv[bf][i], glv, gxv, g);
       if (f >= 0) xr[f] = gxv;
 #pragma unroll
       for (int k = 0; k < TOTAL; ++k) gq[(i / FPL) * NT * 4 + (i % FPL) * TOTAL + k] = f >= 0 ? g[k] : 0.f;
     }
-    if (live && ARXB_ABL != 1 && ARXB_ABL != 3) {  // the gradient in the same packed order (padding slots zero), for the weight gradients
+    // this step's inputs are consumed: their registers take the loads of step s + ARXB_AHEAD — issued BEFORE this step's stores, so that waiting
+    // for them later does not wait for the stores (one in-order counter for both)
+    if constexpr (s + ARXB_AHEAD < NSTEP) fetch(std::integral_constant<int, s + ARXB_AHEAD>{});
+    if (live && ARXB_ABL != 1 && ARXB_ABL != 3 && ARXB_ABL != 8) {  // the gradient in the same packed order (padding slots zero), for the weight gradients
 #pragma unroll
       for (int t = 0; t < SG * NT; ++t) *reinterpret_cast<f32x4*>(gphirow + (s * SG * NT + t) * 16) = f32x4{gq[4 * t], gq[4 * t + 1], gq[4 * t + 2], gq[4 * t + 3]};
     }
-    if constexpr (s + 1 < NSTEP) fetch(s + 1);  // (phi of this step is consumed: the next step's arrives during this step's matrix work)
     ars_for<PPS>([&](auto pl_) ARS_ALWAYS_INLINE {
       constexpr int pl = pl_, pp = s * PPS + pl, B0 = S::PB[pp], B1 = S::PB[pp + 1];
       if constexpr (B1 > B0) {
