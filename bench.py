@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-side-configs", action="store_true",
                     help="default cfg2 run at N=1: do not append the cfg3 / cfg4 / cfg5 side measurements (each a short run of this script in a process of its own)")
     ap.add_argument("--side-steps", type=int, default=0, help="timed steps of every side configuration (0 = a per-config default)")
+    ap.add_argument("--side-paths", action="store_true", help="print the training / sampling report of the cfg2 and cfg3 flows (the `side_paths` object of the default line) and exit")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
                     help="cfg2 = the headline NSF workload (default, the only graded line); cfg3 = MAF(64,T=8,H=256x3); "
                          "cfg4 = RealNVP(256,T=16,H=512x3); cfg5 = NSF(1024,T=12,K=16,H=1024x3) in bf16 (use --batch-log2 19) — "
@@ -531,6 +532,101 @@ def run_side_configs(args) -> dict:
     return out
 
 
+def side_paths_report() -> dict:
+    """The paths either side of log_prob for the cfg2 / cfg3 flows: one Adam step of the README training loop at batch 2^16 (with the
+    gradients of the one-node path checked against the two-node path on the same weights) and flow().transform.inv at 2^18 (with the round trip through
+    the forward).  Short, after everything else; the headline's timed region never sees it."""
+    import torch
+
+    from zuko_amd import flows as F
+
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    out = {}
+    for name, ctor, kw in (("nsf_cfg2", "NSF", CONFIGS["cfg2"][1]), ("maf_cfg3", "MAF", CONFIGS["cfg3"][1])):
+        entry = {}
+        try:
+            torch.manual_seed(0)
+            flow = getattr(F, ctor)(**kw).to(dev)
+            B = 1 << 16
+            x = torch.randn(B, kw["features"], device=dev)
+            opt = torch.optim.Adam(flow.parameters(), lr=1e-3)
+
+            def step():
+                loss = -flow().log_prob(x).mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                return loss
+
+            def nodes(fn, seen):
+                if fn is not None and fn not in seen:
+                    seen.add(fn)
+                    for nxt, _ in fn.next_functions:
+                        nodes(nxt, seen)
+                return seen
+
+            def grads(rows):
+                flow.zero_grad()
+                loss = -flow().log_prob(x[:rows]).mean()
+                names = {type(f).__name__ for f in nodes(loss.grad_fn, set())}
+                loss.backward()
+                return loss.item(), names, [p.grad.clone() for p in flow.parameters()]
+
+            l1, names, g1 = grads(4096)
+            os.environ["ZUKO_AMD_NO_FUSED_AR_TRAIN"] = "1"
+            try:
+                l2, _, g2 = grads(4096)
+            finally:
+                del os.environ["ZUKO_AMD_NO_FUSED_AR_TRAIN"]
+            rel = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item() for a, b in zip(g1, g2))
+            for _ in range(3):
+                l0 = step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                l = step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            entry["training"] = {"workload": f"{ctor} Adam step of -log_prob(x).mean(), batch 2^16", "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "loss_before_after": [float(l0), float(l)],
+                                 "one_autograd_node_per_transform": "AutoregressiveFnBackward" in names,
+                                 "parity": {"rows": 4096, "grad_max_rel_vs_two_node_path": rel, "loss_abs_diff": abs(l1 - l2), "ok": bool(rel < 1e-4 and abs(l1 - l2) < 1e-4 * max(1.0, abs(l2)))}}
+            del opt
+            with torch.no_grad():
+                Bs = 1 << 18
+                z = torch.randn(Bs, kw["features"], device=dev)
+                t = flow().transform
+                xs = t.inv(z)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    xs = t.inv(z)
+                torch.cuda.synchronize()
+                ds = (time.perf_counter() - t0) / 3
+                back = t(xs)
+                err = (back - z).abs().max().item()
+            entry["sampling"] = {"workload": f"{ctor} flow().transform.inv(z), batch 2^18", "ms": ds * 1e3, "samples_per_s": Bs / ds, "round_trip_max_abs": err, "ok": bool(err < 1e-3)}
+        except Exception as exc:  # never let a side measurement break the headline line
+            entry["error"] = repr(exc)
+        out[name] = entry
+    return out
+
+
+def run_side_paths() -> dict:
+    cmd = [sys.executable, os.path.abspath(__file__), "--side-paths"]
+    try:
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        line = next((l for l in reversed(res.stdout.splitlines()) if l.startswith("{")), None)
+        if res.returncode != 0 or line is None:
+            return {"error": f"exit code {res.returncode}", "stderr_tail": res.stderr[-600:]}
+        return json.loads(line)
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def model_flops(flow) -> dict:
     """Per sample, whole flow: dense conditioner FLOPs (SURVEY 8d column 2) and FLOPs on non-zero (unmasked) weights."""
     dense = nnz = 0
@@ -550,6 +646,9 @@ def model_flops(flow) -> dict:
 
 def main() -> None:
     args = parse()
+    if args.side_paths:
+        print(json.dumps(side_paths_report()))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(relaunch_under_torchrun(args.gpus))
 
@@ -796,6 +895,7 @@ def main() -> None:
             del flow, x
             torch.cuda.empty_cache()
             out["side_configs"] = run_side_configs(args)
+            out["side_paths"] = run_side_paths()  # training step and sampling of the cfg2 / cfg3 flows, each with its own check
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
