@@ -295,3 +295,34 @@ def test_gather_multi_equals_the_single_gathers(dev):
     torch.cuda.synchronize()
     for (src, mask, idx, count, dst, split), ref in zip(items, want):
         assert torch.equal(dst.view(torch.int32), ref.view(torch.int32)), (count, split)
+
+
+@pytest.mark.parametrize("shape", [(300, 37, 50), (1000, 128, 256), (5, 3, 7), (2049, 260, 129)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_layerwise_linear_backward_has_no_library_gemm(dev, shape, masked):
+    """Module trees the sorted plans do not cover (residual blocks; zuko/nn.py:297-309) differentiate layer by layer through
+    zuko_amd/autograd.py:LinearFn, whose dgrad / wgrad / bias gradient are the tile kernels of csrc/train.hip (until round 4: torch.mm): against
+    float64 autograd of F.linear(x, mask * W, b) (zuko/nn.py:217-218)."""
+    from zuko_amd import ops
+
+    N, in_f, out_f = shape
+    g = torch.Generator().manual_seed(N + in_f)
+    x = torch.randn(N, in_f, generator=g)
+    w = torch.randn(out_f, in_f, generator=g) / in_f**0.5
+    b = torch.randn(out_f, generator=g)
+    mask = (torch.rand(out_f, in_f, generator=g) > 0.4) if masked else None
+    gy = torch.randn(N, out_f, generator=g)
+
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    yr = torch.nn.functional.elu(torch.nn.functional.linear(xr, wr if mask is None else wr * mask.double(), br))
+    yr.backward(gy.double())
+
+    xd, wd, bd = (t.to(dev).requires_grad_() for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, None if mask is None else mask.to(dev), 2)  # (2 = ELU)
+    assert type(y.grad_fn).__name__ == "LinearFnBackward"
+    y.backward(gy.to(dev))
+    for name, mine, ref in (("x", xd.grad, xr.grad), ("W", wd.grad, wr.grad), ("b", bd.grad, br.grad)):
+        err = ((mine.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+        assert err < 2e-6, (name, err)
+    if mask is not None:
+        assert (wd.grad.cpu()[~mask] == 0).all()

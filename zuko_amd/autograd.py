@@ -5,8 +5,8 @@ HIP forward kernel that can sit on a differentiable path gets a `torch.autograd.
 backward is a HIP kernel too (csrc/backward.hip: fused adjoint of softclip/softmax/cumsum/exp/bin
 gather/rational-quadratic; affine; base density; activations; csrc/backward_poly.hip: SOS and Bernstein polynomials on
 forward-mode dual numbers).  The dgrad / wgrad of plain conditioner stacks run on the tile-skipping MFMA kernels of
-csrc/train.hip (zuko_amd/train.py); `LinearFn` below (library GEMMs through `torch.mm`) remains for module trees those
-do not cover (residual blocks, SiLU / GELU).
+csrc/train.hip (zuko_amd/train.py); `LinearFn` below serves the module trees those plans do not cover (residual blocks, SiLU / GELU)
+layer by layer on the same tile GEMMs (`_linear_backward`): no library GEMM anywhere on the path.
 
 Scope: fp32; affine, RQS (4, 8 or 16 bins), SOS polynomial (SOSPF default size) and (bounded) Bernstein polynomial
 (BPF default sizes), forward (`log_prob`) and inverse (`rsample`) directions, with MaskedMLP / MLP conditioners
@@ -284,8 +284,47 @@ class UnivariateInverseFn(torch.autograd.Function):
 BACKWARD_ACTS = (0, 1, 2, 3, 6, 7)  # activations whose derivative is a function of their output
 
 
+_ALL_PAIRS: dict = {}  # (out blocks, in blocks, device) -> int32 [n, 2]: every 128 x 128 block of a weight
+
+
+def _linear_backward(g: Tensor, x: Tensor, weight: Tensor, mask, need_x: bool, need_w: bool, need_b: bool):
+    """(gx, gW, gb) of y = x (mask * W)^T + b from g = d loss / dy [N, out], x [N, in] — what autograd derives from zuko/nn.py:217-218 — on the
+    kernels of csrc/train.hip: gx = g (mask * W) through zk_gemm_f32_skip, gW = mask * (g^T x) through zk_wgrad_f32 (operand-split bf16 products,
+    f32 accumulation, split-K with a fixed reduction order), gb through zk_colsum_f32.  No library GEMM."""
+    lib = _C.lib()
+    N, out_f = g.shape
+    in_f = x.shape[1]
+    dev = g.device
+    gx = gw = gb = None
+    if need_x:
+        wm = weight.detach() if mask is None else weight.detach() * mask
+        wt = wm.t().contiguous()  # [in, out]: the "weight" of the product g wt^T
+        gx = torch.empty((N, in_f), dtype=torch.float32, device=dev)
+        _C.check(lib.zk_gemm_f32_skip(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(wt), None, None, 0, None, 0, 0, _ptr(gx), in_f, _stream()), "zk_gemm_f32_skip")
+    if need_w:
+        ob, ib = -(-out_f // 128), -(-in_f // 128)
+        key = (ob, ib, str(dev))
+        pairs = _ALL_PAIRS.get(key)
+        if pairs is None:
+            pairs = _ALL_PAIRS[key] = torch.cartesian_prod(torch.arange(ob), torch.arange(ib)).to(torch.int32).reshape(-1, 2).contiguous().to(dev)
+        npairs = pairs.shape[0]
+        ns = max(1, lib.zk_wgrad_slices(max(N, 1), npairs))
+        partial = torch.empty(ns * npairs * 128 * 128, dtype=torch.float32, device=dev)
+        gw = torch.zeros((out_f, in_f), dtype=torch.float32, device=dev)
+        m8 = None if mask is None else mask.to(torch.uint8).contiguous()
+        _C.check(lib.zk_wgrad_f32(N, out_f, in_f, _ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(pairs), npairs, _ptr(partial), _ptr(m8), _ptr(gw), 0, None, None, _stream()), "zk_wgrad_f32")
+    if need_b:
+        ws = torch.empty(lib.zk_colsum_slices(max(N, 1)) * out_f, dtype=torch.float32, device=dev)
+        gb = torch.empty(out_f, dtype=torch.float32, device=dev)
+        if N == 0:
+            gb.zero_()
+        else:
+            _C.check(lib.zk_colsum_f32(N, out_f, _ptr(g), g.stride(0), _ptr(ws), _ptr(gb), 0, _stream()), "zk_colsum_f32")
+    return gx, gw, gb
+
+
 class LinearFn(torch.autograd.Function):
-    """y = act(x (mask * W)^T + b): forward = zk_linear, backward = act' kernel + library GEMMs."""
+    """y = act(x (mask * W)^T + b): forward = zk_linear, backward = act' kernel + the tile GEMMs of csrc/train.hip (_linear_backward)."""
 
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias, mask, act: int):
@@ -311,17 +350,10 @@ class LinearFn(torch.autograd.Function):
             _C.check(err, "zk_act_backward")
             g2 = gin
         x2 = x.reshape(-1, in_f)
-        wm = weight if mask is None else weight * mask
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.mm(g2, wm).reshape(x.shape)
-        if ctx.needs_input_grad[1]:
-            gw = torch.mm(g2.t(), x2)
-            if mask is not None:
-                gw = gw * mask
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(dim=0)
-        return gx, gw, gb, None, None
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        gx, gw, gb = _linear_backward(g2, x2, weight, mask, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return (None if gx is None else gx.reshape(x.shape)), gw, gb, None, None
 
 
 class DiagNormalLogProbFn(torch.autograd.Function):
