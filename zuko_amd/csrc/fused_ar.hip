@@ -488,6 +488,9 @@ struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and th
   float* phi_out = nullptr;
   int64_t ldphi = 0;
   int phi_packed = 0;
+  const double* gl_nodes01 = nullptr;  // uni_kind 5 (static-shape kernels): quadrature of the SOS map
+  const double* gl_weights01 = nullptr;
+  double eps = 0.0;                    // uni_kind 6: Bernstein continuation margin
   int32_t* bin_out = nullptr;  // diagnostic launch (forward, spline maps): bin index + search knots
   float* knots_out = nullptr;
   const int* sched = nullptr;
@@ -531,6 +534,12 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
     a.l1rev = part.rev;
     for (int l = 0; l < 3; ++l) a.act_out[l] = part.act_out[l];
     a.phi_out = part.phi_out; a.ldphi = part.ldphi; a.phi_packed = part.phi_packed;
+    if (uni_kind == 5) {  // shifted SOS polynomial, 3 x 5 coefficients (zuko/transforms.py:905-963): MonotonicTransform's bound 10 unless given
+      if (!part.gl_nodes01 || !part.gl_weights01) return ZK_EINVAL;
+      a.sos.bound = (float)bound; a.sos.slope = (float)slope; a.sos.P = 3; a.sos.L1 = 5;
+      for (int i = 0; i < 5; ++i) { a.sos.node[i] = (float)part.gl_nodes01[i]; a.sos.weight[i] = (float)part.gl_weights01[i]; }
+    }
+    a.eps = (float)(part.eps > 0.0 ? part.eps : 1e-6);
     return ((ars_launch_fn)part.static_fn)(&a, ARS_ABI, (int)sizeof(ArArgs), part.phi_out != nullptr, stream);
   }
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
@@ -613,6 +622,7 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
   if (!ar_args_ok(args) || !args->launcher) return ZK_EINVAL;
   ArPartial part;
   part.static_fn = args->launcher; part.rev = args->rev;
+  part.gl_nodes01 = args->gl_nodes01; part.gl_weights01 = args->gl_weights01; part.eps = args->eps;
   part.bin_out = args->bin_out; part.knots_out = args->knots_out;  // both set: the kernel's diagnostic twin (operand-split kernels only)
   zk_ar_args_v1 p = *args;
   p.skip = nullptr;  // (act: checked by the kernel against the activation it was generated for)

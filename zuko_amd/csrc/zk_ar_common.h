@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AR_TF 256 /* floats per tile image */
 #define AR_WAVES 8
 #define AR_T 16   /* activation tiles (256 units) */
-#define ARS_ABI 6 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
+#define ARS_ABI 7 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
 
 struct ArArgs {
   int64_t N;
@@ -55,6 +55,9 @@ struct ArArgs {
   // 16 floats at (g NT + t) 16: parameter 4 t + r of the features of lane q = 0..3 at 4 q + r (row stride >= NG * NT * 16), which is
   // how a lane holds them in registers: 16-byte accesses, no regrouping (zuko_amd/train.py keeps such a phi to itself)
   int phi_packed;
+  // polynomial maps (uni_kind 5, 6; operand-split static-shape kernels only): constants of the SOS quadrature, Bernstein continuation margin
+  SosConst<float> sos;
+  float eps;
 };
 
 __device__ __forceinline__ float act_f32(float v, int act) {
@@ -119,6 +122,35 @@ template <int K, bool CIRC> struct UniRqs {
     return CIRC ? shift(x, a.bound) : x;
   }
 };
+// Shifted sum-of-squares polynomial (zuko/transforms.py:905-963 + the learned constant of zuko/flows/polynomial.py:64-70): P polynomials of L1
+// coefficients, then the shift.  FORWARD only (the inverse is a bisection: it stays with the layer-wise kernels).
+template <int P, int L1> struct UniSos {
+  static constexpr int TOTAL = P * L1 + 1, FPL = 1, NT = (TOTAL + 3) / 4, NKNOT = 1;
+  template <bool INV> static __device__ __forceinline__ void poison(float* p, int base, float nan_or_zero) {
+    p[base] += nan_or_zero;             // (a NaN coefficient makes f and g NaN: y and log|dy/dx| NaN, as the reference's all-NaN parameters do)
+    p[base + P * L1] += nan_or_zero;
+  }
+  template <typename Pa, typename A> static __device__ __forceinline__ void fwd(const Pa& p, int base, const A& a, float x, float& y, float& lj, int* k = nullptr, float* ks = nullptr) {
+    auto ld = [&](int j) { return p(base + j); };
+    y = sos_f_static<float, P, L1>(a.sos, ld, x) + p(base + P * L1);
+    lj = t_log(sos_g_static<float, P, L1>(a.sos, ld, x));
+  }
+};
+// Bounded Bernstein polynomial (zuko/transforms.py:779-831) with NC - 5 unconstrained parameters.  FORWARD only.
+template <int NC> struct UniBernBounded {
+  static constexpr int TOTAL = NC - 5, FPL = 1, NT = (TOTAL + 3) / 4, NKNOT = 1;
+  template <bool INV> static __device__ __forceinline__ void poison(float* p, int base, float nan_or_zero) { p[base] += nan_or_zero; }  // (softmax: one NaN makes every coefficient NaN)
+  template <typename Pa, typename A> static __device__ __forceinline__ void fwd(const Pa& p, int base, const A& a, float x, float& y, float& lj, int* k = nullptr, float* ks = nullptr) {
+    float th[NC];
+    bern_theta_bounded<float, NC>([&](int j) { return p(base + j); }, a.bound, th);
+    const BernTails<float> t = bern_tails<float, NC>(th, true, a.bound, a.eps);
+    float d;
+    bern_fwd<float, NC>(th, t, a.bound, x, y, d, a.eps);
+    lj = t_log(d);
+  }
+};
+typedef UniSos<3, 5> UniSos3x5;            // SOSPF defaults (zuko/flows/polynomial.py:51-53)
+typedef UniBernBounded<22> UniBern17;      // BPF default degree 16 (zuko/flows/polynomial.py:97)
 typedef UniRqs<8, false> UniRqs8;
 typedef UniRqs<4, false> UniRqs4;
 typedef UniRqs<16, false> UniRqs16;

@@ -392,6 +392,36 @@ template <typename T, typename Ld> __device__ __forceinline__ T sos_f(const SosC
   return (x - T(0)) * acc;
 }
 
+// sos_g / sos_f with the polynomial count and the degree as template arguments (same expression trees, fully unrolled): for callers whose
+// coefficients live in registers (the fused kernels' epilogue: a run-time loop would index the register array through scratch memory)
+template <typename T, int P, int L1, typename Ld> __device__ __forceinline__ T sos_g_static(const SosConst<T>& c, Ld ld, T x) {
+  T u = x / c.bound;
+  T acc = T(0);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    T pw = T(1);
+    T dot = T(0);
+#pragma unroll
+    for (int j = 0; j < L1; ++j) {
+      dot += ld(p * L1 + j) * pw;
+      pw *= u;
+    }
+    T q = T(1) + dot;
+    acc += q * q;
+  }
+  return acc / T(P) + c.slope;
+}
+template <typename T, int P, int L1, typename Ld> __device__ __forceinline__ T sos_f_static(const SosConst<T>& c, Ld ld, T x) {
+  T acc = T(0);
+#pragma unroll
+  for (int i = 0; i < L1; ++i) {
+    T w = c.node[i];
+    T pt = (w < T(0.5)) ? (T(0) + w * (x - T(0))) : (x - (x - T(0)) * (T(1) - w));
+    acc += c.weight[i] * sos_g_static<T, P, L1>(c, ld, pt);
+  }
+  return (x - T(0)) * acc;
+}
+
 // fixed-count bisection on [-B, B] (utils.py:170-180; n = ceil(log2(2B/eps)), transforms.py:615)
 template <typename T, typename Ld> __device__ __forceinline__ T sos_inv(const SosConst<T>& c, Ld ld, T y, int n) {
   T a = -c.bound, b = c.bound;

@@ -151,7 +151,8 @@ class MaskedAutoregressiveTransform(LazyTransform):
         if isinstance(u, partial) and u.args:
             return None
         shapes = [tuple(s) for s in self.shapes]
-        slope = kw.pop("slope", 1e-3)
+        slope = kw.pop("slope", 1e-3)  # (the Bernstein maps take no slope: a partial with one is not fused, see below)
+        had_slope = isinstance(u, partial) and "slope" in u.keywords
         if f is MonotonicAffineTransform and shapes == [(), ()] and not kw:
             return fused.uni_layout("affine", 2), 5.0, slope
         from .spline import CircularRQSTransform  # (spline.py imports this module)
@@ -166,6 +167,15 @@ class MaskedAutoregressiveTransform(LazyTransform):
             lay = fused.uni_layout("crqs", self.total, shapes[0][0])
             if lay is not None and fused.layout_supports(lay, self.features):
                 return lay, math.pi, slope
+        # the polynomial maps at their flows' default sizes (forward only; operand-split static-shape kernels, zuko_amd/static_ar.py)
+        from ..transforms import BoundedBernsteinTransform, ShiftedSOSPolynomialTransform
+        from ..ops import SOS_BOUND
+
+        if f is ShiftedSOSPolynomialTransform and shapes == [(3, 5), ()] and not kw:
+            return fused.uni_layout("sos", 16), SOS_BOUND, slope
+        if f is BoundedBernsteinTransform and shapes == [(17,)] and set(kw) <= {"bound", "eps"} and not had_slope:
+            lay = fused.uni_layout("bern", 17)
+            return lay, kw.get("bound", 5.0), float(kw.get("eps", 1e-6))  # (third slot: the continuation margin, this kind has no slope)
         return None
 
     def _rqs_spec(self):
@@ -233,10 +243,13 @@ class MaskedAutoregressiveTransform(LazyTransform):
                 variant = fused.default_variant()
                 # conditioners wider than 256 (up to 512) have no generic kernel: forward only, through a static-shape kernel (zuko_amd/static_ar.py)
                 wide = max([l.weight.shape[0] for l in lins[:-1]] + [lins[0].weight.shape[1]]) > fused.MAX_WIDTH
-                plan = None if (wide and inverse) else fused.build_plan([l.mask for l in lins], self.features, lay[0], fused.chunk_of(variant), align_groups=inverse,
+                poly = lay[0].kind in (5, 6)  # forward only (their inverse is a bisection: layer-wise kernels)
+                plan = None if ((wide or poly) and inverse) else fused.build_plan([l.mask for l in lins], self.features, lay[0], fused.chunk_of(variant), align_groups=inverse,
                                                                         max_width=fused.MAX_WIDTH_WIDE if wide else fused.MAX_WIDTH)
                 if plan is not None:
-                    state = fused.FusedAR(plan, device, codes.pop(), lay[1], lay[2], variant)
+                    state = fused.FusedAR(plan, device, codes.pop(), lay[1], 1e-3 if lay[0].kind == 6 else lay[2], variant)
+                    if lay[0].kind == 6:
+                        state.eps = lay[2]
                     if inverse:
                         state.set_sweeps(self.order.cpu().numpy(), self.passes)
             cache[key] = (structure, state)

@@ -25,6 +25,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import ctypes
+
 import numpy as np
 import torch
 from torch import Tensor
@@ -48,7 +50,12 @@ class UniLayout:
 
 
 def uni_layout(kind: str, total: int, bins: int = 0) -> UniLayout | None:
-    """C-ABI kind codes: 0 affine, 1 / 2 / 3 RQS with 8 / 4 / 16 bins, 4 circular RQS with 8 bins."""
+    """C-ABI kind codes: 0 affine, 1 / 2 / 3 RQS with 8 / 4 / 16 bins, 4 circular RQS with 8 bins, 5 shifted SOS polynomial (3 polynomials of
+    degree 4: SOSPF's defaults), 6 bounded Bernstein polynomial of degree 16 (BPF's default) — 5 and 6: forward, operand-split static-shape kernels only."""
+    if kind == "sos" and total == 16:
+        return UniLayout(5, 16, 1, 4)
+    if kind == "bern" and total == 17:
+        return UniLayout(6, 17, 1, 5)
     if kind == "affine" and total == 2:
         return UniLayout(0, 2, 2, 1)
     if kind == "rqs" and total == 3 * bins - 1 and bins in (8, 4, 16):
@@ -421,7 +428,9 @@ class FusedAR:
         self.bias = torch.empty(self.bias_floats, dtype=torch.float32, device=device)
         self._stamp = None
         self._fine_stamp = None
-        self.generic_ok = plan.max_width <= MAX_WIDTH  # (wider plans exist only for the static-shape kernels)
+        self.generic_ok = plan.max_width <= MAX_WIDTH and plan.layout.kind <= 4  # (wider plans and the polynomial maps exist only as static-shape kernels)
+        self.eps = 1e-6     # Bernstein continuation margin (zuko/transforms.py:594); set by the caller when the transform was built with another
+        self._gl = None     # SOS quadrature: ctypes arrays of the Gauss-Legendre nodes / weights on [0, 1] (kept alive here)
         self.static = None          # (StaticKernel, rev) of zuko_amd/static_ar.py once one has been found / compiled
         self._static_tried_rows = -1
         self.fine_gather = self.fine_stream = self.fine_offsets = None
@@ -517,10 +526,19 @@ class FusedAR:
             kern, rev = self.static
             # (a static-shape kernel that stages rows through LDS needs them 16-byte addressable; the generic kernel has an instantiation for the other case)
             if not kern.meta["XLDS"] or (y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0):
+                extra = {}
+                if p.layout.kind == 5:
+                    if self._gl is None:
+                        from .ops import _leggauss01
+
+                        self._gl = _leggauss01(5)
+                    extra = dict(gl_nodes01=ctypes.cast(self._gl[0], ctypes.c_void_p), gl_weights01=ctypes.cast(self._gl[1], ctypes.c_void_p))
+                elif p.layout.kind == 6:
+                    extra = dict(eps=float(self.eps))
                 a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0),
                             y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate), wstream=_ptr(self.fine_stream), bias=_ptr(self.bias),
                             bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=self.fine_n_chunks, act=self.act,
-                            bound=self.bound, slope=self.slope)
+                            bound=self.bound, slope=self.slope, **extra)
                 _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
                 return
         if not self.generic_ok:

@@ -36,11 +36,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
-ARS_ABI = 6  # == ARS_ABI of csrc/zk_ar_common.h
-UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 3: "zk::UniRqs16", 4: "zk::UniCircRqs8"}
+ARS_ABI = 7  # == ARS_ABI of csrc/zk_ar_common.h
+UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 3: "zk::UniRqs16", 4: "zk::UniCircRqs8", 5: "zk::UniSos3x5", 6: "zk::UniBern17"}
 # 16 bins: the twelve accumulator tiles of a feature group do not fit the f32-instruction template's double-buffered last layer (it would
 # spill), but the operand-split template holds them (255 VGPRs, no scratch): that kind exists as a split kernel only, forward only
-SPLIT_ONLY_KINDS = {3}
+SPLIT_ONLY_KINDS = {3, 5, 6}
 _HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_univariate_bwd.h", "zk_common.h")
 
 
@@ -761,6 +761,8 @@ PREBUILT = [
     ("affine", 12, 0, (48, 32), 0, "Tanh"),
     ("rqs", 64, 0, (256, 256, 256), 16),   # NSF(bins=16): operand-split kernel only (SPLIT_ONLY_KINDS)
     ("affine", 12, 0, (64, 64), 0),        # training: a last feature group that is not full (padding slots in the packed phi / g_phi rows)
+    # the polynomial flows (forward, operand-split kernels only): the shapes of the golden flows and a 64-feature one of each
+    ("sos", 4, 2, (32, 32), 0), ("bern", 4, 2, (32, 32), 0), ("sos", 64, 0, (256, 256, 256), 0), ("bern", 64, 0, (256, 256, 256), 0),
 ]
 
 
@@ -772,13 +774,19 @@ def _plans_for(kind: str, features: int, context: int, hidden, bins: int, activa
     from . import fused
     from .flows.autoregressive import MaskedAutoregressiveTransform
     from .nn import MaskedLinear
-    from .transforms import MonotonicAffineTransform, MonotonicRQSTransform
+    from .transforms import BoundedBernsteinTransform, MonotonicAffineTransform, MonotonicRQSTransform, ShiftedSOSPolynomialTransform
 
     out = []
     for order in (torch.arange(features), torch.flipud(torch.arange(features))):
         if kind == "affine":
             t = MaskedAutoregressiveTransform(features, context, order=order, hidden_features=list(hidden), univariate=MonotonicAffineTransform, shapes=[(), ()])
             layout = fused.uni_layout("affine", 2)
+        elif kind == "sos":  # SOSPF's defaults
+            t = MaskedAutoregressiveTransform(features, context, order=order, hidden_features=list(hidden), univariate=ShiftedSOSPolynomialTransform, shapes=[(3, 5), ()])
+            layout = fused.uni_layout("sos", 16)
+        elif kind == "bern":  # BPF's default
+            t = MaskedAutoregressiveTransform(features, context, order=order, hidden_features=list(hidden), univariate=BoundedBernsteinTransform, shapes=[(17,)])
+            layout = fused.uni_layout("bern", 17)
         else:
             t = MaskedAutoregressiveTransform(features, context, order=order, hidden_features=list(hidden), univariate=MonotonicRQSTransform, shapes=[(bins,), (bins,), (bins - 1,)])
             layout = fused.uni_layout("rqs", 3 * bins - 1, bins)
