@@ -609,6 +609,39 @@ def side_paths_report() -> dict:
         except Exception as exc:  # never let a side measurement break the headline line
             entry["error"] = repr(exc)
         out[name] = entry
+    # the polynomial flows: fused layer kernels against the layer-wise path on the same weights
+    from zuko_amd.flows import autoregressive as AR
+
+    for name, ctor in (("sospf_d64", "SOSPF"), ("bpf_d64", "BPF")):
+        entry = {}
+        try:
+            torch.manual_seed(0)
+            flow = getattr(F, ctor)(64, 0, transforms=3, hidden_features=[256] * 3).to(dev)
+            Bp = 1 << 18
+            x = torch.randn(Bp, 64, device=dev)
+            res = {}
+            for mode in ("fused", "layer_wise"):
+                orig = AR.FusedAutoregressiveTransform._fused
+                if mode == "layer_wise":
+                    AR.FusedAutoregressiveTransform._fused = lambda self, x, need_generic=False: None
+                try:
+                    with torch.no_grad():
+                        for _ in range(2):
+                            lp = flow().log_prob(x)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(5):
+                            lp = flow().log_prob(x)
+                        torch.cuda.synchronize()
+                        res[mode] = ((time.perf_counter() - t0) / 5, lp)
+                finally:
+                    AR.FusedAutoregressiveTransform._fused = orig
+            rel = ((res["fused"][1] - res["layer_wise"][1]).abs().max() / res["layer_wise"][1].abs().max()).item()
+            entry["log_prob"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) log_prob, batch 2^18", "ms": res["fused"][0] * 1e3, "samples_per_s": Bp / res["fused"][0],
+                                 "layer_wise_ms": res["layer_wise"][0] * 1e3, "parity": {"log_prob_max_rel_vs_layer_wise_kernels": rel, "ok": bool(rel < 1e-5)}}
+        except Exception as exc:
+            entry["error"] = repr(exc)
+        out[name] = entry
     return out
 
 
