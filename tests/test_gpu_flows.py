@@ -899,9 +899,21 @@ def test_wide_conditioners_run_fused(dev, D, ctx, hidden, monkeypatch):
             t = lazy(cg)
             st = t._fused(x.to(dev))
             assert st is not None and not st.generic_ok and st.static is not None and st.static[0].meta["WAVES"] == 4
+            assert st.static[0].meta.get("split"), "257-512 wide: the operand-split kernel with one wavefront per SIMD (round 4)"
         z, ladj = flow(cg).transform.call_and_ladj(x.to(dev))
         lp = flow(cg).log_prob(x.to(dev))
         from zuko_amd.flows import autoregressive as _ar
+
+        monkeypatch.setenv("ZUKO_AMD_SPLIT_WIDE", "0")  # the f32-instruction static-shape kernel of the same conditioner
+        for lazy in flow.transform.transforms:
+            _ar._FUSED_CACHE.pop(lazy, None)
+        for lazy in flow.transform.transforms:
+            st = lazy(cg)._fused(x.to(dev))
+            assert st is not None and st.static is not None and not st.static[0].meta.get("split")
+        z_f, ladj_f = flow(cg).transform.call_and_ladj(x.to(dev))
+        monkeypatch.delenv("ZUKO_AMD_SPLIT_WIDE")
+        for lazy in flow.transform.transforms:
+            _ar._FUSED_CACHE.pop(lazy, None)
 
         monkeypatch.setenv("ZUKO_AMD_NO_STATIC_AR", "1")  # layer-wise kernels (phi through HBM)
         for lazy in flow.transform.transforms:
@@ -916,6 +928,8 @@ def test_wide_conditioners_run_fused(dev, D, ctx, hidden, monkeypatch):
         assert_parity(z, zo, z64, f"{tag}: z fused")
         assert_parity(ladj, lo, l64, f"{tag}: ladj fused")
         assert_parity(z_l, zo, z64, f"{tag}: z layer-wise")
+        assert_parity(z_f, zo, z64, f"{tag}: z f32-instruction kernel")
+        assert_parity(ladj_f, lo, l64, f"{tag}: ladj f32-instruction kernel")
         assert_parity(lp, O.flow_log_prob(spec, x, c), O.flow_log_prob(spec64, d64(x), d64(c)), f"{tag}: log_prob")
         # inverse: layer-wise sweeps (no fused inverse at this width), round trip
         c64 = None if c is None else c[:64]

@@ -142,9 +142,12 @@ template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ voi
 // DIAG: the diagnostic twin of the product launch (same arithmetic, same instruction order up to two extra stores per feature): also
 // writes the bin index the spline USED and the search-axis knots it searched (bin_out [N, D], knots_out [N, D, NKNOT]), as
 // zk_ar_forward_diag does for the generic kernel — the parity bar on the bin index is asserted on the product path (tests/test_gpu_bins.py).
-template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __launch_bounds__(64 * S::WAVES, 2) void arx_kernel(ArArgs a) {
+// Shape::OCC = wavefronts per SIMD the registers are budgeted for: 2 (widths <= 256: 16 activation tiles + 8 operand pairs per wavefront), 1 for
+// conditioners 257 - 512 wide (32 tiles + 16 pairs = 320 registers; four wavefronts per workgroup, one workgroup per CU).
+template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __launch_bounds__(64 * S::WAVES, S::OCC) void arx_kernel(ArArgs a) {
   typedef ArRingS<S::WAVES, S::CH, S::NR> Ring;
-  static_assert((S::WAVES == 8 || S::WAVES == 4) && (S::NR == 2 || S::NR == 3) && S::TMAX <= 16 && S::TMAX % 2 == 0, "operand-split kernels: widths <= 256, two wavefronts per SIMD");
+  static_assert((S::WAVES == 8 || S::WAVES == 4) && (S::NR == 2 || S::NR == 3) && (S::TMAX <= 16 || (S::TMAX <= 32 && S::OCC == 1 && S::WAVES == 4)) && S::TMAX % 2 == 0,
+                "operand-split kernels: widths <= 256 with two wavefronts per SIMD, <= 512 with one");
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL, WAVES = S::WAVES;
   constexpr int NG = S::NG;
   constexpr int NSTEP = S::GOFF[NG];  // (group, in pair) steps of the last layer, NT blocks each
@@ -688,7 +691,7 @@ template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi
       g = lds;
     }
   }
-  constexpr int MAXG = S::WAVES == 4 ? 512 : 256;  // 4 wavefronts: two independent workgroups per CU (one wavefront per SIMD each)
+  constexpr int MAXG = (S::WAVES == 4 && S::OCC == 2) ? 512 : 256;  // 4 wavefronts at two per SIMD: two independent workgroups per CU (one wavefront per SIMD each)
   const unsigned grid = (unsigned)(a.n_tiles < MAXG ? a.n_tiles : MAXG);
   void* kargs[] = {&a};
   e = hipLaunchKernel(fn, dim3(grid), dim3(64 * S::WAVES), kargs, lds, (hipStream_t)stream);

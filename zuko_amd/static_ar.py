@@ -225,7 +225,10 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     accumulator registers.  Returns (tables, gathers): gathers[l] int32 [blocks_l * 512] into W_l.flatten() (-1 = zero), every layer
     padded to whole 24-image chunks (8 blocks)."""
     t = tables(plan, uni_kind, act)
-    if t is None or t["WAVES"] != 8:
+    if t is None:
+        return None
+    wide = t["WAVES"] != 8  # conditioners 257 - 512 wide: 32 activation tiles + their 16 operand pairs per wavefront = one wavefront per SIMD
+    if wide and os.environ.get("ZUKO_AMD_SPLIT_WIDE", "1") == "0":
         return None
     cached = getattr(plan, "_split_cache", None)
     if cached is not None and cached[0] == (uni_kind, act, split_geometry()):
@@ -233,7 +236,7 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     NH, HT, NIT = t["NH"], t["HT"], t["NIT"]
     tm = plan.fine_tilemask
     n_otg, n_itile = tm.shape[1], tm.shape[2]
-    waves, ch = split_geometry()
+    waves, ch = (4, 24) if wide else split_geometry()
     B_OT, B_IP, NB, BASE, blocks_of = [], [], [], [], []
     cursor = 0  # in 1 KiB images; the layers follow each other without padding (a chunk boundary may fall anywhere, even inside a block)
 
@@ -296,9 +299,10 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     for key in ("S_OTG", "S_IT", "S_MASK", "NS", "GOFF", "G_IT"):
         out.pop(key)
     nr = 2 if ch == 48 else 3  # (48-image chunks: two ring slots, half as many barriers)
-    xlds = int(t["D"] % 4 == 0 and (nr * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * (2 if waves == 4 else 1) <= 160 * 1024)
+    per_cu = 2 if (waves == 4 and not wide) else 1  # workgroups per CU
+    xlds = int(t["D"] % 4 == 0 and (nr * ch * 256 + (t["BIAS_STRIDE"] * NH + t["NG"] * nt * 16) + 1024 + 256 + waves * 16 * (((t["D"] + 3) // 4) * 4 + 4)) * 4 * per_cu <= 160 * 1024)
     out.update({"split": 1, "TMAX": int(2 * -(-t["TMAX"] // 2)), "NB": NB, "B_OT": B_OT, "B_IP": B_IP, "BASE": BASE, "LAST_BASE": last_base, "GOFF": GOFFP, "G_IP": G_IP, "NCHUNK": n_chunks, "STREAM_IMAGES": stream_images,
-                "WAVES": waves, "CH": ch, "NR": nr, "XLDS": xlds})
+                "WAVES": waves, "CH": ch, "NR": nr, "XLDS": xlds, "OCC": 1 if wide else 2})
     plan._split_cache = ((uni_kind, act, split_geometry()), (out, gathers))
     return out, gathers
 
@@ -313,7 +317,7 @@ def emit_split(t: dict) -> str:
         "namespace {",
         "struct Shape {",
         f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NG = {t['NG']}, NCHUNK = {t['NCHUNK']};",
-        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, NR = {t['NR']}, ACT = {t['ACT']};",
+        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, NR = {t['NR']}, ACT = {t['ACT']}, OCC = {t['OCC']};",
         f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'}, HAS_ALT = false, TRAIN_OK = {'true' if t['TRAIN_OK'] else 'false'};",
         _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
         _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
