@@ -1106,3 +1106,36 @@ def test_polynomial_flows_run_on_a_fused_split_kernel(dev, kind, features, conte
                 assert (xi - x).abs().max().item() < 5e-3
             lp = flow(c).log_prob(x)
             assert torch.isfinite(lp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,ctx,hidden", [("nsf", 64, 0, [256] * 3), ("maf", 64, 0, [256] * 3), ("nsf", 3, 5, [128] * 3), ("nsf", 32, 0, [256, 256]), ("nsf", 32, 0, [512, 512]),
+                                               ("maf", 16, 0, [128, 128]), ("nsf", 128, 0, [256] * 3), ("nsf", 64, 8, [256] * 2), ("nsf", 16, 0, [512] * 3), ("nsf16", 64, 0, [256] * 3)])
+def test_static_shape_table(dev, kind, D, ctx, hidden, monkeypatch):
+    """Every conditioner of the static-shape table (profiles/r04/static_shapes.jsonl: the BASELINE shapes, 128 features, a context behind 64 features, 512-wide
+    layers, 16 bins) has a PREBUILT operand-split kernel, and that kernel meets the oracle (fp32 restatement + float64, measured bar) on a ragged batch."""
+    import zuko_amd.flows as F
+
+    monkeypatch.setenv("ZUKO_AMD_JIT", "0")
+    torch.manual_seed(D + ctx)
+    bins = 16 if kind == "nsf16" else 8
+    flow = F.NSF(D, ctx, transforms=2, bins=bins, hidden_features=hidden) if kind.startswith("nsf") else F.MAF(D, ctx, transforms=2, hidden_features=hidden)
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(bins) if kind.startswith("nsf") else O.UNI_AFFINE, D)
+    spec64 = to_f64(spec)
+    flow = flow.to(dev)
+    g = torch.Generator().manual_seed(4)
+    N = 300 + 11
+    x = torch.randn(N, D, generator=g) * 1.1
+    c = torch.randn(N, ctx, generator=g) if ctx else None
+    cg = None if c is None else c.to(dev)
+    with torch.no_grad():
+        for lazy in flow.transform.transforms:
+            st = lazy(cg)._fused(x.to(dev))
+            assert st is not None and st.static is not None and st.static[0].meta.get("split"), "a prebuilt operand-split kernel"
+        z, ladj = flow(cg).transform.call_and_ladj(x.to(dev))
+    zo, lo = O.flow_forward(spec, x, c)
+    z64, l64 = O.flow_forward(spec64, d64(x), d64(c))
+    tag = f"table {kind}({D}, ctx {ctx}, {hidden})"
+    assert_parity(z, zo, z64, f"{tag}: z")
+    assert_parity(ladj, lo, l64, f"{tag}: ladj")

@@ -765,6 +765,9 @@ PREBUILT = [
     ("affine", 12, 0, (48, 32), 0, "Tanh"),
     ("rqs", 64, 0, (256, 256, 256), 16),   # NSF(bins=16): operand-split kernel only (SPLIT_ONLY_KINDS)
     ("affine", 12, 0, (64, 64), 0),        # training: a last feature group that is not full (padding slots in the packed phi / g_phi rows)
+    # three more shapes of the static-shape table (profiles/r04/static_shapes.jsonl, tests/test_gpu_flows.py::test_static_shape_table): 128 features, a context
+    # behind 64 features, three 512-wide layers
+    ("rqs", 128, 0, (256, 256, 256), 8), ("rqs", 64, 8, (256, 256), 8), ("rqs", 16, 0, (512, 512, 512), 8),
     # the polynomial flows (forward, operand-split kernels only): the shapes of the golden flows and a 64-feature one of each
     ("sos", 4, 2, (32, 32), 0), ("bern", 4, 2, (32, 32), 0), ("sos", 64, 0, (256, 256, 256), 0), ("bern", 64, 0, (256, 256, 256), 0),
 ]
