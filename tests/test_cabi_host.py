@@ -199,3 +199,26 @@ def test_jit_build_failures_never_raise_into_the_callers_log_prob(tmp_path, monk
     monkeypatch.setenv("ZUKO_AMD_CACHE_DIR", str(good))
     assert static_ar._jit_dir() == os.path.join(str(good), "ars")
     assert static_ar._arch() == "gfx950"
+
+
+def test_jit_threshold_counts_rows_over_calls(monkeypatch):
+    """A conditioner without a kernel on disk gets one compiled when ONE batch reaches ZUKO_AMD_JIT_MIN_ROWS — or when the batches seen so far add up to
+    eight times that (zuko_amd/static_ar.py: effective_rows): a training loop with small batches does not stay on the generic kernel for ever."""
+    from zuko_amd import static_ar
+
+    monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1000")
+
+    class Holder:
+        pass
+
+    h = Holder()
+    assert static_ar.effective_rows(h, 5000) == 5000  # a large batch: itself
+    h = Holder()
+    got = [static_ar.effective_rows(h, 300) for _ in range(30)]
+    first = next(i for i, g in enumerate(got) if g >= 1000)
+    assert got[:first] == [300] * first and first == -(-8 * 1000 // 300) - 1 and all(g == 1000 for g in got[first:])
+
+    class Slotted:
+        __slots__ = ()
+
+    assert static_ar.effective_rows(Slotted(), 300) == 300  # (nowhere to keep the count: the per-call rule)

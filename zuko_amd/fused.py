@@ -472,7 +472,9 @@ class FusedAR:
     def ready(self, rows: int) -> bool:
         """Whether run() can be served: always for plans the generic kernel covers; for wider ones only with a static-shape kernel
         (compiled now if `rows` makes it worth it)."""
-        self._acquire_static(rows)  # (no-op once the best kernel for this plan is held or `rows` has been tried)
+        from . import static_ar
+
+        self._acquire_static(static_ar.effective_rows(self, rows))  # (no-op once the best kernel for this plan is held or `rows` has been tried)
         return self.generic_ok or self.static is not None
 
     def refresh(self, linears, fine_only: bool = False) -> None:

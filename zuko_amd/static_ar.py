@@ -10,7 +10,7 @@ address to the library (zk_ar_forward_static).
 * Ahead of time (`prebuild()`, run by zuko_amd/_build.py and __graft_entry__.build()): the conditioners of BASELINE.json's
   configurations and a few common shapes (PREBUILT below).  Their .so files travel with the tree.
 * On first use (`lookup(..., rows)`): any other conditioner whose batch is large enough for the compile to pay
-  (ZUKO_AMD_JIT_MIN_ROWS, default 2^15 rows; ZUKO_AMD_JIT=0 disables it).  Without hipcc, or below the threshold, the generic
+  (ZUKO_AMD_JIT_MIN_ROWS, default 2^15 rows in one call or 8 x that in total over the calls; ZUKO_AMD_JIT=0 disables it).  Without hipcc, or below the threshold, the generic
   tile-skipping kernel (widths <= 256) or the layer-wise kernels (wider) run instead — same results.
 
 The kernels are bit-identical to the generic kernel on the same plan (tests/test_gpu_flows.py), so none of this changes a
@@ -466,6 +466,22 @@ def jit_min_rows() -> int:
         return int(os.environ.get("ZUKO_AMD_JIT_MIN_ROWS", str(1 << 15)))
     except ValueError:
         return 1 << 15
+
+
+JIT_CUMULATIVE_FACTOR = 8
+
+
+def effective_rows(holder, rows: int) -> int:
+    """The batch size the JIT threshold is compared with: `rows` itself, or the threshold once `holder` (a plan / state object living as long as
+    the conditioner) has seen JIT_CUMULATIVE_FACTOR x the threshold in TOTAL — a training loop with small batches gets its kernel after a few
+    dozen steps instead of never.  (ZUKO_AMD_JIT=0 still disables every compile.)"""
+    thr = jit_min_rows()
+    seen = getattr(holder, "_jit_rows_seen", 0) + max(int(rows), 0)
+    try:
+        holder._jit_rows_seen = seen
+    except AttributeError:
+        return rows
+    return rows if rows >= thr or seen < JIT_CUMULATIVE_FACTOR * thr else thr
 
 
 def lookup(plan, uni_kind: int, act: int, rows: int | None = None):

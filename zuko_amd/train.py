@@ -272,11 +272,12 @@ class PackedRows:
 _FUSED_TRAIN = weakref.WeakKeyDictionary()  # SortedPlan -> FusedAR (static-shape kernel) or False
 
 
-def _fused_forward_state(plan: "SortedPlan", lins, device):
-    """The static-shape fused kernel (csrc/fused_ar_static.hip, conditioner-only instantiation) for the forward of this
-    network under autograd, or None: the conditioner of MaskedAutoregressiveTransform(64, hidden_features=[256] * 3) with a
-    spline or affine head.  Its hidden activations come out in the kernel's sorted unit order, which is this plan's (both sort
-    stably by dependency count) — checked once against the layer-wise kernels on a random batch."""
+def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0):
+    """The static-shape fused kernel (csrc/fused_ar_static.hip, training instantiation) for the forward of this network under autograd, or
+    None: the conditioner of MaskedAutoregressiveTransform(features, hidden_features=[..up to three..]) with a spline or affine head.  Its
+    hidden activations come out in the kernel's sorted unit order, which is this plan's (both sort stably by dependency count) — checked once
+    against the layer-wise kernels on a random batch.  A kernel that is not on disk yet is compiled once the batches (`rows`, this call's)
+    pass the JIT threshold, as for inference (zuko_amd/static_ar.py: effective_rows)."""
     import os
 
     if os.environ.get("ZUKO_AMD_NO_FUSED_TRAIN", "0") == "1":
@@ -291,33 +292,48 @@ def _fused_forward_state(plan: "SortedPlan", lins, device):
             din = shapes[0][1]
             # (no context: the conditioner's inputs are the features; affine head = 2, 8-bin spline head = 23 parameters per feature)
             total = {2 * din: 2, 23 * din: 23}.get(shapes[-1][0], 0)
-            feats = din
             layout = fused.uni_layout("affine", 2) if total == 2 else fused.uni_layout("rqs", 23, 8)
             ok = (total and 2 <= len(lins) <= 4 and plan.act == 1 and din % 4 == 0
                   and all(getattr(l, "mask", None) is not None for l in lins) and all(s[0] % 16 == 0 and s[0] <= fused.MAX_WIDTH for s in shapes[:-1]))
             if ok:
-                fp = fused.build_plan([l.mask for l in lins], feats, layout)
-                cand = fused.FusedAR(fp, device, 1, 1.0, 1e-3) if fp is not None else None
-                if cand is not None and cand.static is not None and cand.static[0].meta["TRAIN_OK"]:
-                    cand.refresh(lins)
-                    g = torch.Generator(device="cpu").manual_seed(0)
-                    xt = torch.randn(200, din, generator=g).to(device)
-                    with torch.no_grad():
-                        hs_f, phi_f = _fused_forward(cand, xt, shapes[-1][0])
-                        ws, _, bs = plan.gather(lins)
-                        h = xt
-                        same = True
-                        n = len(lins)
-                        for l in range(n):
-                            h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l + 1 < n else 0)
-                            ref = hs_f[l] if l + 1 < n else phi_f
-                            same = same and bool(torch.allclose(ref, h, rtol=1e-4, atol=1e-4))
-                    if same:
-                        st = cand
+                fp = fused.build_plan([l.mask for l in lins], din, layout)
+                if fp is not None:
+                    st = fused.FusedAR(fp, device, 1, 1.0, 1e-3)
+                    st._train_checked = None  # None: not validated yet; True / False afterwards
         except Exception:
             st = False
         _FUSED_TRAIN[plan] = st
-    return st or None
+    if not st:
+        return None
+    if rows > 0 and (st.static is None or not st.static[0].meta.get("split")):
+        held = st.static
+        st.ready(rows)  # (compiles the operand-split kernel when the batches seen so far justify it)
+        if st.static is not held:
+            st._train_checked = None
+    if st.static is None or not st.static[0].meta["TRAIN_OK"] or st._train_checked is False:
+        return None
+    if st._train_checked is None:
+        try:
+            shapes = plan.shapes
+            st.refresh(lins)
+            g = torch.Generator(device="cpu").manual_seed(0)
+            xt = torch.randn(200, shapes[0][1], generator=g).to(device)
+            with torch.no_grad():
+                hs_f, phi_f = _fused_forward(st, xt, shapes[-1][0])
+                ws, _, bs = plan.gather(lins)
+                h = xt
+                same = True
+                n = len(lins)
+                for l in range(n):
+                    h = plan.gemm(h, ws[l], plan.kskip_f[l], bs[l], plan.act if l + 1 < n else 0)
+                    ref = hs_f[l] if l + 1 < n else phi_f
+                    same = same and bool(torch.allclose(ref, h, rtol=1e-4, atol=1e-4))
+            st._train_checked = same
+        except Exception:
+            st._train_checked = False
+        if not st._train_checked:
+            return None
+    return st
 
 
 def _fused_forward(st, x: Tensor, out_features: int, uni=None, packed_width: int = 0):
@@ -430,7 +446,7 @@ def _backward_kernel(plan: SortedPlan, st, rows: int):
         if tg is None:
             _BACKWARDS[plan] = False
             return None
-        kern = static_ar.chain_kernel(tg[0], allow_compile=static_ar.jit_enabled() and rows >= static_ar.jit_min_rows())
+        kern = static_ar.chain_kernel(tg[0], allow_compile=static_ar.jit_enabled() and static_ar.effective_rows(st, rows) >= static_ar.jit_min_rows())
         if kern is None:
             return None  # (not cached: a later, larger batch may be allowed to compile)
         bk = DgradChain(plan, kern, tg[0], tg[1], plan.device)
@@ -454,7 +470,7 @@ def _dgrad_chain(plan: SortedPlan, lins, rows: int):
         if 2 <= n <= 4 and plan.act == 1 and all(m is not None for m in plan.mask_s_cpu):
             from . import static_ar
 
-            allow = static_ar.jit_enabled() and rows >= static_ar.jit_min_rows()
+            allow = static_ar.jit_enabled() and static_ar.effective_rows(plan, rows) >= static_ar.jit_min_rows()
             if static_ar.split_enabled() and plan.shapes[-1][0] % 4 == 0:  # every layer in one launch of the operand-split kernel
                 tg = static_ar.chain_split_tables(plan.mask_s_cpu, plan.rows_cpu, plan.cols_cpu)
                 kern = static_ar.chain_kernel(tg[0], allow_compile=allow) if tg is not None else None
@@ -485,7 +501,7 @@ class ConditionerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: SortedPlan, lins, x: Tensor, *params):
         n = len(lins)
-        st = _fused_forward_state(plan, lins, x.device) if (x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+        st = _fused_forward_state(plan, lins, x.device, x.shape[0]) if (x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
         chain = _dgrad_chain(plan, lins, x.shape[0]) if n >= 2 else None
         ws, wts, bs = plan.gather(lins, forward=st is None, transposes=None if chain is None else (set() if chain.full else {n - 1}))
         if chain is not None:  # (the backward reads this stream instead of the transposes; the stand-alone chain keeps the last layer's)
@@ -634,7 +650,7 @@ def autoregressive(module, uni, x: Tensor):
         x = x.contiguous()
         if x.stride(0) % 4 != 0:
             return None
-    st = _fused_forward_state(plan, lins, x.device)
+    st = _fused_forward_state(plan, lins, x.device, x.shape[0])
     if st is None or not st.static[0].meta.get("split") or st.plan.layout.kind != uni[0]:
         return None
     chain = _backward_kernel(plan, st, x.shape[0]) if n >= 2 else None  # the whole backward in one launch, else adjoint kernel + dgrad chain
