@@ -237,15 +237,15 @@ int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream);
  * `launcher` = zk_ars_dgrad_launch of an operand-split chain kernel (zuko_amd/static_ar.py: chain_split_tables; the products run on the
  * bf16 matrix instruction with every f32 operand split three ways, as zk_gather_split_bf16 describes). */
 int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream);
-/* The whole backward of ONE unconditional autoregressive transform y, ladj = univariate(net(x)).call_and_ladj(x) up to the weight
+/* The whole backward of ONE autoregressive transform y, ladj = univariate(net(cat(x, c))).call_and_ladj(x) up to the weight
  * gradients (what autograd derives from zuko/flows/autoregressive.py:207-218, zuko/transforms.py:436-446 / :480-490, :554-567 and
  * zuko/nn.py:217-218), in one launch of a generated kernel (`launcher` = zk_ars_dgrad_launch of zuko_amd/static_ar.py:
  * chain_split_tables(packed=...)):
- *   reads   x [N, D] (ldx), phi [N, n_groups * NT * 16] (ldphi) in the PACKED order of zk_ar_forward_train(phi_packed = 1), y_in = d loss / dy [N, D] (row stride ldo),
+ *   reads   x [N, DIN] = cat(x, c) zero-padded as for the forward (ldx; DIN % 4 == 0), phi [N, n_groups * NT * 16] (ldphi) in the PACKED order of zk_ar_forward_train(phi_packed = 1), y_in = d loss / dy [N, D] (row stride ldo),
  *           ladj = d loss / d ladj [N] (READ here), h1 .. h_{n-1} (the forward's hidden activations), wstream / n_chunks (the kernel's
  *           stream of transposed weights), featmap / n_groups (the forward plan's), uni_kind (0 affine, 1 spline with 8 bins), bound, slope;
  *   writes  x_out = d loss / d phi in the same packed order (row stride ldphi; padding slots zero; for the weight gradients, whose row table maps
- *           packed slots to rows of the last linear layer), gh1 .. gh_{n-1}, y = d loss / dx [N, D]
+ *           packed slots to rows of the last linear layer), gh1 .. gh_{n-1}, y = d loss / d cat(x, c) [N, DIN]
  *           (row stride ldy, a multiple of 4; accumulate != 0: added to what y holds) — the chain's input gradient plus the univariate
  *           map's own d/dx term. */
 int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream);

@@ -350,3 +350,33 @@ def test_one_launch_backward_with_padding_slots(dev, monkeypatch):
     for k, g in grads_u.items():
         assert ((grads_f[k] - g).abs().max() / g.abs().max().clamp_min(1e-6)).item() < 2e-5, k
     assert ((gx_f - gx_u).abs().max() / gx_u.abs().max()).item() < 2e-5
+
+
+def test_conditional_flow_trains_through_the_one_node_path(dev, monkeypatch):
+    """flow(c).log_prob(x) with a context (zuko/flows/autoregressive.py:209-210: the conditioner sees cat(x, c)): when features + context is a multiple
+    of 4 the transform is still ONE autograd node — forward one launch on cat(x, c), backward one launch whose input gradient autograd splits into
+    d/dx (chain + the map's direct term) and d/dc — with the gradients of the two-node path, d/dc included."""
+    flow, entry = build_flow("nsf_cfg1")  # NSF(3, context 5, hidden [128] * 3)
+    flow = flow.to(dev)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(515, 3, generator=gen).to(dev)
+    c = torch.randn(515, 5, generator=gen).to(dev)
+
+    def step():
+        flow.zero_grad()
+        xg, cg = x.clone().requires_grad_(), c.clone().requires_grad_()
+        loss = -flow(cg).log_prob(xg).mean()
+        names = {type(f).__name__ for f in _graph_nodes(loss.grad_fn)}
+        loss.backward()
+        return loss.item(), names, {k: p.grad.clone() for k, p in flow.named_parameters()}, xg.grad, cg.grad
+
+    loss_f, names_f, grads_f, gx_f, gc_f = step()
+    assert "AutoregressiveFnBackward" in names_f and "ConditionerFnBackward" not in names_f, names_f
+    monkeypatch.setenv("ZUKO_AMD_NO_FUSED_AR_TRAIN", "1")
+    loss_u, names_u, grads_u, gx_u, gc_u = step()
+    assert "AutoregressiveFnBackward" not in names_u
+    assert abs(loss_f - loss_u) < 1e-5 * max(1.0, abs(loss_u))
+    for k, g in grads_u.items():
+        assert ((grads_f[k] - g).abs().max() / g.abs().max().clamp_min(1e-6)).item() < 2e-5, k
+    assert ((gx_f - gx_u).abs().max() / gx_u.abs().max()).item() < 2e-5
+    assert ((gc_f - gc_u).abs().max() / gc_u.abs().max()).item() < 2e-5

@@ -695,14 +695,14 @@ int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream) {
   return ((ars_dgrad_fn)args->launcher)(&a, ARS_ABI, (int)sizeof(ArArgs), stream);
 }
 
-// The whole backward of one unconditional autoregressive transform up to the weight gradients, in one launch of a generated kernel
+// The whole backward of one autoregressive transform (x = cat(features, context) as for the forward) up to the weight gradients, in one launch of a generated kernel
 // (zuko_amd/static_ar.py: chain_split_tables(packed=...), csrc/fused_ar_split_impl.h: arxb_kernel): from (gy, gl) = d loss / d (y, ladj)
 // the univariate adjoint gives d loss / d phi — written to x_out for the weight gradients — and the map's own d/dx term; the dgrad chain
 // runs from there through every linear layer (gh1 .. = gradients of the hidden pre-activations); y = d loss / dx = chain + direct term.
 int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream) {
   if (!ar_args_ok(args) || !args->launcher || !args->x || !args->y || !args->wstream || !args->phi || !args->x_out || !args->y_in || !args->ladj || !args->featmap) return ZK_EINVAL;
   const int n = args->n_layers;
-  if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff || args->uni_kind < 0 || args->uni_kind > 1 || args->DIN != args->D) return ZK_EINVAL;
+  if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff || args->uni_kind < 0 || args->uni_kind > 1 || args->DIN < args->D || args->D < 1) return ZK_EINVAL;
   if (args->N == 0) return 0;
   const void* hs[3] = {args->h1, args->h2, args->h3};
   void* gs[3] = {args->gh1, args->gh2, args->gh3};

@@ -473,7 +473,8 @@ template <class S> __global__ __launch_bounds__(512, 2) void arxd_kernel(ArArgs 
 // g_phi leaves in that same packed order (ArArgs::phi_packed: the training forward stores its accumulators as they are, the weight
 // gradients read the packed gradient through a row table), 16 bytes per lane and tile — lane-wise dword accesses to module-order rows
 // (23 per feature, each instruction scattering 64 dwords over 16 rows) cost this kernel a third of its time (profiles/r04).  The map's
-// direct d/dx term waits in a wave-private LDS row and is added to the chain's input gradient at the end.
+// direct d/dx term waits in a wave-private LDS row and is added to the chain's input gradient at the end (the conditioner's input may carry
+// context columns behind the D features: x is cat(x, c), the input gradient covers both, the direct term only the features).
 //   Shape::NG, PB[]     feature groups; first block (of layer 0, in-pair major) of every packed pair, PB[NG * NT / 2] = NB[0]
 template <typename Uni, typename A> __device__ __forceinline__ void arxb_adjoint(const float* p, const A& a, float x, float gy, float gl, float& gx, float* g) {
   if constexpr (Uni::TOTAL == 2) affine_backward_element(p, x, gy, gl, a.ls, gx, g);
@@ -596,6 +597,10 @@ template <class S, typename Uni> __global__ __launch_bounds__(512, 2) void arxb_
     const int64_t nc = live ? n : a.N - 1;
     ArxB in[S::TMAX / 2];
     f32x4 out[S::TMAX];
+    if (a.D < S::DOUT) {  // context columns (and padding) of the conditioner's input have no direct term
+#pragma unroll 1
+      for (int i = a.D + q; i < a.xs - 4; i += 4) xr[i] = 0.f;
+    }
     arxb_first<S, Uni>(ring, a, fmap_lds, xr, q, n, nc, live, out);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -609,7 +614,7 @@ template <class S, typename Uni> __global__ __launch_bounds__(512, 2) void arxb_
 template <class S, typename Uni> static int arxb_launch(const ArArgs* in, int abi, int args_bytes, void* stream) {
   if (abi != ARS_ABI || args_bytes != (int)sizeof(ArArgs)) return ZK_EINVAL;
   ArArgs a = *in;
-  if (a.DIN != S::DOUT || a.D != S::DOUT || a.L != S::NH || a.NG != S::NG || a.n_chunks != S::NCHUNK || !a.x || !a.phi_out || !a.phi_in || !a.gphi_out || !a.gy || !a.gl || !a.featmap ||
+  if (a.DIN != S::DOUT || a.D < 1 || a.D > S::DOUT || a.D > S::NG * 4 * Uni::FPL || a.L != S::NH || a.NG != S::NG || a.n_chunks != S::NCHUNK || !a.x || !a.phi_out || !a.phi_in || !a.gphi_out || !a.gy || !a.gl || !a.featmap ||
       a.ldx % 4 || a.ldphi % 4 || a.ldpin < (int64_t)S::NG * Uni::NT * 16 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.phi_out % 16))
     return ZK_EINVAL;
   for (int l = 0; l + 1 < S::NH; ++l)

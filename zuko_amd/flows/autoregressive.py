@@ -342,10 +342,13 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         return self._run_fused(st, x, None)
 
     def _train_fused(self, x: Tensor):
-        """Under autograd: the whole transform as one autograd node (zuko_amd/train.py: AutoregressiveFn) when it is unconditional, fp32 and
-        its conditioner has an operand-split static-shape kernel; None otherwise (conditioner and univariate map as separate nodes)."""
-        lazy = self.lazy
-        if self.c is not None or not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1 and x.shape[-1] == lazy.features):
+        """Under autograd: the whole transform as one autograd node (zuko_amd/train.py: AutoregressiveFn) when it is fp32, features + context is a
+        multiple of 4 and its conditioner has an operand-split static-shape kernel; None otherwise (conditioner and univariate map as separate nodes)."""
+        lazy, c = self.lazy, self.c
+        D = lazy.features
+        if not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1 and x.shape[-1] == D):
+            return None
+        if c is not None and not (c.is_cuda and c.dtype == torch.float32 and (D + c.shape[-1]) % 4 == 0):
             return None
         lay = lazy._fusable_layout()
         if lay is None or lay[0].kind not in (0, 1):
@@ -353,9 +356,14 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         from .. import train
 
         sizes = (1, 1) if lay[0].kind == 0 else (lay[0].bins, lay[0].bins, lay[0].bins - 1)
-        batch = x.shape[:-1]
-        out = train.autoregressive(lazy.hyper, (lay[0].kind, float(lay[1]), float(lay[2]), sizes), x.reshape(-1, lazy.features))
-        return None if out is None else (out[0].reshape(batch + (lazy.features,)), out[1].reshape(batch))
+        if c is not None:  # the conditioner's input, as the reference builds it (zuko/flows/autoregressive.py:209-210): autograd splits its gradient
+            xb, cb = broadcast(x, c, ignore=1)
+            inp = torch.cat((xb, cb), dim=-1)
+        else:
+            xb, inp = x, x
+        batch = xb.shape[:-1]
+        out = train.autoregressive(lazy.hyper, (lay[0].kind, float(lay[1]), float(lay[2]), sizes), inp.reshape(-1, inp.shape[-1]), features=D)
+        return None if out is None else (out[0].reshape(batch + (D,)), out[1].reshape(batch))
 
     def call_and_accumulate_ladj(self, x: Tensor, total: Tensor):
         """y of call_and_ladj(x), with log|dy/dx| ADDED to `total` by the kernel (`accumulate` of zk_ar_forward) instead of returned:

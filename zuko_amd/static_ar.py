@@ -606,14 +606,14 @@ def chain_split_tables(masks_sorted: list, rows: list, cols: list, packed: dict 
         return None
     hidden = [m.shape[0] for m in masks_sorted[:-1]]
     din, dphi = masks_sorted[0].shape[1], masks_sorted[-1].shape[0]
-    if any(w % 16 or w > 256 for w in hidden) or din % 4 or din > 256 or dphi % 4:
-        return None
+    if any(w % 16 or w > 256 for w in hidden) or din % 4 or din > 256 or (packed is None and dphi % 4):
+        return None  # (module-order g_phi rows are read 16 bytes at a time; packed rows are whole tiles)
     masks_sorted, rows = list(masks_sorted), list(rows)
     if packed is not None:
         fm, nt, fpl, total = np.asarray(packed["featmap"]), int(packed["nt"]), int(packed["fpl"]), int(packed["total"])
         ng = len(fm) // (4 * fpl)
-        if ng * 4 * fpl != len(fm) or (ng * nt) % 2 or (nt % 2 and ng % 2) or fpl * total > 4 * nt or dphi != din * total or rows[-1] is None:
-            return None
+        if ng * 4 * fpl != len(fm) or (ng * nt) % 2 or (nt % 2 and ng % 2) or fpl * total > 4 * nt or dphi % total or dphi // total > din or rows[-1] is None:
+            return None  # (dphi / total features, the other din - features inputs are context)
         u = np.arange(ng * nt * 16)
         g_, t_, q_, r_ = u // (16 * nt), (u // 16) % nt, (u % 16) // 4, u % 4
         fi_, k_ = np.divmod(4 * t_ + r_, total)
@@ -831,7 +831,7 @@ def chain_tables_for(lins, full: bool = False, packed: dict | None = None):
     if n < 2 or n > 4 or any(m is None for m in sp.mask_s_cpu):
         return None
     if full:
-        return chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu, packed=packed) if sp.shapes[-1][0] % 4 == 0 else None
+        return chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu, packed=packed) if (packed is not None or sp.shapes[-1][0] % 4 == 0) else None
     return chain_tables(sp.mask_s_cpu[: n - 1], sp.rows_cpu[: n - 1], sp.cols_cpu[: n - 1])
 
 
@@ -872,7 +872,7 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
         if act == 1 and layout.kind not in SPLIT_ONLY_KINDS:  # the training backward of the same conditioners (one kernel per feature order)
             for lins, pl in ((lins_a, pa), (lins_d, pd)):
                 cands = [chain_tables_for(lins), chain_tables_for(lins, full=True)]
-                if context == 0 and layout.kind in (0, 1) and layout.total in (2, 23) and pl is not None:  # what zuko_amd/train.py:autoregressive() covers
+                if (features + context) % 4 == 0 and layout.kind in (0, 1) and layout.total in (2, 23) and pl is not None:  # what zuko_amd/train.py:autoregressive() covers
                     cands.append(chain_tables_for(lins, full=True, packed={"uni": layout.kind, "featmap": pl.featmap, "nt": layout.nt, "fpl": layout.fpl, "total": layout.total}))
                 for tg in cands:
                     if tg is not None and not any(c[0] == tg[0] for c in chains):

@@ -272,7 +272,7 @@ class PackedRows:
 _FUSED_TRAIN = weakref.WeakKeyDictionary()  # SortedPlan -> FusedAR (static-shape kernel) or False
 
 
-def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0):
+def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0, features: int | None = None, total: int | None = None):
     """The static-shape fused kernel (csrc/fused_ar_static.hip, training instantiation) for the forward of this network under autograd, or
     None: the conditioner of MaskedAutoregressiveTransform(features, hidden_features=[..up to three..]) with a spline or affine head.  Its
     hidden activations come out in the kernel's sorted unit order, which is this plan's (both sort stably by dependency count) — checked once
@@ -290,13 +290,17 @@ def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0):
 
             shapes = plan.shapes
             din = shapes[0][1]
-            # (no context: the conditioner's inputs are the features; affine head = 2, 8-bin spline head = 23 parameters per feature)
-            total = {2 * din: 2, 23 * din: 23}.get(shapes[-1][0], 0)
+            if features is None:
+                # (not told: no context — the conditioner's inputs are the features; affine head = 2, 8-bin spline head = 23 parameters per feature)
+                total = {2 * din: 2, 23 * din: 23}.get(shapes[-1][0], 0)
+                features = din
+            elif total not in (2, 23) or features * total != shapes[-1][0] or features > din:
+                total = 0
             layout = fused.uni_layout("affine", 2) if total == 2 else fused.uni_layout("rqs", 23, 8)
             ok = (total and 2 <= len(lins) <= 4 and plan.act == 1 and din % 4 == 0
                   and all(getattr(l, "mask", None) is not None for l in lins) and all(s[0] % 16 == 0 and s[0] <= fused.MAX_WIDTH for s in shapes[:-1]))
             if ok:
-                fp = fused.build_plan([l.mask for l in lins], din, layout)
+                fp = fused.build_plan([l.mask for l in lins], features, layout)
                 if fp is not None:
                     st = fused.FusedAR(fp, device, 1, 1.0, 1e-3)
                     st._train_checked = None  # None: not validated yet; True / False afterwards
@@ -418,7 +422,7 @@ class DgradChain:
         gphi = torch.empty_like(phi)
         hp = [_ptr(hs[1 + l]) for l in range(n - 1)] + [None] * 3
         gp = [_ptr(g) for g in gs] + [None] * 3
-        a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, uni_kind=uni[0], N=N, D=x.shape[1], DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
+        a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, uni_kind=uni[0], N=N, D=st.plan.features, DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
                     gh1=gp[0], gh2=gp[1], gh3=gp[2], y=_ptr(gx), ldy=gx.stride(0), y_in=_ptr(gy), ldo=gy.stride(0), ladj=_ptr(gl), phi=_ptr(phi), x_out=_ptr(gphi), ldphi=phi.stride(0),
                     wstream=_ptr(stream), featmap=_ptr(st.featmap), n_layers=n, n_groups=st.plan.n_groups, n_chunks=self.t["NCHUNK"], act=1, bound=float(uni[1]), slope=float(uni[2]))
         _C.check(_C.lib().zk_ar_backward_full(a, _stream()), "zk_ar_backward_full")
@@ -595,6 +599,7 @@ class AutoregressiveFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan: SortedPlan, lins, st, chain, uni, x: Tensor, *params):
+        # x: the conditioner's input [N, features + context] (features first), as the reference's cat(x, c) (zuko/flows/autoregressive.py:209-210)
         n = len(lins)
         st.refresh(lins, fine_only=True)
         stream = chain.gather(plan, lins)
@@ -613,14 +618,20 @@ class AutoregressiveFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         hs, phi, stream = saved[:n], saved[n], saved[n + 1]
         x = hs[0]
-        N, D = x.shape
-        gy = torch.zeros_like(x) if gy is None else gy.contiguous()
+        N, D = x.shape[0], ctx.st.plan.features
+        gy = torch.zeros((N, D), dtype=torch.float32, device=x.device) if gy is None else gy.contiguous()
         gl = torch.zeros(N, dtype=torch.float32, device=x.device) if gl is None else gl.contiguous()
         if chain.fused:
             gphi, gs, gx = chain.run_backward(plan, stream, ctx.st, ctx.uni, x, phi, gy, gl, hs)
         else:
-            gx, gphi = _adj_any((kind, bound, slope, sizes, ()), x, phi.view(N, D, -1), gy, gl, True)
+            xf = x if x.shape[1] == D else x[:, :D].contiguous()
+            gxf, gphi = _adj_any((kind, bound, slope, sizes, ()), xf, phi.view(N, D, -1), gy, gl, True)
             gphi = gphi.view(N, -1)
+            if x.shape[1] == D:
+                gx = gxf
+            else:  # (context columns: no direct term)
+                gx = torch.zeros_like(x)
+                gx[:, :D] = gxf
             gs, gx = chain.run(plan, stream, gphi, hs, gx_add=gx)
         res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else gphi, hs[l]) for l in range(n)], packed_last=chain.packed if chain.fused else None)
         grads = []
@@ -629,17 +640,19 @@ class AutoregressiveFn(torch.autograd.Function):
         return (None, None, None, None, None, gx if ctx.needs_input_grad[5] else None, *grads)
 
 
-def autoregressive(module, uni, x: Tensor):
-    """(y, ladj) of an unconditional masked autoregressive transform under autograd through AutoregressiveFn, or None when this
-    conditioner / batch is not covered (then the caller composes ConditionerFn and the univariate map's own autograd node):
-    a masked ReLU (linear, activation)* stack with an operand-split static-shape kernel and its one-launch dgrad chain, every
-    weight and bias trainable, x [N, D] fp32 with 16-byte aligned rows.  ZUKO_AMD_NO_FUSED_AR_TRAIN=1 switches it off."""
+def autoregressive(module, uni, x: Tensor, features: int | None = None):
+    """(y, ladj) of a masked autoregressive transform under autograd through AutoregressiveFn, or None when this conditioner / batch is
+    not covered (then the caller composes ConditionerFn and the univariate map's own autograd node): a masked ReLU (linear, activation)*
+    stack with an operand-split static-shape kernel and its one-launch dgrad chain, every weight and bias trainable.  x [N, features +
+    context] fp32 — the conditioner's input cat(x, c), features first, its width a multiple of 4 — with 16-byte aligned rows; `features`
+    defaults to all of its columns.  ZUKO_AMD_NO_FUSED_AR_TRAIN=1 switches it off."""
     import os
 
     if os.environ.get("ZUKO_AMD_NO_FUSED_AR_TRAIN", "0") == "1" or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0):
         return None
+    features = x.shape[1] if features is None else features
     plan, lins = plan_for(module, x.device)
-    if plan is None or plan.act != 1 or x.shape[1] != plan.shapes[0][1] or sum(uni[3]) * x.shape[1] != plan.shapes[-1][0]:
+    if plan is None or plan.act != 1 or x.shape[1] != plan.shapes[0][1] or sum(uni[3]) * features != plan.shapes[-1][0] or features > x.shape[1]:
         return None
     n = len(lins)
     if not all(l.bias is not None and l.weight.requires_grad and l.bias.requires_grad and plan.cs_flag[i] is not None and plan.pairs[i].shape[0] > 0 for i, l in enumerate(lins)):
@@ -650,8 +663,8 @@ def autoregressive(module, uni, x: Tensor):
         x = x.contiguous()
         if x.stride(0) % 4 != 0:
             return None
-    st = _fused_forward_state(plan, lins, x.device, x.shape[0])
-    if st is None or not st.static[0].meta.get("split") or st.plan.layout.kind != uni[0]:
+    st = _fused_forward_state(plan, lins, x.device, x.shape[0], features=features, total=sum(uni[3]))
+    if st is None or not st.static[0].meta.get("split") or st.plan.layout.kind != uni[0] or st.plan.features != features:
         return None
     chain = _backward_kernel(plan, st, x.shape[0]) if n >= 2 else None  # the whole backward in one launch, else adjoint kernel + dgrad chain
     if chain is None:
