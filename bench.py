@@ -542,17 +542,23 @@ def side_paths_report() -> dict:
 
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     out = {}
-    for name, ctor, kw in (("nsf_cfg2", "NSF", CONFIGS["cfg2"][1]), ("maf_cfg3", "MAF", CONFIGS["cfg3"][1])):
+    cfg1 = dict(features=3, context=5, transforms=3, bins=8, hidden_features=[128] * 3)  # BASELINE.json configs[0]: the conditional flow
+    for name, ctor, kw in (("nsf_cfg2", "NSF", CONFIGS["cfg2"][1]), ("maf_cfg3", "MAF", CONFIGS["cfg3"][1]), ("nsf_cfg1_conditional", "NSF", cfg1)):
         entry = {}
         try:
             torch.manual_seed(0)
             flow = getattr(F, ctor)(**kw).to(dev)
             B = 1 << 16
             x = torch.randn(B, kw["features"], device=dev)
+            ctx = torch.randn(1 << 18, kw["context"], device=dev) if kw.get("context") else None
+
+            def dist(rows):  # flow(c) on the first `rows` context rows / flow() without a context
+                return flow() if ctx is None else flow(ctx[:rows])
+
             opt = torch.optim.Adam(flow.parameters(), lr=1e-3)
 
             def step():
-                loss = -flow().log_prob(x).mean()
+                loss = -dist(B).log_prob(x).mean()
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
                 opt.step()
@@ -567,7 +573,7 @@ def side_paths_report() -> dict:
 
             def grads(rows):
                 flow.zero_grad()
-                loss = -flow().log_prob(x[:rows]).mean()
+                loss = -dist(rows).log_prob(x[:rows]).mean()
                 names = {type(f).__name__ for f in nodes(loss.grad_fn, set())}
                 loss.backward()
                 return loss.item(), names, [p.grad.clone() for p in flow.parameters()]
@@ -595,7 +601,7 @@ def side_paths_report() -> dict:
             with torch.no_grad():
                 Bs = 1 << 18
                 z = torch.randn(Bs, kw["features"], device=dev)
-                t = flow().transform
+                t = dist(Bs).transform
                 xs = t.inv(z)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
