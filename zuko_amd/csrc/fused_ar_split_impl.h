@@ -679,7 +679,7 @@ template <class S, typename Uni> static int arx_launch(const ArArgs* in, int abi
   if (train) {
     if constexpr (S::TRAIN_OK) fn = (const void*)arx_kernel<S, Uni, true>;
   } else if (a.bin_out) {
-    fn = (const void*)arx_kernel<S, Uni, false, true>;
+    if constexpr (Uni::NKNOT > 1) fn = (const void*)arx_kernel<S, Uni, false, true>;  // (the diagnostic twin exists for the spline maps only)
   } else {
     fn = (const void*)arx_kernel<S, Uni, false>;
   }
