@@ -181,3 +181,46 @@ def _walk_split_chain(cfg, packed):
             assert np.abs(out[:width] - want).max() <= 4e-6 * scale, (c, np.abs(out[:width] - want).max(), scale)
             vec = np.zeros_like(vec)
             vec[:width] = out[:width].astype(np.float32)
+
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 12, 0, (64, 64), 0), ("rqs", 3, 5, (128, 128, 128), 8)])
+def test_packed_rows_tables_give_the_module_order_weight_gradient(cfg):
+    """zuko_amd/train.py:PackedRows — the row table, sorted-domain mask, live 128 x 128 blocks and column-sum flags the weight-gradient kernels use when
+    d loss / d phi arrives in the fused kernels' packed order (padding slots included): walked in numpy, they must give dW and db of the LAST linear
+    layer in the module's order (what autograd derives from zuko/nn.py:217-218), with every padding slot skipped and every live weight inside a listed block."""
+    from zuko_amd.train import PackedRows
+
+    rng = np.random.default_rng(11)
+    for plan, layout, lins in static_ar._plans_for(*cfg):
+        sp = SortedPlan(lins, 1, torch.device("cpu"))
+        tg = static_ar.chain_split_tables(sp.mask_s_cpu, sp.rows_cpu, sp.cols_cpu, packed={"uni": layout.kind, "featmap": plan.featmap, "nt": layout.nt, "fpl": layout.fpl, "total": layout.total})
+        assert tg is not None
+        pk = PackedRows(sp, tg[0]["MODROW"], torch.device("cpu"))
+        last = len(lins) - 1
+        out_f, in_f = sp.shapes[last]
+        assert pk.ok and pk.width == len(tg[0]["MODROW"]) and pk.width % 16 == 0
+        rows, cols = pk.rows.numpy(), sp.cols_cpu[last]
+        assert sorted(rows[rows >= 0].tolist()) == list(range(out_f)), "every row of the layer has exactly one packed slot"
+        N = 50
+        g_mod = rng.standard_normal((N, out_f))
+        h_mod = rng.standard_normal((N, in_f))        # the layer's input in the MODULE's unit order
+        mask = lins[last].mask.numpy().astype(bool)
+        dw_ref, db_ref = mask * (g_mod.T @ h_mod), g_mod.sum(axis=0)
+        g_packed = np.where(rows >= 0, g_mod[:, np.maximum(rows, 0)], 0.0)  # what the backward launch writes: padding slots are zero
+        h_sorted = h_mod[:, cols]                                             # what the forward stores: units in the plan's sorted order
+        ms = pk.mask_s.numpy().astype(bool)
+        dw, db = np.zeros((out_f, in_f)), np.zeros(out_f)
+        live = np.zeros_like(ms)
+        for ob, ib in pk.pairs.numpy():
+            live[ob * 128 : (ob + 1) * 128, ib * 128 : (ib + 1) * 128] = True
+        assert not (ms & ~live).any(), "a non-zero weight outside the listed blocks"
+        full = g_packed.T @ h_sorted  # [width, in] in the sorted domain
+        for u in range(pk.width):
+            if rows[u] < 0:
+                assert not ms[u].any()
+                continue
+            dw[rows[u], cols] = np.where(ms[u] & live[u], full[u], 0.0)
+            db[rows[u]] = g_packed[:, u].sum()
+        assert np.abs(dw - dw_ref).max() < 1e-9 and np.abs(db - db_ref).max() < 1e-9
+        flagged = {int(ob) for (ob, _), f in zip(pk.pairs.numpy(), pk.cs_flag.numpy()) if f}
+        assert flagged == set(range(-(-pk.width // 128))), "one column-sum block per 128 packed columns (the bias gradient rides on the weight pass)"
