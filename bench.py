@@ -472,11 +472,11 @@ def side_parity(config: str, flow, flow_cpu, dev) -> dict:
     with torch.no_grad():
         spec_b = O.spec_from_state_dict(sdb, "ar", O.uni_rqs(K), D)
         zb, lb = O.flow_forward(spec_b, xs)
-        lpb = O.flow_log_prob(spec_b, xs)
+        lpb = O.diag_normal_log_prob(zb, spec_b.loc, spec_b.scale) + lb  # (= O.flow_log_prob(spec_b, xs) without a second pass over the 630 M parameters on the CPU)
         del spec_b
         spec_32 = O.spec_from_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sdb.items()}, "ar", O.uni_rqs(K), D)
         z32, l32 = O.flow_forward(spec_32, xs.float())
-        lp32 = O.flow_log_prob(spec_32, xs.float())
+        lp32 = O.diag_normal_log_prob(z32, spec_32.loc, spec_32.scale) + l32
         del spec_32, sdb
         dist = flow()
         lp = dist.log_prob(xs.to(dev)).cpu()
