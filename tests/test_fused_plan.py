@@ -431,3 +431,23 @@ def test_coupling_split_stream_is_the_f32_stream_regrouped():
     l2 = list(t2.hyper)[0::2]
     p2 = cp.build_coupling_plan([tuple(l.weight.shape) for l in l2], t2.mask.nonzero().squeeze(-1).numpy(), (~t2.mask).nonzero().squeeze(-1).numpy(), 12, 2)
     assert p2.split_gather is None
+
+
+def test_polynomial_flows_are_recognised_at_their_default_sizes_only():
+    """`_fusable_layout` of a lazy autoregressive transform: SOSPF / BPF at the reference's default sizes (zuko/flows/polynomial.py:51-53, :97) map to the
+    fused kernels' uni kinds 5 / 6 with the maps' own constants; other sizes (and Bernstein maps given a slope) stay on the layer-wise path."""
+    import zuko_amd.flows as F
+
+    lz = F.SOSPF(6, 2, transforms=1, hidden_features=[32]).transform.transforms[0]
+    lay, bound, slope = lz._fusable_layout()
+    assert (lay.kind, lay.total, lay.nt, lay.fpl) == (5, 16, 4, 1) and bound == 10.0 and slope == 1e-3
+    lz = F.SOSPF(6, 0, transforms=1, hidden_features=[32], slope=1e-2).transform.transforms[0]
+    assert lz._fusable_layout()[2] == 1e-2
+    assert F.SOSPF(6, 0, degree=3, transforms=1, hidden_features=[32]).transform.transforms[0]._fusable_layout() is None
+    assert F.SOSPF(6, 0, polynomials=2, transforms=1, hidden_features=[32]).transform.transforms[0]._fusable_layout() is None
+    lz = F.BPF(6, 0, transforms=1, hidden_features=[32]).transform.transforms[0]
+    lay, bound, eps = lz._fusable_layout()
+    assert (lay.kind, lay.total, lay.nt, lay.fpl) == (6, 17, 5, 1) and bound == 5.0 and eps == 1e-6
+    assert F.BPF(6, 0, degree=8, transforms=1, hidden_features=[32]).transform.transforms[0]._fusable_layout() is None
+    # the inverse of these kinds stays layer-wise: no group-aligned fused state for the sweeps
+    assert F.BPF(6, 0, transforms=1, hidden_features=[32]).transform.transforms[0].fused_state(__import__("torch").device("cpu"), inverse=True) is None
