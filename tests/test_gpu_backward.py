@@ -380,3 +380,35 @@ def test_conditional_flow_trains_through_the_one_node_path(dev, monkeypatch):
         assert ((grads_f[k] - g).abs().max() / g.abs().max().clamp_min(1e-6)).item() < 2e-5, k
     assert ((gx_f - gx_u).abs().max() / gx_u.abs().max()).item() < 2e-5
     assert ((gc_f - gc_u).abs().max() / gc_u.abs().max()).item() < 2e-5
+
+
+def test_conditional_flow_with_the_stand_alone_adjoint(dev, monkeypatch):
+    """NSF(64, context 8): the one-node path with the one-launch backward, with the stand-alone adjoint kernel + dgrad chain (ZUKO_AMD_NO_FUSED_AR_BACKWARD=1:
+    the direct d/dx term covers the feature columns of cat(x, c) only) and the two-node path give the same gradients, d/dc included."""
+    from zuko_amd.flows import NSF
+
+    monkeypatch.setenv("ZUKO_AMD_JIT", "0")  # prebuilt kernels (zuko_amd/static_ar.py: PREBUILT holds this conditioner)
+    torch.manual_seed(3)
+    flow = NSF(64, 8, transforms=2, bins=8, hidden_features=[256, 256]).to(dev)
+    x = torch.randn(700, 64, device=dev)
+    c = torch.randn(700, 8, device=dev)
+
+    def step():
+        flow.zero_grad()
+        xg, cg = x.clone().requires_grad_(), c.clone().requires_grad_()
+        loss = -flow(cg).log_prob(xg).mean()
+        names = {type(f).__name__ for f in _graph_nodes(loss.grad_fn)}
+        loss.backward()
+        return loss.item(), names, {k: p.grad.clone() for k, p in flow.named_parameters()}, xg.grad, cg.grad
+
+    ref = step()
+    assert "AutoregressiveFnBackward" in ref[1]
+    for env in ("ZUKO_AMD_NO_FUSED_AR_BACKWARD", "ZUKO_AMD_NO_FUSED_AR_TRAIN"):
+        monkeypatch.setenv(env, "1")
+        got = step()
+        assert ("AutoregressiveFnBackward" in got[1]) == (env == "ZUKO_AMD_NO_FUSED_AR_BACKWARD")
+        assert abs(got[0] - ref[0]) < 1e-5 * max(1.0, abs(ref[0]))
+        for k, g in got[2].items():
+            assert ((ref[2][k] - g).abs().max() / g.abs().max().clamp_min(1e-6)).item() < 2e-5, (env, k)
+        assert ((ref[3] - got[3]).abs().max() / got[3].abs().max()).item() < 2e-5, env
+        assert ((ref[4] - got[4]).abs().max() / got[4].abs().max()).item() < 2e-5, env
