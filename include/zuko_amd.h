@@ -440,7 +440,8 @@ int zk_act_backward(int64_t n, const void* y, const void* gout, int act, void* g
  *   zk_wgrad_slices(N, npairs) sample slices whose partial blocks go to `partial` (>= slices * npairs * 16384 floats)
  *   and are summed in slice order (deterministic).  mask: uint8 [OUT, IN] or NULL.  rows / cols (device int32 [OUT] / [IN], or
  *   NULL = identity): the product is formed on a row / column permuted weight (units sorted by dependency count) and element (o, c)
- *   is WRITTEN to dw[rows[o], cols[c]], i.e. where the module keeps that weight — no scatter pass afterwards.
+ *   is WRITTEN to dw[rows[o], cols[c]], i.e. where the module keeps that weight — no scatter pass afterwards.  rows[o] < 0: column o of g is a
+ *   padding slot (the packed gradient of zk_ar_backward_full, always zero): nothing is written for it; dw then has max(rows) + 1 rows, not OUT.
  * zk_colsum_f32:  out[C] (+)= sum_n x[n, c] (bias gradients); workspace >= zk_colsum_slices(N) * C floats. */
 int zk_gemm_f32_skip(int64_t N, int in_features, int out_features, const void* x, int64_t ldx, const void* w, const uint64_t* kskip,
                      const void* bias, int act, const void* gate, int64_t ldg, int gate_act, void* y, int64_t ldy, void* stream);
