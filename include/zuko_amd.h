@@ -161,7 +161,11 @@ int zk_linear_bf16_rqs(int64_t N, int in_features, int panels, const void* h, in
  * ARGUMENT BLOCK.  The fused entry points take ONE versioned struct instead of 20-28 positional arguments (a transposed pair of
  * ints is a silent wrong answer; a mis-named field is a compile error / a Python KeyError): set struct_size = sizeof(the struct)
  * and version = 1, fill the fields the entry point reads (listed per function), leave the rest zero.  The library rejects a
- * struct_size / version it does not know with hipErrorInvalidValue.  zuko_amd/_C.py builds its ctypes.Structure classes by
+ * version it does not know, and a struct_size larger than its own, with hipErrorInvalidValue.  zk_ar_args_v1 GREW within version 1
+ * (phi_packed .. eps were appended after gh3): a block of the earlier size — struct_size == offsetof(zk_ar_args_v1, phi_packed) or anything
+ * between that and sizeof — is accepted and the fields it lacks read as zero, so callers built against the earlier header keep working.
+ * Behaviour change that came with the growth: zk_ar_forward_train used to ignore y / ladj / bound / slope / accumulate and now honours
+ * them when y != NULL (y == NULL keeps the conditioner-only launch).  zuko_amd/_C.py builds its ctypes.Structure classes by
  * parsing THESE definitions, so header and binding cannot drift apart. */
 typedef struct zk_ar_args_v1 {
   uint32_t struct_size;    /* sizeof(zk_ar_args_v1) */

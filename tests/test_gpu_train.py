@@ -326,3 +326,46 @@ def test_layerwise_linear_backward_has_no_library_gemm(dev, shape, masked):
         assert err < 2e-6, (name, err)
     if mask is not None:
         assert (wd.grad.cpu()[~mask] == 0).all()
+
+
+def test_wgrad_bias_skips_padding_rows(dev):
+    """include/zuko_amd.h: rows[o] < 0 marks a padding column of g — neither dw nor db has a destination for it.  zk_wgrad_bias_f32 called
+    directly with a row table holding -1 entries: rows of dw / entries of db of the real outputs equal g^T h / colsum(g) (zuko/nn.py:217-218
+    under autograd), and the guard words placed BEFORE db and dw (where index -1 would land) are untouched."""
+    from zuko_amd import _C
+    from zuko_amd.ops import _ptr, _stream
+
+    lib = _C.lib()
+    gen = torch.Generator().manual_seed(21)
+    N, width, in_f = 700, 128, 128
+    rows_h = torch.full((width,), -1, dtype=torch.int32)
+    real = torch.randperm(width, generator=gen)[:96]
+    rows_h[real] = torch.randperm(96, generator=gen).to(torch.int32)  # 96 module rows, 32 padding slots
+    g = torch.randn(N, width, generator=gen)
+    g[:, rows_h < 0] = 0.0  # (padding columns of the packed gradient are always zero)
+    h = torch.randn(N, in_f, generator=gen)
+    pairs = torch.tensor([[0, 0]], dtype=torch.int32).to(dev)
+    flag = torch.ones(1, dtype=torch.uint8, device=dev)
+    ns = max(1, lib.zk_wgrad_slices(N, 1))
+    partial = torch.empty(ns * 128 * 128, device=dev)
+    cs_partial = torch.empty(ns * 128, device=dev)
+    guard = 12345.0
+    dwbuf = torch.full((in_f + 96 * in_f,), guard, device=dev)
+    dbbuf = torch.full((8 + 96,), guard, device=dev)
+    dw, db = dwbuf[in_f:].view(96, in_f), dbbuf[8:]
+    dw.zero_(); db.zero_()
+    gd, hd, rows = g.to(dev), h.to(dev), rows_h.to(dev)
+    err = lib.zk_wgrad_bias_f32(N, width, in_f, _ptr(gd), gd.stride(0), _ptr(hd), hd.stride(0), _ptr(pairs), 1, _ptr(partial), None, _ptr(dw), 0,
+                                _ptr(flag), _ptr(cs_partial), _ptr(db), _ptr(rows), None, _stream())
+    _C.check(err, "zk_wgrad_bias_f32")
+    torch.cuda.synchronize()
+    assert (dwbuf[:in_f] == guard).all() and (dbbuf[:8] == guard).all()
+    want_w = torch.zeros(96, in_f, dtype=torch.float64)
+    want_b = torch.zeros(96, dtype=torch.float64)
+    full = g.double().T @ h.double()
+    for o in range(width):
+        if rows_h[o] >= 0:
+            want_w[rows_h[o]] = full[o]
+            want_b[rows_h[o]] = g[:, o].double().sum()
+    assert (dw.cpu().double() - want_w).abs().max().item() < 1e-4 * want_w.abs().max().item()
+    assert (db.cpu().double() - want_b).abs().max().item() < 1e-4 * want_b.abs().max().item()

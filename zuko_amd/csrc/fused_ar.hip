@@ -26,6 +26,7 @@
 // Host-side planning (permutations, stream order, skip masks): zuko_amd/fused.py.
 #include "../../include/zuko_amd.h"
 #include "zk_ar_common.h"
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -589,7 +590,17 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
 }
 
 // (argument block: include/zuko_amd.h — every entry point checks struct_size / version before it reads a field)
-static bool ar_args_ok(const zk_ar_args_v1* p) { return p && p->struct_size == sizeof(zk_ar_args_v1) && p->version == 1; }
+// A caller compiled against the first layout of version 1 (which ended with gh3) passes a SHORTER block: it is accepted and the fields
+// it does not have (phi_packed, gl_nodes01, gl_weights01, eps) read as zero — the point of carrying struct_size.  A block longer than this
+// library knows, another version, or one cut inside the original fields is ZK_EINVAL.
+static bool ar_args_norm(const zk_ar_args_v1* p, zk_ar_args_v1* out) {
+  if (!p || p->version != 1 || p->struct_size < offsetof(zk_ar_args_v1, phi_packed) || p->struct_size > sizeof(zk_ar_args_v1)) return false;
+  std::memset(out, 0, sizeof(*out));
+  std::memcpy(out, p, p->struct_size);
+  out->struct_size = sizeof(zk_ar_args_v1);
+  return true;
+}
+#define AR_ARGS_OK(args) (ar_args_norm(args, &args##_norm_) ? ((args) = &args##_norm_, true) : false)
 
 static int ar_launch_v1(const ArPartial& part, bool inverse, const zk_ar_args_v1& p, void* stream) {
   return ar_launch(part, inverse, p.uni_kind, p.N, p.D, p.DIN, p.x, p.ldx, inverse ? p.y_in : nullptr, inverse ? p.ldy : 0, inverse ? p.x_out : p.y, inverse ? p.ldo : p.ldy,
@@ -598,7 +609,8 @@ static int ar_launch_v1(const ArPartial& part, bool inverse, const zk_ar_args_v1
 }
 
 int zk_ar_forward(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args)) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args)) return ZK_EINVAL;
   return ar_launch_v1(ArPartial{}, false, *args, stream);
 }
 
@@ -606,7 +618,8 @@ int zk_ar_forward(const zk_ar_args_v1* args, void* stream) {
 // bin_out[N, D] (k = #(knots < x) - 1, zuko/transforms.py:521-523) and knots_out[N, D, K+1] (the horizontal knots the
 // search compared).  Lets the tests assert the bin index of the FUSED path on its own knots.
 int zk_ar_forward_diag(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args)) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args)) return ZK_EINVAL;
   ArPartial part;
   part.bin_out = args->bin_out; part.knots_out = args->knots_out;
   zk_ar_args_v1 p = *args;
@@ -619,7 +632,8 @@ int zk_ar_forward_diag(const zk_ar_args_v1* args, void* stream) {
 // feature order).  wstream is the PER-TILE stream of the plan (ArPlan.fine_gather), n_chunks its length.  The kernel re-checks
 // D / DIN / n_layers / n_groups / n_chunks against the shape it was generated for and returns hipErrorInvalidValue on a mismatch.
 int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args) || !args->launcher) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args) || !args->launcher) return ZK_EINVAL;
   ArPartial part;
   part.static_fn = args->launcher; part.rev = args->rev;
   part.gl_nodes01 = args->gl_nodes01; part.gl_weights01 = args->gl_weights01; part.eps = args->eps;
@@ -633,7 +647,8 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
 // h_l [N, width_l] (up to three; units in the stream's sorted order), for the backward pass of zuko_amd/train.py.  With y != NULL (operand-split
 // kernels only) the same launch also yields y [N, D] and ladj [N] as zk_ar_forward_static does (bound, slope, accumulate are read then).
 int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args) || !args->launcher || !args->phi || !args->h1) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args) || !args->launcher || !args->phi || !args->h1) return ZK_EINVAL;
   const int n_layers = args->n_layers;
   if (n_layers < 2 || n_layers > 4 || (n_layers > 2 && !args->h2) || (n_layers > 3 && !args->h3)) return ZK_EINVAL;
   if (((uintptr_t)args->h1 % 16) || ((uintptr_t)args->h2 % 16) || ((uintptr_t)args->h3 % 16)) return ZK_EINVAL;
@@ -656,7 +671,8 @@ int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
 // conditioner's input.  wstream = the kernel's weight stream (transposed masked weights in its tile order), n_chunks its length.
 typedef int (*ars_dgrad_fn)(const ArArgs* a, int abi, int args_bytes, void* stream);
 int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args) || !args->launcher || !args->x || !args->y || !args->wstream) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args) || !args->launcher || !args->x || !args->y || !args->wstream) return ZK_EINVAL;
   const int n = args->n_layers;
   if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff) return ZK_EINVAL;
   if (args->N == 0) return 0;
@@ -678,7 +694,8 @@ int zk_ar_dgrad_chain(const zk_ar_args_v1* args, void* stream) {
 // pre-activations, y the gradient w.r.t. the conditioner's input; `launcher` = zk_ars_dgrad_launch of an operand-split chain kernel
 // (zuko_amd/static_ar.py: chain_split_tables), whose first layer streams x from global memory.
 int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args) || !args->launcher || !args->x || !args->y || !args->wstream) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args) || !args->launcher || !args->x || !args->y || !args->wstream) return ZK_EINVAL;
   const int n = args->n_layers;
   if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff) return ZK_EINVAL;
   if (args->N == 0) return 0;
@@ -700,7 +717,8 @@ int zk_ar_dgrad_full(const zk_ar_args_v1* args, void* stream) {
 // the univariate adjoint gives d loss / d phi — written to x_out for the weight gradients — and the map's own d/dx term; the dgrad chain
 // runs from there through every linear layer (gh1 .. = gradients of the hidden pre-activations); y = d loss / dx = chain + direct term.
 int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args) || !args->launcher || !args->x || !args->y || !args->wstream || !args->phi || !args->x_out || !args->y_in || !args->ladj || !args->featmap) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args) || !args->launcher || !args->x || !args->y || !args->wstream || !args->phi || !args->x_out || !args->y_in || !args->ladj || !args->featmap) return ZK_EINVAL;
   const int n = args->n_layers;
   if (n < 2 || n > 4 || args->N < 0 || args->N > 0x7fffffff || args->uni_kind < 0 || args->uni_kind > 1 || args->DIN < args->D || args->D < 1) return ZK_EINVAL;
   if (args->N == 0) return 0;
@@ -723,7 +741,8 @@ int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream) {
 // One sweep of the autoregressive inverse (zuko/transforms.py:997-998): x_out = univariate(conditioner(x_cond)).inv(y).
 // x_out may alias x_cond (a wave reads its rows of x_cond completely before it writes them).
 int zk_ar_inverse_sweep(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args)) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args)) return ZK_EINVAL;
   return ar_launch_v1(ArPartial{}, true, *args, stream);
 }
 
@@ -735,7 +754,8 @@ int zk_ar_inverse_sweep(const zk_ar_args_v1* args, void* stream) {
 // to later sweeps, so running, for s = 0..passes-1, the partial sweep of the groups holding order s
 // yields the same x as `passes` full sweeps at a fraction of the work (hard part 4).
 int zk_ar_inverse_partial(const zk_ar_args_v1* args, void* stream) {
-  if (!ar_args_ok(args) || !args->sched || !args->olim) return ZK_EINVAL;
+  zk_ar_args_v1 args_norm_;
+  if (!AR_ARGS_OK(args) || !args->sched || !args->olim) return ZK_EINVAL;
   ArPartial part;
   part.sched = args->sched; part.n_sched = args->n_sched; part.olim = args->olim; part.g0 = args->g0; part.g1 = args->g1;
   return ar_launch_v1(part, true, *args, stream);

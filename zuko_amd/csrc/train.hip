@@ -635,6 +635,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int C, int nslices, c
   }
   for (; s < nslices; ++s) sum += partial[(size_t)s * stride + c];
   const int d = rows ? rows[c] : c;  // (sorted-domain column -> where the module keeps it)
+  if (d < 0) return;                 // padding slot of a packed row table (include/zuko_amd.h): no destination
   out[d] = accumulate ? out[d] + sum : sum;
 }
 

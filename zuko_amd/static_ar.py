@@ -132,12 +132,19 @@ def _build_so(stem: str, source, meta: dict | None, verbose: bool, out_dir: str 
         return None
 
 
+_HEADER_DIGEST: str | None = None
+
+
 def _header_digest() -> str:
-    h = hashlib.sha256(str(ARS_ABI).encode())
-    for name in _HEADERS:
-        with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:12]
+    """Digest of the kernel headers the generated units include (read once per process: it is consulted on every lookup of a kernel)."""
+    global _HEADER_DIGEST
+    if _HEADER_DIGEST is None:
+        h = hashlib.sha256(str(ARS_ABI).encode())
+        for name in _HEADERS:
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(f.read())
+        _HEADER_DIGEST = h.hexdigest()[:12]
+    return _HEADER_DIGEST
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -471,12 +478,12 @@ def jit_min_rows() -> int:
 JIT_CUMULATIVE_FACTOR = 8
 
 
-def effective_rows(holder, rows: int) -> int:
+def effective_rows(holder, rows: int, count: bool = True) -> int:
     """The batch size the JIT threshold is compared with: `rows` itself, or the threshold once `holder` (a plan / state object living as long as
     the conditioner) has seen JIT_CUMULATIVE_FACTOR x the threshold in TOTAL — a training loop with small batches gets its kernel after a few
     dozen steps instead of never.  (ZUKO_AMD_JIT=0 still disables every compile.)"""
     thr = jit_min_rows()
-    seen = getattr(holder, "_jit_rows_seen", 0) + max(int(rows), 0)
+    seen = getattr(holder, "_jit_rows_seen", 0) + (max(int(rows), 0) if count else 0)  # (count=False: a second consultation within the same step)
     try:
         holder._jit_rows_seen = seen
     except AttributeError:

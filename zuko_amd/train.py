@@ -269,7 +269,7 @@ class PackedRows:
         self.rows = torch.from_numpy(mod_row.astype(np.int32)).to(device)
 
 
-_FUSED_TRAIN = weakref.WeakKeyDictionary()  # SortedPlan -> FusedAR (static-shape kernel) or False
+_FUSED_TRAIN = weakref.WeakKeyDictionary()  # SortedPlan -> {(features, total) as passed: FusedAR (static-shape kernel) or False}
 
 
 def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0, features: int | None = None, total: int | None = None):
@@ -282,7 +282,9 @@ def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0, featur
 
     if os.environ.get("ZUKO_AMD_NO_FUSED_TRAIN", "0") == "1":
         return None
-    st = _FUSED_TRAIN.get(plan)
+    per_plan = _FUSED_TRAIN.setdefault(plan, {})  # keyed by what the head was said to be: a call that cannot know (features=None) must not decide for one that does
+    key = (features, total)
+    st = per_plan.get(key)
     if st is None:
         st = False
         try:
@@ -306,7 +308,7 @@ def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0, featur
                     st._train_checked = None  # None: not validated yet; True / False afterwards
         except Exception:
             st = False
-        _FUSED_TRAIN[plan] = st
+        per_plan[key] = st
     if not st:
         return None
     if rows > 0 and (st.static is None or not st.static[0].meta.get("split")):
@@ -445,12 +447,12 @@ def _backward_kernel(plan: SortedPlan, st, rows: int):
         from . import static_ar
 
         lay = st.plan.layout
-        tg = static_ar.chain_split_tables(plan.mask_s_cpu, plan.rows_cpu, plan.cols_cpu,
-                                          packed={"uni": lay.kind, "featmap": st.plan.featmap, "nt": lay.nt, "fpl": lay.fpl, "total": lay.total})
+        tg = _memo(plan, ("packed", lay.kind, lay.nt, lay.fpl, lay.total), lambda: static_ar.chain_split_tables(
+            plan.mask_s_cpu, plan.rows_cpu, plan.cols_cpu, packed={"uni": lay.kind, "featmap": st.plan.featmap, "nt": lay.nt, "fpl": lay.fpl, "total": lay.total}))
         if tg is None:
             _BACKWARDS[plan] = False
             return None
-        kern = static_ar.chain_kernel(tg[0], allow_compile=static_ar.jit_enabled() and static_ar.effective_rows(st, rows) >= static_ar.jit_min_rows())
+        kern = static_ar.chain_kernel(tg[0], allow_compile=static_ar.jit_enabled() and static_ar.effective_rows(st, rows, count=False) >= static_ar.jit_min_rows())  # (st.ready counted this step's rows)
         if kern is None:
             return None  # (not cached: a later, larger batch may be allowed to compile)
         bk = DgradChain(plan, kern, tg[0], tg[1], plan.device)
@@ -458,6 +460,15 @@ def _backward_kernel(plan: SortedPlan, st, rows: int):
             bk = False
         _BACKWARDS[plan] = bk
     return bk or None
+
+
+def _memo(plan, key, make):
+    """Tables derived from a plan's masks alone (numpy work + digests), computed once per plan: the kernel lookups below run on every
+    forward while a kernel is still waiting for its JIT threshold."""
+    cache = plan.__dict__.setdefault("_table_memo", {})
+    if key not in cache:
+        cache[key] = make()
+    return cache[key]
 
 
 def _dgrad_chain(plan: SortedPlan, lins, rows: int):
@@ -476,7 +487,7 @@ def _dgrad_chain(plan: SortedPlan, lins, rows: int):
 
             allow = static_ar.jit_enabled() and static_ar.effective_rows(plan, rows) >= static_ar.jit_min_rows()
             if static_ar.split_enabled() and plan.shapes[-1][0] % 4 == 0:  # every layer in one launch of the operand-split kernel
-                tg = static_ar.chain_split_tables(plan.mask_s_cpu, plan.rows_cpu, plan.cols_cpu)
+                tg = _memo(plan, "split", lambda: static_ar.chain_split_tables(plan.mask_s_cpu, plan.rows_cpu, plan.cols_cpu))
                 kern = static_ar.chain_kernel(tg[0], allow_compile=allow) if tg is not None else None
                 if kern is not None:
                     st = DgradChain(plan, kern, tg[0], tg[1], plan.device)
@@ -485,13 +496,15 @@ def _dgrad_chain(plan: SortedPlan, lins, rows: int):
                 split_pending = tg is not None and not allow and static_ar.jit_enabled()  # a later, larger batch may compile the one-launch split chain
             else:
                 split_pending = False
-            tg = static_ar.chain_tables(plan.mask_s_cpu[: n - 1], plan.rows_cpu[: n - 1], plan.cols_cpu[: n - 1])
+            tg = _memo(plan, "f32", lambda: static_ar.chain_tables(plan.mask_s_cpu[: n - 1], plan.rows_cpu[: n - 1], plan.cols_cpu[: n - 1]))
             if tg is not None:
-                kern = static_ar.chain_kernel(tg[0], allow_compile=allow)
+                held = getattr(plan, "_f32_chain", None)  # (the un-cached f32 chain of earlier small batches: its index uploads are made once)
+                kern = held.kernel if held is not None else static_ar.chain_kernel(tg[0], allow_compile=allow)
                 if kern is not None:
-                    st = DgradChain(plan, kern, tg[0], tg[1], plan.device)
+                    st = held if held is not None else DgradChain(plan, kern, tg[0], tg[1], plan.device)
                     if split_pending:
-                        return st  # (the f32 chain serves this batch, but is NOT cached: re-probe, as FusedAR._acquire_static does)
+                        plan._f32_chain = st
+                        return st  # (the f32 chain serves this batch, but is NOT entered as the plan's chain: re-probe, as FusedAR._acquire_static does)
                 else:
                     return None  # (not cached: a later, larger batch may be allowed to compile)
         _CHAINS[plan] = st
