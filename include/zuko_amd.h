@@ -135,6 +135,18 @@ int zk_linear_bf16(int64_t N, int in_features, int out_features, const void* x, 
 int zk_linear_bf16_rqs(int64_t N, int in_features, int panels, const void* h, int64_t ldh, const void* weight_panels, const uint64_t* tile_live_mask,
                        const void* bias_panels, int K, int features, double bound, double slope, const void* x, int64_t ldx, void* y, int64_t ldy,
                        float* partial, float* ladj, void* stream);
+/* The same layer + spline on the second-generation kernel (round 5; csrc/linear_bf16_lanes.hip): the weight rows are ordered so that a LANE's
+ * accumulators hold every parameter of a whole feature of its samples, and the spline runs on those registers (no LDS image of the tile, no
+ * workgroup barrier in the epilogue).  Panels have 192 rows and FPP = 4 (K = 16) or 8 (K = 8) features; with TS = 48 (K = 16) or 24 (K = 8) slots
+ * per feature and FPL = 48 / TS, row o of panel p holds
+ *     wn = o / 96, c = o % 96, j = c / 32, q = (c % 32) / 8, kg = (c % 8) / 4, t = c % 4, slot s = 16 j + 4 q + t,
+ *     feature p FPP + wn 2 FPL + kg FPL + s / TS, parameter s % TS      (a zero row when parameter >= 3K - 1 or feature >= features)
+ * (zuko_amd/nn.py: _Bf16Plan.spline_lane_panels); panels = ceil(features / FPP); in_features % 32 == 0.  tile_live_mask[p]: bit k = inputs
+ * [32 k, 32 k + 32) of the panel carry a non-zero weight (NULL, or in_features > 2048: everything is multiplied).  `partial`: fp32 workspace
+ * [2 * panels, N].  Other arguments and results as zk_linear_bf16_rqs; y is bit-identical to it and to the unfused path. */
+int zk_linear_bf16_rqs_lanes(int64_t N, int in_features, int panels, const void* h, int64_t ldh, const void* weight_panels,
+                             const uint64_t* tile_live_mask, const void* bias_panels, int K, int features, double bound, double slope, const void* x,
+                             int64_t ldx, void* y, int64_t ldy, float* partial, float* ladj, void* stream);
 
 /* ---- fused masked-autoregressive layer (the dominant kernel of NSF / MAF log_prob) ----------------- *
  * Replaces, for one MaskedAutoregressiveTransform (zuko/flows/autoregressive.py:207-218 `meta` +

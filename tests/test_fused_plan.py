@@ -451,3 +451,66 @@ def test_polynomial_flows_are_recognised_at_their_default_sizes_only():
     assert F.BPF(6, 0, degree=8, transforms=1, hidden_features=[32]).transform.transforms[0]._fusable_layout() is None
     # the inverse of these kinds stays layer-wise: no group-aligned fused state for the sweeps
     assert F.BPF(6, 0, transforms=1, hidden_features=[32]).transform.transforms[0].fused_state(__import__("torch").device("cpu"), inverse=True) is None
+
+
+def test_lane_owned_spline_panels_follow_the_header_formula():
+    """zk_linear_bf16_rqs_lanes (include/zuko_amd.h) wants the last layer's rows in panels of 192 in which the 16 outputs a lane of the matrix
+    instruction owns per 32-row block hold whole features: _Bf16Plan.spline_lane_panels against a loop restatement of the header's formula, for
+    both bin counts, a feature count that leaves the last panel partly empty, and the 192 x 32 liveness words (host logic: runs on the CPU)."""
+    import torch
+
+    from zuko_amd.nn import MaskedMLP, _Bf16Plan
+
+    for K, features in ((16, 10), (8, 21)):
+        total = 3 * K - 1
+        ts = 48 if K == 16 else 24
+        fpl = 48 // ts
+        fpp = 4 * fpl
+        torch.manual_seed(K)
+        order = torch.arange(features)
+        adjacency = (order[:, None] > order[None, :]).repeat_interleave(total, dim=0)  # row f * total + j (zuko/flows/autoregressive.py:188-190)
+        net = MaskedMLP(adjacency, hidden_features=[64, 128])
+        lins = list(net)[0::2]
+        plan = _Bf16Plan(lins)
+        plan.refresh(lins)
+        wp, bp, live = plan.spline_lane_panels(lins, K, features)
+        w, b, mp = plan.weights[-1], plan.biases[-1], plan.masks_p[-1]
+        panels = -(-features // fpp)
+        assert wp.shape == (panels * 192, w.shape[1]) and bp.shape == (panels * 192,) and live.shape == (panels,)
+        seen = set()
+        for p in range(panels):
+            for o in range(192):
+                wn, c = divmod(o, 96)
+                j, q, kg, t = c // 32, (c % 32) // 8, (c % 8) // 4, c % 4
+                slot = 16 * j + 4 * q + t
+                feat, par = p * fpp + wn * 2 * fpl + kg * fpl + slot // ts, slot % ts
+                row = p * 192 + o
+                if par < total and feat < features:
+                    src = feat * total + par
+                    seen.add(src)
+                    assert torch.equal(wp[row], w[src]) and bp[row] == b[src], (K, p, o)
+                else:
+                    assert not wp[row].any() and bp[row] == 0, (K, p, o)
+        assert seen == set(range(features * total))  # every parameter row of the reference's layout sits in exactly one slot
+        kt = w.shape[1] // 32
+        for p in range(panels):
+            for k in range(kt):
+                assert bool((int(live[p]) >> k) & 1) == bool(_panel_mask_any(plan, lins, K, features, p, k)), (K, p, k)
+
+
+def _panel_mask_any(plan, lins, K, features, p, k):
+    """Does panel p of the lane-owned layout hold a row whose MASK is non-zero in inputs [32 k, 32 k + 32)?  (liveness follows the mask, not the
+    weights' values: a weight that happens to be zero today may be trained tomorrow without the plan being rebuilt)"""
+    total = 3 * K - 1
+    ts = 48 if K == 16 else 24
+    fpl = 48 // ts
+    fpp = 4 * fpl
+    mp = plan.masks_p[-1].bool()
+    for o in range(192):
+        wn, c = divmod(o, 96)
+        j, q, kg, t = c // 32, (c % 32) // 8, (c % 8) // 4, c % 4
+        slot = 16 * j + 4 * q + t
+        feat, par = p * fpp + wn * 2 * fpl + kg * fpl + slot // ts, slot % ts
+        if par < total and feat < features and bool(mp[feat * total + par, 32 * k : 32 * k + 32].any()):
+            return True
+    return False

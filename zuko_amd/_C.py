@@ -104,6 +104,7 @@ SIGNATURES = {
     "zk_linear": [I, L, I, I, P, L, P, P, P, I, P, L, P],
     "zk_linear_bf16": [L, I, I, P, L, P, P, P, I, P, L, P],
     "zk_linear_bf16_rqs": [L, I, I, P, L, P, P, P, I, I, F, F, P, L, P, L, P, P, P],
+    "zk_linear_bf16_rqs_lanes": [L, I, I, P, L, P, P, P, I, I, F, F, P, L, P, L, P, P, P],
     "zk_diag_normal_log_prob": [I, L, L, P, P, P, P, P, P],
     "zk_sum_f64": [I, L, P, F, P, P, P],
     "zk_gather_f32": [P, P, P, L, P, P],

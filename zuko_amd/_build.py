@@ -28,6 +28,7 @@ SOURCES = {
     "elementwise.hip": ["-ffp-contract=off"],
     "linear.hip": [],
     "linear_bf16.hip": ["-ffp-contract=off"],  # its spline epilogue must round like elementwise.hip's
+    "linear_bf16_lanes.hip": ["-ffp-contract=off"],
     "fused_ar.hip": ["-ffp-contract=off"],
     "backward.hip": [],
     "train.hip": [],

@@ -172,16 +172,16 @@ def _param_stamp(lins) -> tuple:
     return tuple((l.weight._version, l.weight.data_ptr(), -1 if l.bias is None else l.bias._version, 0 if l.bias is None else l.bias.data_ptr()) for l in lins)
 
 
-def live_tile_masks(mask: Tensor) -> Tensor:
-    """int64 [ceil(out / 256)]: bit k of word p is set iff rows [256 p, 256 p + 256) x columns [64 k, 64 k + 64) of
-    `mask` (bool or numeric [out, in], in % 64 == 0, in <= 4096) hold a non-zero — the `tile_live_mask` argument of
-    zk_linear_bf16."""
+def live_tile_masks(mask: Tensor, rows: int = 256, cols: int = 64) -> Tensor:
+    """int64 [ceil(out / rows)]: bit k of word p is set iff rows [rows p, rows p + rows) x columns [cols k, cols k + cols) of
+    `mask` (bool or numeric [out, in], in % cols == 0, in / cols <= 64) hold a non-zero — the `tile_live_mask` argument of
+    zk_linear_bf16 / zk_linear_bf16_rqs (256 x 64 tiles) and of zk_linear_bf16_rqs_lanes (192 x 32)."""
     out_f, in_f = mask.shape
-    kt = in_f // 64
-    pad = (-out_f) % 256
+    kt = in_f // cols
+    pad = (-out_f) % rows
     t = mask != 0
     t = torch.nn.functional.pad(t, (0, 0, 0, pad)) if pad else t
-    live = t.reshape(-1, 256, kt, 64).any(dim=3).any(dim=1)  # [panels, kt]
+    live = t.reshape(-1, rows, kt, cols).any(dim=3).any(dim=1)  # [panels, kt]
     weights = torch.ones(kt, dtype=torch.int64, device=mask.device) << torch.arange(kt, dtype=torch.int64, device=mask.device)
     return (live.to(torch.int64) * weights).sum(dim=1).contiguous()  # (bit 63 lands in the sign bit: the kernel reads raw bits)
 
@@ -264,6 +264,41 @@ class _Bf16Plan:
             self._sp_key, self._sp = key, (wp, bp, live)
         return self._sp
 
+    def spline_lane_panels(self, lins: Sequence["MaskedLinear"], K: int, features: int):
+        """(weight_panels, bias_panels, live) of the LAST layer for zk_linear_bf16_rqs_lanes (include/zuko_amd.h): panels of 192 rows in which
+        the 16 outputs a lane of the matrix instruction owns per 32-row block hold the parameters of whole features.  Cached per parameter
+        version (call after `refresh`)."""
+        key = (self.version, K, features)
+        if self.__dict__.get("_lp_key") != key:
+            total = 3 * K - 1
+            ts = 48 if K == 16 else 24
+            fpl = 48 // ts
+            fpp = 4 * fpl
+            panels = -(-features // fpp)
+            w, b, mp = self.weights[-1], self.biases[-1], self.masks_p[-1]
+            in_f = w.shape[1]
+            dev = w.device
+            o = torch.arange(192, device=dev)
+            wn, c = o // 96, o % 96
+            j, q, kg, t = c // 32, (c % 32) // 8, (c % 8) // 4, c % 4
+            slot = 16 * j + 4 * q + t
+            feat = torch.arange(panels, device=dev)[:, None] * fpp + (wn * 2 * fpl + kg * fpl + slot // ts)[None, :]  # [panels, 192]
+            par = (slot % ts)[None, :].expand_as(feat)
+            ok = (par < total) & (feat < features)
+            src = (feat * total + par)[ok]  # the reference's row f * total + j (zuko/flows/autoregressive.py:188-190)
+            dst = torch.nonzero(ok.reshape(-1)).squeeze(1)
+            wp = torch.zeros((panels * 192, in_f), dtype=w.dtype, device=dev)
+            wp[dst] = w[src]
+            bp = None
+            if b is not None:
+                bp = torch.zeros(panels * 192, dtype=b.dtype, device=dev)
+                bp[dst] = b[src]
+            mpan = torch.zeros((panels * 192, in_f), dtype=torch.bool, device=dev)
+            mpan[dst] = mp.bool()[src]
+            live = live_tile_masks(mpan, 192, 32)
+            self._lp_key, self._lp = key, (wp, bp, live)
+        return self._lp
+
     def live_fraction(self) -> list[float]:
         """Fraction of 256 x 64 weight tiles each layer actually multiplies."""
         out = []
@@ -343,6 +378,11 @@ class MaskedMLP(_FusedSequential):
         h = inp
         for w, b, live in zip(plan.weights[:-1], plan.biases[:-1], plan.live[:-1]):
             h = ops.linear_bf16(h, w, b, live, plan.act)
+        import os
+
+        if os.environ.get("ZUKO_AMD_BF16_PANELS256", "0") != "1" and h.shape[-1] % 64 == 0 and h.shape[-1] <= 2048:  # second-generation kernel (lane-owned features)
+            wp, bp, lv = plan.spline_lane_panels(lins, K, x.shape[-1])
+            return ops.linear_bf16_rqs(h, wp, bp, lv, x, K, bound, slope, lanes=True)
         wp, bp, lv = plan.spline_panels(lins, K, x.shape[-1])
         return ops.linear_bf16_rqs(h, wp, bp, lv, x, K, bound, slope)
 

@@ -450,14 +450,15 @@ def linear_bf16(x: Tensor, weight_masked: Tensor, bias: Tensor | None, tile_live
 
 
 def linear_bf16_rqs(h: Tensor, weight_panels: Tensor, bias_panels: Tensor | None, tile_live: Tensor | None, x: Tensor, K: int, bound: float = 5.0,
-                    slope: float = 1e-3):
+                    slope: float = 1e-3, lanes: bool = False):
     """(y bf16 [N, D], ladj fp32 [N]) of a bf16 autoregressive spline layer whose last conditioner layer and spline run
-    in one kernel (zk_linear_bf16_rqs): h [N, in] last hidden activation, x [N, D] transform input, weights in
-    feature panels (zuko_amd.nn._Bf16Plan.spline_panels)."""
+    in one kernel: h [N, in] last hidden activation, x [N, D] transform input, weights in feature panels — of 256 rows
+    (zuko_amd.nn._Bf16Plan.spline_panels, zk_linear_bf16_rqs) or, with lanes=True, of 192 rows in the lane-owned order
+    (spline_lane_panels, zk_linear_bf16_rqs_lanes)."""
     _require_device(h, weight_panels, bias_panels, tile_live, x)
     _no_grad_only(h, weight_panels, bias_panels, x)
     rows, in_f = weight_panels.shape
-    panels = rows // 256
+    panels = rows // (192 if lanes else 256)
     N, D = x.shape
     if h.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or weight_panels.dtype != torch.bfloat16:
         raise TypeError("zuko_amd.linear_bf16_rqs: bfloat16 tensors expected")
@@ -465,10 +466,11 @@ def linear_bf16_rqs(h: Tensor, weight_panels: Tensor, bias_panels: Tensor | None
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     y = torch.empty((N, D), dtype=torch.bfloat16, device=x.device)
     ladj = torch.empty(N, dtype=torch.float32, device=x.device)
-    partial = torch.empty((panels, N), dtype=torch.float32, device=x.device)
-    err = _C.lib().zk_linear_bf16_rqs(N, in_f, panels, _ptr(h2), h2.stride(0) if N > 1 else in_f, _ptr(weight_panels), _ptr(tile_live), _ptr(bias_panels), K, D,
-                                      bound, slope, _ptr(x2), x2.stride(0) if N > 1 else D, _ptr(y), D, _ptr(partial), _ptr(ladj), _stream())
-    _C.check(err, "zk_linear_bf16_rqs")
+    partial = torch.empty((2 * panels if lanes else panels, N), dtype=torch.float32, device=x.device)
+    fn = _C.lib().zk_linear_bf16_rqs_lanes if lanes else _C.lib().zk_linear_bf16_rqs
+    err = fn(N, in_f, panels, _ptr(h2), h2.stride(0) if N > 1 else in_f, _ptr(weight_panels), _ptr(tile_live), _ptr(bias_panels), K, D,
+             bound, slope, _ptr(x2), x2.stride(0) if N > 1 else D, _ptr(y), D, _ptr(partial), _ptr(ladj), _stream())
+    _C.check(err, "zk_linear_bf16_rqs_lanes" if lanes else "zk_linear_bf16_rqs")
     return y, ladj
 
 
