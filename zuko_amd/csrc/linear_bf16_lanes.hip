@@ -57,7 +57,8 @@ typedef unsigned int ln_u32x2 __attribute__((ext_vector_type(2)));
                                             the vmcnt waits count with this minimum, which only makes them stricter for the others */
 #ifndef ZK_LANES_ABLATE
 #define ZK_LANES_ABLATE 0 /* probe builds only (WRONG results): 1 = no epilogue (accumulators kept alive), 3 = k loop without DMAs,
-                             6 = epilogue without the spline arithmetic, 7 = epilogue without the bias loads and the y stores */
+                             6 = epilogue without the spline arithmetic, 7 = epilogue without the bias loads and the y stores,
+                             8 = every DMA instruction issued with ONE active lane (the issue slots stay, the bytes go) */
 #endif
 
 struct LaneArgs {
@@ -171,9 +172,17 @@ template <int SK> __global__ __launch_bounds__(512, 2) void linear_bf16_rqs_lane
     if (i < 2) {
       const int rl = rl_act[i] < p_nvalid1 ? rl_act[i] : p_nvalid1;
       const unsigned off = (unsigned)(rl * pitch_h + ((i & 1) ? c16_b : c16_a));
+#if ZK_LANES_ABLATE == 8
+      { unsigned long long sv_; asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\ts_add_i32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv_) : "v"(off), "s"(p_base_h), "s"(p_lds), "s"(act_lds[i]) : "memory"); }
+#else
       asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(p_base_h), "s"(p_lds), "s"(act_lds[i]) : "memory");
-    } else if (i == 2 || four) {
+#endif
+    } else {  // (piece 3: wavefronts 0..3 only — the caller's instantiation)
+#if ZK_LANES_ABLATE == 8
+      { unsigned long long sv_; asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\ts_add_i32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv_) : "v"((unsigned)off_w[i - 2]), "s"(p_base_w), "s"(p_lds), "s"(w_lds[i - 2]) : "memory"); }
+#else
       asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)off_w[i - 2]), "s"(p_base_w), "s"(p_lds), "s"(w_lds[i - 2]) : "memory");
+#endif
     }
   };
 
@@ -225,7 +234,8 @@ template <int SK> __global__ __launch_bounds__(512, 2) void linear_bf16_rqs_lane
 #pragma unroll 1
   for (int s_ = 0; s_ < 3; ++s_) {
     produce_next();
-    dma_piece(0); dma_piece(1); dma_piece(2); dma_piece(3);
+    dma_piece(0); dma_piece(1); dma_piece(2);
+    if (four) dma_piece(3);
   }
 
   // x of the lane's (sample, feature) elements, requested a whole tile ahead from inline assembly (2 FPL registers).  x is read once, i.e. from
@@ -275,26 +285,35 @@ template <int SK> __global__ __launch_bounds__(512, 2) void linear_bf16_rqs_lane
   while (true) {
     const unsigned b_off = c_off + LN_STAGE == LN_NS * LN_STAGE ? 0u : c_off + LN_STAGE;
     const unsigned n_off = b_off + LN_STAGE == LN_NS * LN_STAGE ? 0u : b_off + LN_STAGE;
-    // everything between two LN_SB() is issued in this order; the fragment reads of a half ride in front of the previous half's matrix
-    // instructions, the first ones behind the barrier are covered by the producer's scalar work and two DMA pieces
+    // Everything between two LN_SB() is issued in this order.  The fragment reads of a half ride in front of the previous half's matrix
+    // instructions; the first ones behind the barrier are covered by the producer's scalar work.  The two wavefronts of a SIMD (w and w + 4)
+    // run this loop in lock-step — the barrier aligns them — and a DMA piece holds its wavefront's issue for ~50 cycles: with the pieces at the
+    // same places in both, the matrix pipe idled through every one of them (the probe build without DMAs: 7 ms of 33 faster).  So wavefronts
+    // 0..3 issue theirs in the first and third quarter of the super-step, wavefronts 4..7 in the second and fourth: a wavefront in a DMA issue
+    // has a partner in a stretch of bare matrix instructions.
+    // (`four` = wavefronts 0..3 = the early ones; scalar branches around single DMA instructions)
+#define LN_E(i) if (four) dma_piece(i)
+#define LN_L(i) if (!four) dma_piece(i)
     LN_READ(0, c_off, xf0, wf0);
     produce_next();
-    dma_piece(0); dma_piece(1);
+    LN_E(0);
     LN_READ(1, c_off, xf1, wf1);
     LN_SB();
-    LN_M(0, 0, 0); LN_M(0, 1, 0); dma_piece(2); LN_M(0, 0, 1); LN_M(0, 1, 1); LN_M(0, 0, 2); dma_piece(3); LN_M(0, 1, 2);
+    LN_M(0, 0, 0); LN_E(1); LN_M(0, 1, 0); LN_M(0, 0, 1); LN_E(2); LN_M(0, 1, 1); LN_M(0, 0, 2); LN_E(3); LN_M(0, 1, 2);
     LN_SB();
     LN_READ(0, b_off, xf0, wf0);
     LN_SB();
-    LN_M(1, 0, 0); LN_M(1, 1, 0); LN_M(1, 0, 1); LN_M(1, 1, 1); LN_M(1, 0, 2); LN_M(1, 1, 2);
+    LN_M(1, 0, 0); LN_L(0); LN_M(1, 1, 0); LN_M(1, 0, 1); LN_L(1); LN_M(1, 1, 1); LN_M(1, 0, 2); LN_L(2); LN_M(1, 1, 2);
     LN_SB();
     produce_next();
     LN_READ(1, b_off, xf1, wf1);
     LN_SB();
-    LN_M(0, 0, 0); LN_M(0, 1, 0); dma_piece(0); LN_M(0, 0, 1); LN_M(0, 1, 1); dma_piece(1); LN_M(0, 0, 2); LN_M(0, 1, 2); dma_piece(2);
+    LN_M(0, 0, 0); LN_E(0); LN_M(0, 1, 0); LN_E(1); LN_M(0, 0, 1); LN_M(0, 1, 1); LN_E(2); LN_M(0, 0, 2); LN_E(3); LN_M(0, 1, 2);
     LN_SB();
-    LN_M(1, 0, 0); LN_M(1, 1, 0); dma_piece(3); LN_M(1, 0, 1); LN_M(1, 1, 1); LN_M(1, 0, 2); LN_M(1, 1, 2);
+    LN_M(1, 0, 0); LN_L(0); LN_M(1, 1, 0); LN_M(1, 0, 1); LN_L(1); LN_M(1, 1, 1); LN_M(1, 0, 2); LN_L(2); LN_M(1, 1, 2);
     LN_SB();
+#undef LN_E
+#undef LN_L
     c_off = n_off;
     rem &= rem - 1;
     rem &= rem - 1;
