@@ -27,6 +27,13 @@
 #include "fused_ar_static_impl.h"
 #include "zk_univariate_bwd.h"
 
+#ifndef ARX_LOOK
+#define ARX_LOOK 1
+#endif
+#ifndef ARX_FENCE
+#define ARX_FENCE 1
+#endif
+
 namespace zk {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -87,20 +94,26 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arx_hidden
     if constexpr (!P::tile_has_blocks(L, t)) out[t] = *reinterpret_cast<const f32x4*>(bias_q + t * 16);  // units that depend on nothing: bias only
   });
   if constexpr (NB > 0) {
-    f32x4 a[2][3];
-    ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[0][p] = ring.template read<BASE + decltype(p)::value>(); });
+    // weight images are requested ARX_LOOK blocks ahead of the matrix instructions that consume them (probe builds: -DARX_LOOK=1|2|3,
+    // -DARX_FENCE=0 drops the scheduling fences around a block's six matrix instructions; profiles/r05/headline.md)
+    constexpr int LOOK = ARX_LOOK < NB ? ARX_LOOK : NB;
+    f32x4 a[LOOK + 1][3];
+    ars_for<LOOK>([&](auto b_) ARS_ALWAYS_INLINE {
+      constexpr int b = b_;
+      ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[b][p] = ring.template read<BASE + 3 * b + decltype(p)::value>(); });
+    });
     ars_for<NB>([&](auto s_) ARS_ALWAYS_INLINE {
-      constexpr int s = s_, ot = P::ot(L, s), ip = P::ip(L, s);
+      constexpr int s = s_, ot = P::ot(L, s), ip = P::ip(L, s), cur = s % (LOOK + 1);
       if constexpr (s == 0 || P::ot(L, s - 1) != ot) out[ot] = *reinterpret_cast<const f32x4*>(bias_q + ot * 16);  // accumulators start at the bias
-      if constexpr (s + 1 < NB) {
-        ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[(s + 1) & 1][p] = ring.template read<BASE + 3 * (s + 1) + decltype(p)::value>(); });
-        ars_settle<3>(a[s & 1][0], a[s & 1][1], a[s & 1][2]);  // this block's images are in; only the next block's may be outstanding
-      } else {
-        ars_settle<0>(a[s & 1][0], a[s & 1][1], a[s & 1][2]);
+      if constexpr (s + LOOK < NB) {
+        constexpr int nx = (s + LOOK) % (LOOK + 1);
+        ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[nx][p] = ring.template read<BASE + 3 * (s + LOOK) + decltype(p)::value>(); });
       }
-      __builtin_amdgcn_sched_barrier(0);
-      arx_block(a[s & 1], in[ip], out[ot]);
-      __builtin_amdgcn_sched_barrier(0);
+      constexpr int ahead = (s + LOOK < NB ? LOOK : NB - 1 - s);  // blocks behind this one whose images may still be outstanding
+      ars_settle<3 * ahead>(a[cur][0], a[cur][1], a[cur][2]);
+      if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
+      arx_block(a[cur], in[ip], out[ot]);
+      if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
     });
   }
 }
@@ -227,10 +240,13 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
 
     // ---- last layer + univariate transform, one group of 4 * FPL features at a time --------------------------------
     float lacc = 0.f;
-    f32x4 w[2][3];
-    if constexpr (NSTEP > 0) {
-      ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[0][p] = ring.template read<S::LAST_BASE + decltype(p)::value>(); });
-    }
+    constexpr int NBL = NSTEP * NT;                          // blocks of the last layer
+    constexpr int LOOKL = ARX_LOOK < NBL ? ARX_LOOK : NBL;   // (read ahead as in arx_hidden; the groups' epilogues sit between the blocks, so the
+    f32x4 w[LOOKL + 1][3];                                   //  images of the next group's first blocks travel while the spline is evaluated)
+    ars_for<LOOKL>([&](auto b_) ARS_ALWAYS_INLINE {
+      constexpr int b = b_;
+      ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[b][p] = ring.template read<S::LAST_BASE + 3 * b + decltype(p)::value>(); });
+    });
     ars_for<NG>([&](auto g_) ARS_ALWAYS_INLINE {
       constexpr int g = g_, ST0 = S::GOFF[g], GN = S::GOFF[g + 1] - S::GOFF[g];
       int fid[FPL];
@@ -251,16 +267,16 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
       ars_for<GN>([&](auto i_) ARS_ALWAYS_INLINE {
         constexpr int st = ST0 + decltype(i_)::value, ip = S::G_IP[st];
         ars_for<NT>([&](auto t_) ARS_ALWAYS_INLINE {
-          constexpr int t = t_, blk = st * NT + t;
-          if constexpr (blk + 1 < NSTEP * NT) {
-            ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[(blk + 1) & 1][p] = ring.template read<S::LAST_BASE + 3 * (blk + 1) + decltype(p)::value>(); });
-            ars_settle<3>(w[blk & 1][0], w[blk & 1][1], w[blk & 1][2]);
-          } else {
-            ars_settle<0>(w[blk & 1][0], w[blk & 1][1], w[blk & 1][2]);
+          constexpr int t = t_, blk = st * NT + t, cur = blk % (LOOKL + 1);
+          if constexpr (blk + LOOKL < NBL) {
+            constexpr int nx = (blk + LOOKL) % (LOOKL + 1);
+            ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[nx][p] = ring.template read<S::LAST_BASE + 3 * (blk + LOOKL) + decltype(p)::value>(); });
           }
-          __builtin_amdgcn_sched_barrier(0);
-          arx_block(w[blk & 1], in[ip], acc[t]);
-          __builtin_amdgcn_sched_barrier(0);
+          constexpr int ahead = (blk + LOOKL < NBL ? LOOKL : NBL - 1 - blk);
+          ars_settle<3 * ahead>(w[cur][0], w[cur][1], w[cur][2]);
+          if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
+          arx_block(w[cur], in[ip], acc[t]);
+          if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
         });
       });
       float p[4 * NT];
