@@ -38,7 +38,11 @@ FEATURES, TRANSFORMS, BINS, HIDDEN = 64, 8, 8, [256, 256, 256]
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA, same guide
-MFMA_16x16x32_ISSUE_CEILING = 0.61  # fraction of that peak at which a SIMD can issue v_mfma_f32_16x16x32_bf16 (scripts/probes/mfma32_probe.hip)
+# What a SIMD can issue v_mfma_f32_16x16x32_bf16 at (scripts/probes/mfma_clock_probe.hip, profiles/r05/mfma_clock_probe.txt; real shader cycles from s_memtime):
+# with TWO wavefronts per SIMD — the headline kernel's geometry — 16.2-16.5 cycles per instruction = the matrix pipe's own rate (16), i.e. 0.96 of the
+# 2.5 PFLOP/s peak on zero operands and 0.88 on random ones (the chip clocks down to ~2.2 GHz).  Round 4 quoted 0.61 from a ONE-wavefront probe with
+# four accumulators in rotation (23.5 real cycles; one accumulator: 17.0, eight: 31.0) and called it the form's ceiling; it is not.
+MFMA_16x16x32_ISSUE_CEILING = 0.88
 
 CONFIGS = {
     # name: (constructor name, kwargs, workload string, bf16)
@@ -253,6 +257,52 @@ def cpu_baseline(flow_cpu, seconds: float):
         "cpu_model": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown"),
     }
     return out, {"x": xall, "spec": spec, "out": keep}
+
+
+def gpu_aten_baseline(flow_cpu, dev, ours: float) -> dict:
+    """What a zuko user has on THIS machine without this library: the reference is pure PyTorch and runs unchanged on PyTorch-ROCm, so the
+    oracle's `flow_log_prob` body (zuko/distributions.py:115-119; bitwise the reference on the CPU) is timed with its tensors on the GPU —
+    ATen-ROCm kernels and library GEMMs, chunks of 2^14 .. 2^18 rows (phi of one transform at 2^18 rows is 1.4 GiB).  Baseline leg only."""
+    import torch
+
+    from oracle import zuko_oracle as O
+
+    sd = {k: v.to(dev) for k, v in flow_cpu.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(BINS), FEATURES)
+    out = {"unit": "samples/s", "what": "the reference's algorithm (oracle/zuko_oracle.py) on ATen-ROCm kernels, same model, fp32", "chunk_sweep_samples_per_s": {}}
+    best = 0.0
+    with torch.no_grad():
+        for lg in (14, 16, 18):
+            n = 1 << lg
+            x = torch.randn(n, FEATURES, generator=torch.Generator().manual_seed(1)).to(dev)
+
+            def once():
+                z, ladj = O.flow_forward(spec, x)
+                return O.diag_normal_log_prob(z, spec.loc, spec.scale) + ladj
+
+            try:
+                for _ in range(2):
+                    once()
+                torch.cuda.synchronize()
+                reps = 5
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    lp = once()
+                e1.record()
+                torch.cuda.synchronize()
+                rate = n * reps / (e0.elapsed_time(e1) * 1e-3)
+                out["chunk_sweep_samples_per_s"][f"2^{lg}"] = round(rate, 1)
+                best = max(best, rate)
+                del lp
+            except Exception as exc:  # (out of memory at the largest chunk: keep what was measured)
+                out["chunk_sweep_samples_per_s"][f"2^{lg}"] = repr(exc)[:120]
+            del x
+            torch.cuda.empty_cache()
+    out["value"] = best
+    if best > 0:
+        out["speedup_vs_gpu_aten"] = ours / best
+    return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -800,7 +850,7 @@ def main() -> None:
                     blk = cargs[0]
                     sizes = (blk.N, blk.D, blk.DIN) if name != "zk_coupling_forward" else (blk.N, blk.D, blk.C)
                     shown = "zk_ar_forward" if name != "zk_coupling_forward" else name  # (generic and static-shape instantiation of the same layer kernel)
-                elif name == "zk_linear_bf16_rqs":  # N, in, panels, K, features
+                elif name in ("zk_linear_bf16_rqs", "zk_linear_bf16_rqs_lanes"):  # N, in, panels, K, features
                     sizes = (cargs[0], cargs[1], cargs[2], cargs[8], cargs[9])
                 else:
                     sizes = cargs[0:3] if name == "zk_linear_bf16" else cargs[1:4]  # (dtype-less signature)
@@ -922,6 +972,12 @@ def main() -> None:
                 out["parity"] = parity_report(flow, x, sample, dev)
             except Exception as exc:
                 out["parity"] = {"error": repr(exc), "ok": False}
+            try:
+                out["gpu_aten_baseline"] = gpu_aten_baseline(flow_cpu, dev, value)
+                if "speedup_vs_gpu_aten" in out["gpu_aten_baseline"]:
+                    out["speedup_vs_gpu_aten"] = out["gpu_aten_baseline"]["speedup_vs_gpu_aten"]
+            except Exception as exc:
+                out["gpu_aten_baseline"] = {"error": repr(exc)}
         elif world == 1 and not args.no_cpu_baseline:
             try:
                 del x
@@ -967,7 +1023,7 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
         row = {"kernel": name, **rec}
         parts = name.split()
         t = rec["avg_ms"] * 1e-3
-        if parts[0] == "zk_linear_bf16_rqs":  # last layer + spline in one kernel
+        if parts[0] in ("zk_linear_bf16_rqs", "zk_linear_bf16_rqs_lanes"):  # last layer + spline in one kernel (first / second generation)
             n, fin, k, feats = int(parts[1]), int(parts[2]), int(parts[4]), int(parts[5])
             dense = 2.0 * n * fin * feats * (3 * k - 1)
             row.update(bound="mfma", achieved=dense * flop_per_transform.get("last_layer_nnz_frac", 1.0) / t / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
@@ -990,10 +1046,11 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
                 row["instantiation"] = "static-shape, operand-split (3 x bf16 per f32 operand, 6 partial products, f32 accumulate)"
                 row["peak_basis"] = f"{PEAK_BF16_MFMA_TFLOPS:g} TFLOP/s dense bf16 / 6 matrix products per f32 product; f32-equivalent FLOP"
                 row["f32_instruction_peak"] = PEAK_F32_MFMA_TFLOPS
-                # measured on this chip (scripts/probes/mfma32_probe.hip, profiles/r04/mfma32_probe.txt): a SIMD issues v_mfma_f32_16x16x32_bf16 — the form
-                # these kernels are built on — at 61 % of the bf16 peak at best (one or two wavefronts); the 32x32x16 form reaches 85 %
-                row["instruction_form_ceiling"] = {"form": "v_mfma_f32_16x16x32_bf16", "frac_of_bf16_peak": MFMA_16x16x32_ISSUE_CEILING,
-                                                   "source": "profiles/r04/mfma32_probe.txt (a constant of the chip, not re-measured in this run)"}
+                row["instruction_form_ceiling"] = {"form": "v_mfma_f32_16x16x32_bf16, two wavefronts per SIMD", "frac_of_bf16_peak": MFMA_16x16x32_ISSUE_CEILING,
+                                                   "real_cycles_per_instruction_and_simd": 16.3, "pipe_cycles_per_instruction": 16,
+                                                   "source": "profiles/r05/mfma_clock_probe.txt (random operands, ~2.2 GHz under that load; a property of the chip, not re-measured in this run)",
+                                                   "note": "the kernel's matrix pipe is busy 0.61 of the launch (profiles/r04/traffic.json, GRBM_GUI_ACTIVE / 8 = 2.4 GHz x launch time): it is NOT at this ceiling; "
+                                                           "its conversion / spline / ring phases run beside idle matrix pipes (profiles/r05/headline.md)"}
             row["algorithmic_flop_per_launch"] = float(B) * flop_per_transform["nnz"]
             row["dense_equiv_tflops"] = float(B) * flop_per_transform["dense"] / t / 1e12
             if executed_per_sample and parts[0] == "zk_ar_forward":

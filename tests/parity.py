@@ -6,12 +6,19 @@ path is itself a rounded evaluation: its distance from a float64 evaluation of t
 different summation orders / exponentials can therefore sit further apart than 1e-5 without either being wrong.
 The bar asserted everywhere a kernel cannot meet allclose(1e-5, 1e-5) element by element is the MEASURED one:
 
-    |hip - f64|  <=  C * |reference_fp32 - f64|       in max, 99.9th percentile and median        (C = 4)
+    |hip - f64|  <=  C * |reference_fp32 - f64|       in max, 99.9th percentile and median        (C = 3; until round 5: 4)
 
 with f64 = the oracle evaluated in float64 on the same inputs (the oracle is pinned bitwise to the live reference in
 fp32 and fp64, tests/golden/make_golden.py), plus a floor of two fp32 ulps of the values' scale (a correctly rounded
 fp32 result is already half an ulp away from the float64 one).  Every comparison is appended to REPORT and written to
 gpurun_out/parity_report.json at the end of the session, so the measured ratios are on record, not just pass / fail.
+
+Round 5: of 887 recorded comparisons 866 meet allclose(1e-5, 1e-5) literally, 19 more have a ratio <= 1.2 and two sit above 2
+(`rqs golden f32: ladj from parameters` 2.56, `bern golden f32: ladj` 2.93), both on the adversarial golden sets.  scripts/parity_emulation.py
+(output: profiles/r05/parity_emulation.txt) shows why the literal bar is out of reach THERE for anything that is not bitwise the reference: the
+reference's own expression tree evaluated in float32 with a +-1 ulp exponential lands 5e-5 .. 7e-5 from the float32 reference, and rqs_lean with
+EXACT division / exp2 / log2 reproduces the GPU's 6.3e-5 / 8.8e-5 to three digits — the distance belongs to the formulation on ill-conditioned
+splines, not to v_rcp / v_exp / v_log; on random parameters its 99.9th percentile against float64 equals the reference's own.
 """
 
 from __future__ import annotations
@@ -22,7 +29,7 @@ import os
 import numpy as np
 import torch
 
-C_NOISE = 4.0
+C_NOISE = 3.0
 REPORT: list[dict] = []
 
 
