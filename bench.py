@@ -584,7 +584,7 @@ def run_side_configs(args) -> dict:
 
 def side_paths_report() -> dict:
     """The paths either side of log_prob for the cfg2 / cfg3 flows: one Adam step of the README training loop at batch 2^16 (with the
-    gradients of the one-node path checked against the two-node path on the same weights) and flow().transform.inv at 2^18 (with the round trip through
+    gradients checked against float64 autograd through the oracle on 4 096 of the rows) and flow().transform.inv at 2^18 (with the round trip through
     the forward).  Short, after everything else; the headline's timed region never sees it."""
     import torch
 
@@ -629,12 +629,21 @@ def side_paths_report() -> dict:
                 return loss.item(), names, [p.grad.clone() for p in flow.parameters()]
 
             l1, names, g1 = grads(4096)
-            os.environ["ZUKO_AMD_NO_FUSED_AR_TRAIN"] = "1"
-            try:
-                l2, _, g2 = grads(4096)
-            finally:
-                del os.environ["ZUKO_AMD_NO_FUSED_AR_TRAIN"]
-            rel = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item() for a, b in zip(g1, g2))
+            # the yardstick is autograd through the ORACLE (the reference's algorithm on PyTorch-CPU ops, float64) on the same 4 096 rows and weights —
+            # which is how the reference itself obtains its gradients (tests/test_flows.py:22-29); until round 4 this block compared two HIP paths
+            from oracle import zuko_oracle as O
+
+            sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in flow.state_dict().items() if v is not None}
+            pnames = [k for k, _ in flow.named_parameters()]
+            leaves = {k: sd[k].requires_grad_() for k in pnames}
+            sd.update(leaves)
+            spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(kw["bins"]) if ctor == "NSF" else O.UNI_AFFINE, kw["features"])
+            l2t = -O.flow_log_prob(spec, x[:4096].cpu().double(), None if ctx is None else ctx[:4096].cpu().double()).mean()
+            l2t.backward()
+            l2 = float(l2t.detach())
+            g2 = [leaves[k].grad for k in pnames]
+            rel = max(((a.cpu().double() - b).abs().max() / b.abs().max().clamp_min(1e-12)).item() for a, b in zip(g1, g2))
+            del spec, leaves, sd
             for _ in range(3):
                 l0 = step()
             torch.cuda.synchronize()
@@ -646,7 +655,8 @@ def side_paths_report() -> dict:
             dt = (time.perf_counter() - t0) / n
             entry["training"] = {"workload": f"{ctor} Adam step of -log_prob(x).mean(), batch 2^16", "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "loss_before_after": [float(l0), float(l)],
                                  "one_autograd_node_per_transform": "AutoregressiveFnBackward" in names,
-                                 "parity": {"rows": 4096, "grad_max_rel_vs_two_node_path": rel, "loss_abs_diff": abs(l1 - l2), "ok": bool(rel < 1e-4 and abs(l1 - l2) < 1e-4 * max(1.0, abs(l2)))}}
+                                 "parity": {"rows": 4096, "against": "float64 autograd through the oracle (oracle/zuko_oracle.py) on the same rows and weights",
+                                            "grad_max_rel_vs_oracle_autograd": rel, "loss_abs_diff": abs(l1 - l2), "ok": bool(rel < 1e-4 and abs(l1 - l2) < 1e-4 * max(1.0, abs(l2)))}}
             del opt
             with torch.no_grad():
                 Bs = 1 << 18
@@ -662,6 +672,25 @@ def side_paths_report() -> dict:
                 back = t(xs)
                 err = (back - z).abs().max().item()
             entry["sampling"] = {"workload": f"{ctor} flow().transform.inv(z), batch 2^18", "ms": ds * 1e3, "samples_per_s": Bs / ds, "round_trip_max_abs": err, "ok": bool(err < 1e-3)}
+            if name == "nsf_cfg1_conditional":  # BASELINE.json configs[0] at ITS batch: what a call costs when the launch, not the arithmetic, is the time
+                from zuko_amd import _C
+
+                with torch.no_grad():
+                    xb = x[:4096]
+                    for _ in range(3):
+                        lp = dist(4096).log_prob(xb)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        lp = dist(4096).log_prob(xb)
+                    torch.cuda.synchronize()
+                    dl = (time.perf_counter() - t0) / 50
+                    _C.PROFILE = {}
+                    lp = dist(4096).log_prob(xb)
+                    torch.cuda.synchronize()
+                    prof, _C.PROFILE = _C.PROFILE, None
+                entry["log_prob_batch_4096"] = {"workload": "NSF(3, 5, transforms=3, hidden=[128]*3) flow(c).log_prob(x), batch 4096 (BASELINE.json configs[0])", "ms": dl * 1e3, "samples_per_s": 4096 / dl,
+                                                "library_calls_per_log_prob": {k: len(v) for k, v in prof.items()}}
         except Exception as exc:  # never let a side measurement break the headline line
             entry["error"] = repr(exc)
         out[name] = entry

@@ -22,6 +22,42 @@ def _oracle_grads(flow, entry, x, c):
     return loss.detach(), {k: v.grad for k, v in leaves.items()}, xr.grad
 
 
+@pytest.mark.parametrize("name", ["nsf_cfg2", "maf_cfg3", "nsf_cfg1"])
+def test_gradients_match_reference_autograd_over_many_tiles(dev, name):
+    """The same comparison at 4 096 rows: the weight-gradient reduction then spans 32 sample tiles of 128 and several
+    slices per 128 x 128 block — an error in the slice / tile reduction, invisible at 96 rows (one tile), shows up here.  float64 autograd
+    through the oracle is the yardstick (a float32 sum over 4 096 rows in another order differs by ~1e-6 relative on its own)."""
+    flow, entry = build_flow(name)
+    gen = torch.Generator().manual_seed(22)
+    D, C = entry[1]["features"], entry[1].get("context", 0)
+    n = 4096
+    x = torch.randn(n, D, generator=gen)
+    c = torch.randn(n, C, generator=gen) if C else None
+    flow64 = {k: (v.detach().double() if v.is_floating_point() else v.detach()) for k, v in flow.state_dict().items() if v is not None}
+    leaves = {k: v.requires_grad_() for k, v in flow64.items() if v.is_floating_point() and ("weight" in k or "bias" in k)}
+    flow64.update(leaves)
+    spec = O.spec_from_state_dict(flow64, entry[3], entry[4], entry[1]["features"], **entry[5])
+    xr = x.double().requires_grad_()
+    ref_loss = -O.flow_log_prob(spec, xr, None if c is None else c.double()).mean()
+    ref_loss.backward()
+
+    flow = flow.to(dev)
+    xg = x.to(dev).requires_grad_()
+    loss = -flow(None if c is None else c.to(dev)).log_prob(xg).mean()
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
+    params = dict(flow.named_parameters())
+    worst = 0.0
+    for k, v in leaves.items():
+        g = v.grad
+        err = ((params[k].grad.cpu().double() - g).abs().max() / g.abs().max().clamp_min(1e-9)).item()
+        worst = max(worst, err)
+        assert err < 1e-4, f"{k}: relative (to max |grad|) error {err:.2e} at {n} rows"
+    gx_err = ((xg.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max().clamp_min(1e-9)).item()
+    assert gx_err < 1e-4, f"grad x: {gx_err:.2e}"
+    print(f"{name} at {n} rows: worst parameter-gradient error {worst:.2e}, grad-x error {gx_err:.2e} (vs float64 autograd through the oracle)")
+
+
 @pytest.mark.parametrize("name", ["nsf_cfg1", "maf_doc", "nice_small", "nsf_p2", "maf_cfg3", "nsf_cfg2"])
 def test_gradients_match_reference_autograd(dev, name):
     """End to end: d(-log_prob.mean()) / d(every parameter) and / dx of the whole flow (the headline NSF cfg2 and MAF cfg3 take the
