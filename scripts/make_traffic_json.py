@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 KERNEL = "arx_kernel"  # dominant kernel: zk::arx_kernel<Shape, UniRqs<8, false>, false, false>
@@ -57,7 +57,11 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
                    "busy_cycles_per_simd": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, "launch_cycles": cyc,
                    "busy_frac": None if not cyc else c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc,
                    "coexec_share_of_busy": None if not c.get("SQ_VALU_MFMA_COEXEC_CYCLES") else c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"],
-                   "note": "16 busy cycles per v_mfma_f32_16x16x32_bf16; the instruction form issues at 26 nominal cycles per instruction at best (profiles/r04/mfma32_probe.txt): a busy fraction of 0.62 IS that ceiling"}
+                   "shader_clock_ghz_under_the_profiler": None if not (cyc and stats.get("avg_ms")) else cyc / (stats["avg_ms"] * 1e-3) / 1e9,
+                   "real_cycles_per_matrix_instruction_and_simd": None if not (cyc and c.get("SQ_INSTS_MFMA")) else cyc / (c["SQ_INSTS_MFMA"] / 1024.0),
+                   "note": "launch_cycles = GRBM_GUI_ACTIVE / 8 (a MEASURED cycle count: summed over the 8 XCDs); 16 busy cycles per v_mfma_f32_16x16x32_bf16.  With two wavefronts per SIMD — "
+                           "this kernel's geometry — a SIMD issues the form every 16.2-16.5 real cycles (profiles/r05/mfma_clock_probe.txt); the kernel's ~26 are NOT the form's ceiling "
+                           "(round 4 said so from a one-wavefront probe): its conversion / spline / ring phases run beside idle matrix pipes (profiles/r05/headline.md)"}
 out["waves"] = {k: c[k] for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_IFETCH") if k in c}
 out["lds"] = {k: c[k] for k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS") if k in c}
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
