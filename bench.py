@@ -593,12 +593,13 @@ def side_paths_report() -> dict:
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     out = {}
     cfg1 = dict(features=3, context=5, transforms=3, bins=8, hidden_features=[128] * 3)  # BASELINE.json configs[0]: the conditional flow
-    for name, ctor, kw in (("nsf_cfg2", "NSF", CONFIGS["cfg2"][1]), ("maf_cfg3", "MAF", CONFIGS["cfg3"][1]), ("nsf_cfg1_conditional", "NSF", cfg1)):
+    for name, ctor, kw in (("nsf_cfg2", "NSF", CONFIGS["cfg2"][1]), ("maf_cfg3", "MAF", CONFIGS["cfg3"][1]), ("nsf_cfg1_conditional", "NSF", cfg1), ("realnvp_cfg4", "RealNVP", CONFIGS["cfg4"][1])):
         entry = {}
         try:
             torch.manual_seed(0)
             flow = getattr(F, ctor)(**kw).to(dev)
-            B = 1 << 16
+            coupling = ctor == "RealNVP"  # (cfg4 trains layer by layer — zuko_amd/flows/coupling.py — there is no one-node path for coupling transforms)
+            B = 1 << 14 if coupling else 1 << 16
             x = torch.randn(B, kw["features"], device=dev)
             ctx = torch.randn(1 << 18, kw["context"], device=dev) if kw.get("context") else None
 
@@ -628,7 +629,8 @@ def side_paths_report() -> dict:
                 loss.backward()
                 return loss.item(), names, [p.grad.clone() for p in flow.parameters()]
 
-            l1, names, g1 = grads(4096)
+            prows = 1024 if coupling else 4096
+            l1, names, g1 = grads(prows)
             # the yardstick is autograd through the ORACLE (the reference's algorithm on PyTorch-CPU ops, float64) on the same 4 096 rows and weights —
             # which is how the reference itself obtains its gradients (tests/test_flows.py:22-29); until round 4 this block compared two HIP paths
             from oracle import zuko_oracle as O
@@ -637,8 +639,8 @@ def side_paths_report() -> dict:
             pnames = [k for k, _ in flow.named_parameters()]
             leaves = {k: sd[k].requires_grad_() for k in pnames}
             sd.update(leaves)
-            spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(kw["bins"]) if ctor == "NSF" else O.UNI_AFFINE, kw["features"])
-            l2t = -O.flow_log_prob(spec, x[:4096].cpu().double(), None if ctx is None else ctx[:4096].cpu().double()).mean()
+            spec = O.spec_from_state_dict(sd, "coupling" if coupling else "ar", O.uni_rqs(kw["bins"]) if ctor == "NSF" else O.UNI_AFFINE, kw["features"])
+            l2t = -O.flow_log_prob(spec, x[:prows].cpu().double(), None if ctx is None else ctx[:prows].cpu().double()).mean()
             l2t.backward()
             l2 = float(l2t.detach())
             g2 = [leaves[k].grad for k in pnames]
@@ -654,9 +656,9 @@ def side_paths_report() -> dict:
                 l = step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
-            entry["training"] = {"workload": f"{ctor} Adam step of -log_prob(x).mean(), batch 2^16", "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "loss_before_after": [float(l0), float(l)],
+            entry["training"] = {"workload": f"{ctor} Adam step of -log_prob(x).mean(), batch 2^{B.bit_length() - 1}", "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "loss_before_after": [float(l0), float(l)],
                                  "one_autograd_node_per_transform": "AutoregressiveFnBackward" in names,
-                                 "parity": {"rows": 4096, "against": "float64 autograd through the oracle (oracle/zuko_oracle.py) on the same rows and weights",
+                                 "parity": {"rows": prows, "against": "float64 autograd through the oracle (oracle/zuko_oracle.py) on the same rows and weights",
                                             "grad_l1_rel_vs_oracle_autograd": rel1, "grad_max_rel_vs_oracle_autograd": rel, "loss_abs_diff": abs(l1 - l2),
                                             "bar": "1-norm distance per parameter tensor < 2e-3 (tests/test_gpu_backward.py::test_gradients_over_many_tiles: the max-norm moves by O(1 / rows) per "
                                                    "hidden unit whose pre-activation lies within float32 rounding of zero — profiles/r05/grad_error_probe.txt; the same test holds one launch over "
@@ -664,7 +666,7 @@ def side_paths_report() -> dict:
                                             "ok": bool(rel1 < 2e-3 and abs(l1 - l2) < 1e-4 * max(1.0, abs(l2)))}}
             del opt
             with torch.no_grad():
-                Bs = 1 << 18
+                Bs = 1 << 16 if coupling else 1 << 18
                 z = torch.randn(Bs, kw["features"], device=dev)
                 t = dist(Bs).transform
                 xs = t.inv(z)
@@ -676,7 +678,7 @@ def side_paths_report() -> dict:
                 ds = (time.perf_counter() - t0) / 3
                 back = t(xs)
                 err = (back - z).abs().max().item()
-            entry["sampling"] = {"workload": f"{ctor} flow().transform.inv(z), batch 2^18", "ms": ds * 1e3, "samples_per_s": Bs / ds, "round_trip_max_abs": err, "ok": bool(err < 1e-3)}
+            entry["sampling"] = {"workload": f"{ctor} flow().transform.inv(z), batch 2^{Bs.bit_length() - 1}", "ms": ds * 1e3, "samples_per_s": Bs / ds, "round_trip_max_abs": err, "ok": bool(err < 1e-3)}
             if name == "nsf_cfg1_conditional":  # BASELINE.json configs[0] at ITS batch: what a call costs when the launch, not the arithmetic, is the time
                 from zuko_amd import _C
 
@@ -696,6 +698,31 @@ def side_paths_report() -> dict:
                     prof, _C.PROFILE = _C.PROFILE, None
                 entry["log_prob_batch_4096"] = {"workload": "NSF(3, 5, transforms=3, hidden=[128]*3) flow(c).log_prob(x), batch 4096 (BASELINE.json configs[0])", "ms": dl * 1e3, "samples_per_s": 4096 / dl,
                                                 "library_calls_per_log_prob": {k: len(v) for k, v in prof.items()}}
+                # the same call captured in a HIP graph (the library launches on torch's current stream, so torch.cuda.graph captures it): what is left
+                # when the Python / ctypes / launch overhead of the four calls is paid once
+                try:
+                    with torch.no_grad():
+                        cstat = ctx[:4096].clone()
+                        s_ = torch.cuda.Stream()
+                        s_.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(s_):
+                            for _ in range(3):
+                                lp_g = flow(cstat).log_prob(xb)
+                        torch.cuda.current_stream().wait_stream(s_)
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            lp_g = flow(cstat).log_prob(xb)
+                        graph.replay()
+                        torch.cuda.synchronize()
+                        same = bool(torch.equal(lp_g, lp))
+                        t0 = time.perf_counter()
+                        for _ in range(200):
+                            graph.replay()
+                        torch.cuda.synchronize()
+                        dg = (time.perf_counter() - t0) / 200
+                    entry["log_prob_batch_4096"]["hip_graph_replay"] = {"ms": dg * 1e3, "samples_per_s": 4096 / dg, "bitwise_equal_to_eager": same}
+                except Exception as exc:
+                    entry["log_prob_batch_4096"]["hip_graph_replay"] = {"error": repr(exc)[:200]}
         except Exception as exc:  # never let a side measurement break the headline line
             entry["error"] = repr(exc)
         out[name] = entry
