@@ -373,10 +373,11 @@ def test_nsf_bf16_log_prob(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,D,K,ctx", [(300, 128, 8, 0), (77, 64, 16, 64), (1024, 192, 16, 0)])
+@pytest.mark.parametrize("N,D,K,ctx", [(300, 128, 8, 0), (77, 64, 16, 64), (1024, 192, 16, 0), (64 * 256 + 77, 64, 16, 0), (16 * 256 + 64, 128, 8, 0)])
 def test_bf16_layer_with_spline_epilogue_equals_unfused_layer(dev, N, D, K, ctx, monkeypatch):
-    """zk_linear_bf16_rqs (phi on chip) against zk_linear_bf16 + the bf16 stream kernel (phi through HBM) on ragged
-    batches, a last panel that is only partly filled, and a context: the same bf16 phi, so y is bit-identical."""
+    """zk_linear_bf16_rqs_lanes (phi on chip; round 5: the lane-owned kernel) against zk_linear_bf16 + the bf16 stream kernel (phi through HBM) on ragged
+    batches, a last panel that is only partly filled, and a context: the same bf16 phi, so y is bit-identical.  The two large cases walk the tiles in the
+    XCD-aware order (>= 64 / >= 16 row tiles) with a ragged last row tile; the first-generation kernel is held to the same in the last assertion."""
     from zuko_amd.flows import MaskedAutoregressiveTransform
     from zuko_amd.transforms import MonotonicRQSTransform
 
@@ -393,6 +394,11 @@ def test_bf16_layer_with_spline_epilogue_equals_unfused_layer(dev, N, D, K, ctx,
             y_u, l_u = t(c).call_and_ladj(x)
             assert torch.equal(y_f, y_u)
             assert torch.allclose(l_f, l_u, rtol=1e-5, atol=1e-4)
+        monkeypatch.delenv("ZUKO_AMD_BF16_UNFUSED")
+        monkeypatch.setenv("ZUKO_AMD_BF16_PANELS256", "1")  # the first-generation fused kernel (256-row panels)
+        y_p, l_p = t(c).call_and_ladj(x)
+        monkeypatch.delenv("ZUKO_AMD_BF16_PANELS256")
+        assert torch.equal(y_f, y_p) and torch.allclose(l_f, l_p, rtol=1e-5, atol=1e-4)
         # and against float32 arithmetic on the same bf16 values (fp32 layer-wise kernels)
         t32 = MaskedAutoregressiveTransform(D, ctx, univariate=MonotonicRQSTransform, shapes=[(K,), (K,), (K - 1,)], hidden_features=[128, 192]).to(dev)
         t32.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in t.state_dict().items()})

@@ -58,7 +58,8 @@ typedef unsigned int ln_u32x2 __attribute__((ext_vector_type(2)));
 #ifndef ZK_LANES_ABLATE
 #define ZK_LANES_ABLATE 0 /* probe builds only (WRONG results): 1 = no epilogue (accumulators kept alive), 3 = k loop without DMAs,
                              6 = epilogue without the spline arithmetic, 7 = epilogue without the bias loads and the y stores,
-                             8 = every DMA instruction issued with ONE active lane (the issue slots stay, the bytes go) */
+                             8 = every DMA instruction issued with ONE active lane (the issue slots stay, the bytes go),
+                             9 = no workgroup barrier in the k loop, 10 = no wait for the DMAs, 4 = no fragment reads (opaque zero operands) */
 #endif
 
 struct LaneArgs {
@@ -193,7 +194,10 @@ template <int SK> __global__ __launch_bounds__(512, 2) void linear_bf16_rqs_lane
   const unsigned xf0 = (unsigned)(wm * (64 * 64)) + foff0, xf1 = (unsigned)(wm * (64 * 64)) + foff1;
   const unsigned wf0 = (unsigned)(LN_ACT_BYTES + wn * (96 * 64)) + foff0, wf1 = (unsigned)(LN_ACT_BYTES + wn * (96 * 64)) + foff1;
 #define LN_READ(b, stage_off, xo, wo)                                                                                           \
-  {                                                                                                                             \
+  if (ZK_LANES_ABLATE == 4) {                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { fx[b][i_] = ln_bf16x8{}; asm volatile("" : "+v"(fx[b][i_])); }           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) { fw[b][j_] = ln_bf16x8{}; asm volatile("" : "+v"(fw[b][j_])); }           \
+  } else {                                                                                                                      \
     const unsigned char* xp_ = ln_lds + ((stage_off) + (xo));                                                                   \
     const unsigned char* wp_ = ln_lds + ((stage_off) + (wo));                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) fx[b][i_] = *reinterpret_cast<const ln_bf16x8*>(xp_ + i_ * 2048);          \
@@ -264,7 +268,13 @@ template <int SK> __global__ __launch_bounds__(512, 2) void linear_bf16_rqs_lane
   // My DMAs of every stream position but the last requested one have landed (in-order completion; that one has at least LN_DPS pieces per
   // wavefront), then the workgroup barrier: everybody's have, and everybody has finished reading the stage that is overwritten next.  Stores and loads
   // of an epilogue in between only make the count stricter.
+#if ZK_LANES_ABLATE == 9
+#define LN_WAITBAR() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LN_DPS) : "memory")
+#elif ZK_LANES_ABLATE == 10
+#define LN_WAITBAR() asm volatile("s_barrier" ::: "memory")
+#else
 #define LN_WAITBAR() asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LN_DPS) : "memory")
+#endif
   // (the barrier right behind an epilogue: the next tile's 2 FPL loads of x were issued after that position's pieces as well — without the
   //  allowance the wait would stand on the epilogue's stores)
 #define LN_WAITBAR_TILE() asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LN_DPS + 2 * FPL) : "memory")
