@@ -234,6 +234,15 @@ typedef struct zk_ar_args_v1 {
 /* y, ladj of one layer on the generic tile-skipping kernel.  Reads: uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream,
  * bias, bias_floats, skip, featmap, n_layers, n_groups, n_chunks, act, bound, slope. */
 int zk_ar_forward(const zk_ar_args_v1* args, void* stream);
+/* zk_ar_forward at the bf16 matrix rate for ANY plan zk_ar_forward covers (no kernel generated for the shape): the generic kernel's run-time
+ * skip tests around the operand-split arithmetic of the static-shape split kernels (every f32 operand as three bf16 numbers, six partial
+ * products on v_mfma_f32_16x16x32_bf16, f32 accumulation — csrc/fused_ar_gsplit.hip).  Fields as zk_ar_forward, except: wstream is the
+ * plan's OPERAND-SPLIT stream (zuko_amd/fused.py: gsplit_gather through zk_gather_split_bf16: per hidden layer, out-group of 4 tiles and
+ * live in-PAIR, 4 blocks; per last-layer group and live in-pair, NT blocks; three 1 KiB bf16 images per 16 x 32 block; every layer padded
+ * to whole 24-image chunks) and n_chunks its length in 24-image chunks (>= 1).  A pair is live when either of its two skip bits is set.
+ * uni_kind 0-4 (2-4: D % 4 == 0 and y 16-byte aligned rows, as zk_ar_forward); forward only.  The result is BIT-IDENTICAL to the
+ * static-shape operand-split kernel of the same conditioner (zk_ar_forward_static), and agrees with zk_ar_forward to f32 rounding. */
+int zk_ar_forward_split(const zk_ar_args_v1* args, void* stream);
 /* Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3, LDS-staged tiles: D % 4 == 0): the same kernel
  * template and arithmetic plus bin_out[N, D] (int32) and knots_out[N, D, K+1] (fp32), as zk_rqs_diag.  Reads additionally:
  * bin_out, knots_out (accumulate is ignored). */

@@ -62,12 +62,24 @@ def main():
                 rec["static_tflops_nnz"] = round(N * nnz / (ms * 1e-3) / 1e12, 1)
                 y_s, l_s = lazy(c).call_and_ladj(x)
             if st is not None and st.generic_ok:
-                os.environ["ZUKO_AMD_NO_STATIC_AR"] = "1"  # (static_ar.lookup returns None: the plan's generic kernel runs)
+                os.environ["ZUKO_AMD_NO_STATIC_AR"] = "1"  # (static_ar.lookup returns None: the plan's generic kernels run)
                 AR._FUSED_CACHE.pop(lazy, None)
-                assert lazy(c)._fused(x).static is None
+                stg = lazy(c)._fused(x)
+                assert stg.static is None
+                if stg._gsplit() is not None:  # the generic operand-split kernel (csrc/fused_ar_gsplit.hip): what such a plan runs on by default
+                    ms = timed(lambda: lazy(c).call_and_ladj(x))
+                    y_x, l_x = lazy(c).call_and_ladj(x)
+                    rec["generic_split_ms"] = round(ms, 4)
+                    rec["generic_split_frac_nnz"] = round(N * nnz / (ms * 1e-3) / PEAK_SPLIT, 4)
+                    if rec["static"] is not None and rec["static"]["split"]:
+                        rec["generic_split_over_static"] = round(ms / rec["static_ms"], 3)
+                        rec["generic_split_bit_identical_to_static"] = bool(torch.equal(y_x, y_s) and torch.equal(l_x, l_s))
+                os.environ["ZUKO_AMD_GSPLIT"] = "0"  # the generic kernel on the f32 matrix instruction
+                AR._FUSED_CACHE.pop(lazy, None)
                 ms = timed(lambda: lazy(c).call_and_ladj(x))
                 y_g, l_g = lazy(c).call_and_ladj(x)
                 os.environ.pop("ZUKO_AMD_NO_STATIC_AR")
+                os.environ.pop("ZUKO_AMD_GSPLIT")
                 AR._FUSED_CACHE.pop(lazy, None)
                 rec["generic_ms"] = round(ms, 4)
                 rec["generic_frac_nnz"] = round(N * nnz / (ms * 1e-3) / PEAK, 4)

@@ -158,7 +158,7 @@ def test_entry_points_reject_foreign_argument_blocks_without_touching_the_device
 
     lib = C.lib()
     EINVAL = 1
-    for struct, fns in (("zk_ar_args_v1", ["zk_ar_forward", "zk_ar_forward_static", "zk_ar_forward_train", "zk_ar_inverse_sweep", "zk_ar_dgrad_chain", "zk_ar_dgrad_full", "zk_ar_backward_full"]),
+    for struct, fns in (("zk_ar_args_v1", ["zk_ar_forward", "zk_ar_forward_split", "zk_ar_forward_static", "zk_ar_forward_train", "zk_ar_inverse_sweep", "zk_ar_dgrad_chain", "zk_ar_dgrad_full", "zk_ar_backward_full"]),
                         ("zk_coupling_args_v1", ["zk_coupling_forward", "zk_coupling_inverse"]), ("zk_ar_inc_args_v1", ["zk_ar_inverse_incremental"])):
         good = C.args(struct)
         for fn in fns:

@@ -514,3 +514,91 @@ def _panel_mask_any(plan, lins, K, features, p, k):
         if par < total and feat < features and bool(mp[feat * total + par, 32 * k : 32 * k + 32].any()):
             return True
     return False
+
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 10, 3, (40, 72), 0), ("rqs", 3, 5, (128, 128, 128), 8), ("rqs", 20, 3, (100, 72), 8), ("rqs", 8, 2, (48, 48), 4),
+                                 ("rqs", 8, 0, (64,), 16), ("affine", 2, 0, (24, 24), 0)])
+def test_generic_split_stream_follows_the_kernels_walk(cfg):
+    """The stream of the generic operand-split kernel (fused.gsplit_gather; csrc/fused_ar_gsplit.hip) walked as that kernel walks it — the
+    plan's own skip words, an in-PAIR live when either of its tiles is, 4 blocks per (out-group, pair) / NT per (feature group, pair), the ring
+    moving on in whole chunks of 8 blocks at every layer end — must consume exactly n_chunks chunks and give the masked MLP (float64: the
+    bf16 x 3 arithmetic is tests/test_fused_plan.py::test_split_kernel_tables_describe_the_plan's subject)."""
+    from zuko_amd import fused, static_ar
+
+    kind, D, C, hidden, bins = cfg
+    rng = np.random.default_rng(5)
+    for plan, lay, lins in static_ar._plans_for(kind, D, C, hidden, bins):
+        got = fused.gsplit_gather(plan)
+        assert got is not None
+        gathers, offsets, n_chunks = got
+        assert all(len(g) % (512 * fused.GS_BLOCKS_PER_CHUNK) == 0 for g in gathers) and offsets[0] == 0
+        assert [o // 768 for o in offsets] == [sum(len(g) // 512 for g in gathers[:l]) for l in range(len(gathers))]
+        W = [(l.weight.detach().double().numpy() * l.mask.numpy()) for l in lins]
+        Bv = [l.bias.detach().double().numpy() for l in lins]
+        x = rng.standard_normal(plan.din)
+        h = x.copy()
+        for l in range(len(W)):
+            h = W[l] @ h + Bv[l]
+            if l + 1 < len(W):
+                h = np.maximum(h, 0.0)
+        ref = h
+        stream = np.concatenate([np.where(g >= 0, W[l].reshape(-1)[np.maximum(g, 0)], 0.0) for l, g in enumerate(gathers)]).reshape(-1, 64, 8)
+        pos = 0  # block cursor
+
+        def block(ip, vec):  # one 16 x 32 block times the pair's 32 activations -> 16 outputs
+            nonlocal pos
+            blk = stream[pos]
+            pos += 1
+            out = np.zeros(16)
+            for lane in range(64):
+                i, kq = lane % 16, lane // 16
+                units = np.concatenate([np.arange(4) + (2 * ip) * 16 + 4 * kq, np.arange(4) + (2 * ip + 1) * 16 + 4 * kq])
+                out[i] += blk[lane] @ vec[units]
+            return out
+
+        def end_layer():
+            nonlocal pos
+            pos = -(-pos // fused.GS_BLOCKS_PER_CHUNK) * fused.GS_BLOCKS_PER_CHUNK
+
+        vec = np.zeros(256)
+        vec[: plan.din] = x
+        for l in range(plan.n_layers - 1):
+            assert pos * 768 == offsets[l]
+            out = np.where(plan.bias_gather[l] >= 0, Bv[l][np.maximum(plan.bias_gather[l], 0)], 0.0)
+            for otg in range(4):
+                bits = int(plan.skip[l * 4 + otg])
+                for ip in range(8):
+                    if (bits | bits >> 1) & 0x5555 & (1 << 2 * ip):
+                        for t in range(4):
+                            out[(otg * 4 + t) * 16 : (otg * 4 + t + 1) * 16] += block(ip, vec)
+            end_layer()
+            vec = np.maximum(out, 0.0)
+        assert pos * 768 == offsets[-1]
+        nt = lay.nt
+        bias_last = plan.bias_gather[-1].reshape(-1, nt, 16)
+        res = np.full(D * lay.total, np.nan)
+        for g in range(plan.n_groups):
+            acc = np.where(bias_last[g] >= 0, Bv[-1][np.maximum(bias_last[g], 0)], 0.0)
+            bits = int(plan.skip[(plan.n_layers - 1) * 4 + g])
+            for ip in range(8):
+                if (bits | bits >> 1) & 0x5555 & (1 << 2 * ip):
+                    for t in range(nt):
+                        acc[t] += block(ip, vec)
+            for t in range(nt):
+                for i in range(16):
+                    if bias_last[g, t, i] >= 0:
+                        res[bias_last[g, t, i]] = acc[t, i]
+        end_layer()
+        assert pos == max(0, n_chunks * fused.GS_BLOCKS_PER_CHUNK) or (pos == 0 and n_chunks == 1)
+        assert not np.isnan(res).any() and np.abs(res - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_generic_split_kernel_is_not_offered_where_it_does_not_exist():
+    from zuko_amd import fused
+    from zuko_amd.flows import NSF
+
+    t = NSF(8, 0, transforms=1, hidden_features=[64, 64]).transform.transforms[0]
+    masks = [m.mask for m in t.hyper if hasattr(m, "mask")]
+    lay = fused.uni_layout("rqs", 23, 8)
+    assert fused.gsplit_gather(fused.build_plan(masks, 8, lay)) is not None
+    assert fused.gsplit_gather(fused.build_plan(masks, 8, lay, align_groups=True)) is None  # (the wavefront inverse's plans: f32 kernel)

@@ -737,7 +737,7 @@ def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
         keep = st.static
         y, ladj = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
         st.run(inp, y, ladj, False)
-        st.static = None
+        st.static, st.gs_mode = None, "0"  # (the reference here: the generic kernel on the f32 matrix instruction)
         y0, ladj0 = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
         st.run(inp, y0, ladj0, False)
         st.static = keep
@@ -757,6 +757,97 @@ def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
         st.run(inp, torch.empty(N, D, device=dev), l2, True)
         ok = ~torch.isnan(ladj)
         assert torch.equal(l2[ok], (ladj + ladj)[ok])
+
+
+GSPLIT_CASES = STATIC_CASES + [("nsf16", 64, 0, [256] * 3), ("nsf4", 8, 2, [48, 48]), ("nsf", 6, 0, [32, 32]), ("maf", 5, 1, [24])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GSPLIT_CASES, ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}" + (f"-{c[4]}" if len(c) > 4 else ""))
+@pytest.mark.parametrize("N", [1, 129, 40000])
+def test_generic_split_kernel_equals_the_static_one(dev, case, N, monkeypatch):
+    """zk_ar_forward_split (csrc/fused_ar_gsplit.hip: ONE kernel for any conditioner up to 256 wide, run-time skip tests around the operand-split
+    arithmetic) against the operand-split kernel GENERATED for the conditioner: every accumulator receives the same blocks in the same order (a
+    block the generated kernel drops adds exact zeros), so y and ladj must agree bit for bit — both feature orders, ragged batches, poisoned rows,
+    widths that are not multiples of 16 / 32, a context, 4 / 8 / 16 bins, ELU / tanh, D % 4 != 0 (rows not staged through LDS)."""
+    from zuko_amd.flows import MAF, NSF
+    from zuko_amd.nn import MaskedLinear
+
+    kind, D, C, hidden = case[:4]
+    kw = dict(activation=getattr(torch.nn, case[4])) if len(case) > 4 else {}
+    monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
+    torch.manual_seed(3)
+    bins = {"nsf": 8, "nsf16": 16, "nsf4": 4}.get(kind)
+    flow = (NSF(D, C, transforms=2, bins=bins, hidden_features=hidden, **kw) if bins else MAF(D, C, transforms=2, hidden_features=hidden, **kw)).to(dev)
+    g = torch.Generator().manual_seed(N)
+    din = D + C
+    inp = torch.zeros(N, -(-din // 4) * 4)
+    inp[:, :din] = torch.randn(N, din, generator=g) * 1.5
+    if N >= 127:
+        inp[5, min(7, D - 1)] = float("nan")
+        inp[100, din - 1] = float("inf")
+    inp = inp.to(dev)
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for i, lazy in enumerate(flow.transform.transforms):
+        st = lazy.fused_state(dev)
+        assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
+        lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+        st.refresh(lins)
+        y, ladj = _run_static(st, inp, N, D, dev)
+        st.gs_mode = "force"
+        st.refresh(lins)
+        assert st._gs_stamp is not None, "the generic split kernel's stream was not built"
+        yg, lg = _run_static(st, inp, N, D, dev)
+        assert same(y, yg) and same(ladj, lg), f"transform {i}: generic split kernel differs from the generated one"
+        l2 = lg.clone()
+        st.run(inp, torch.empty(N, D, device=dev), l2, True)
+        ok = ~torch.isnan(lg)
+        assert torch.equal(l2[ok], (lg + lg)[ok])
+        # parameters change: the stream follows
+        with torch.no_grad():
+            lins[0].weight.mul_(1.25)
+        st.refresh(lins)
+        yg2, _ = _run_static(st, inp, N, D, dev)
+        st.gs_mode = "1"
+        y2, _ = _run_static(st, inp, N, D, dev)
+        assert same(y2, yg2) and (N < 2 or not same(y2, y))
+
+
+@pytest.mark.gpu
+def test_a_conditioner_without_a_generated_kernel_runs_on_the_generic_split_kernel(dev, monkeypatch):
+    """No compiler on the box / a batch too small to pay for a compile: the layer is served by zk_ar_forward_split (6/16 of the f32 matrix time)
+    instead of zk_ar_forward; the two agree to f32 rounding (bar of tests/parity.py against float64), and ZUKO_AMD_EXACT_F32=1 / ZUKO_AMD_GSPLIT=0
+    keep the f32 instruction."""
+    from zuko_amd.flows import NSF
+    from zuko_amd.nn import MaskedLinear
+
+    monkeypatch.setenv("ZUKO_AMD_JIT", "0")
+    torch.manual_seed(9)
+    D, C, N = 12, 3, 5000
+    flow = NSF(D, C, transforms=1, hidden_features=[88, 120]).to(dev)  # (not a prebuilt shape)
+    lazy = flow.transform.transforms[0]
+    lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+    inp = torch.zeros(N, 16)
+    inp[:, : D + C] = torch.randn(N, D + C) * 1.5
+    inp = inp.to(dev)
+    st = lazy.fused_state(dev)
+    assert st is not None and st.ready(N) and st.static is None
+    st.refresh(lins)
+    assert st._gs_stamp is not None
+    y, ladj = _run_static(st, inp, N, D, dev)
+    st.gs_mode = "0"
+    y0, ladj0 = _run_static(st, inp, N, D, dev)
+    assert not torch.equal(y, y0), "the f32-instruction kernel rounds differently: the two launches cannot be the same kernel"
+    uni = O.uni_rqs(8)
+    with torch.no_grad():
+        phi = O.mlp_forward(inp.cpu()[:, : D + C].double(), [l.weight.detach().cpu().double() for l in lins], [l.bias.detach().cpu().double() for l in lins], [l.mask.cpu() for l in lins], act=torch.relu)
+        y64, l64 = O.univariate_forward(uni, phi.reshape(N, D, uni.total), inp.cpu()[:, :D].double())
+    assert_parity(y, y0, y64, "generic split kernel: y", c=2.0)
+    assert_parity(ladj, ladj0, l64.sum(dim=-1), "generic split kernel: ladj", c=2.0)
+    # through the flow: log_prob uses it too
+    x, c = inp[:, :D].contiguous(), inp[:, D : D + C].contiguous()
+    lp = flow(c).log_prob(x)
+    assert torch.isfinite(lp).all()
 
 
 def _run_static(st, inp, N, D, dev):
@@ -804,7 +895,7 @@ def test_split_kernels_away_from_default_init(dev, kind, regime, monkeypatch):
     assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
     st.refresh(lins)
     y, ladj = _run_static(st, inp, N, D, dev)
-    keep, st.static = st.static, None
+    keep, st.static, st.gs_mode = st.static, None, "0"  # (the reference here: the generic kernel on the f32 matrix instruction)
     y0, ladj0 = _run_static(st, inp, N, D, dev)
     st.static = keep
     uni = O.uni_rqs(8) if kind == "nsf" else O.UNI_AFFINE
@@ -1067,7 +1158,7 @@ def test_sixteen_bin_spline_runs_on_a_split_kernel(dev, N, monkeypatch):
         lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
         st.refresh(lins)
         y, ladj = _run_static(st, inp, N, D, dev)
-        keep, st.static = st.static, None
+        keep, st.static, st.gs_mode = st.static, None, "0"  # (the reference here: the generic kernel on the f32 matrix instruction)
         y0, ladj0 = _run_static(st, inp, N, D, dev)
         st.static = keep
         uni = O.uni_rqs(16)

@@ -130,6 +130,7 @@ SIGNATURES = {
     "zk_ar_backward_full": [_AR, P],
     "zk_wgrad_multi": [I, P, L, P],
     "zk_ar_forward": [_AR, P],
+    "zk_ar_forward_split": [_AR, P],
     "zk_ar_forward_diag": [_AR, P],
     "zk_ar_inverse_sweep": [_AR, P],
     "zk_coupling_forward": [_CP, P],

@@ -30,6 +30,7 @@ SOURCES = {
     "linear_bf16.hip": ["-ffp-contract=off"],  # its spline epilogue must round like elementwise.hip's
     "linear_bf16_lanes.hip": ["-ffp-contract=off"],
     "fused_ar.hip": ["-ffp-contract=off"],
+    "fused_ar_gsplit.hip": ["-ffp-contract=off"],
     "backward.hip": [],
     "train.hip": [],
     # (pragma-unroll-threshold: the 8 x 32 tile loop of a 512-wide layer exceeds the default cap of forced unrolling; a

@@ -1,0 +1,349 @@
+// zuko_amd — GENERIC operand-split layer kernel: zk_ar_forward for ANY masked conditioner up to 256 wide at the bf16 matrix rate, without a
+// kernel generated for its shape (round 5; VERDICT r03 5(c) / r04 "missing" 4).
+//
+//     y, log|dy/dx| = univariate(conditioner(cat(x, c))).call_and_ladj(x)      (zuko/flows/autoregressive.py:207-218, zuko/nn.py:217-218)
+//
+// Until now a conditioner had three ways to run: a static-shape operand-split kernel generated for its masks (prebuilt, or compiled by hipcc on first
+// use: 10-25 s, needs a compiler on the box), and otherwise the generic kernel of fused_ar.hip on v_mfma_f32_16x16x4_f32 — 1/16 of the bf16 rate where
+// the split needs 6/16.  This kernel is the generic kernel's control structure (run-time, wave-uniform skip tests over a static loop nest; the plan's own
+// skip words) around the static-shape split kernels' arithmetic (csrc/fused_ar_split_impl.h: arx_split / arx_block — every f32 operand as three bf16
+// numbers, six partial products on v_mfma_f32_16x16x32_bf16, f32 accumulation, smallest terms first):
+//   * hidden layers: out-groups of 4 tiles x in-PAIRS of 2 tiles; a pair is multiplied when the plan's skip word has either of its tiles set:
+//     4 blocks (16 out x 32 in) = 12 one-KiB images = half a ring chunk, 24 matrix instructions;
+//   * last layer: per feature group and live in-pair, NT blocks;
+//   * the stream (zuko_amd/fused.py: gsplit_gather) holds exactly those blocks in that order, three images (h, m, l) per block, layers padded to whole
+//     24-image chunks; images are read raw from inline assembly and become usable through counted lgkmcnt waits (as in fused_ar_static_impl.h: a
+//     compiler-visible LDS read behind an LDS-DMA waits for vmcnt(0));
+//   * per accumulator the blocks arrive in the same order (in-pairs ascending) as in a static-shape split kernel, and a block the static kernel drops
+//     (all zero) adds exact zeros here: the two are BIT-IDENTICAL (tests/test_gpu_flows.py::test_generic_split_kernel_equals_the_static_one).
+// Forward only (inverse sweeps, partial sweeps and the diagnostic twin stay on fused_ar.hip's f32 instruction).
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+
+#include "../../include/zuko_amd.h"
+#include "fused_ar_split_impl.h"
+
+namespace zk {
+
+#define GS_CH 24 /* images per ring chunk */
+#define GS_NR 3  /* ring slots */
+
+struct GsRing {
+  float* lds;
+  const float* stream;
+  unsigned lds_off;  // LDS byte address of the ring + lane * 16
+  int n_chunks, pos, slot, load_chunk, load_slot, wave, lane;
+  template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
+    if constexpr (I < GS_CH / AR_WAVES) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, I * AR_TF * 4, 0);
+      dma<I + 1>(g, l);
+    }
+  }
+  __device__ __forceinline__ void issue() {
+    const int b0 = wave * (GS_CH / AR_WAVES);
+    dma<0>(stream + ((size_t)load_chunk * GS_CH + b0) * AR_TF + lane * 4, lds + (load_slot * GS_CH + b0) * AR_TF);
+    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
+    load_slot = (load_slot + 1 == GS_NR) ? 0 : load_slot + 1;
+  }
+  __device__ __forceinline__ void advance() {  // all 8 wavefronts, at the same point of the (uniform) control flow
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GS_NR - 2) * (GS_CH / AR_WAVES)) : "memory");
+    __builtin_amdgcn_s_barrier();  // (bare: __syncthreads() would drain the look-ahead DMAs)
+    asm volatile("" ::: "memory");
+    issue();
+    slot = (slot + 1 == GS_NR) ? 0 : slot + 1;
+    pos = 0;
+  }
+  // NB consecutive blocks (3 images each) at the current position, requested raw; the caller settles them
+  template <int NB> __device__ __forceinline__ void read_blocks(f32x4 (&a)[NB][3]) {
+    if (pos == GS_CH) advance();
+    const unsigned addr = lds_off + (unsigned)((slot * GS_CH + pos) * (AR_TF * 4));
+    rd<0, NB>(a, addr);
+    pos += 3 * NB;
+  }
+  template <int I, int NB> static __device__ __forceinline__ void rd(f32x4 (&a)[NB][3], unsigned addr) {
+    if constexpr (I < 3 * NB) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[I / 3][I % 3]) : "v"(addr), "n"(I * AR_TF * 4));
+      rd<I + 1, NB>(a, addr);
+    }
+  }
+  __device__ __forceinline__ void end_layer() {
+    if (pos != 0) pos = GS_CH;
+  }
+};
+
+template <int N> __device__ __forceinline__ void gs_settle(f32x4 (&a)[3]) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N)); }
+
+extern __shared__ __attribute__((aligned(16))) float gs_lds[];
+
+// one masked layer with <= 256 inputs / outputs on the operand split: out = W in + bias, blocks skipped per (group of 4 out tiles, in pair)
+__device__ __forceinline__ void gs_hidden_layer(GsRing& ring, const uint32_t* __restrict__ skip4, const float* bias_q, const ArxB (&in)[AR_T / 2], f32x4 (&out)[AR_T]) {
+#pragma unroll
+  for (int otg = 0; otg < 4; ++otg) {
+    const uint32_t bits = skip4[otg];
+    const uint32_t pairs = (bits | (bits >> 1)) & 0x5555u;  // bit 2 ip: in pair ip has a live tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[otg * 4 + t] = *reinterpret_cast<const f32x4*>(bias_q + (otg * 4 + t) * 16);  // accumulators start at the bias
+#pragma unroll
+    for (int ip = 0; ip < AR_T / 2; ++ip) {
+      if (pairs & (1u << (2 * ip))) {
+        f32x4 a[4][3];
+        ring.read_blocks<4>(a);  // 12 images = half a chunk: never across a chunk boundary
+        gs_settle<9>(a[0]);
+        arx_block(a[0], in[ip], out[otg * 4 + 0]);
+        gs_settle<6>(a[1]);
+        arx_block(a[1], in[ip], out[otg * 4 + 1]);
+        gs_settle<3>(a[2]);
+        arx_block(a[2], in[ip], out[otg * 4 + 2]);
+        gs_settle<0>(a[3]);
+        arx_block(a[3], in[ip], out[otg * 4 + 3]);
+      }
+    }
+    // (pin the accumulators: otherwise the two sides of every skip branch may get different registers, reconciled by moves — fused_ar.hip)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(out[otg * 4 + t]));
+  }
+  ring.end_layer();
+}
+
+template <typename Uni, bool XLDS> __global__ __launch_bounds__(512, 2) void ar_gsplit_kernel(ArArgs a) {
+  constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  float* ring_lds = gs_lds;
+  float* bias_lds = gs_lds + GS_NR * GS_CH * AR_TF;
+
+  GsRing ring;
+  ring.lds = ring_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)ring_lds) + (unsigned)lane * 16u;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < GS_NR - 1; ++i) ring.issue();
+  ring.slot = GS_NR - 1;
+  ring.pos = GS_CH;
+
+  for (int i = tid; i < a.bias_floats; i += 512) bias_lds[i] = a.bias[i];
+  int* fmap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);  // feature map of the last layer
+  int* skip_lds = fmap_lds + 1024;                                   // skip words of every layer: LDS copies (a vector-memory load in the pass would wait behind the ring DMAs)
+  float* xr = reinterpret_cast<float*>(fmap_lds + 1024 + 256) + wave * 16 * a.xs + j * a.xs;  // wave-private [16 samples x D] tile (XLDS)
+  for (int i = tid; i < a.NG * 4 * FPL; i += 512) fmap_lds[i] = a.featmap[i];
+  for (int i = tid; i < (a.L - 1) * 4 + a.NG; i += 512) skip_lds[i] = (int)a.skip[i];
+  __syncthreads();
+
+  const float* bias_last = bias_lds + (a.L - 1) * 256;
+  const int* skip_last = skip_lds + (a.L - 1) * 4;
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n = tile * 128 + wave * 16 + j;
+    const bool live = n < a.N;
+    const int64_t nc = live ? n : a.N - 1;
+    const float* xrow = a.x + nc * a.ldx;
+
+    // ---- input tile: xin[it][r] = input[16 it + 4 q + r], then its three-way split as the first layer's B operands ----------------
+    ArxB in[AR_T / 2];
+    f32x4 out[AR_T];
+    float poison = 0.f;
+    {
+      f32x4 xin[AR_T];
+#pragma unroll
+      for (int it = 0; it < AR_T; ++it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (it * 16 < a.DIN) {
+          const int i0 = it * 16 + 4 * q;
+          if (i0 < a.DIN) v = *reinterpret_cast<const f32x4*>(xrow + i0);
+        }
+        xin[it] = v;
+      }
+      // a NaN / inf input makes every parameter of its sample NaN in the reference (x * (mask * W), zuko/nn.py:217-218): flag the sample (fused_ar.hip)
+      int bad = 0;
+#pragma unroll
+      for (int it = 0; it < AR_T; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= !(fabsf(xin[it][r]) < __builtin_inff());
+      bad |= __shfl_xor(bad, 16, 64);
+      bad |= __shfl_xor(bad, 32, 64);
+      if (bad) poison = __builtin_nanf("");
+      if (XLDS) {
+#pragma unroll
+        for (int it = 0; it < AR_T; ++it) {
+          if (it * 16 < a.D) {
+            const int i0 = it * 16 + 4 * q;
+            if (i0 < a.D) *reinterpret_cast<f32x4*>(xr + i0) = xin[it];
+          }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int p = 0; p < AR_T / 2; ++p) arx_split(xin[2 * p], xin[2 * p + 1], in[p]);
+    }
+
+    // ---- hidden layers -------------------------------------------------------------------------------------------------------------
+    for (int l = 0; l < a.L - 1; ++l) {
+      uint32_t sk[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) sk[o] = (uint32_t)__builtin_amdgcn_readfirstlane(skip_lds[l * 4 + o]);
+      gs_hidden_layer(ring, sk, bias_lds + l * 256 + 4 * q, in, out);
+      switch (a.act) {  // (wave-uniform: one switch around 64-element loops)
+        case 1:
+#pragma unroll
+          for (int t = 0; t < AR_T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
+          break;
+        case 0: break;
+        default:
+#pragma unroll 1
+          for (int rep = 0; rep < 1; ++rep) {
+#pragma unroll
+            for (int t = 0; t < AR_T; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) out[t][r] = act_f32(out[t][r], a.act);
+          }
+          break;
+      }
+#pragma unroll
+      for (int p = 0; p < AR_T / 2; ++p) arx_split(out[2 * p], out[2 * p + 1], in[p]);
+    }
+
+    // ---- last layer + univariate transform, one group of 4 * FPL features at a time ----------------------------------------------
+    float lacc = 0.f;
+    for (int g = 0; g < a.NG; ++g) {
+      const uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane(skip_last[g]);
+      const uint32_t pairs = (bits | (bits >> 1)) & 0x5555u;
+      int fid[FPL];
+      float xv[FPL];
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) {
+        fid[fi] = fmap_lds[(g * 4 + q) * FPL + fi];
+        const int fc = fid[fi] < 0 ? 0 : fid[fi];
+        xv[fi] = XLDS ? xr[fc] : xrow[fc];
+      }
+      f32x4 acc[NT];  // the accumulators start at the bias
+      {
+        const float* bg = bias_last + (g * NT) * 16 + 4 * q;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(bg + t * 16);
+      }
+#pragma unroll
+      for (int ip = 0; ip < AR_T / 2; ++ip) {
+        if (pairs & (1u << (2 * ip))) {
+          // NT blocks, each requested while the previous one multiplies (a block never straddles a chunk: 24 = 8 x 3 images)
+          f32x4 w[2][1][3];
+          ring.read_blocks<1>(w[0]);
+          ars_for<NT>([&](auto t_) ARS_ALWAYS_INLINE {
+            constexpr int t = decltype(t_)::value;
+            if constexpr (t + 1 < NT) {
+              ring.read_blocks<1>(w[(t + 1) & 1]);
+              gs_settle<3>(w[t & 1][0]);
+            } else {
+              gs_settle<0>(w[t & 1][0]);
+            }
+            arx_block(w[t & 1][0], in[ip], acc[t]);
+          });
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
+      float p[4 * NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r];
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) Uni::template poison<false>(p, fi * TOTAL, poison);
+      auto ld = [&](int i) { return p[i]; };
+#pragma unroll
+      for (int fi = 0; fi < FPL; ++fi) {
+        const int f = fid[fi];
+        if (f >= 0) {
+          float yv, lj;
+          Uni::fwd(ld, fi * TOTAL, a, xv[fi], yv, lj);
+          if (XLDS) xr[f] = yv;
+          else if (live) a.y[n * a.ldy + f] = yv;
+          lacc += lj;
+        }
+      }
+    }
+    ring.end_layer();
+    if (XLDS) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < AR_T; ++it) {
+        if (it * 16 < a.D) {
+          const int i0 = it * 16 + 4 * q;
+          if (i0 < a.D && live) *reinterpret_cast<f32x4*>(a.y + n * a.ldy + i0) = *reinterpret_cast<const f32x4*>(xr + i0);
+        }
+      }
+    }
+    if (a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must land before the LDS is released
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+static int gs_base_lds_floats(int bias_floats) { return GS_CH * GS_NR * AR_TF + bias_floats + 1024 + 256; }  // ring + bias + feature map + skip words
+
+// y, ladj of one masked autoregressive layer on the generic operand-split kernel.  Arguments as zk_ar_forward (include/zuko_amd.h) except `wstream`:
+// the operand-split stream of zuko_amd/fused.py: gsplit_gather (3 bf16 images per 16 x 32 block, written by zk_gather_split_bf16) and `n_chunks` its length
+// in 24-image chunks.  uni_kind 0-4; forward only.  Bit-identical to the static-shape operand-split kernel of the same conditioner.
+extern "C" int zk_ar_forward_split(const zk_ar_args_v1* p, void* stream) {
+  zk_ar_args_v1 q;
+  if (!p || p->version != 1 || p->struct_size < offsetof(zk_ar_args_v1, phi_packed) || p->struct_size > sizeof(zk_ar_args_v1)) return ZK_EINVAL;
+  std::memset(&q, 0, sizeof(q));
+  std::memcpy(&q, p, p->struct_size);
+  if (q.N <= 0) return 0;
+  if (q.n_groups * 8 > 1024 || q.n_groups > 252 || q.n_layers < 2 || q.n_layers > 9) return ZK_EINVAL;  // (skip words: 4 per hidden layer + one per group in 256 LDS words)
+  if (q.DIN > 256 || q.DIN < q.D || q.DIN % 4 || q.ldx % 4 || ((uintptr_t)q.x % 16) || q.n_chunks < 1 || !q.x || !q.y || !q.wstream || !q.bias || !q.skip || !q.featmap) return ZK_EINVAL;
+  ArArgs a{};
+  a.N = q.N; a.D = q.D; a.DIN = q.DIN;
+  a.x = (const float*)q.x; a.ldx = q.ldx;
+  a.y = (float*)q.y; a.ldy = q.ldy; a.ladj = (float*)q.ladj; a.accumulate = q.accumulate;
+  a.stream = (const float*)q.wstream; a.bias = (const float*)q.bias; a.skip = q.skip; a.featmap = q.featmap;
+  a.L = q.n_layers; a.NG = q.n_groups; a.n_chunks = q.n_chunks; a.act = q.act; a.bias_floats = q.bias_floats;
+  a.bound = (float)q.bound; a.ls = (float)log(q.slope);
+  a.lc = rqs_lean_const(q.bound, log(q.slope));
+  a.n_tiles = (q.N + 127) / 128;
+  a.xs = ((q.D + 3) / 4) * 4 + 4;
+  const bool vec_ok = (q.D % 4 == 0) && (q.ldy % 4 == 0) && ((uintptr_t)q.y % 16 == 0);
+  a.xlds = vec_ok && (gs_base_lds_floats(q.bias_floats) + 8 * 16 * a.xs) * 4 <= 160 * 1024;
+  const int lds = (gs_base_lds_floats(q.bias_floats) + (a.xlds ? 8 * 16 * a.xs : 0)) * (int)sizeof(float);
+  if (lds > 160 * 1024) return ZK_EINVAL;
+  const void* fn = nullptr;
+#define GS_PICK(UNI) (a.xlds ? (const void*)ar_gsplit_kernel<UNI, true> : (const void*)ar_gsplit_kernel<UNI, false>)
+  if (q.uni_kind == 0) fn = GS_PICK(UniAffine);
+  else if (q.uni_kind == 1) fn = GS_PICK(UniRqs8);
+  else if (q.uni_kind >= 2 && q.uni_kind <= 4 && !a.xlds) return ZK_EINVAL;  // (as zk_ar_forward: 4 / 16 bins and the circular map are built for the LDS-staged epilogue only)
+  else if (q.uni_kind == 2) fn = (const void*)ar_gsplit_kernel<UniRqs4, true>;
+  else if (q.uni_kind == 3) fn = (const void*)ar_gsplit_kernel<UniRqs16, true>;
+  else if (q.uni_kind == 4) fn = (const void*)ar_gsplit_kernel<UniCircRqs8, true>;
+  else return ZK_EINVAL;
+#undef GS_PICK
+  hipError_t e = hipSuccess;
+  {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    int& g = granted[fn];
+    if (g < lds) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      g = lds;
+    }
+  }
+  const unsigned grid = (unsigned)(a.n_tiles < 256 ? a.n_tiles : 256);
+  void* kargs[] = {&a};
+  e = hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, lds, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  return ZK_LAUNCH_CHECK();
+}

@@ -26,6 +26,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -400,6 +401,71 @@ def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], 
 # --------------------------------------------------------------------------------------------------
 
 
+GS_BLOCKS_PER_CHUNK = 8  # csrc/fused_ar_gsplit.hip: GS_CH = 24 one-KiB images = 8 blocks of three
+
+
+def gsplit_gather(plan: ArPlan):
+    """Gather indices of the GENERIC operand-split kernel's stream (csrc/fused_ar_gsplit.hip: zk_ar_forward_split), or None.
+
+    The kernel walks the plan's own skip words: hidden layer l, out-group otg (4 out tiles), in-PAIR ip live when either in tile 2 ip /
+    2 ip + 1 has its skip bit set -> 4 blocks (out tile 4 otg + t, t = 0..3); last layer: group g, live in-pair ip -> NT blocks.  A block
+    is the 16 x 32 weight block as static_ar.split_tables describes it: lane L's 8 values are [tile(ot, 2 ip)[L, 0:4] | tile(ot, 2 ip + 1)
+    [L, 0:4]] of the plan's f32 tiles (plan.gather), a tile the plan does not hold being zeros.  Returns (gathers, offsets, n_chunks):
+    gathers[l] int32 [blocks_l * 512] into W_l.flatten() (-1 = zero), every layer padded to whole chunks of 8 blocks; offsets[l] the
+    layer's first float in the stream; n_chunks >= 1."""
+    if plan.max_width > MAX_WIDTH or plan.layout.kind > 4 or plan.group_chunk0:
+        return None  # (wider plans, the polynomial maps and group-aligned plans have no generic split kernel)
+    L, n_otg, n_it = plan.n_layers, MAX_WIDTH // TILE // GROUP_HIDDEN, MAX_WIDTH // TILE
+    zero = -np.ones((64, 4), dtype=np.int64)
+
+    def finish(blocks):
+        pad = -len(blocks) % GS_BLOCKS_PER_CHUNK
+        blocks = blocks + [-np.ones((64, 8), dtype=np.int64)] * pad
+        return np.stack(blocks).astype(np.int32).reshape(-1) if blocks else np.zeros(0, np.int32)
+
+    gathers = []
+    for l in range(L - 1):
+        tiles = plan.gather[l].reshape(-1, 64, 4)
+        at, k = {}, 0
+        for otg in range(n_otg):
+            bits = int(plan.skip[l * n_otg + otg])
+            for it in range(n_it):
+                if bits >> it & 1:
+                    for t in range(GROUP_HIDDEN):
+                        at[(otg * GROUP_HIDDEN + t, it)] = k
+                        k += 1
+        blocks = []
+        for otg in range(n_otg):
+            bits = int(plan.skip[l * n_otg + otg])
+            for ip in range(n_it // 2):
+                if bits >> (2 * ip) & 3:
+                    for t in range(GROUP_HIDDEN):
+                        t0, t1 = at.get((otg * GROUP_HIDDEN + t, 2 * ip)), at.get((otg * GROUP_HIDDEN + t, 2 * ip + 1))
+                        blocks.append(np.concatenate([zero if t0 is None else tiles[t0], zero if t1 is None else tiles[t1]], axis=1))
+        gathers.append(finish(blocks))
+    nt = plan.layout.nt
+    tiles = plan.gather[L - 1].reshape(-1, 64, 4)
+    blocks, k = [], 0
+    for g in range(plan.n_groups):
+        bits = int(plan.skip[(L - 1) * n_otg + g])
+        at = {}
+        for it in range(n_it):
+            if bits >> it & 1:
+                at[it] = k
+                k += nt
+        for ip in range(n_it // 2):
+            if bits >> (2 * ip) & 3:
+                for t in range(nt):
+                    t0, t1 = at.get(2 * ip), at.get(2 * ip + 1)
+                    blocks.append(np.concatenate([zero if t0 is None else tiles[t0 + t], zero if t1 is None else tiles[t1 + t]], axis=1))
+    gathers.append(finish(blocks))
+    offsets, cursor = [], 0
+    for g in gathers:
+        offsets.append(cursor * 768)
+        cursor += len(g) // 512
+    return gathers, offsets, max(1, cursor // GS_BLOCKS_PER_CHUNK)
+
+
 def chunk_of(variant: int = 0) -> int:
     """Tiles per chunk the stream is padded to (= AR_CH of csrc/fused_ar.hip: a 3 x 24-tile LDS ring)."""
     return CHUNK
@@ -436,6 +502,11 @@ class FusedAR:
         self.fine_gather = self.fine_stream = self.fine_offsets = None
         self.fine_n_chunks = 0
         self._acquire_static(None)  # kernels already on disk (prebuilt or compiled earlier) are used whatever the batch size
+        # the generic operand-split kernel (csrc/fused_ar_gsplit.hip): what run() launches while there is no static-shape kernel for the plan
+        # (its tables are built on first use).  ZUKO_AMD_GSPLIT=0: keep such plans on the f32 matrix instruction; =force: even when there is one
+        self.gs_mode = os.environ.get("ZUKO_AMD_GSPLIT", "1")
+        self.gs = None              # (gathers on the device, offsets, n_chunks, stream) | False: the plan has no generic split kernel
+        self._gs_stamp = self._seen_stamp = None
 
     @property
     def static_variant(self) -> int:
@@ -477,6 +548,22 @@ class FusedAR:
         self._acquire_static(static_ar.effective_rows(self, rows))  # (no-op once the best kernel for this plan is held or `rows` has been tried)
         return self.generic_ok or self.static is not None
 
+    def _gsplit(self):
+        """The generic operand-split kernel's tables if run() is to use that kernel, else None."""
+        from . import static_ar
+
+        if self.gs_mode == "0" or (self.static is not None and self.gs_mode != "force") or not self.generic_ok or not static_ar.split_enabled():
+            return None
+        if self.gs is None:
+            t = gsplit_gather(self.plan)
+            if t is None:
+                self.gs = False
+            else:
+                gathers, offsets, n_chunks = t
+                self.gs = ([torch.from_numpy(g).to(self.device) for g in gathers], offsets, n_chunks,
+                           torch.zeros(n_chunks * GS_BLOCKS_PER_CHUNK * 768, dtype=torch.float32, device=self.device))
+        return self.gs or None
+
     def refresh(self, linears, fine_only: bool = False) -> None:
         """(Re)build the weight streams / bias image if any parameter changed since they were last gathered.  The generic (block)
         stream and the static-shape kernels' per-tile stream carry separate stamps; fine_only (training forward, which re-gathers
@@ -487,9 +574,12 @@ class FusedAR:
         from .nn import _param_stamp
 
         stamp = _param_stamp(linears)
+        self._seen_stamp = stamp
         want_generic = self.generic_ok and not (fine_only and self.static is not None) and stamp != self._stamp
         want_fine = self.static is not None and stamp != self._fine_stamp
-        if not (want_generic or want_fine):
+        gs = self._gsplit()
+        want_gs = gs is not None and stamp != self._gs_stamp
+        if not (want_generic or want_fine or want_gs):
             return
         items = []
         for l, m in enumerate(linears):
@@ -505,6 +595,8 @@ class FusedAR:
                     items.append((w, mask, self.fine_gather[l], self.fine_gather[l].numel() // 512, fdst, 1))
                 else:
                     items.append((w, mask, self.fine_gather[l], self.fine_gather[l].numel(), fdst, 0))
+            if want_gs and gs[0][l].numel():
+                items.append((w, mask, gs[0][l], gs[0][l].numel() // 512, gs[3][gs[1][l] :], 1))
             nb = self.bias_gather[l].numel()
             bdst = self.bias[self.plan.bias_off[l] :]
             if m.bias is None:
@@ -516,6 +608,8 @@ class FusedAR:
             self._stamp = stamp
         if want_fine:
             self._fine_stamp = stamp
+        if want_gs:
+            self._gs_stamp = stamp
 
     def run(self, inp: Tensor, y: Tensor, ladj: Tensor | None, accumulate: bool) -> None:
         """inp [N, DINP] (cat(x, c), zero-padded to a multiple of 4 columns), y [N, D], ladj [N]."""
@@ -524,6 +618,13 @@ class FusedAR:
 
         p = self.plan
         N = inp.shape[0]
+        gs = self._gsplit()
+        if gs is not None and self._gs_stamp is not None and self._gs_stamp == self._seen_stamp and (p.layout.kind <= 1 or (p.features % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)):
+            # (4 / 16 bins and the circular map exist for the LDS-staged epilogue only, like the generic f32 kernel's)
+            a = self._generic_args(N=N, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0), y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate))
+            a.wstream, a.n_chunks = gs[3].data_ptr(), gs[2]
+            _C.check(_C.lib().zk_ar_forward_split(a, _stream()), "zk_ar_forward_split")
+            return
         if self.static is not None:
             kern, rev = self.static
             # (a static-shape kernel that stages rows through LDS needs them 16-byte addressable; the generic kernel has an instantiation for the other case)
