@@ -756,10 +756,89 @@ def side_paths_report() -> dict:
             rel = ((res["fused"][1] - res["layer_wise"][1]).abs().max() / res["layer_wise"][1].abs().max()).item()
             entry["log_prob"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) log_prob, batch 2^18", "ms": res["fused"][0] * 1e3, "samples_per_s": Bp / res["fused"][0],
                                  "layer_wise_ms": res["layer_wise"][0] * 1e3, "parity": {"log_prob_max_rel_vs_layer_wise_kernels": rel, "ok": bool(rel < 1e-5)}}
+            # sampling: the bisection inverse has no fused kernel; it runs layer by layer in wavefront form (FusedAutoregressiveTransform._ordered_inverse:
+            # per sweep the hidden layers, then the last layer's rows and the bisections of that sweep's feature only) — beside the reference's loop
+            # (zuko/transforms.py:994-1000: everything, every sweep; ZUKO_AMD_FULL_SWEEPS=1), which must give the same x bit for bit
+            Bs = 1 << 14
+            with torch.no_grad():
+                tr = flow().transform
+                x0 = 0.8 * torch.randn(Bs, 64, device=dev)
+                z = tr(x0)  # (inside the maps' invertible range: the bisection works on [-B, B], as the reference's)
+                samp = {}
+                for mode in ("wavefront", "reference_loop"):
+                    keep = os.environ.get("ZUKO_AMD_FULL_SWEEPS")
+                    if mode == "reference_loop":
+                        os.environ["ZUKO_AMD_FULL_SWEEPS"] = "1"
+                    try:
+                        xs = tr.inv(z)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        xs = tr.inv(z)
+                        torch.cuda.synchronize()
+                        samp[mode] = (time.perf_counter() - t0, xs)
+                    finally:
+                        if keep is None:
+                            os.environ.pop("ZUKO_AMD_FULL_SWEEPS", None)
+                        else:
+                            os.environ["ZUKO_AMD_FULL_SWEEPS"] = keep
+                back = (samp["wavefront"][1] - x0).abs().max().item()
+            entry["sampling"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) flow().transform.inv(z), batch 2^14", "ms": samp["wavefront"][0] * 1e3, "samples_per_s": Bs / samp["wavefront"][0],
+                                 "reference_loop_ms": samp["reference_loop"][0] * 1e3, "bitwise_equal_to_reference_loop": bool(torch.equal(samp["wavefront"][1], samp["reference_loop"][1])),
+                                 "round_trip_max_abs": back}
         except Exception as exc:
             entry["error"] = repr(exc)
         out[name] = entry
+    out["generic_split_kernel"] = generic_split_report(dev)
     return out
+
+
+def generic_split_report(dev) -> dict:
+    """The headline flow with NO kernel generated for its conditioner (a box without hipcc, a shape that was not prebuilt): zk_ar_forward_split
+    (csrc/fused_ar_gsplit.hip: run-time skip tests around the operand-split arithmetic) beside the generated kernels of the headline line and the
+    generic f32-instruction kernel it replaces.  Same weights, same rows; log_prob must be bit-identical to the generated kernels'."""
+    import torch
+
+    from zuko_amd import flows as F
+    from zuko_amd.flows import autoregressive as AR
+
+    entry = {"workload": CONFIGS["cfg2"][2] if len(CONFIGS["cfg2"]) > 2 else "NSF cfg2 log_prob, batch 2^20"}
+    try:
+        torch.manual_seed(0)
+        flow = F.NSF(**CONFIGS["cfg2"][1]).to(dev)
+        B = 1 << 20
+        x = torch.randn(B, 64, device=dev)
+        res = {}
+        for mode, env in (("generated_split_kernels", {}), ("generic_split_kernel", {"ZUKO_AMD_NO_STATIC_AR": "1"}), ("generic_f32_kernel", {"ZUKO_AMD_NO_STATIC_AR": "1", "ZUKO_AMD_GSPLIT": "0"})):
+            keep = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                for lazy in flow.transform.transforms:
+                    AR._FUSED_CACHE.pop(lazy, None)
+                with torch.no_grad():
+                    for _ in range(2):
+                        lp = flow().log_prob(x)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        lp = flow().log_prob(x)
+                    torch.cuda.synchronize()
+                    res[mode] = ((time.perf_counter() - t0) / 5, lp)
+            finally:
+                for k, v in keep.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                for lazy in flow.transform.transforms:
+                    AR._FUSED_CACHE.pop(lazy, None)
+        for mode, (dt, _) in res.items():
+            entry[mode] = {"ms": dt * 1e3, "samples_per_s": B / dt}
+        entry["generic_split_over_generated"] = res["generic_split_kernel"][0] / res["generated_split_kernels"][0]
+        entry["generic_split_bitwise_equal_to_generated"] = bool(torch.equal(res["generic_split_kernel"][1], res["generated_split_kernels"][1]))
+        entry["generic_f32_max_rel_diff"] = ((res["generic_f32_kernel"][1] - res["generated_split_kernels"][1]).abs().max() / res["generated_split_kernels"][1].abs().max()).item()
+    except Exception as exc:
+        entry["error"] = repr(exc)
+    return entry
 
 
 def run_side_paths() -> dict:
@@ -1110,7 +1189,7 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
                 row["instruction_form_ceiling"] = {"form": "v_mfma_f32_16x16x32_bf16, two wavefronts per SIMD", "frac_of_bf16_peak": MFMA_16x16x32_ISSUE_CEILING,
                                                    "real_cycles_per_instruction_and_simd": 16.3, "pipe_cycles_per_instruction": 16,
                                                    "source": "profiles/r05/mfma_clock_probe.txt (random operands, ~2.2 GHz under that load; a property of the chip, not re-measured in this run)",
-                                                   "note": "the kernel's matrix pipe is busy 0.61 of the launch (profiles/r04/traffic.json, GRBM_GUI_ACTIVE / 8 = 2.4 GHz x launch time): it is NOT at this ceiling; "
+                                                   "note": "the kernel's matrix pipe is busy 0.62 of the launch (profiles/r05/traffic.json: GRBM_GUI_ACTIVE / 8 = 5.97e6 real cycles per launch, 2.25 GHz under the profiler): it is NOT at this ceiling; "
                                                            "its conversion / spline / ring phases run beside idle matrix pipes (profiles/r05/headline.md)"}
             row["algorithmic_flop_per_launch"] = float(B) * flop_per_transform["nnz"]
             row["dense_equiv_tflops"] = float(B) * flop_per_transform["dense"] / t / 1e12

@@ -759,7 +759,7 @@ def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
         assert torch.equal(l2[ok], (ladj + ladj)[ok])
 
 
-GSPLIT_CASES = STATIC_CASES + [("nsf16", 64, 0, [256] * 3), ("nsf4", 8, 2, [48, 48]), ("nsf", 6, 0, [32, 32]), ("maf", 5, 1, [24])]
+GSPLIT_CASES = STATIC_CASES + [("nsf16", 64, 0, [256] * 3), ("nsf4", 8, 2, [48, 48]), ("nsf", 6, 0, [32, 32]), ("maf", 5, 1, [24]), ("ncsf", 8, 3, [64, 40])]
 
 
 @pytest.mark.gpu
@@ -769,16 +769,16 @@ def test_generic_split_kernel_equals_the_static_one(dev, case, N, monkeypatch):
     """zk_ar_forward_split (csrc/fused_ar_gsplit.hip: ONE kernel for any conditioner up to 256 wide, run-time skip tests around the operand-split
     arithmetic) against the operand-split kernel GENERATED for the conditioner: every accumulator receives the same blocks in the same order (a
     block the generated kernel drops adds exact zeros), so y and ladj must agree bit for bit — both feature orders, ragged batches, poisoned rows,
-    widths that are not multiples of 16 / 32, a context, 4 / 8 / 16 bins, ELU / tanh, D % 4 != 0 (rows not staged through LDS)."""
-    from zuko_amd.flows import MAF, NSF
+    widths that are not multiples of 16 / 32, a context, 4 / 8 / 16 bins, NCSF's circular spline, ELU / tanh, D % 4 != 0 (rows not staged through LDS)."""
+    from zuko_amd.flows import MAF, NCSF, NSF
     from zuko_amd.nn import MaskedLinear
 
     kind, D, C, hidden = case[:4]
     kw = dict(activation=getattr(torch.nn, case[4])) if len(case) > 4 else {}
     monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
     torch.manual_seed(3)
-    bins = {"nsf": 8, "nsf16": 16, "nsf4": 4}.get(kind)
-    flow = (NSF(D, C, transforms=2, bins=bins, hidden_features=hidden, **kw) if bins else MAF(D, C, transforms=2, hidden_features=hidden, **kw)).to(dev)
+    bins = {"nsf": 8, "nsf16": 16, "nsf4": 4, "ncsf": 8}.get(kind)
+    flow = ((NCSF if kind == "ncsf" else NSF)(D, C, transforms=2, bins=bins, hidden_features=hidden, **kw) if bins else MAF(D, C, transforms=2, hidden_features=hidden, **kw)).to(dev)
     g = torch.Generator().manual_seed(N)
     din = D + C
     inp = torch.zeros(N, -(-din // 4) * 4)
@@ -1236,3 +1236,49 @@ def test_static_shape_table(dev, kind, D, ctx, hidden, monkeypatch):
     tag = f"table {kind}({D}, ctx {ctx}, {hidden})"
     assert_parity(z, zo, z64, f"{tag}: z")
     assert_parity(ladj, lo, l64, f"{tag}: ladj")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sospf", "bpf", "nsf_wide", "maf_softplus", "nsf_passes2", "nsf_ctx_reversed", "maf_randperm_passes3"])
+def test_layer_wise_inverse_in_wavefront_form_equals_the_reference_loop(dev, name, monkeypatch):
+    """Layers without a fused inverse kernel (the polynomial maps' bisection, conditioners wider than 256, an activation the kernels do not know)
+    invert through FusedAutoregressiveTransform._ordered_inverse: per sweep the hidden layers once, then the last layer's rows and the inverse map
+    of the features of that sweep's order only.  Every feature must receive exactly the value the reference's loop (zuko/transforms.py:994-1000,
+    ZUKO_AMD_FULL_SWEEPS=1: all rows, all features, every sweep) gives it, and the result must invert the forward map."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(11)
+    D, C = 24, 0
+    if name == "sospf":
+        flow = F.SOSPF(D, 0, transforms=2, hidden_features=[64, 64])
+    elif name == "bpf":
+        flow = F.BPF(D, 0, transforms=2, hidden_features=[64, 64])
+    elif name == "nsf_wide":
+        flow = F.NSF(D, 0, transforms=2, hidden_features=[320, 320])
+    elif name == "maf_softplus":
+        flow = F.MAF(D, 0, transforms=2, hidden_features=[64, 64], activation=torch.nn.Softplus)
+    elif name == "nsf_passes2":
+        flow = F.NSF(D, 0, transforms=2, hidden_features=[320], passes=2)
+    elif name == "maf_randperm_passes3":  # (the features of a sweep are scattered: gathered rows instead of slices)
+        flow = F.MAF(D, 0, transforms=2, hidden_features=[320], randperm=True, passes=3)
+    else:
+        C = 3
+        flow = F.NSF(D, C, transforms=2, hidden_features=[300, 300])
+    flow = flow.to(dev)
+    N = 1000
+    x = (0.8 * torch.randn(N, D)).to(dev)
+    c = torch.randn(N, C).to(dev) if C else None
+    calls = []
+    from zuko_amd.flows.autoregressive import FusedAutoregressiveTransform as FT
+
+    orig = FT._ordered_inverse
+    monkeypatch.setattr(FT, "_ordered_inverse", lambda self, y: (calls.append(1), orig(self, y))[1])
+    with torch.no_grad():
+        t = flow(c).transform
+        z = t(x)
+        xr = t.inv(z)
+        assert len(calls) >= 2, "the wavefront form was not used"
+        monkeypatch.setenv("ZUKO_AMD_FULL_SWEEPS", "1")
+        x_ref = flow(c).transform.inv(z)
+    assert torch.equal(xr, x_ref), f"{name}: max |wavefront - reference loop| = {(xr - x_ref).abs().max().item():.3e}"
+    assert (xr - x).abs().max().item() < (5e-3 if name in ("sospf", "bpf") else 1e-4)

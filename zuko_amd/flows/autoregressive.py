@@ -142,6 +142,24 @@ class MaskedAutoregressiveTransform(LazyTransform):
     def forward(self, c: Tensor | None = None) -> Transform:
         return FusedAutoregressiveTransform(self, c)
 
+    def _sweep_features(self, device, passes: int) -> list:
+        """Per sweep s of the inverse, the features of order s: (lo, hi) when they are consecutive, else their indices on `device`; empty sweeps
+        are dropped.  Host-side, cached per (order version, device): the sweeps themselves then run without a device synchronisation."""
+        key = (str(device), passes, self.order._version, self.order.data_ptr())
+        cached = getattr(self, "_sweep_cache", None)
+        if cached is None or cached[0] != key:
+            order = self.order.detach().cpu()
+            out = []
+            for s_ in range(passes):
+                idx = (order == s_).nonzero().squeeze(-1)
+                if idx.numel() == 0:
+                    continue
+                lo, hi = int(idx[0]), int(idx[-1]) + 1
+                out.append((lo, hi) if hi - lo == idx.numel() else idx.to(device))
+            cached = (key, out)
+            self._sweep_cache = cached
+        return cached[1]
+
     # ---- fused-kernel support ----------------------------------------------------------------
 
     def _fusable_layout(self):
@@ -428,7 +446,7 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         conditioner fits the aligned-tile plan, else one fused launch per (partial) sweep, updating the buffer in place."""
         st = self._fused(y, need_generic=True)  # (the sweeps below run on the generic kernel)
         if st is None:
-            return super()._inverse(y)
+            return self._ordered_inverse(y)
         self._check_widths(y, st)
         lazy, c = self.lazy, self.c
         D = lazy.features
@@ -462,6 +480,48 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             for _ in range(self.passes):
                 st.run_inverse_sweep(buf, y2)
         return buf[:, :D].reshape(batch + (D,)).contiguous() if buf.shape[1] != D else buf.reshape(batch + (D,))
+
+
+    def _ordered_inverse(self, y: Tensor) -> Tensor:
+        """The reference's loop (zuko/transforms.py:994-1000: `passes` times x <- meta(x).inv(y) from x = 0) for layers that have no fused
+        inverse kernel (the polynomial maps' bisection, conditioners wider than 256, activations / univariate maps the kernels do not know),
+        in WAVEFRONT form: sweep s evaluates the hidden layers once, then only the last layer's rows of the features of order s and only
+        their univariate inverse — the features of lower order are final and keep their values, those of higher order are not read by
+        anything sweep s computes (their weights are masked), so every feature receives exactly the value the reference's last sweep gives
+        it, with 1 / passes of the last layer's and of the inverse map's work per sweep (for SOSPF / BPF: of the bisections)."""
+        lazy, c = self.lazy, self.c
+        mods = list(lazy.hyper) if isinstance(lazy.hyper, torch.nn.Sequential) else []
+        grad = torch.is_grad_enabled() and (y.requires_grad or (c is not None and c.requires_grad) or any(p.requires_grad for p in lazy.hyper.parameters()))
+        if lazy.order is None or grad or not mods or type(mods[-1]) is not MaskedLinear or not y.is_cuda or y.dtype not in (torch.float32, torch.float64) or os.environ.get("ZUKO_AMD_FULL_SWEEPS", "0") == "1":
+            return super()._inverse(y)  # free-form adjacency / a graph for autograd / a residual conditioner: the loop as the reference writes it
+        from .. import ops
+        from ..nn import apply_stack
+
+        D, total, last = lazy.features, lazy.total, mods[-1]
+        if c is not None:
+            yb, cb = broadcast(y, c, ignore=1)
+        else:
+            yb, cb = y, None
+        batch = yb.shape[:-1]
+        y2 = yb.reshape(-1, D)
+        x2 = torch.zeros_like(y2)
+        c2 = None if cb is None else cb.reshape(-1, cb.shape[-1])
+        for idx in lazy._sweep_features(y.device, self.passes):
+            h = apply_stack(mods[:-1], x2 if c2 is None else torch.cat((x2, c2), dim=-1))
+            if isinstance(idx, tuple):  # a run of consecutive features (the usual orders): row / column slices are views, no gather launches
+                lo, hi = idx
+                rows, k = slice(lo * total, hi * total), hi - lo
+                w, b, m, ys = last.weight[rows], None if last.bias is None else last.bias[rows], last.mask[rows], y2[:, lo:hi]
+            else:
+                rows, k = (idx[:, None] * total + torch.arange(total, device=y.device)[None, :]).reshape(-1), idx.numel()
+                w, b, m, ys = last.weight.index_select(0, rows), None if last.bias is None else last.bias.index_select(0, rows), last.mask.index_select(0, rows), y2.index_select(1, idx)
+            phi = ops.linear(h, w, b, m)
+            u = lazy.univariate(*unpack(phi.unflatten(-1, (k, total)), lazy.shapes))
+            if isinstance(idx, tuple):
+                x2[:, idx[0] : idx[1]] = u.inv(ys)
+            else:
+                x2[:, idx] = u.inv(ys)
+        return x2.reshape(batch + (D,))
 
 
 class _FusedInverse(Transform):

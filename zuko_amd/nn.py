@@ -73,6 +73,27 @@ class MaskedLinear(nn.Linear):
         return ops.linear(x, self.weight, self.bias, self.mask, act)
 
 
+def apply_stack(mods: Sequence[nn.Module], x: Tensor) -> Tensor:
+    """mods applied in order, every (linear, activation) pair as ONE kernel when the activation is one the GEMM epilogue knows."""
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, (Linear, MaskedLinear)):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            code = _act_code(nxt) if nxt is not None and not isinstance(nxt, (Linear, MaskedLinear)) else None
+            if code is not None and torch.is_grad_enabled() and code not in (0, 1, 2, 3, 6, 7):
+                code = None  # SiLU / GELU need the pre-activation for their derivative: leave them to torch
+            if code is not None and nxt is not None:
+                x = m(x, code)
+                i += 2
+                continue
+            x = m(x)
+        else:
+            x = m(x)
+        i += 1
+    return x
+
+
 class _FusedSequential(nn.Sequential):
     """Sequential whose (linear, activation) pairs run as ONE kernel when the activation is one
     the GEMM epilogue knows; other modules are applied as-is."""
@@ -84,24 +105,7 @@ class _FusedSequential(nn.Sequential):
             out = train.conditioner(self, x)  # HIP forward + mask-aware dgrad / wgrad (csrc/train.hip) for plain (linear, act)* stacks
             if out is not None:
                 return out
-        mods = list(self)
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, (Linear, MaskedLinear)):
-                nxt = mods[i + 1] if i + 1 < len(mods) else None
-                code = _act_code(nxt) if nxt is not None and not isinstance(nxt, (Linear, MaskedLinear)) else None
-                if code is not None and torch.is_grad_enabled() and code not in (0, 1, 2, 3, 6, 7):
-                    code = None  # SiLU / GELU need the pre-activation for their derivative: leave them to torch
-                if code is not None and nxt is not None:
-                    x = m(x, code)
-                    i += 2
-                    continue
-                x = m(x)
-            else:
-                x = m(x)
-            i += 1
-        return x
+        return apply_stack(list(self), x)
 
 
 class MLP(_FusedSequential):
