@@ -1242,9 +1242,11 @@ def test_static_shape_table(dev, kind, D, ctx, hidden, monkeypatch):
 @pytest.mark.parametrize("name", ["sospf", "bpf", "nsf_wide", "maf_softplus", "nsf_passes2", "nsf_ctx_reversed", "maf_randperm_passes3"])
 def test_layer_wise_inverse_in_wavefront_form_equals_the_reference_loop(dev, name, monkeypatch):
     """Layers without a fused inverse kernel (the polynomial maps' bisection, conditioners wider than 256, an activation the kernels do not know)
-    invert through FusedAutoregressiveTransform._ordered_inverse: per sweep the hidden layers once, then the last layer's rows and the inverse map
-    of the features of that sweep's order only.  Every feature must receive exactly the value the reference's loop (zuko/transforms.py:994-1000,
-    ZUKO_AMD_FULL_SWEEPS=1: all rows, all features, every sweep) gives it, and the result must invert the forward map."""
+    invert through FusedAutoregressiveTransform._ordered_inverse: per sweep only the hidden units that have just become final (skinny GEMMs over
+    gathered weight rows into persistent activation buffers), then the last layer's rows and the inverse map of the features of that sweep's order
+    only.  Every feature must receive exactly the value the reference's loop (zuko/transforms.py:994-1000, ZUKO_AMD_FULL_SWEEPS=1: all units, all
+    rows, all features, every sweep) gives it — bit for bit: the same dot products over inputs that no longer change — and the result must invert
+    the forward map.  Orders: ascending, descending with a context, two sweeps of twelve features, a random order in three sweeps (scattered rows)."""
     import zuko_amd.flows as F
 
     torch.manual_seed(11)

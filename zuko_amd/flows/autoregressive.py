@@ -143,7 +143,7 @@ class MaskedAutoregressiveTransform(LazyTransform):
         return FusedAutoregressiveTransform(self, c)
 
     def _sweep_features(self, device, passes: int) -> list:
-        """Per sweep s of the inverse, the features of order s: (lo, hi) when they are consecutive, else their indices on `device`; empty sweeps
+        """Per sweep s of the inverse, (s, the features of order s): (lo, hi) when they are consecutive, else their indices on `device`; empty sweeps
         are dropped.  Host-side, cached per (order version, device): the sweeps themselves then run without a device synchronisation."""
         key = (str(device), passes, self.order._version, self.order.data_ptr())
         cached = getattr(self, "_sweep_cache", None)
@@ -155,9 +155,34 @@ class MaskedAutoregressiveTransform(LazyTransform):
                 if idx.numel() == 0:
                     continue
                 lo, hi = int(idx[0]), int(idx[-1]) + 1
-                out.append((lo, hi) if hi - lo == idx.numel() else idx.to(device))
+                out.append((s_, (lo, hi) if hi - lo == idx.numel() else idx.to(device)))
             cached = (key, out)
             self._sweep_cache = cached
+        return cached[1]
+
+    def _sweep_units(self, device, passes: int):
+        """For a plain (MaskedLinear, activation)* MaskedLinear conditioner: per hidden layer and sweep s, the units that become FINAL at the start
+        of sweep s — every input they are connected to is a context column or a feature of order < s, or a unit of the layer before that was final
+        by then (r(unit) = max over its unmasked inputs; features: order + 1, context: 0).  A unit is evaluated once, in the sweep it becomes
+        final; units that are never final within `passes` sweeps feed nothing the inverse reads.  Returns None for other conditioner structures.
+        Host-side, cached per (mask / order versions, device)."""
+        mods = list(self.hyper) if isinstance(self.hyper, nn.Sequential) else []
+        lins = mods[0::2]
+        if not mods or len(mods) % 2 == 0 or any(type(m) is not MaskedLinear for m in lins) or any(isinstance(m, (nn.Linear, MaskedLinear)) for m in mods[1::2]):
+            return None
+        key = (str(device), passes, self.order._version, self.order.data_ptr()) + tuple((l.mask._version, l.mask.data_ptr()) for l in lins)
+        cached = getattr(self, "_unit_cache", None)
+        if cached is None or cached[0] != key:
+            order = self.order.detach().cpu()
+            ready = torch.cat((order + 1, torch.zeros(lins[0].mask.shape[1] - order.numel(), dtype=order.dtype)))
+            table = []
+            for lin in lins[:-1]:
+                m = lin.mask.detach().cpu()
+                ready = torch.where(m, ready[None, :].expand_as(m), torch.zeros((), dtype=ready.dtype)).amax(dim=1)  # [out]
+                table.append([(ready == s_).nonzero().squeeze(-1) for s_ in range(passes)])
+            table = [[(None if u.numel() == 0 else u.to(device)) for u in row] for row in table]
+            cached = (key, table)
+            self._unit_cache = cached
         return cached[1]
 
     # ---- fused-kernel support ----------------------------------------------------------------
@@ -506,8 +531,32 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         y2 = yb.reshape(-1, D)
         x2 = torch.zeros_like(y2)
         c2 = None if cb is None else cb.reshape(-1, cb.shape[-1])
-        for idx in lazy._sweep_features(y.device, self.passes):
-            h = apply_stack(mods[:-1], x2 if c2 is None else torch.cat((x2, c2), dim=-1))
+        units = lazy._sweep_units(y.device, self.passes)
+        if units is not None:
+            # incremental form: a hidden unit is evaluated ONCE, in the sweep in which its inputs are all final (skinny GEMMs over gathered weight
+            # rows, written into persistent activation buffers) — the reference's loop re-evaluates every unit in every sweep and obtains the
+            # same number from the same dot product, because the inputs a unit is connected to no longer change
+            hbuf = [y2.new_zeros((y2.shape[0], m.weight.shape[0])) for m in mods[0:-1:2]]
+            codes = [_act_code(a_) for a_ in mods[1::2]]
+        sweep_no = {}
+        for s_, idx in lazy._sweep_features(y.device, self.passes):
+            if units is None:
+                h = apply_stack(mods[:-1], x2 if c2 is None else torch.cat((x2, c2), dim=-1))
+            else:
+                h = x2 if c2 is None else torch.cat((x2, c2), dim=-1)
+                for l, lin in enumerate(mods[0:-1:2]):
+                    # (sweeps without features were dropped by _sweep_features: their units join the next sweep that has some)
+                    todo = [units[l][t] for t in range(sweep_no.get(l, 0), s_ + 1) if units[l][t] is not None]
+                    sweep_no[l] = s_ + 1
+                    if todo:
+                        u_ = todo[0] if len(todo) == 1 else torch.cat(todo)
+                        bias = None if lin.bias is None else lin.bias.index_select(0, u_)
+                        if codes[l] is not None:
+                            out = ops.linear(h, lin.weight.index_select(0, u_), bias, lin.mask.index_select(0, u_), codes[l])
+                        else:
+                            out = mods[2 * l + 1](ops.linear(h, lin.weight.index_select(0, u_), bias, lin.mask.index_select(0, u_)))
+                        hbuf[l].index_copy_(1, u_, out)
+                    h = hbuf[l]
             if isinstance(idx, tuple):  # a run of consecutive features (the usual orders): row / column slices are views, no gather launches
                 lo, hi = idx
                 rows, k = slice(lo * total, hi * total), hi - lo
