@@ -240,7 +240,8 @@ int zk_ar_forward(const zk_ar_args_v1* args, void* stream);
  * plan's OPERAND-SPLIT stream (zuko_amd/fused.py: gsplit_gather through zk_gather_split_bf16: per hidden layer, out-group of 4 tiles and
  * live in-PAIR, 4 blocks; per last-layer group and live in-pair, NT blocks; three 1 KiB bf16 images per 16 x 32 block; every layer padded
  * to whole 24-image chunks) and n_chunks its length in 24-image chunks (>= 1).  A pair is live when either of its two skip bits is set.
- * uni_kind 0-4 (2-4: D % 4 == 0 and y 16-byte aligned rows, as zk_ar_forward); forward only.  The result is BIT-IDENTICAL to the
+ * uni_kind 0-4 (2-4: D % 4 == 0 and y 16-byte aligned rows, as zk_ar_forward); forward only.  bin_out + knots_out set (uni_kind 1-3,
+ * LDS-staged rows): the diagnostic twin of the same launch, as zk_ar_forward_diag.  The result is BIT-IDENTICAL to the
  * static-shape operand-split kernel of the same conditioner (zk_ar_forward_static), and agrees with zk_ar_forward to f32 rounding. */
 int zk_ar_forward_split(const zk_ar_args_v1* args, void* stream);
 /* Diagnostic twin of zk_ar_forward for the spline maps (uni_kind 1-3, LDS-staged tiles: D % 4 == 0): the same kernel

@@ -16,7 +16,7 @@
 //     compiler-visible LDS read behind an LDS-DMA waits for vmcnt(0));
 //   * per accumulator the blocks arrive in the same order (in-pairs ascending) as in a static-shape split kernel, and a block the static kernel drops
 //     (all zero) adds exact zeros here: the two are BIT-IDENTICAL (tests/test_gpu_flows.py::test_generic_split_kernel_equals_the_static_one).
-// Forward only (inverse sweeps, partial sweeps and the diagnostic twin stay on fused_ar.hip's f32 instruction).
+// Forward only (inverse sweeps and partial sweeps stay on fused_ar.hip's f32 instruction); the spline kinds have a diagnostic twin (DIAG).
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -106,7 +106,7 @@ __device__ __forceinline__ void gs_hidden_layer(GsRing& ring, const uint32_t* __
   ring.end_layer();
 }
 
-template <typename Uni, bool XLDS> __global__ __launch_bounds__(512, 2) void ar_gsplit_kernel(ArArgs a) {
+template <typename Uni, bool XLDS, bool DIAG = false> __global__ __launch_bounds__(512, 2) void ar_gsplit_kernel(ArArgs a) {
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -260,7 +260,18 @@ template <typename Uni, bool XLDS> __global__ __launch_bounds__(512, 2) void ar_
         const int f = fid[fi];
         if (f >= 0) {
           float yv, lj;
-          Uni::fwd(ld, fi * TOTAL, a, xv[fi], yv, lj);
+          if constexpr (DIAG) {  // the diagnostic twin: same arithmetic, the bin index and the search knots stored as well (zk_ar_forward_diag)
+            int kb = 0;
+            float ks[Uni::NKNOT];
+            Uni::fwd(ld, fi * TOTAL, a, xv[fi], yv, lj, &kb, ks);
+            if (live) {
+              a.bin_out[n * a.D + f] = kb;
+#pragma unroll
+              for (int jj = 0; jj < Uni::NKNOT; ++jj) a.knots_out[(n * a.D + f) * Uni::NKNOT + jj] = ks[jj];
+            }
+          } else {
+            Uni::fwd(ld, fi * TOTAL, a, xv[fi], yv, lj);
+          }
           if (XLDS) xr[f] = yv;
           else if (live) a.y[n * a.ldy + f] = yv;
           lacc += lj;
@@ -297,6 +308,7 @@ static int gs_base_lds_floats(int bias_floats) { return GS_CH * GS_NR * AR_TF + 
 // y, ladj of one masked autoregressive layer on the generic operand-split kernel.  Arguments as zk_ar_forward (include/zuko_amd.h) except `wstream`:
 // the operand-split stream of zuko_amd/fused.py: gsplit_gather (3 bf16 images per 16 x 32 block, written by zk_gather_split_bf16) and `n_chunks` its length
 // in 24-image chunks.  uni_kind 0-4; forward only.  Bit-identical to the static-shape operand-split kernel of the same conditioner.
+// bin_out + knots_out set (uni_kind 1-3, D % 4 == 0): its diagnostic twin, as zk_ar_forward_diag is the f32 kernel's.
 extern "C" int zk_ar_forward_split(const zk_ar_args_v1* p, void* stream) {
   zk_ar_args_v1 q;
   if (!p || p->version != 1 || p->struct_size < offsetof(zk_ar_args_v1, phi_packed) || p->struct_size > sizeof(zk_ar_args_v1)) return ZK_EINVAL;
@@ -329,6 +341,14 @@ extern "C" int zk_ar_forward_split(const zk_ar_args_v1* p, void* stream) {
   else if (q.uni_kind == 4) fn = (const void*)ar_gsplit_kernel<UniCircRqs8, true>;
   else return ZK_EINVAL;
 #undef GS_PICK
+  if (q.bin_out || q.knots_out) {  // diagnostic twin (spline maps, LDS-staged rows): same template, same arithmetic, extra stores
+    if (!a.xlds || !q.bin_out || !q.knots_out) return ZK_EINVAL;
+    a.bin_out = q.bin_out; a.knots_out = (float*)q.knots_out;
+    if (q.uni_kind == 1) fn = (const void*)ar_gsplit_kernel<UniRqs8, true, true>;
+    else if (q.uni_kind == 2) fn = (const void*)ar_gsplit_kernel<UniRqs4, true, true>;
+    else if (q.uni_kind == 3) fn = (const void*)ar_gsplit_kernel<UniRqs16, true, true>;
+    else return ZK_EINVAL;
+  }
   hipError_t e = hipSuccess;
   {
     static std::mutex mu;

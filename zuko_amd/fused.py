@@ -674,6 +674,12 @@ class FusedAR:
             _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
             return
         a = self._generic_args(N=inp.shape[0], DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0), y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), bin_out=_ptr(bins), knots_out=_ptr(knots))
+        gs = self._gsplit()
+        if gs is not None and self._gs_stamp is not None and self._gs_stamp == self._seen_stamp and p.features % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0:
+            # the product launch is the generic operand-split kernel: ITS diagnostic instantiation
+            a.wstream, a.n_chunks = gs[3].data_ptr(), gs[2]
+            _C.check(_C.lib().zk_ar_forward_split(a, _stream()), "zk_ar_forward_split")
+            return
         err = _C.lib().zk_ar_forward_diag(a, _stream())
         _C.check(err, "zk_ar_forward_diag")
 
