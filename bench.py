@@ -600,6 +600,9 @@ def side_paths_report() -> dict:
 
     from zuko_amd import flows as F
 
+    # the oracle legs of this report run on the HOST: PyTorch-CPU does not scale to the box's 256 hardware threads on these sizes (cpu_baseline's
+    # sweep: 16 threads are fastest, all of them hundreds of times slower) — measured in round 5: this report took 331 s at the default, most of it here
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     out = {}
     cfg1 = dict(features=3, context=5, transforms=3, bins=8, hidden_features=[128] * 3)  # BASELINE.json configs[0]: the conditional flow
@@ -899,6 +902,8 @@ def main() -> None:
 
     import torch
 
+    if args.config != "cfg2":  # side configs: model construction and the CPU-oracle parity leg (cfg5: 629 M parameters) at a thread count PyTorch-CPU scales to
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     rank, world, local, dist = init_ranks(args)
     if os.environ.get("ZUKO_BENCH_LAUNCH_SELFTEST") == "1":
         got = 1
