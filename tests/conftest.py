@@ -20,6 +20,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs on the host: PyTorch-CPU at the GPU box's default of 128-256 threads is pathologically slow on these sizes (bench.py measured
+    # 197 s -> 3 s for one float64 autograd pass of the oracle when capped at 16 threads, round 5); a no-op on smaller machines
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
 
 
 def pytest_sessionstart(session):
