@@ -27,6 +27,8 @@ def invalidate(module) -> None:
         m.__dict__.pop("_bf16_plan_cache", None)
         m.__dict__.pop("_coupling_cache", None)
         m.__dict__.pop("_split_cache", None)
+        for k in ("_sweep_cache", "_unit_cache", "_unit_rows_cache"):  # wavefront form of the layer-wise inverse (flows/autoregressive.py)
+            m.__dict__.pop(k, None)
         from . import train as _train
         from .flows import coupling as _cp
 

@@ -315,7 +315,8 @@ extern "C" int zk_ar_forward_split(const zk_ar_args_v1* p, void* stream) {
   std::memset(&q, 0, sizeof(q));
   std::memcpy(&q, p, p->struct_size);
   if (q.N <= 0) return 0;
-  if (q.n_groups * 8 > 1024 || q.n_groups > 252 || q.n_layers < 2 || q.n_layers > 9) return ZK_EINVAL;  // (skip words: 4 per hidden layer + one per group in 256 LDS words)
+  if (q.n_groups < 1 || q.n_groups * 8 > 1024 || q.n_layers < 2 || (q.n_layers - 1) * 4 + q.n_groups > 256) return ZK_EINVAL;  // (feature map: 1024 LDS words; skip words: 4 per hidden layer + one per group in 256)
+  if (q.bias_floats % 4 || q.bias_floats < (q.n_layers - 1) * 256 + q.n_groups * 16) return ZK_EINVAL;  // (256 per hidden layer + NT x 16 per group; 16-byte rows behind it)
   if (q.DIN > 256 || q.DIN < q.D || q.DIN % 4 || q.ldx % 4 || ((uintptr_t)q.x % 16) || q.n_chunks < 1 || !q.x || !q.y || !q.wstream || !q.bias || !q.skip || !q.featmap) return ZK_EINVAL;
   ArArgs a{};
   a.N = q.N; a.D = q.D; a.DIN = q.DIN;

@@ -185,6 +185,35 @@ class MaskedAutoregressiveTransform(LazyTransform):
             self._unit_cache = cached
         return cached[1]
 
+    def _sweep_unit_rows(self, device, passes: int):
+        """The hidden layers' weights, masks and biases with their ROWS gathered sweep by sweep (the units of _sweep_units, in that order), so
+        that a sweep's skinny GEMM takes a row slice — a view — instead of three gathers.  Columns stay in module order: a unit's dot product
+        runs over the same operands in the same order as in the reference's full GEMM.  Per hidden layer: (weight, mask, bias | None, start
+        offset of every sweep's rows); cached per parameter version (zuko_amd.invalidate drops it)."""
+        from ..nn import _param_stamp
+
+        units = self._sweep_units(device, passes)
+        if units is None:
+            return None
+        lins = list(self.hyper)[0:-1:2]
+        key = (str(device), passes, id(units), _param_stamp(lins))
+        cached = getattr(self, "_unit_rows_cache", None)
+        if cached is None or cached[0] != key:
+            out = []
+            with torch.no_grad():
+                for l, lin in enumerate(lins):
+                    rows = [u for u in units[l] if u is not None]
+                    starts, n = [], 0
+                    for u in units[l]:
+                        starts.append(n)
+                        n += 0 if u is None else u.numel()
+                    starts.append(n)
+                    perm = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long, device=device)
+                    out.append((lin.weight.detach().index_select(0, perm), lin.mask.index_select(0, perm), None if lin.bias is None else lin.bias.detach().index_select(0, perm), starts))
+            cached = (key, out)
+            self._unit_rows_cache = cached
+        return cached[1]
+
     # ---- fused-kernel support ----------------------------------------------------------------
 
     def _fusable_layout(self):
@@ -538,6 +567,7 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
             # same number from the same dot product, because the inputs a unit is connected to no longer change
             hbuf = [y2.new_zeros((y2.shape[0], m.weight.shape[0])) for m in mods[0:-1:2]]
             codes = [_act_code(a_) for a_ in mods[1::2]]
+            urows = lazy._sweep_unit_rows(y.device, self.passes) if y.dtype == mods[0].weight.dtype else None
         sweep_no = {}
         for s_, idx in lazy._sweep_features(y.device, self.passes):
             if units is None:
@@ -546,15 +576,18 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
                 h = x2 if c2 is None else torch.cat((x2, c2), dim=-1)
                 for l, lin in enumerate(mods[0:-1:2]):
                     # (sweeps without features were dropped by _sweep_features: their units join the next sweep that has some)
-                    todo = [units[l][t] for t in range(sweep_no.get(l, 0), s_ + 1) if units[l][t] is not None]
+                    first_t = sweep_no.get(l, 0)
+                    todo = [units[l][t] for t in range(first_t, s_ + 1) if units[l][t] is not None]
                     sweep_no[l] = s_ + 1
                     if todo:
                         u_ = todo[0] if len(todo) == 1 else torch.cat(todo)
-                        bias = None if lin.bias is None else lin.bias.index_select(0, u_)
-                        if codes[l] is not None:
-                            out = ops.linear(h, lin.weight.index_select(0, u_), bias, lin.mask.index_select(0, u_), codes[l])
+                        if urows is not None:  # the sweeps' rows are consecutive in the gathered copies: slices
+                            wr, mr, br, starts = urows[l]
+                            r0, r1 = starts[first_t], starts[s_ + 1]
+                            w_, m_, bias = wr[r0:r1], mr[r0:r1], None if br is None else br[r0:r1]
                         else:
-                            out = mods[2 * l + 1](ops.linear(h, lin.weight.index_select(0, u_), bias, lin.mask.index_select(0, u_)))
+                            w_, m_, bias = lin.weight.index_select(0, u_), lin.mask.index_select(0, u_), None if lin.bias is None else lin.bias.index_select(0, u_)
+                        out = ops.linear(h, w_, bias, m_, codes[l]) if codes[l] is not None else mods[2 * l + 1](ops.linear(h, w_, bias, m_))
                         hbuf[l].index_copy_(1, u_, out)
                     h = hbuf[l]
             if isinstance(idx, tuple):  # a run of consecutive features (the usual orders): row / column slices are views, no gather launches
