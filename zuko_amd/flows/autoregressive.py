@@ -549,61 +549,77 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         if lazy.order is None or grad or not mods or type(mods[-1]) is not MaskedLinear or not y.is_cuda or y.dtype not in (torch.float32, torch.float64) or os.environ.get("ZUKO_AMD_FULL_SWEEPS", "0") == "1":
             return super()._inverse(y)  # free-form adjacency / a graph for autograd / a residual conditioner: the loop as the reference writes it
         from .. import ops
-        from ..nn import apply_stack
 
-        D, total, last = lazy.features, lazy.total, mods[-1]
         if c is not None:
             yb, cb = broadcast(y, c, ignore=1)
         else:
             yb, cb = y, None
         batch = yb.shape[:-1]
-        y2 = yb.reshape(-1, D)
-        x2 = torch.zeros_like(y2)
+        y2 = yb.reshape(-1, lazy.features)
         c2 = None if cb is None else cb.reshape(-1, cb.shape[-1])
-        units = lazy._sweep_units(y.device, self.passes)
-        if units is not None:
-            # incremental form: a hidden unit is evaluated ONCE, in the sweep in which its inputs are all final (skinny GEMMs over gathered weight
-            # rows, written into persistent activation buffers) — the reference's loop re-evaluates every unit in every sweep and obtains the
-            # same number from the same dot product, because the inputs a unit is connected to no longer change
-            hbuf = [y2.new_zeros((y2.shape[0], m.weight.shape[0])) for m in mods[0:-1:2]]
-            codes = [_act_code(a_) for a_ in mods[1::2]]
-            urows = lazy._sweep_unit_rows(y.device, self.passes) if y.dtype == mods[0].weight.dtype else None
-        sweep_no = {}
-        for s_, idx in lazy._sweep_features(y.device, self.passes):
-            if units is None:
-                h = apply_stack(mods[:-1], x2 if c2 is None else torch.cat((x2, c2), dim=-1))
-            else:
-                h = x2 if c2 is None else torch.cat((x2, c2), dim=-1)
-                for l, lin in enumerate(mods[0:-1:2]):
-                    # (sweeps without features were dropped by _sweep_features: their units join the next sweep that has some)
-                    first_t = sweep_no.get(l, 0)
-                    todo = [units[l][t] for t in range(first_t, s_ + 1) if units[l][t] is not None]
-                    sweep_no[l] = s_ + 1
-                    if todo:
-                        u_ = todo[0] if len(todo) == 1 else torch.cat(todo)
-                        if urows is not None:  # the sweeps' rows are consecutive in the gathered copies: slices
-                            wr, mr, br, starts = urows[l]
-                            r0, r1 = starts[first_t], starts[s_ + 1]
-                            w_, m_, bias = wr[r0:r1], mr[r0:r1], None if br is None else br[r0:r1]
-                        else:
-                            w_, m_, bias = lin.weight.index_select(0, u_), lin.mask.index_select(0, u_), None if lin.bias is None else lin.bias.index_select(0, u_)
-                        out = ops.linear(h, w_, bias, m_, codes[l]) if codes[l] is not None else mods[2 * l + 1](ops.linear(h, w_, bias, m_))
-                        hbuf[l].index_copy_(1, u_, out)
-                    h = hbuf[l]
-            if isinstance(idx, tuple):  # a run of consecutive features (the usual orders): row / column slices are views, no gather launches
-                lo, hi = idx
-                rows, k = slice(lo * total, hi * total), hi - lo
-                w, b, m, ys = last.weight[rows], None if last.bias is None else last.bias[rows], last.mask[rows], y2[:, lo:hi]
-            else:
-                rows, k = (idx[:, None] * total + torch.arange(total, device=y.device)[None, :]).reshape(-1), idx.numel()
-                w, b, m, ys = last.weight.index_select(0, rows), None if last.bias is None else last.bias.index_select(0, rows), last.mask.index_select(0, rows), y2.index_select(1, idx)
-            phi = ops.linear(h, w, b, m)
-            u = lazy.univariate(*unpack(phi.unflatten(-1, (k, total)), lazy.shapes))
-            if isinstance(idx, tuple):
-                x2[:, idx[0] : idx[1]] = u.inv(ys)
-            else:
-                x2[:, idx] = u.inv(ys)
-        return x2.reshape(batch + (D,))
+
+        def linear(h, w, b, m, act_module):
+            code = None if act_module is None else _act_code(act_module)
+            if act_module is None or code is not None:
+                return ops.linear(h, w, b, m, code or 0)
+            return act_module(ops.linear(h, w, b, m))
+
+        x2 = wavefront_inverse(lazy, y2, c2, self.passes, linear, lambda phi, ys: lazy.univariate(*unpack(phi, lazy.shapes)).inv(ys))
+        return x2.reshape(batch + (lazy.features,))
+
+
+def wavefront_inverse(lazy: "MaskedAutoregressiveTransform", y2: Tensor, c2: Tensor | None, passes: int, linear, inverse_of) -> Tensor:
+    """The sweep loop of FusedAutoregressiveTransform._ordered_inverse on y2 [N, D] / c2 [N, C] | None; `linear(h, weight, bias, mask, activation
+    module | None)` evaluates act(h (mask * weight)^T + bias) and `inverse_of(phi [N, k, total], y [N, k])` inverts the univariate maps of k
+    features — the product passes the HIP kernels (ops.linear, the univariate transform's inv), tests/test_wavefront_inverse.py torch / oracle
+    stand-ins to check the schedule on the CPU against the reference's loop."""
+    from ..nn import apply_stack
+
+    mods = list(lazy.hyper)
+    D, total, last = lazy.features, lazy.total, mods[-1]
+    dev = y2.device
+    x2 = torch.zeros_like(y2)
+    units = lazy._sweep_units(dev, passes)
+    if units is not None:
+        # incremental form: a hidden unit is evaluated ONCE, in the sweep in which its inputs are all final (skinny GEMMs over gathered weight
+        # rows, written into persistent activation buffers) — the reference's loop re-evaluates every unit in every sweep and obtains the
+        # same number from the same dot product, because the inputs a unit is connected to no longer change
+        hbuf = [y2.new_zeros((y2.shape[0], m.weight.shape[0])) for m in mods[0:-1:2]]
+        urows = lazy._sweep_unit_rows(dev, passes) if y2.dtype == mods[0].weight.dtype else None
+    sweep_no = {}
+    for s_, idx in lazy._sweep_features(dev, passes):
+        if units is None:
+            h = apply_stack(mods[:-1], x2 if c2 is None else torch.cat((x2, c2), dim=-1))
+        else:
+            h = x2 if c2 is None else torch.cat((x2, c2), dim=-1)
+            for l, lin in enumerate(mods[0:-1:2]):
+                # (sweeps without features were dropped by _sweep_features: their units join the next sweep that has some)
+                first_t = sweep_no.get(l, 0)
+                todo = [units[l][t] for t in range(first_t, s_ + 1) if units[l][t] is not None]
+                sweep_no[l] = s_ + 1
+                if todo:
+                    u_ = todo[0] if len(todo) == 1 else torch.cat(todo)
+                    if urows is not None:  # the sweeps' rows are consecutive in the gathered copies: slices
+                        wr, mr, br, starts = urows[l]
+                        r0, r1 = starts[first_t], starts[s_ + 1]
+                        w_, m_, bias = wr[r0:r1], mr[r0:r1], None if br is None else br[r0:r1]
+                    else:
+                        w_, m_, bias = lin.weight.index_select(0, u_), lin.mask.index_select(0, u_), None if lin.bias is None else lin.bias.index_select(0, u_)
+                    hbuf[l].index_copy_(1, u_, linear(h, w_, bias, m_, mods[2 * l + 1]))
+                h = hbuf[l]
+        if isinstance(idx, tuple):  # a run of consecutive features (the usual orders): row / column slices are views, no gather launches
+            lo, hi = idx
+            rows, k = slice(lo * total, hi * total), hi - lo
+            w, b, m, ys = last.weight[rows], None if last.bias is None else last.bias[rows], last.mask[rows], y2[:, lo:hi]
+        else:
+            rows, k = (idx[:, None] * total + torch.arange(total, device=dev)[None, :]).reshape(-1), idx.numel()
+            w, b, m, ys = last.weight.index_select(0, rows), None if last.bias is None else last.bias.index_select(0, rows), last.mask.index_select(0, rows), y2.index_select(1, idx)
+        xs = inverse_of(linear(h, w, b, m, None).unflatten(-1, (k, total)), ys)
+        if isinstance(idx, tuple):
+            x2[:, idx[0] : idx[1]] = xs
+        else:
+            x2[:, idx] = xs
+    return x2
 
 
 class _FusedInverse(Transform):
