@@ -74,6 +74,9 @@ struct GsRing {
 
 template <int N> __device__ __forceinline__ void gs_settle(f32x4 (&a)[3]) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N)); }
 
+// an operand pair no block reads: "defined" without an instruction, so that its previous value does not stay live across the pass
+__device__ __forceinline__ void gs_undef(ArxB& b) { asm volatile("" : "=v"(b.h), "=v"(b.m), "=v"(b.l)); }
+
 extern __shared__ __attribute__((aligned(16))) float gs_lds[];
 
 // one masked layer with <= 256 inputs / outputs on the operand split: out = W in + bias, blocks skipped per (group of 4 out tiles, in pair)
@@ -134,6 +137,11 @@ template <typename Uni, bool XLDS, bool DIAG = false> __global__ __launch_bounds
 
   const float* bias_last = bias_lds + (a.L - 1) * 256;
   const int* skip_last = skip_lds + (a.L - 1) * 4;
+  // in-pairs the last layer multiplies at all (any group): the activations of the other pairs are never converted to operands.  (Narrow
+  // conditioners: a 128-wide layer fills 4 of the 8 pairs; converting all 8 after every layer cost as much as its matrix instructions.)
+  uint32_t need_last = 0;
+  for (int g = 0; g < a.NG; ++g) need_last |= (uint32_t)skip_last[g];
+  need_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)((need_last | (need_last >> 1)) & 0x5555u));
 
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n = tile * 128 + wave * 16 + j;
@@ -176,8 +184,12 @@ template <typename Uni, bool XLDS, bool DIAG = false> __global__ __launch_bounds
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
       }
+      uint32_t need0 = (uint32_t)(skip_lds[0] | skip_lds[1] | skip_lds[2] | skip_lds[3]);  // (the first layer's live in-pairs; n_layers >= 2)
+      need0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((need0 | (need0 >> 1)) & 0x5555u));
 #pragma unroll
-      for (int p = 0; p < AR_T / 2; ++p) arx_split(xin[2 * p], xin[2 * p + 1], in[p]);
+      for (int p = 0; p < AR_T / 2; ++p)
+        if (need0 & (1u << (2 * p))) arx_split(xin[2 * p], xin[2 * p + 1], in[p]);
+        else gs_undef(in[p]);
     }
 
     // ---- hidden layers -------------------------------------------------------------------------------------------------------------
@@ -186,6 +198,12 @@ template <typename Uni, bool XLDS, bool DIAG = false> __global__ __launch_bounds
 #pragma unroll
       for (int o = 0; o < 4; ++o) sk[o] = (uint32_t)__builtin_amdgcn_readfirstlane(skip_lds[l * 4 + o]);
       gs_hidden_layer(ring, sk, bias_lds + l * 256 + 4 * q, in, out);
+      uint32_t need = need_last;  // in-pairs the NEXT layer multiplies (wave-uniform)
+      if (l + 2 < a.L) {
+        const int* sn = skip_lds + (l + 1) * 4;
+        const uint32_t w = (uint32_t)(sn[0] | sn[1] | sn[2] | sn[3]);
+        need = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w | (w >> 1)) & 0x5555u));
+      }
       switch (a.act) {  // (wave-uniform: one switch around 64-element loops)
         case 1:
 #pragma unroll
@@ -199,13 +217,17 @@ template <typename Uni, bool XLDS, bool DIAG = false> __global__ __launch_bounds
           for (int rep = 0; rep < 1; ++rep) {
 #pragma unroll
             for (int t = 0; t < AR_T; ++t)
+              if (need & (1u << (2 * (t / 2)))) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) out[t][r] = act_f32(out[t][r], a.act);
+                for (int r = 0; r < 4; ++r) out[t][r] = act_f32(out[t][r], a.act);
+              }
           }
           break;
       }
 #pragma unroll
-      for (int p = 0; p < AR_T / 2; ++p) arx_split(out[2 * p], out[2 * p + 1], in[p]);
+      for (int p = 0; p < AR_T / 2; ++p)
+        if (need & (1u << (2 * p))) arx_split(out[2 * p], out[2 * p + 1], in[p]);
+        else gs_undef(in[p]);
     }
 
     // ---- last layer + univariate transform, one group of 4 * FPL features at a time ----------------------------------------------
