@@ -87,19 +87,33 @@ __device__ __forceinline__ void gs_hidden_layer(GsRing& ring, const uint32_t* __
     const uint32_t pairs = (bits | (bits >> 1)) & 0x5555u;  // bit 2 ip: in pair ip has a live tile
 #pragma unroll
     for (int t = 0; t < 4; ++t) out[otg * 4 + t] = *reinterpret_cast<const f32x4*>(bias_q + (otg * 4 + t) * 16);  // accumulators start at the bias
+    // (used here: the compiler's wait for these LDS loads — lgkmcnt(0), it cannot count the raw reads below — falls before the step's images are
+    //  requested instead of in front of the out-group's first matrix instruction, where it drained all twelve)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(out[otg * 4 + t]));
 #pragma unroll
     for (int ip = 0; ip < AR_T / 2; ++ip) {
       if (pairs & (1u << (2 * ip))) {
         f32x4 a[4][3];
         ring.read_blocks<4>(a);  // 12 images = half a chunk: never across a chunk boundary
+        // (scheduling fences: without them the compiler sinks all 24 matrix instructions below the LAST wait — the whole 12 KiB LDS round trip
+        //  exposed in front of every step, found in the ISA; the generated kernels fence their blocks the same way, ARX_FENCE)
         gs_settle<9>(a[0]);
+        __builtin_amdgcn_sched_barrier(0);
         arx_block(a[0], in[ip], out[otg * 4 + 0]);
+        __builtin_amdgcn_sched_barrier(0);
         gs_settle<6>(a[1]);
+        __builtin_amdgcn_sched_barrier(0);
         arx_block(a[1], in[ip], out[otg * 4 + 1]);
+        __builtin_amdgcn_sched_barrier(0);
         gs_settle<3>(a[2]);
+        __builtin_amdgcn_sched_barrier(0);
         arx_block(a[2], in[ip], out[otg * 4 + 2]);
+        __builtin_amdgcn_sched_barrier(0);
         gs_settle<0>(a[3]);
+        __builtin_amdgcn_sched_barrier(0);
         arx_block(a[3], in[ip], out[otg * 4 + 3]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // (pin the accumulators: otherwise the two sides of every skip branch may get different registers, reconciled by moves — fused_ar.hip)
@@ -248,6 +262,8 @@ template <typename Uni, bool XLDS, bool DIAG = false> __global__ __launch_bounds
         const float* bg = bias_last + (g * NT) * 16 + 4 * q;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(bg + t * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));  // (the compiler's LDS wait here, not in front of the first block's matrix instructions)
       }
 #pragma unroll
       for (int ip = 0; ip < AR_T / 2; ++ip) {
@@ -263,7 +279,9 @@ template <typename Uni, bool XLDS, bool DIAG = false> __global__ __launch_bounds
             } else {
               gs_settle<0>(w[t & 1][0]);
             }
+            __builtin_amdgcn_sched_barrier(0);
             arx_block(w[t & 1][0], in[ip], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
           });
         }
       }

@@ -94,9 +94,9 @@ def _build_so(stem: str, source, meta: dict | None, verbose: bool, out_dir: str 
         return have
     hipcc = _hipcc()
     if hipcc is None:
-        # (this used to be silent — the caller stays on the generic kernels: zk_ar_forward_split, correct but 1.1-1.7x slower)
+        # (this used to be silent — the caller stays on the generic kernels: zk_ar_forward_split, correct but 1.1-1.6x slower)
         _warn_once("nohipcc", f"no hipcc on this machine: the static-shape kernel {stem} cannot be compiled; this conditioner runs on the generic operand-split kernel "
-                              "(same results; 1.1-1.7x the generated kernel's time; conditioners wider than 256 run layer by layer).  Build it where a ROCm compiler is installed (zuko_amd.static_ar.prebuild, or one call at the "
+                              "(same results; 1.1-1.6x the generated kernel's time; conditioners wider than 256 run layer by layer).  Build it where a ROCm compiler is installed (zuko_amd.static_ar.prebuild, or one call at the "
                               "target batch size) and ship zuko_amd/lib/ars/ or ZUKO_AMD_CACHE_DIR with the package.")
         return None
     d = out_dir or _jit_dir()
