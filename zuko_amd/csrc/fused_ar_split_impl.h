@@ -75,6 +75,17 @@ __device__ __forceinline__ void arx_block(const f32x4 (&a)[3], const ArxB& b, f3
   ARX_MFMA(a[0], b.h, c);
 }
 
+// A bias tile read RAW (as the weight images are, fused_ar_static_impl.h): issued in front of the look-ahead block's images, it is older than them, so the
+// counted wait that settles the current block settles it too.  As a compiler-visible load its wait was lgkmcnt(0) — the compiler cannot count the raw reads —
+// in front of the tile's first matrix instruction: the look-ahead block drained with it, 64 exposed LDS round trips per pass of the headline conditioner
+// (found in the ISA, round 5).
+template <int OFF> __device__ __forceinline__ f32x4 arx_lds_raw(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ unsigned arx_lds_addr(const float* p) { return (unsigned)(size_t)((const __attribute__((address_space(3))) float*)p); }
+
 template <class S> struct ArxPat {
   static constexpr int ot(int l, int s) { return S::B_OT[S::BOFF[l] + s]; }
   static constexpr int ip(int l, int s) { return S::B_IP[S::BOFF[l] + s]; }
@@ -98,19 +109,23 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arx_hidden
     // -DARX_FENCE=0 drops the scheduling fences around a block's six matrix instructions; profiles/r05/headline.md)
     constexpr int LOOK = ARX_LOOK < NB ? ARX_LOOK : NB;
     f32x4 a[LOOK + 1][3];
+    const unsigned bias_addr = arx_lds_addr(bias_q);
     ars_for<LOOK>([&](auto b_) ARS_ALWAYS_INLINE {
       constexpr int b = b_;
       ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[b][p] = ring.template read<BASE + 3 * b + decltype(p)::value>(); });
     });
     ars_for<NB>([&](auto s_) ARS_ALWAYS_INLINE {
       constexpr int s = s_, ot = P::ot(L, s), ip = P::ip(L, s), cur = s % (LOOK + 1);
-      if constexpr (s == 0 || P::ot(L, s - 1) != ot) out[ot] = *reinterpret_cast<const f32x4*>(bias_q + ot * 16);  // accumulators start at the bias
+      constexpr bool first_of_tile = (s == 0 || P::ot(L, s - 1) != ot);
+      if constexpr (first_of_tile) out[ot] = arx_lds_raw<ot * 64>(bias_addr);  // accumulators start at the bias (raw read: see arx_lds_raw)
       if constexpr (s + LOOK < NB) {
         constexpr int nx = (s + LOOK) % (LOOK + 1);
         ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { a[nx][p] = ring.template read<BASE + 3 * (s + LOOK) + decltype(p)::value>(); });
       }
       constexpr int ahead = (s + LOOK < NB ? LOOK : NB - 1 - s);  // blocks behind this one whose images may still be outstanding
-      ars_settle<3 * ahead>(a[cur][0], a[cur][1], a[cur][2]);
+      // (with the tile's bias: only the images requested in THIS step are younger than it — equal to 3 * ahead at the default look-ahead of one block)
+      if constexpr (first_of_tile) ars_settle<(s + LOOK < NB ? 3 : 0)>(a[cur][0], a[cur][1], a[cur][2], out[ot]);
+      else ars_settle<3 * ahead>(a[cur][0], a[cur][1], a[cur][2]);
       if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
       arx_block(a[cur], in[ip], out[ot]);
       if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
@@ -188,6 +203,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
   for (int i = tid; i < NG * 4 * FPL; i += 64 * WAVES) fmap_lds[i] = a.featmap[i];
   __syncthreads();
   const float* bias_last = bias_lds + S::NH * S::BIAS_STRIDE;
+  const unsigned bias_last_addr = arx_lds_addr(bias_last + 4 * q);
   int fids[FID_REGS ? NG * FPL : 1];
   if constexpr (FID_REGS) {
 #pragma unroll
@@ -259,8 +275,10 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
         if constexpr (XLDS) xin[fi] = xr[fc];
         else xin[fi] = xrow[fc];
       }
-      f32x4 acc[NT];  // the accumulators start at the bias
-      {
+      f32x4 acc[NT];  // the accumulators start at the bias (raw reads, older than every image requested below: the first block's wait settles them all)
+      if constexpr (GN > 0) {
+        ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE { acc[t] = arx_lds_raw<(g * NT + decltype(t)::value) * 64>(bias_last_addr); });
+      } else {
         const float* bg = bias_last + (g * NT) * 16 + 4 * q;
         ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE { acc[t] = *reinterpret_cast<const f32x4*>(bg + t * 16); });
       }
@@ -273,7 +291,10 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
             ars_for<3>([&](auto p) ARS_ALWAYS_INLINE { w[nx][p] = ring.template read<S::LAST_BASE + 3 * (blk + LOOKL) + decltype(p)::value>(); });
           }
           constexpr int ahead = (blk + LOOKL < NBL ? LOOKL : NBL - 1 - blk);
-          ars_settle<3 * ahead>(w[cur][0], w[cur][1], w[cur][2]);
+          // (the group's first blocks: their accumulator's bias with them; at the very first only this step's request is younger than the bias reads)
+          if constexpr (decltype(i_)::value == 0 && t == 0) ars_settle<(blk + LOOKL < NBL ? 3 : 0)>(w[cur][0], w[cur][1], w[cur][2], acc[t]);
+          else if constexpr (decltype(i_)::value == 0) ars_settle<3 * ahead>(w[cur][0], w[cur][1], w[cur][2], acc[t]);
+          else ars_settle<3 * ahead>(w[cur][0], w[cur][1], w[cur][2]);
           if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
           arx_block(w[cur], in[ip], acc[t]);
           if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
