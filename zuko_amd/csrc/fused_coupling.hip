@@ -616,6 +616,16 @@ template <int N> __device__ __forceinline__ void cp_settle12(f32x4c (&a)[12]) {
 template <int N> __device__ __forceinline__ void cp_settle6(f32x4c (&a)[6]) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]) : "n"(N));
 }
+// the step's images together with the four bias tiles of an out-group's first step (read raw in front of the look-ahead images: see cp_layer_split)
+template <int N> __device__ __forceinline__ void cp_settle12o(f32x4c (&a)[12], f32x4c& o0, f32x4c& o1, f32x4c& o2, f32x4c& o3) {
+  asm volatile("s_waitcnt lgkmcnt(%16)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]),
+               "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) : "n"(N));
+}
+template <int OFF> __device__ __forceinline__ f32x4c cp_lds_raw(unsigned addr) {
+  f32x4c v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
 #define CP_XMFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cbf16x8, A), B, C, 0, 0, 0)
 
 // one dense layer: out[ot] = bias + sum_ip W[ot, ip] in[ip]; NP in pairs, HT out tiles
@@ -623,16 +633,22 @@ template <int NP, int HT> __device__ __forceinline__ void cp_layer_split(CpRingS
   constexpr int STEPS = (HT / 4) * NP;
   f32x4c a[2][12];  // images (t, part) of the step: a[.][3 t + part], part 0 = h, 1 = m, 2 = l
   cp_for<12>([&](auto i) CP_ALWAYS_INLINE { a[0][i] = ring.template read<decltype(i)::value>(); });
+  // The out-group's accumulators start at the bias, read RAW in front of the next step's images: older than those twelve, the counted wait of the
+  // step settles them too.  (As compiler-visible loads their wait was lgkmcnt(0) — the compiler cannot count the raw reads — in front of the group's
+  // first matrix instruction: the twelve look-ahead images drained with it, once per out-group, with no second wavefront on the SIMD to hide it.)
+  const unsigned bias_addr = (unsigned)(size_t)((const __attribute__((address_space(3))) float*)bias_q);
   cp_for<STEPS>([&](auto st_) CP_ALWAYS_INLINE {
     constexpr int st = st_, otg = st / NP, ip = st % NP;
     if constexpr (ip == 0) {
-      cp_for<4>([&](auto t) CP_ALWAYS_INLINE { out[otg * 4 + t] = *reinterpret_cast<const f32x4c*>(bias_q + (otg * 4 + t) * 16); });
+      cp_for<4>([&](auto t) CP_ALWAYS_INLINE { out[otg * 4 + t] = cp_lds_raw<(otg * 4 + decltype(t)::value) * 64>(bias_addr); });
     }
     if constexpr (st + 1 < STEPS) {
       cp_for<12>([&](auto i) CP_ALWAYS_INLINE { a[(st + 1) & 1][i] = ring.template read<(st + 1) * 12 + decltype(i)::value>(); });
-      cp_settle12<12>(a[st & 1]);
+      if constexpr (ip == 0) cp_settle12o<12>(a[st & 1], out[otg * 4 + 0], out[otg * 4 + 1], out[otg * 4 + 2], out[otg * 4 + 3]);
+      else cp_settle12<12>(a[st & 1]);
     } else {
-      cp_settle12<0>(a[st & 1]);
+      if constexpr (ip == 0) cp_settle12o<0>(a[st & 1], out[otg * 4 + 0], out[otg * 4 + 1], out[otg * 4 + 2], out[otg * 4 + 3]);
+      else cp_settle12<0>(a[st & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
     const cbf16x8 bh = in.h(ip), bm = in.m(ip), bl = in.l(ip);
