@@ -602,3 +602,34 @@ def test_generic_split_kernel_is_not_offered_where_it_does_not_exist():
     lay = fused.uni_layout("rqs", 23, 8)
     assert fused.gsplit_gather(fused.build_plan(masks, 8, lay)) is not None
     assert fused.gsplit_gather(fused.build_plan(masks, 8, lay, align_groups=True)) is None  # (the wavefront inverse's plans: f32 kernel)
+
+
+def test_generic_split_kernel_selection(monkeypatch):
+    """Which kernel FusedAR.run() launches (host logic, no GPU): the generic operand-split kernel exactly when no generated kernel is held, unless
+    ZUKO_AMD_GSPLIT=0 / ZUKO_AMD_EXACT_F32=1 keep the f32 matrix instruction; `force` prefers it even beside a generated kernel; its stream is sized
+    in whole chunks of 8 blocks of three 1 KiB images."""
+    from zuko_amd import fused
+    from zuko_amd.flows import NSF
+
+    monkeypatch.setenv("ZUKO_AMD_JIT", "0")
+    monkeypatch.delenv("ZUKO_AMD_GSPLIT", raising=False)
+    monkeypatch.delenv("ZUKO_AMD_EXACT_F32", raising=False)
+    cpu = torch.device("cpu")
+    st = NSF(12, 3, transforms=1, hidden_features=[88, 120]).transform.transforms[0].fused_state(cpu)  # (not a prebuilt shape)
+    assert st is not None and st.static is None and st.generic_ok
+    gs = st._gsplit()
+    assert gs is not None
+    gathers, offsets, n_chunks, stream = gs
+    assert stream.numel() == n_chunks * fused.GS_BLOCKS_PER_CHUNK * 768 and sum(g.numel() for g in gathers) == n_chunks * fused.GS_BLOCKS_PER_CHUNK * 512
+    assert offsets == [768 * sum(g.numel() // 512 for g in gathers[:l]) for l in range(len(gathers))]
+    st.gs_mode = "0"
+    assert st._gsplit() is None
+    st.gs_mode = "1"
+    monkeypatch.setenv("ZUKO_AMD_EXACT_F32", "1")
+    assert st._gsplit() is None
+    monkeypatch.delenv("ZUKO_AMD_EXACT_F32")
+    st2 = NSF(64, 0, transforms=1, hidden_features=[256] * 3).transform.transforms[0].fused_state(cpu)  # the headline conditioner: prebuilt
+    if st2.static is not None:
+        assert st2._gsplit() is None
+        st2.gs_mode = "force"
+        assert st2._gsplit() is not None
