@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-side-configs", action="store_true",
                     help="default cfg2 run at N=1: do not append the cfg3 / cfg4 / cfg5 side measurements (each a short run of this script in a process of its own)")
     ap.add_argument("--side-steps", type=int, default=0, help="timed steps of every side configuration (0 = a per-config default)")
+    ap.add_argument("--full-line", action="store_true", help="print the full detail object as the line (what the side-config children of a default run do); "
+                                                                 "default: the compact headline line (<= 8 KB) on stdout and the full object in gpurun_out/bench_detail.json")
     ap.add_argument("--side-paths", action="store_true", help="print the training / sampling report of the cfg2 and cfg3 flows (the `side_paths` object of the default line) and exit")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
                     help="cfg2 = the headline NSF workload (default, the only graded line); cfg3 = MAF(64,T=8,H=256x3); "
@@ -182,6 +184,28 @@ def init_ranks(args):
 # --------------------------------------------------------------------------------------------------
 
 
+REFERENCE_ROOT = "/root/reference"  # exists in the build container only; never on the GPU box
+
+
+def _reference_flow(flow_cpu):
+    """zuko.flows.NSF from the reference checkout with this run's weights, or None when there is no checkout (the GPU box) or it does not import.
+    Baseline leg only: nothing else in this file touches the reference."""
+    if os.environ.get("ZUKO_BENCH_NO_REFERENCE") == "1" or not os.path.isdir(os.path.join(REFERENCE_ROOT, "zuko")):
+        return None
+    try:
+        sys.path.append(REFERENCE_ROOT)
+        import zuko  # noqa: F401
+
+        ref = zuko.flows.NSF(features=FEATURES, context=0, transforms=TRANSFORMS, bins=BINS, hidden_features=HIDDEN)
+        ref.load_state_dict(flow_cpu.state_dict())
+        return ref
+    except Exception:
+        return None
+    finally:
+        if REFERENCE_ROOT in sys.path:
+            sys.path.remove(REFERENCE_ROOT)
+
+
 def cpu_baseline(flow_cpu, seconds: float):
     """The oracle (a restatement of the reference on PyTorch-CPU ops, bitwise equal to it in the build container:
     tests/golden/make_golden.py) timed on this host on chunks of 2^12, 2^14 and 2^16 rows of the same workload (SURVEY
@@ -199,11 +223,18 @@ def cpu_baseline(flow_cpu, seconds: float):
     xall = torch.randn(chunks[-1], FEATURES, generator=torch.Generator().manual_seed(1))
     keep = {}
 
+    ref_flow = _reference_flow(flow_cpu)  # the reference itself when its checkout is mounted (the build container); the pinned port on the GPU box
+
     def once(n: int) -> float:
         x = xall[:n]
         t0 = time.perf_counter()
-        z, ladj = O.flow_forward(spec, x)  # (= the body of O.flow_log_prob: zuko/distributions.py:115-119)
-        lp = O.diag_normal_log_prob(z, spec.loc, spec.scale) + ladj
+        if ref_flow is not None:  # the body of zuko.distributions.NormalizingFlow.log_prob (zuko/distributions.py:115-119), z and ladj kept for the parity block
+            d = ref_flow()
+            z, ladj = d.transform.call_and_ladj(x)
+            lp = d.base.log_prob(z) + ladj
+        else:
+            z, ladj = O.flow_forward(spec, x)  # (= the body of O.flow_log_prob: the same lines restated)
+            lp = O.diag_normal_log_prob(z, spec.loc, spec.scale) + ladj
         dt = time.perf_counter() - t0
         keep[n] = (z, ladj, lp)
         return dt
@@ -248,7 +279,8 @@ def cpu_baseline(flow_cpu, seconds: float):
         "unit": "samples/s",
         "cores": threads,
         "host_cpus": ncpu,
-        "kind": "port",
+        "kind": "reference" if ref_flow is not None else "port",
+        "kind_note": "zuko imported from the mounted reference checkout" if ref_flow is not None else "no reference checkout on this host: the oracle port (oracle/zuko_oracle.py)",
         "pinned_bitwise": True,  # the port equals the live reference bit for bit (fixtures regenerated by tests/golden/make_golden.py)
         "thread_sweep_samples_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
         "chunk_sweep_samples_per_s": {f"2^{n.bit_length() - 1}": round(r, 1) for n, r in rates.items()},
@@ -565,7 +597,7 @@ def run_side_configs(args) -> dict:
     for cfg, (blog, warm, steps) in SIDE_RUNS.items():
         steps = args.side_steps or steps
         cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--gpus", "1", "--batch-log2", str(blog), "--warmup", str(warm), "--steps", str(steps),
-               "--no-bin-report", "--no-side-configs"]
+               "--no-bin-report", "--no-side-configs", "--full-line"]
         t0 = time.perf_counter()
         try:
             env = dict(os.environ)
@@ -892,6 +924,123 @@ def model_flops(flow) -> dict:
     return {"dense": dense, "nnz": nnz}
 
 
+# --------------------------------------------------------------------------------------------------
+# the printed line: a compact view (<= LINE_BUDGET bytes) of the full object, which goes to a file
+# --------------------------------------------------------------------------------------------------
+
+LINE_BUDGET = 8192  # bytes: round 5's 20 KB line was not picked up by the driver (BENCH_r05.json "parsed": null)
+DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")  # relative to the repo root; copied to profiles/rNN/ by the round scripts
+
+
+def _sig(v, digits: int = 6):
+    """Floats to `digits` significant digits, recursively (the line is for reading and parsing, the detail file keeps everything)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    return v
+
+
+def _pick(d, *keys):
+    d = d or {}
+    return {k: d[k] for k in keys if d.get(k) is not None}
+
+
+def write_detail(out: dict):
+    """The full object (per-kernel table, sweeps, float64 comparisons, wall-clock split, every side entry in full) as a file."""
+    path = os.path.join(ROOT, DETAIL_PATH)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        return DETAIL_PATH
+    except OSError as exc:  # read-only checkout: the line still prints
+        return f"not written: {exc!r}"[:120]
+
+
+def headline_line(out: dict) -> dict:
+    """What bench.py prints: the contract's keys, `roofline`, `cpu_baseline`, the in-run parity verdicts and ONE compact entry per side
+    configuration / side path.  Everything else lives in the detail file.  Guaranteed to serialise to <= LINE_BUDGET bytes: optional
+    groups are dropped, least important first, should a run ever exceed it (tests/test_bench_line.py)."""
+    line = _pick(out, "metric", "value", "unit", "n_gpus", "rccl_world_size", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling")
+    line["vs_baseline"] = out.get("vs_baseline")
+    line.update(_pick(out, "dtype", "data"))
+    if out.get("dtype_note"):
+        line["dtype_note"] = "f32 in/out/accumulate; products as 3-way bf16 operand splits on the bf16 matrix instruction (f32 dot-product rounding: see parity)"
+    line["config"] = _pick(out.get("config"), "workload", "batch_per_gpu", "global_batch", "parallelism")
+    roof = out.get("roofline")
+    line["roofline"] = None if roof is None else {
+        **_pick(roof, "bound", "achieved", "peak", "unit", "frac"), "traffic": roof.get("traffic"),
+        **_pick(roof, "kernel", "avg_launch_ms", "algorithmic_flop_per_launch", "executed_flop_per_launch", "frac_executed", "peak_basis", "f32_instruction_peak", "traffic_source")}
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = _pick(out["cpu_baseline"], "value", "unit", "cores", "kind", "sample", "median_samples_per_s", "host_cpus", "cpu_model", "pinned_bitwise")
+        line.update(_pick(out, "speedup_vs_cpu_baseline"))
+    if out.get("parity"):
+        line["parity"] = _pick(out["parity"], "ok", "rows", "log_prob_max_rel", "z_max_abs", "ladj_max_abs", "error")
+        line["parity"]["bar"] = "log_prob max rel <= 1e-5 vs the oracle, fp32"
+    if out.get("bin_index"):
+        line["bin_index"] = _pick(out["bin_index"], "elements", "mismatch_vs_own_knots", "flips_vs_oracle_sample", "oracle_sample_elements", "error")
+    if out.get("gpu_aten_baseline"):
+        line["gpu_aten_baseline"] = _pick(out["gpu_aten_baseline"], "value", "unit", "error")
+        line.update(_pick(out, "speedup_vs_gpu_aten"))
+    line.update(_pick(out, "nll", "per_rank_ms_per_step", "rank0_alone_before_group", "weak_scaling_efficiency"))
+    if out.get("cpu_affinity"):
+        line["cpu_affinity"] = _pick(out["cpu_affinity"], "bound", "source", "cpus", "numa_node")
+    side = {}
+    for cfg, e in (out.get("side_configs") or {}).items():
+        if "error" in e:
+            side[cfg] = {"error": str(e["error"])[:120]}
+            continue
+        r, p = e.get("roofline") or {}, e.get("parity") or {}
+        side[cfg] = {**_pick(e, "value", "ms_per_step", "batch_per_gpu", "dtype"), **_pick(r, "frac", "kernel", "avg_launch_ms"),
+                     "parity_ok": p.get("ok"), **({"parity_rows": p["rows"]} if p.get("rows") else {})}
+    if side:
+        line["side_configs"] = side
+    paths = {}
+    for name, e in (out.get("side_paths") or {}).items():
+        if not isinstance(e, dict):
+            continue
+        if "error" in e:
+            paths[name] = {"error": str(e["error"])[:120]}
+            continue
+        c = {}
+        tr, sa, lp = e.get("training"), e.get("sampling"), e.get("log_prob")
+        if tr:
+            c["train"] = {**_pick(tr, "ms_per_step", "samples_per_s", "one_autograd_node_per_transform"), "ok": (tr.get("parity") or {}).get("ok")}
+        if sa:
+            c["sample"] = {**_pick(sa, "samples_per_s", "ms", "batch_log2", "ok", "bitwise_equal_to_reference_loop")}
+        if lp:
+            c["log_prob"] = {**_pick(lp, "samples_per_s", "ms"), "ok": (lp.get("parity") or {}).get("ok")}
+        if e.get("log_prob_batch_4096"):
+            b = e["log_prob_batch_4096"]
+            c["log_prob_4096"] = {**_pick(b, "ms"), **{"graph_" + k: v for k, v in _pick(b.get("hip_graph_replay"), "ms", "bitwise_equal_to_eager").items()},
+                                  **{"one_launch_" + k: v for k, v in _pick(b.get("one_launch"), "ms", "bitwise_equal_to_eager").items()}}
+        for k in ("generated_split_kernels", "generic_split_kernel", "generic_f32_kernel"):
+            if isinstance(e.get(k), dict):
+                c[k + "_ms"] = e[k].get("ms")
+        c.update(_pick(e, "generic_split_bitwise_equal_to_generated"))
+        paths[name] = c
+    if paths:
+        line["side_paths"] = paths
+    if out.get("wall_s"):
+        line["wall_s"] = _pick(out["wall_s"], "total")
+    line["detail"] = out.get("detail")
+    line = _sig(line)
+    # the guard: never print more than the budget
+    for drop in ("cpu_affinity", "gpu_aten_baseline", "side_paths", "side_configs", "dtype_note", "bin_index", "per_rank_ms_per_step"):
+        if len(json.dumps(line)) <= LINE_BUDGET - 256:
+            break
+        if drop in line:
+            line[drop] = {"dropped": "line budget", "see": out.get("detail")}
+    return line
+
+
 def main() -> None:
     args = parse()
     if args.side_paths:
@@ -1169,7 +1318,12 @@ def main() -> None:
             lap("side_paths")
         wall["total"] = round(time.perf_counter() - T_START, 1)
         out["wall_s"] = wall
-        print(json.dumps(out))
+        if args.full_line:
+            print(json.dumps(out))
+        else:
+            out["detail"] = write_detail(out)
+            sys.stdout.flush()
+            print(json.dumps(headline_line(out)), flush=True)  # the LAST stdout line, <= LINE_BUDGET bytes
     if dist is not None:
         dist.destroy_process_group()
 

@@ -217,6 +217,26 @@ def test_sampling_paths(dev, name):
         assert_parity(lp, O.flow_log_prob(spec, xs.cpu(), c), O.flow_log_prob(spec64, d64(xs), d64(c)), f"{name}: rsample_and_log_prob")
 
 
+def test_inverse_with_a_per_unit_activation(dev):
+    """MAF(6, hidden=[40], activation=lambda: nn.PReLU(40)) — a flow the reference supports (one slope per hidden unit): the inverse must not
+    apply the activation to a subset of units (round-5 advisor finding: it raised inside wavefront_inverse); round trip and log_prob hold."""
+    import zuko_amd.flows as F
+
+    torch.manual_seed(0)
+    flow = F.MAF(6, 0, transforms=2, hidden_features=[40], activation=lambda: torch.nn.PReLU(40)).to(dev)
+    with torch.no_grad():
+        for m in flow.modules():
+            if isinstance(m, torch.nn.PReLU):
+                m.weight.uniform_(0.05, 0.9)
+        x = torch.randn(257, 6, device=dev)
+        t = flow().transform
+        z, ladj = t.call_and_ladj(x)
+        xr = t.inv(z)
+        assert (xr - x).abs().max().item() < 1e-4
+        xi, li = t.inv.call_and_ladj(z)
+        assert (xi - x).abs().max().item() < 1e-4 and (li + ladj).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("kind,kw", [("nsf", dict(features=8, context=2, transforms=2, bins=4, hidden_features=[48, 48])),
                                       ("nsf", dict(features=16, context=0, transforms=2, bins=16, hidden_features=[64, 64])),
                                       ("ncsf", dict(features=8, context=3, transforms=2, hidden_features=[40, 40]))])

@@ -110,3 +110,43 @@ def test_every_hidden_unit_is_scheduled_at_most_once_and_before_its_readers():
         for f in range(lazy.features):
             ins = last.mask[f * lazy.total : (f + 1) * lazy.total].any(dim=0).nonzero().squeeze(-1)
             assert ins.numel() == 0 or int(ready[ins].max()) <= int(order[f])
+
+
+def test_stateful_or_unknown_activations_do_not_take_the_per_unit_sweeps():
+    """The per-sweep schedule applies an activation to a subset of a layer's units: only elementwise, state-free modules qualify.  nn.PReLU(H)
+    (one slope per unit), a subclass of a known activation, or a module the list does not know must fall to the whole-layer form (round-5 advisor finding:
+    MAF(6, hidden=[40], activation=lambda: nn.PReLU(40)) raised inside wavefront_inverse) — and there the schedule equals the reference's loop."""
+    import torch.nn as nn
+
+    import zuko_amd.flows as F
+    from zuko_amd.flows.autoregressive import wavefront_inverse
+
+    class MyTanh(nn.Tanh):
+        pass
+
+    torch.manual_seed(3)
+    for act in (lambda: nn.PReLU(40), MyTanh, lambda: nn.Threshold(0.1, 0.0)):  # (unit-mixing modules — LayerNorm, Softmax — are not autoregressive conditioners at all)
+        flow = F.MAF(6, 0, transforms=1, hidden_features=[40], activation=act).double()
+        lazy = flow.transform.transforms[0]
+        assert lazy._sweep_units(torch.device("cpu"), lazy.passes) is None
+        assert lazy._sweep_unit_rows(torch.device("cpu"), lazy.passes) is None
+        mods = list(lazy.hyper)
+        y = torch.randn(11, 6, dtype=torch.float64)
+
+        def linear(h, w, b, m, a):
+            out = Fn.linear(h, w * m, b)
+            return out if a is None else a(out)
+
+        inverse_of = lambda phi, ys: O.univariate_inverse(O.UNI_AFFINE, phi, ys)
+        with torch.no_grad():
+            whole = lambda ms, h: linear(h, ms[0].weight, ms[0].bias, ms[0].mask, ms[1])
+            x_w = wavefront_inverse(lazy, y, None, lazy.passes, linear, inverse_of, stack=whole)
+            x_r = torch.zeros_like(y)
+            for _ in range(lazy.passes):
+                h = linear(x_r, mods[0].weight, mods[0].bias, mods[0].mask, mods[1])
+                phi = linear(h, mods[2].weight, mods[2].bias, mods[2].mask, None).unflatten(-1, (6, lazy.total))
+                x_r = inverse_of(phi, y)
+        assert (x_w - x_r).abs().max().item() <= 1e-12
+    for act in (nn.ReLU, nn.ELU, nn.Softplus, nn.SiLU):
+        lazy = F.MAF(6, 0, transforms=1, hidden_features=[40], activation=act).transform.transforms[0]
+        assert lazy._sweep_units(torch.device("cpu"), lazy.passes) is not None

@@ -59,6 +59,15 @@ def dag_diameter(adjacency: BoolTensor) -> int:
     return generations
 
 
+_ELEMENTWISE = (nn.ReLU, nn.ReLU6, nn.Tanh, nn.Sigmoid, nn.ELU, nn.CELU, nn.SELU, nn.SiLU, nn.GELU, nn.LeakyReLU, nn.Softplus, nn.Softsign, nn.Hardtanh,
+                nn.Hardswish, nn.Hardsigmoid, nn.Mish, nn.Tanhshrink, nn.LogSigmoid, nn.Identity)
+
+
+def _elementwise_stateless(m: nn.Module) -> bool:
+    """True for activations that map every element on its own and hold no parameters or buffers (exact types: a subclass may do anything)."""
+    return type(m) in _ELEMENTWISE and next(m.parameters(), None) is None and next(m.buffers(), None) is None
+
+
 class MaskedAutoregressiveTransform(LazyTransform):
     r"""Lazy masked autoregressive transformation.
 
@@ -170,6 +179,10 @@ class MaskedAutoregressiveTransform(LazyTransform):
         lins = mods[0::2]
         if not mods or len(mods) % 2 == 0 or any(type(m) is not MaskedLinear for m in lins) or any(isinstance(m, (nn.Linear, MaskedLinear)) for m in mods[1::2]):
             return None
+        # the sweeps apply the activation to a SUBSET of a layer's units: only modules known to act element by element, without per-unit
+        # state, may take that path (nn.PReLU(H), a normalisation layer, Softmax ... fall to the whole-layer wavefront form)
+        if any(not _elementwise_stateless(m) for m in mods[1::2]):
+            return None
         key = (str(device), passes, self.order._version, self.order.data_ptr()) + tuple((l.mask._version, l.mask.data_ptr()) for l in lins)
         cached = getattr(self, "_unit_cache", None)
         if cached is None or cached[0] != key:
@@ -196,7 +209,7 @@ class MaskedAutoregressiveTransform(LazyTransform):
         if units is None:
             return None
         lins = list(self.hyper)[0:-1:2]
-        key = (str(device), passes, id(units), _param_stamp(lins))
+        key = (str(device), passes, self._unit_cache[0], _param_stamp(lins))  # (the unit table's own key: an id() can be reused by a rebuilt table)
         cached = getattr(self, "_unit_rows_cache", None)
         if cached is None or cached[0] != key:
             out = []
@@ -568,12 +581,15 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         return x2.reshape(batch + (lazy.features,))
 
 
-def wavefront_inverse(lazy: "MaskedAutoregressiveTransform", y2: Tensor, c2: Tensor | None, passes: int, linear, inverse_of) -> Tensor:
+def wavefront_inverse(lazy: "MaskedAutoregressiveTransform", y2: Tensor, c2: Tensor | None, passes: int, linear, inverse_of, stack=None) -> Tensor:
     """The sweep loop of FusedAutoregressiveTransform._ordered_inverse on y2 [N, D] / c2 [N, C] | None; `linear(h, weight, bias, mask, activation
     module | None)` evaluates act(h (mask * weight)^T + bias) and `inverse_of(phi [N, k, total], y [N, k])` inverts the univariate maps of k
     features — the product passes the HIP kernels (ops.linear, the univariate transform's inv), tests/test_wavefront_inverse.py torch / oracle
-    stand-ins to check the schedule on the CPU against the reference's loop."""
+    stand-ins to check the schedule on the CPU against the reference's loop.  `stack(modules, h)` evaluates the hidden layers as a whole when
+    the conditioner has no per-unit schedule (default: nn.apply_stack, the HIP layer kernels)."""
     from ..nn import apply_stack
+
+    stack = apply_stack if stack is None else stack
 
     mods = list(lazy.hyper)
     D, total, last = lazy.features, lazy.total, mods[-1]
@@ -589,7 +605,7 @@ def wavefront_inverse(lazy: "MaskedAutoregressiveTransform", y2: Tensor, c2: Ten
     sweep_no = {}
     for s_, idx in lazy._sweep_features(dev, passes):
         if units is None:
-            h = apply_stack(mods[:-1], x2 if c2 is None else torch.cat((x2, c2), dim=-1))
+            h = stack(mods[:-1], x2 if c2 is None else torch.cat((x2, c2), dim=-1))
         else:
             h = x2 if c2 is None else torch.cat((x2, c2), dim=-1)
             for l, lin in enumerate(mods[0:-1:2]):
