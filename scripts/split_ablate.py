@@ -25,6 +25,10 @@ def plan():
 def build():
     pa, lay = plan()
     t, _ = sa.split_tables(pa, lay.kind, 1)
+    t = dict(t)
+    for kv in filter(None, os.environ.get("ABL_SHAPE", "").split(",")):  # probe builds: ABL_SHAPE="NR=2,LAG=2,XLDS=0" overrides entries of the generated shape
+        k, v = kv.split("=")
+        t[k] = int(v)
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(OUT, "arx_cfg2.hip")
     with open(src, "w") as f:
@@ -59,6 +63,8 @@ def run():
     y, ladj = torch.empty(N, 64, device=dev), torch.empty(N, device=dev)
     p = st.plan
     only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+    with torch.no_grad():  # the product kernel's result on the same rows: what variant 0 of a probe build has to reproduce bit for bit
+        y_ref, l_ref = flow.transform.transforms[0]().call_and_ladj(x)
     for k, name in NAMES.items():
         so = os.path.join(OUT, f"arx_abl{k}.so")
         if not os.path.exists(so) or (only is not None and k not in only):
@@ -78,7 +84,8 @@ def run():
             fn()
         e1.record()
         torch.cuda.synchronize()
-        print(f"ARX_ABL={k} {name:34s} {e0.elapsed_time(e1) / 10:7.3f} ms per launch (2^{lb} rows)", flush=True)
+        same = "" if k else f"  bitwise == product kernel: y {torch.equal(y, y_ref)} ladj {torch.equal(ladj, l_ref)}  max|dy| {(y - y_ref).abs().max().item():.2e}"
+        print(f"ARX_ABL={k} {name:34s} {e0.elapsed_time(e1) / 10:7.3f} ms per launch (2^{lb} rows){same}", flush=True)
 
 
 if __name__ == "__main__":
