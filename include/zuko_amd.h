@@ -229,6 +229,10 @@ typedef struct zk_ar_args_v1 {
   const double* gl_nodes01;   /* uni_kind 5: HOST arrays of the 5 Gauss-Legendre nodes / weights on [0, 1] (zuko/utils.py:328-347), as zk_sos_forward takes them */
   const double* gl_weights01;
   double eps;              /* uni_kind 6: continuation margin of the Bernstein map (zuko/transforms.py:594; 0 = its default 1e-6) */
+  double wdescale0;        /* zk_ar_forward_static with a TWO-PART (f16) operand-split kernel: for linear layer 0 .. 3, 2^-e = the inverse of the power */
+  double wdescale1;        /* of two zk_gather_split_f16 stored that layer's weights with (0 = not given: such a kernel declines the launch) */
+  double wdescale2;
+  double wdescale3;
 } zk_ar_args_v1;
 
 /* y, ladj of one layer on the generic tile-skipping kernel.  Reads: uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream,
@@ -412,6 +416,10 @@ int zk_gather_f32(const void* src, const uint8_t* mask, const int32_t* idx, int6
  * weight as three bf16 numbers h + m + l.  idx [n_blocks * 512] int32 (lane-major, 8 per lane, -1 = zero) into src, mask as
  * zk_gather_f32; dst receives three 1 KiB images per block. */
 int zk_gather_split_bf16(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n_blocks, void* dst, void* stream);
+/* Weight stream of a TWO-PART operand-split kernel (csrc/fused_ar_half_impl.h): as zk_gather_split_bf16, but every weight is first multiplied by
+ * `scale` (a power of two chosen by the caller so that the layer's largest magnitude lands in [2^14, 2^15): exact) and written as TWO f16
+ * images h = f16(w scale), l = f16(w scale - h) — 2 KiB per block.  The kernel is told 1 / scale through zk_ar_args_v1.wdescale. */
+int zk_gather_split_f16(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n_blocks, void* dst, double scale, void* stream);
 /* Up to eight of the two gathers above in ONE launch (the streams and bias images of a conditioner are a dozen tiny gathers; training
  * re-gathers them every step).  split != 0: zk_gather_split_bf16 with count = blocks; else zk_gather_f32 with count = elements. */
 typedef struct zk_gather_desc_v1 {

@@ -392,6 +392,174 @@ def test_split_kernel_tables_describe_the_plan(cfg):
         assert np.abs(got - ref).max() <= 2e-6 * scale, (np.abs(got - ref).max(), scale)
 
 
+def _split2_f16(x: np.ndarray):
+    x = np.asarray(x, dtype=np.float32)
+    h = x.astype(np.float16).astype(np.float32)
+    return h, (x - h).astype(np.float16).astype(np.float32)
+
+
+def _pow2_scale(amax: float) -> float:
+    """2^e with amax 2^e in [2^14, 2^15) — the scale of csrc/fused_ar_half_impl.h (arh_scale) and zuko_amd/fused.py (half_scales); 1 for zero."""
+    import math
+
+    return 1.0 if amax == 0 else 2.0 ** (15 - math.frexp(float(amax))[1])
+
+
+@pytest.mark.parametrize("cfg", [("rqs", 64, 0, (256, 256, 256), 8), ("affine", 64, 0, (256, 256, 256), 0), ("rqs", 3, 5, (128, 128, 128), 8), ("rqs", 20, 3, (100, 72), 8),
+                                 ("affine", 7, 2, (40,), 0)])
+def test_half_kernel_tables_describe_the_plan(cfg):
+    """Tables + gathers of the TWO-PART operand-split kernels (static_ar.half_tables; csrc/fused_ar_half_impl.h) walked on the CPU as the kernel
+    walks them — the blocks of split_tables as two f16 images of the layer's weights times a power of two, the sample's activations times its own
+    power of two, three partial products per block, one fma(acc, descale, bias) per output — must give the masked MLP's output to f32 accuracy;
+    the weight scales and the eligibility verdict come from fused.half_scales as in the product."""
+    from zuko_amd import fused, static_ar
+
+    kind, D, C, hidden, bins = cfg
+    rng = np.random.default_rng(12)
+    for plan, lay, lins in static_ar._plans_for(kind, D, C, hidden, bins):
+        th, ts = static_ar.half_tables(plan, lay.kind, 1), static_ar.split_tables(plan, lay.kind, 1)
+        assert th is not None
+        t, gathers = th
+        t3 = ts[0]
+        NH, nt = t["NH"], lay.nt
+        assert (t["NB"], t["B_OT"], t["B_IP"], t["GOFF"], t["G_IP"]) == (t3["NB"], t3["B_OT"], t3["B_IP"], t3["GOFF"], t3["G_IP"]), "same blocks, same order as the three-part kernel"
+        images = 2 * (sum(t["NB"]) + t["GOFF"][-1] * nt)
+        assert t["NCHUNK"] == -(-images // t["CH"]) and t["BASE"] == [2 * sum(t["NB"][:l]) for l in range(NH)] and t["LAST_BASE"] == 2 * sum(t["NB"])
+        assert t["NCHUNK"] * t["CH"] <= 2 * sum(len(g) // 512 for g in gathers) <= t["STREAM_IMAGES"] < t["NCHUNK"] * t["CH"] + 2
+        for l in range(NH):
+            assert np.array_equal(gathers[l], ts[1][l])
+        scales = fused.half_scales(lins)
+        assert all(ok for ok, _ in scales), "random-init weights are eligible"
+        W = [l.weight.detach().numpy().astype(np.float32) * l.mask.numpy() for l in lins]
+        for (ok, e), w in zip(scales, W):
+            assert 2.0 ** 14 <= np.abs(w).max() * 2.0 ** e < 2.0 ** 15
+        Bv = [l.bias.detach().numpy().astype(np.float64) for l in lins]
+        x = rng.standard_normal(plan.din).astype(np.float32) * 3.0
+        h = x.astype(np.float64)
+        for l in range(NH + 1):
+            h = W[l].astype(np.float64) @ h + Bv[l]
+            if l < NH:
+                h = np.maximum(h, 0.0)
+        ref = h
+
+        def images_of(l):
+            idx = gathers[l].reshape(-1, 64, 8)
+            flat = W[l].reshape(-1)
+            vals = np.where(idx >= 0, flat[np.maximum(idx, 0)], 0.0).astype(np.float32) * np.float32(2.0 ** scales[l][1])
+            return _split2_f16(vals)
+
+        vec = np.zeros(t["TMAX"] * 16, dtype=np.float32)
+        vec[: plan.din] = x
+        boff = 0
+
+        def operands(v):
+            s_ = np.float32(_pow2_scale(np.abs(v).max()))
+            return _split2_f16(v * s_), 1.0 / float(s_)
+
+        for l in range(NH):
+            ah, al = images_of(l)
+            bias_img = np.where(plan.bias_gather[l] >= 0, Bv[l][np.maximum(plan.bias_gather[l], 0)], 0.0)[: t["TMAX"] * 16]
+            (vh, vl), inv_s = operands(vec)
+            acc = np.zeros(t["TMAX"] * 16)
+            for s in range(t["NB"][l]):
+                ot, ip = t["B_OT"][boff + s], t["B_IP"][boff + s]
+                for lane in range(64):
+                    i, kq = lane % 16, lane // 16
+                    units = np.concatenate([np.arange(4) + (2 * ip) * 16 + 4 * kq, np.arange(4) + (2 * ip + 1) * 16 + 4 * kq])
+                    for a_, b_ in ((al, vh), (ah, vl), (ah, vh)):
+                        acc[ot * 16 + i] += float(np.dot(a_[s, lane].astype(np.float64), b_[units].astype(np.float64)))
+            out = acc * (2.0 ** -scales[l][1] * inv_s) + bias_img
+            boff += t["NB"][l]
+            vec = np.zeros_like(vec)
+            vec[: t["HT"][l] * 16] = np.maximum(out[: t["HT"][l] * 16], 0.0).astype(np.float32)
+        ah, al = images_of(NH)
+        (vh, vl), inv_s = operands(vec)
+        total = lay.total
+        got = np.full(D * total, np.nan)
+        blk = 0
+        bias_last = plan.bias_gather[NH].reshape(-1, nt, 16)
+        for g in range(t["NG"]):
+            acc = np.zeros((nt, 16))
+            for st in range(t["GOFF"][g], t["GOFF"][g + 1]):
+                ip = t["G_IP"][st]
+                for b in range(nt):
+                    for lane in range(64):
+                        i, kq = lane % 16, lane // 16
+                        units = np.concatenate([np.arange(4) + (2 * ip) * 16 + 4 * kq, np.arange(4) + (2 * ip + 1) * 16 + 4 * kq])
+                        for a_, b_ in ((al, vh), (ah, vl), (ah, vh)):
+                            acc[b, i] += float(np.dot(a_[blk, lane].astype(np.float64), b_[units].astype(np.float64)))
+                    blk += 1
+            for b in range(nt):
+                for i in range(16):
+                    r = bias_last[g, b, i]
+                    if r >= 0:
+                        got[r] = acc[b, i] * (2.0 ** -scales[NH][1] * inv_s) + Bv[NH][r]
+        assert not np.isnan(got).any()
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 4e-6 * scale, (np.abs(got - ref).max(), scale)
+
+
+def test_half_eligibility_follows_the_weights():
+    """fused.half_scales: per-layer power of two from the largest masked magnitude; a layer whose magnitudes spread beyond what two f16 parts
+    carry (many weights 2^14 below the largest, an out unit 2^12 below, a magnitude outside 2^+-40, a non-finite weight) is not eligible."""
+    import zuko_amd.flows as F
+    from zuko_amd import fused
+    from zuko_amd.nn import MaskedLinear
+
+    def lins_of(seed=0):
+        torch.manual_seed(seed)
+        lazy = F.NSF(8, 0, transforms=1, hidden_features=[64, 64]).transform.transforms[0]
+        return [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
+
+    lins = lins_of()
+    base = fused.half_scales(lins)
+    assert all(ok for ok, _ in base)
+    with torch.no_grad():
+        lins[1].weight.mul_(2.0 ** -20)  # a whole layer far down: its own scale follows, still eligible
+    moved = fused.half_scales(lins)
+    assert moved[1] == (True, base[1][1] + 20) and moved[0] == base[0] and moved[2] == base[2]
+    with torch.no_grad():
+        lins = lins_of()
+        g = torch.Generator().manual_seed(1)
+        lins[0].weight.mul_(torch.exp2(torch.rand(lins[0].weight.shape, generator=g) * 24.0 - 20.0))  # the "wide-range" regime of tests/test_gpu_flows.py
+    assert [ok for ok, _ in fused.half_scales(lins)] == [False, True, True]
+    with torch.no_grad():
+        lins = lins_of()
+        row = int(lins[2].mask.any(dim=1).nonzero()[0])
+        lins[2].weight[row].mul_(2.0 ** -16)  # one out unit's weights far below the layer's
+    assert [ok for ok, _ in fused.half_scales(lins)] == [True, True, False]
+    with torch.no_grad():
+        lins = lins_of()
+        lins[1].weight.mul_(2.0 ** -60)
+    assert [ok for ok, _ in fused.half_scales(lins)] == [True, False, True]
+    with torch.no_grad():
+        lins = lins_of()
+        lins[0].weight[lins[0].mask][0] = float("inf")
+        w = lins[0].weight
+        idx = lins[0].mask.nonzero()[0]
+        w[idx[0], idx[1]] = float("nan")
+    assert fused.half_scales(lins)[0][0] is False
+    with torch.no_grad():
+        lins = lins_of()
+        lins[1].weight.zero_()
+    assert fused.half_scales(lins)[1] == (True, 0)
+
+
+def test_matmul_precision_switch():
+    import zuko_amd
+    from zuko_amd import fused
+
+    keep = fused.matmul_precision()
+    try:
+        for name, mode in (("highest", "bf16x3"), ("bf16x3", "bf16x3"), ("high", "f16x2"), ("F16x2", "f16x2")):
+            zuko_amd.set_matmul_precision(name)
+            assert zuko_amd.matmul_precision() == mode
+        with pytest.raises(ValueError):
+            zuko_amd.set_matmul_precision("tf32")
+    finally:
+        zuko_amd.set_matmul_precision(keep)
+
+
 def test_coupling_split_stream_is_the_f32_stream_regrouped():
     """coupling_plan.build_coupling_plan's operand-split stream (cfg4's shape: 128 inputs, hidden [512] * 3): block (out tile, in pair) =
     the f32 stream's images of in tiles 2 ip and 2 ip + 1 side by side, in the kernel's step order (4 out tiles x 1 in pair; the last layer

@@ -109,6 +109,7 @@ SIGNATURES = {
     "zk_sum_f64": [I, L, P, F, P, P, P],
     "zk_gather_f32": [P, P, P, L, P, P],
     "zk_gather_split_bf16": [P, P, P, L, P, P],
+    "zk_gather_split_f16": [P, P, P, L, P, F, P],
     "zk_gather_multi": [I, P, P],
     "zk_univariate_backward": [I, L, L, I, F, F, P, P, P, P, I, P, P, P],
     "zk_diag_normal_backward": [L, L, P, P, P, P, P, P],

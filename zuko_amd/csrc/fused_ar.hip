@@ -382,6 +382,28 @@ __global__ __launch_bounds__(256) void gather_split_kernel(const float* __restri
   }
 }
 
+// Weight stream of the two-part split kernels (fused_ar_half_impl.h): per block two 1 KiB f16 images h = f16(w s), l = f16(w s - h), s a power of two.
+__global__ __launch_bounds__(256) void gather_split_f16_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, const int32_t* __restrict__ idx, int64_t n_lanes,
+                                                               uint4* __restrict__ dst, float scale) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_lanes; i += (int64_t)gridDim.x * 256) {
+    const int4 k0 = *reinterpret_cast<const int4*>(idx + i * 8), k1 = *reinterpret_cast<const int4*>(idx + i * 8 + 4);
+    const int k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = 0.f;
+      if (k[e] >= 0 && (!mask || mask[k[e]])) v = src[k[e]] * scale;
+      const _Float16 hh = (_Float16)v;
+      h[e] = hh; l[e] = (_Float16)(v - (float)hh);
+    }
+    const int64_t b = i >> 6;
+    const int lane = (int)(i & 63);
+    dst[(b * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, h);
+    dst[(b * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, l);
+  }
+}
+
 // Up to eight gathers (f32 elements or operand-split blocks) in one launch: the streams and bias images of a conditioner are a dozen tiny
 // gathers that the GPU finishes faster than the host queues them (training re-gathers every step).
 struct GatherMulti {
@@ -451,6 +473,16 @@ int zk_gather_split_bf16(const void* src, const uint8_t* mask, const int32_t* id
   return ZK_LAUNCH_CHECK();
 }
 
+// Weight stream of a two-part operand-split kernel: as zk_gather_split_bf16 with the weights multiplied by `scale` (a power of two) and two f16 images
+// per block (2 KiB).
+int zk_gather_split_f16(const void* src, const uint8_t* mask, const int32_t* idx, int64_t n_blocks, void* dst, double scale, void* stream) {
+  if (n_blocks <= 0) return 0;
+  if (!src || !idx || !dst || ((uintptr_t)idx % 16) || ((uintptr_t)dst % 16) || !(scale > 0.0) || !(scale < 1e38)) return ZK_EINVAL;
+  const int64_t n_lanes = n_blocks * 64, nb = (n_lanes + 255) / 256;
+  hipLaunchKernelGGL(gather_split_f16_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, (const float*)src, mask, idx, n_lanes, (uint4*)dst, (float)scale);
+  return ZK_LAUNCH_CHECK();
+}
+
 // Up to eight zk_gather_f32 / zk_gather_split_bf16 in one launch; `descs`: HOST array (include/zuko_amd.h: zk_gather_desc_v1).
 int zk_gather_multi(int n, const zk_gather_desc_v1* descs, void* stream) {
   if (n < 1 || n > 8 || !descs) return ZK_EINVAL;
@@ -494,6 +526,7 @@ struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and th
   double eps = 0.0;                    // uni_kind 6: Bernstein continuation margin
   int32_t* bin_out = nullptr;  // diagnostic launch (forward, spline maps): bin index + search knots
   float* knots_out = nullptr;
+  double wdescale[4] = {0.0, 0.0, 0.0, 0.0};  // two-part split kernels: 1 / (the power of two every layer's weights were stored with)
   const int* sched = nullptr;
   int n_sched = 0;
   const int* olim = nullptr;  // host array, one entry per hidden layer
@@ -541,6 +574,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
       for (int i = 0; i < 5; ++i) { a.sos.node[i] = (float)part.gl_nodes01[i]; a.sos.weight[i] = (float)part.gl_weights01[i]; }
     }
     a.eps = (float)(part.eps > 0.0 ? part.eps : 1e-6);
+    for (int l = 0; l < 4; ++l) a.wdescale[l] = (float)part.wdescale[l];
     return ((ars_launch_fn)part.static_fn)(&a, ARS_ABI, (int)sizeof(ArArgs), part.phi_out != nullptr, stream);
   }
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
@@ -638,6 +672,7 @@ int zk_ar_forward_static(const zk_ar_args_v1* args, void* stream) {
   part.static_fn = args->launcher; part.rev = args->rev;
   part.gl_nodes01 = args->gl_nodes01; part.gl_weights01 = args->gl_weights01; part.eps = args->eps;
   part.bin_out = args->bin_out; part.knots_out = args->knots_out;  // both set: the kernel's diagnostic twin (operand-split kernels only)
+  part.wdescale[0] = args->wdescale0; part.wdescale[1] = args->wdescale1; part.wdescale[2] = args->wdescale2; part.wdescale[3] = args->wdescale3;
   zk_ar_args_v1 p = *args;
   p.skip = nullptr;  // (act: checked by the kernel against the activation it was generated for)
   return ar_launch_v1(part, false, p, stream);

@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AR_TF 256 /* floats per tile image */
 #define AR_WAVES 8
 #define AR_T 16   /* activation tiles (256 units) */
-#define ARS_ABI 7 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
+#define ARS_ABI 8 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
 
 struct ArArgs {
   int64_t N;
@@ -58,6 +58,8 @@ struct ArArgs {
   // polynomial maps (uni_kind 5, 6; operand-split static-shape kernels only): constants of the SOS quadrature, Bernstein continuation margin
   SosConst<float> sos;
   float eps;
+  // two-part (f16) operand-split kernels (fused_ar_half_impl.h): 2^-ew_l of every linear layer, the power of two its weights were stored with
+  float wdescale[4];
 };
 
 __device__ __forceinline__ float act_f32(float v, int act) {

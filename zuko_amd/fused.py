@@ -26,6 +26,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 
 import ctypes
+import math
 import os
 
 import numpy as np
@@ -466,6 +467,69 @@ def gsplit_gather(plan: ArPlan):
     return gathers, offsets, max(1, cursor // GS_BLOCKS_PER_CHUNK)
 
 
+# --------------------------------------------------------------------------------------------------
+# precision of the conditioner's matrix products on the fused inference kernels
+# --------------------------------------------------------------------------------------------------
+
+_PRECISIONS = {"f16x2": "f16x2", "high": "f16x2", "bf16x3": "bf16x3", "highest": "bf16x3"}
+_precision = None
+
+
+def matmul_precision() -> str:
+    """"f16x2" (default) or "bf16x3": how the fused autoregressive INFERENCE kernels evaluate the conditioner's f32 products — see set_matmul_precision."""
+    global _precision
+    if _precision is None:
+        _precision = _PRECISIONS.get(os.environ.get("ZUKO_AMD_MATMUL", "f16x2").lower(), "f16x2")
+    return _precision
+
+
+def set_matmul_precision(mode: str) -> None:
+    """The operand split of the conditioner's matrix products in the fused autoregressive inference kernels (torch.set_float32_matmul_precision's
+    role; the reference computes them in f32, zuko/nn.py:217-218 — gfx950's f32 matrix instruction runs at 1/16 of the 16-bit rate):
+
+      "f16x2" / "high" (default)  every operand as TWO f16 numbers scaled into f16's range by exact powers of two, three partial products
+                                  (csrc/fused_ar_half_impl.h): 22 significant bits per operand, the error of an f32 dot product measured end to
+                                  end (tests/test_gpu_flows.py, scripts/split_scheme_emulation.py).  Used when a conditioner's weights allow
+                                  it (FusedAR._half_eligible), else the next form;
+      "bf16x3" / "highest"        every operand as THREE bf16 numbers, six partial products (csrc/fused_ar_split_impl.h): 24 bits, any range.
+
+    Training launches, the inverse and every other kernel are not affected.  Environment: ZUKO_AMD_MATMUL; ZUKO_AMD_EXACT_F32=1 selects the f32
+    matrix instruction for everything."""
+    global _precision
+    if mode.lower() not in _PRECISIONS:
+        raise ValueError(f"zuko_amd.set_matmul_precision: unknown mode '{mode}' (one of {sorted(_PRECISIONS)})")
+    _precision = _PRECISIONS[mode.lower()]
+
+
+HALF_SPREAD_LOG2 = 14        # a weight more than 2^14 below its layer's largest magnitude counts as "small" ...
+HALF_SMALL_FRACTION = 0.01   # ... and a layer with more than 1 % of them keeps the three-part kernel
+HALF_ROW_LOG2 = 12           # so does a layer with an out unit whose largest weight is more than 2^12 below the layer's
+HALF_MAX_LOG2 = 40           # or whose largest magnitude is outside [2^-40, 2^40]
+
+
+def half_scales(linears):
+    """Per linear layer of a conditioner: (eligible, e) with 2^e the power of two its masked weights are stored with in the two-part kernels' stream
+    (largest magnitude in [2^14, 2^15)).  One device synchronisation (a handful of floats) per call — made when the weights changed, inference only."""
+    stats = []
+    for m in linears:
+        w = m.weight.detach()
+        a = (w * m.mask).abs() if getattr(m, "mask", None) is not None else w.abs()
+        big = a.amax()
+        nz = a > 0
+        small = (nz & (a < big * 2.0 ** -HALF_SPREAD_LOG2)).sum() / nz.sum().clamp_min(1)
+        rowmax = a.amax(dim=1)
+        minrow = torch.where(rowmax > 0, rowmax, big).amin()
+        stats.append(torch.stack([big.float(), small.float(), minrow.float()]))
+    out = []
+    for big, small, minrow in torch.stack(stats).tolist():
+        if big == 0.0:
+            out.append((True, 0))
+            continue
+        ok = math.isfinite(big) and 2.0 ** -HALF_MAX_LOG2 <= big <= 2.0 ** HALF_MAX_LOG2 and small <= HALF_SMALL_FRACTION and minrow >= big * 2.0 ** -HALF_ROW_LOG2
+        out.append((bool(ok), 15 - math.frexp(big)[1] if math.isfinite(big) else 0))
+    return out
+
+
 def chunk_of(variant: int = 0) -> int:
     """Tiles per chunk the stream is padded to (= AR_CH of csrc/fused_ar.hip: a 3 x 24-tile LDS ring)."""
     return CHUNK
@@ -501,6 +565,13 @@ class FusedAR:
         self._static_tried_rows = -1
         self.fine_gather = self.fine_stream = self.fine_offsets = None
         self.fine_n_chunks = 0
+        # the two-part (f16 x 2) twin of an operand-split kernel: inference launches when the weights allow it (set_matmul_precision)
+        self.half = None            # StaticKernel
+        self.half_gather = self.half_stream = self.half_offsets = None
+        self.half_n_chunks = 0
+        self.half_ok = False        # the weights of _half_stamp are eligible and their stream is built
+        self.half_descale = None    # per linear layer 2^-e
+        self._half_stamp = None
         self._acquire_static(None)  # kernels already on disk (prebuilt or compiled earlier) are used whatever the batch size
         # the generic operand-split kernel (csrc/fused_ar_gsplit.hip): what run() launches while there is no static-shape kernel for the plan
         # (its tables are built on first use).  ZUKO_AMD_GSPLIT=0: keep such plans on the f32 matrix instruction; =force: even when there is one
@@ -519,6 +590,7 @@ class FusedAR:
 
         # (an f32 static kernel found on disk can still be replaced by the operand-split one once a batch is large enough to compile it)
         upgradable = self.static is not None and not self.static[0].meta.get("split") and static_ar.split_enabled() and rows is not None
+        self._acquire_half(rows)
         if (self.static is not None and not upgradable) or self.plan.fine_gather is None or (rows is not None and rows <= self._static_tried_rows):
             return
         if rows is not None:
@@ -539,6 +611,59 @@ class FusedAR:
                 stream_images = self.fine_n_chunks * 24
             self.fine_stream = torch.zeros(stream_images * 256, dtype=torch.float32, device=self.device)
             self._fine_stamp = None
+
+    def _acquire_half(self, rows) -> None:
+        """The plan's two-part kernel (zuko_amd/static_ar.py: lookup_half), looked up once per batch size class like the static kernel."""
+        from . import static_ar
+
+        if self.half is not None or self.plan.fine_gather is None or not static_ar.half_enabled() or (rows is not None and rows <= getattr(self, "_half_tried_rows", -1)):
+            return
+        if rows is not None:
+            self._half_tried_rows = rows if rows < static_ar.jit_min_rows() else 1 << 62
+        kern = static_ar.lookup_half(self.plan, self.plan.layout.kind, self.act, rows)
+        if kern is not None:
+            t, gathers = static_ar.half_tables(self.plan, self.plan.layout.kind, self.act)
+            self.half = kern
+            self.half_gather = [torch.from_numpy(g).to(self.device) for g in gathers]
+            self.half_offsets = [b * 256 for b in t["BASE"]] + [t["LAST_BASE"] * 256]
+            self.half_n_chunks = t["NCHUNK"]
+            self.half_stream = torch.zeros(t["STREAM_IMAGES"] * 256, dtype=torch.float32, device=self.device)
+            self._half_stamp = None
+
+    def _refresh_half(self, linears, stamp) -> None:
+        """(Re)build the two-part kernel's stream for the current weights: eligibility + per-layer scales (one synchronisation), then one gather per layer."""
+        from . import _C
+        from .ops import _ptr, _stream
+
+        scales = half_scales(linears)
+        self._half_stamp = stamp
+        self.half_ok = all(ok for ok, _ in scales)
+        if not self.half_ok:
+            return
+        self.half_descale = [2.0 ** -e for _, e in scales]
+        for l, (m, (_, e)) in enumerate(zip(linears, scales)):
+            w = m.weight.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            nb = self.half_gather[l].numel() // 512
+            if nb:
+                _C.check(_C.lib().zk_gather_split_f16(_ptr(w), _ptr(m.mask.contiguous().view(torch.uint8)), _ptr(self.half_gather[l]), nb, _ptr(self.half_stream[self.half_offsets[l] :]), 2.0 ** e,
+                                                      _stream()), "zk_gather_split_f16")
+
+    def _half_args(self, **io):
+        p = self.plan
+        from . import _C
+        from .ops import _ptr
+
+        d = list(self.half_descale) + [1.0] * (4 - len(self.half_descale))
+        return _C.args("zk_ar_args_v1", launcher=self.half.launcher, rev=0, uni_kind=p.layout.kind, D=p.features, wstream=_ptr(self.half_stream), bias=_ptr(self.bias),
+                       bias_floats=self.bias_floats, featmap=_ptr(self.featmap), n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=self.half_n_chunks, act=self.act,
+                       bound=self.bound, slope=self.slope, wdescale0=d[0], wdescale1=d[1], wdescale2=d[2], wdescale3=d[3], **io)
+
+    def _half_serves(self, y: Tensor) -> bool:
+        """Whether this inference launch goes to the two-part kernel: one is held, the mode allows it, the current weights are eligible and gathered."""
+        return (self.half is not None and self.half_ok and self._half_stamp is not None and self._half_stamp == self._seen_stamp and matmul_precision() == "f16x2"
+                and self.gs_mode != "force" and (not self.half.meta["XLDS"] or (y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)))
 
     def ready(self, rows: int) -> bool:
         """Whether run() can be served: always for plans the generic kernel covers; for wider ones only with a static-shape kernel
@@ -579,6 +704,8 @@ class FusedAR:
         want_fine = self.static is not None and stamp != self._fine_stamp
         gs = self._gsplit()
         want_gs = gs is not None and stamp != self._gs_stamp
+        if self.half is not None and not fine_only and stamp != self._half_stamp and matmul_precision() == "f16x2":
+            self._refresh_half(linears, stamp)
         if not (want_generic or want_fine or want_gs):
             return
         items = []
@@ -618,6 +745,10 @@ class FusedAR:
 
         p = self.plan
         N = inp.shape[0]
+        if self._half_serves(y):
+            a = self._half_args(N=N, DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0), y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=int(accumulate))
+            _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
+            return
         gs = self._gsplit()
         if gs is not None and self._gs_stamp is not None and self._gs_stamp == self._seen_stamp and (p.layout.kind <= 1 or (p.features % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)):
             # (4 / 16 bins and the circular map exist for the LDS-staged epilogue only, like the generic f32 kernel's)
@@ -664,6 +795,11 @@ class FusedAR:
         from .ops import _ptr, _stream
 
         p = self.plan
+        if self._half_serves(y) and p.layout.kind in (1, 2, 3) and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0:
+            # the product launch is the two-part kernel: ITS diagnostic instantiation
+            a = self._half_args(N=inp.shape[0], DIN=inp.shape[1], x=_ptr(inp), ldx=inp.stride(0), y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), accumulate=0, bin_out=_ptr(bins), knots_out=_ptr(knots))
+            _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
+            return
         if self.static is not None and self.static[0].meta.get("split") and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0:
             # the product launch is an operand-split kernel: its own diagnostic instantiation (the generic kernel differs from it by rounding)
             kern, rev = self.static

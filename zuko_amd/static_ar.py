@@ -36,7 +36,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
-ARS_ABI = 7  # == ARS_ABI of csrc/zk_ar_common.h
+ARS_ABI = 8  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 3: "zk::UniRqs16", 4: "zk::UniCircRqs8", 5: "zk::UniSos3x5", 6: "zk::UniBern17"}
 # 16 bins: the twelve accumulator tiles of a feature group do not fit the f32-instruction template's double-buffered last layer (it would
 # spill), but the operand-split template holds them (255 VGPRs, no scratch): that kind exists as a split kernel only, forward only
@@ -149,6 +149,24 @@ def _header_digest() -> str:
                 h.update(f.read())
         _HEADER_DIGEST = h.hexdigest()[:12]
     return _HEADER_DIGEST
+
+
+_HALF_DIGEST = None
+
+
+def _half_digest() -> str:
+    """_header_digest() extended by the two-part kernels' own header (an edit there rebuilds those kernels only)."""
+    global _HALF_DIGEST
+    if _HALF_DIGEST is None:
+        h = hashlib.sha256(_header_digest().encode())
+        with open(os.path.join(CSRC, "fused_ar_half_impl.h"), "rb") as f:
+            h.update(f.read())
+        _HALF_DIGEST = h.hexdigest()[:12]
+    return _HALF_DIGEST
+
+
+def _stamp_of(meta: dict) -> str:
+    return _half_digest() if meta.get("half") else _header_digest()
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -318,6 +336,100 @@ def split_tables(plan, uni_kind: int, act: int = 1):
     return out, gathers
 
 
+def half_enabled() -> bool:
+    """Whether the TWO-PART (2 x f16, three partial products) twins of the operand-split kernels may serve inference launches
+    (zuko_amd.set_matmul_precision / ZUKO_AMD_MATMUL: "f16x2" default, "bf16x3" keeps every product on the three-part kernels)."""
+    from . import fused
+
+    return split_enabled() and fused.matmul_precision() == "f16x2"
+
+
+def half_tables(plan, uni_kind: int, act: int = 1):
+    """Tables + gather indices of the two-part twin of an operand-split kernel (csrc/fused_ar_half_impl.h), or None.
+
+    Same blocks in the same order as split_tables — a block is the 16 x 32 weight block (one out tile, one pair of in tiles) — as TWO 1 KiB f16
+    images (h, l) of the layer's weights times a power of two (zuko_amd/fused.py picks it: the layer's largest magnitude lands in [2^14, 2^15)),
+    three partial products (lh, hl, hh) on v_mfma_f32_16x16x32_f16.  Eight wavefronts, conditioners up to 256 wide and three hidden layers (the
+    kernel takes one descale factor per linear layer, four at most); the polynomial maps keep the three-part kernels."""
+    ts = split_tables(plan, uni_kind, act)
+    if ts is None:
+        return None
+    t, gathers = ts
+    if t["WAVES"] != 8 or t["NH"] > 3 or uni_kind in SPLIT_ONLY_KINDS or t["CH"] != 24:
+        return None
+    cached = getattr(plan, "_half_cache", None)
+    if cached is not None and cached[0] == (uni_kind, act):
+        return cached[1]
+    ch, NH, nt = t["CH"], t["NH"], plan.layout.nt
+    n_last = t["GOFF"][-1] * nt
+    cursor = 2 * (sum(t["NB"]) + n_last)
+    n_chunks = -(-cursor // ch)
+    pad_blocks = -(-(n_chunks * ch - cursor) // 2)
+    last = gathers[NH][: n_last * 512]
+    g = [np.asarray(x) for x in gathers[:NH]] + [np.concatenate([last, -np.ones(pad_blocks * 512, dtype=np.int32)]).astype(np.int32)]
+    out = {k: v for k, v in t.items() if k not in ("split", "TRAIN_OK")}
+    out.update({"half": 1, "BASE": [2 * sum(t["NB"][:l]) for l in range(NH)], "LAST_BASE": 2 * sum(t["NB"]), "NCHUNK": n_chunks, "STREAM_IMAGES": max(n_chunks * ch, cursor + 2 * pad_blocks),
+                "NR": 3, "TRAIN_OK": 0})
+    plan._half_cache = ((uni_kind, act), (out, g))
+    return out, g
+
+
+def emit_half(t: dict) -> str:
+    boff = [0]
+    for n in t["NB"]:
+        boff.append(boff[-1] + n)
+    lines = [
+        "// generated by zuko_amd/static_ar.py — do not edit",
+        '#include "fused_ar_half_impl.h"',
+        "namespace {",
+        "struct Shape {",
+        f"  static constexpr int D = {t['D']}, DIN = {t['DIN']}, NIT = {t['NIT']}, NH = {t['NH']}, TMAX = {t['TMAX']}, NG = {t['NG']}, NCHUNK = {t['NCHUNK']};",
+        f"  static constexpr int BIAS_STRIDE = {t['BIAS_STRIDE']}, LAST_BASE = {t['LAST_BASE']}, WAVES = {t['WAVES']}, CH = {t['CH']}, NR = {t['NR']}, ACT = {t['ACT']}, OCC = {t['OCC']};",
+        f"  static constexpr bool XLDS = {'true' if t['XLDS'] else 'false'};",
+        _arr("HT", "int", t["HT"]), _arr("NB", "int", t["NB"]), _arr("BOFF", "int", boff), _arr("BASE", "int", t["BASE"]),
+        _arr("B_OT", "unsigned char", t["B_OT"]), _arr("B_IP", "unsigned char", t["B_IP"]), _arr("GOFF", "int", t["GOFF"]), _arr("G_IP", "unsigned char", t["G_IP"]),
+        "};",
+        "}  // namespace",
+        f'extern "C" int zk_ars_launch(const zk::ArArgs* a, int abi, int args_bytes, int train, void* stream) {{ return zk::arh_launch<Shape, {UNI_TYPES[t["uni"]]}>(a, abi, args_bytes, train, stream); }}',
+        "",
+    ]
+    return "\n".join(lines)
+
+
+def compile_half(t: dict, verbose: bool = False, out_dir: str | None = None) -> dict | None:
+    """Build arh_<sig>.so, the two-part operand-split kernel of tables `t` (half_tables); returns its meta or None."""
+    stamp = _half_digest()
+    sig = _digest({"half": t, "headers": stamp})
+    meta = {"so": f"arh_{sig}.so", "core": "h" + _digest(t), "half": 1, "split": 2, "l0": [], "alt": None, "headers": stamp, "uni": t["uni"], "ACT": t["ACT"], "D": t["D"], "DIN": t["DIN"], "HT": t["HT"],
+            "WAVES": t["WAVES"], "CH": t["CH"], "TRAIN_OK": 0, "XLDS": t["XLDS"], "NCHUNK": t["NCHUNK"]}
+    so = _build_so(f"arh_{sig}", lambda: emit_half(t), meta, verbose, out_dir)
+    if so is None:
+        return None
+    global _INDEX
+    _INDEX = None
+    return dict(meta, dir=os.path.dirname(so))
+
+
+def lookup_half(plan, uni_kind: int, act: int, rows: int | None = None):
+    """The two-part kernel (StaticKernel) for this plan, or None: found on disk, or compiled when `rows` reaches the JIT threshold."""
+    if os.environ.get("ZUKO_AMD_NO_STATIC_AR", "0") == "1" or not split_enabled():
+        return None
+    ts = half_tables(plan, uni_kind, act)
+    if ts is None:
+        return None
+    cdx = "h" + _digest(ts[0])
+    with _LOCK:
+        idx = _INDEX if _INDEX is not None else _scan()
+        for meta in idx.get(cdx, []):
+            return _load(meta)
+    if rows is not None and rows >= jit_min_rows() and jit_enabled():
+        meta = compile_half(ts[0], verbose=os.environ.get("ZUKO_AMD_JIT_VERBOSE", "0") == "1")
+        if meta is not None:
+            with _LOCK:
+                return _load(meta)
+    return None
+
+
 def emit_split(t: dict) -> str:
     boff = [0]
     for n in t["NB"]:
@@ -417,7 +529,7 @@ def _scan() -> dict:
                         meta = json.load(f)
                 except (OSError, ValueError):
                     continue
-                if meta.get("headers") == stamp and os.path.exists(os.path.join(d, meta["so"])):
+                if meta.get("headers") == _stamp_of(meta) and os.path.exists(os.path.join(d, meta["so"])):
                     meta["dir"] = d
                     idx.setdefault(meta["core"], []).append(meta)
     _INDEX = idx
@@ -857,7 +969,8 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
             if name.endswith(".json"):
                 try:
                     with open(os.path.join(ARS_DIR, name)) as f:
-                        stale = json.load(f).get("headers") != stamp
+                        m_ = json.load(f)
+                        stale = m_.get("headers") != _stamp_of(m_)
                 except (OSError, ValueError):
                     stale = True
                 if stale:
@@ -871,7 +984,7 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
                     os.remove(os.path.join(ARS_DIR, name))
                 except OSError:
                     pass
-    work, chains, splits = [], [], []
+    work, chains, splits, halves = [], [], [], []
     for entry in PREBUILT:
         kind, features, context, hidden, bins = entry[:5]
         import torch
@@ -892,6 +1005,9 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
             ts = split_tables(pl, layout.kind, act)
             if ts is not None and not any(x == ts[0] for x in splits):
                 splits.append(ts[0])
+            th = half_tables(pl, layout.kind, act)  # the two-part twin (inference launches)
+            if th is not None and not any(x == th[0] for x in halves):
+                halves.append(th[0])
         if layout.kind in SPLIT_ONLY_KINDS:
             continue  # (no f32-instruction kernel, no training chain for this kind)
         ta, td = tables(pa, layout.kind, act), tables(pd, layout.kind, act)
@@ -919,9 +1035,10 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
         metas = list(ex.map(lambda w: compile_kernel(w[0], w[1], verbose, ARS_DIR), work))
         kerns = list(ex.map(lambda tg: chain_kernel(tg[0], True, verbose, ARS_DIR), chains))
         xmetas = list(ex.map(lambda t: compile_split(t, verbose, ARS_DIR), splits))
-    if any(m is None for m in metas + xmetas) or any(k is None for k in kerns):
+        hmetas = list(ex.map(lambda t: compile_half(t, verbose, ARS_DIR), halves))
+    if any(m is None for m in metas + xmetas + hmetas) or any(k is None for k in kerns):
         raise RuntimeError("zuko_amd.static_ar: a prebuilt static kernel failed to compile")
-    return [m["so"] for m in metas + xmetas] + [os.path.basename(k.so) for k in kerns]
+    return [m["so"] for m in metas + xmetas + hmetas] + [os.path.basename(k.so) for k in kerns]
 
 
 if __name__ == "__main__":
