@@ -859,9 +859,14 @@ def generic_split_report(dev) -> dict:
         B = 1 << 20
         x = torch.randn(B, 64, device=dev)
         res = {}
-        for mode, env in (("generated_split_kernels", {}), ("generic_split_kernel", {"ZUKO_AMD_NO_STATIC_AR": "1"}), ("generic_f32_kernel", {"ZUKO_AMD_NO_STATIC_AR": "1", "ZUKO_AMD_GSPLIT": "0"})):
+        import zuko_amd
+
+        keep_precision = zuko_amd.matmul_precision()
+        for mode, env, precision in (("two_part_kernels", {}, "f16x2"), ("generated_split_kernels", {}, "bf16x3"), ("generic_split_kernel", {"ZUKO_AMD_NO_STATIC_AR": "1"}, "bf16x3"),
+                                     ("generic_f32_kernel", {"ZUKO_AMD_NO_STATIC_AR": "1", "ZUKO_AMD_GSPLIT": "0"}, "bf16x3")):
             keep = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
+            zuko_amd.set_matmul_precision(precision)
             try:
                 for lazy in flow.transform.transforms:
                     AR._FUSED_CACHE.pop(lazy, None)
@@ -875,6 +880,7 @@ def generic_split_report(dev) -> dict:
                     torch.cuda.synchronize()
                     res[mode] = ((time.perf_counter() - t0) / 5, lp)
             finally:
+                zuko_amd.set_matmul_precision(keep_precision)
                 for k, v in keep.items():
                     if v is None:
                         os.environ.pop(k, None)
@@ -884,6 +890,7 @@ def generic_split_report(dev) -> dict:
                     AR._FUSED_CACHE.pop(lazy, None)
         for mode, (dt, _) in res.items():
             entry[mode] = {"ms": dt * 1e3, "samples_per_s": B / dt}
+        entry["two_part_max_rel_diff_vs_three_part"] = ((res["two_part_kernels"][1] - res["generated_split_kernels"][1]).abs().max() / res["generated_split_kernels"][1].abs().max()).item()
         entry["generic_split_over_generated"] = res["generic_split_kernel"][0] / res["generated_split_kernels"][0]
         entry["generic_split_bitwise_equal_to_generated"] = bool(torch.equal(res["generic_split_kernel"][1], res["generated_split_kernels"][1]))
         entry["generic_f32_max_rel_diff"] = ((res["generic_f32_kernel"][1] - res["generated_split_kernels"][1]).abs().max() / res["generated_split_kernels"][1].abs().max()).item()
@@ -972,12 +979,15 @@ def headline_line(out: dict) -> dict:
     line["vs_baseline"] = out.get("vs_baseline")
     line.update(_pick(out, "dtype", "data"))
     if out.get("dtype_note"):
-        line["dtype_note"] = "f32 in/out/accumulate; products as 3-way bf16 operand splits on the bf16 matrix instruction (f32 dot-product rounding: see parity)"
+        line["dtype_note"] = ("f32 in/out/accumulate; products as 2-way f16 operand splits scaled by exact powers of two, 3 partial products on the f16 matrix instruction (f32 dot-product error: see parity)"
+                              if "TWO f16" in out["dtype_note"] else "f32 in/out/accumulate; products as 3-way bf16 operand splits on the bf16 matrix instruction (f32 dot-product rounding: see parity)")
+    line.update(_pick(out, "matmul_precision"))
     line["config"] = _pick(out.get("config"), "workload", "batch_per_gpu", "global_batch", "parallelism")
     roof = out.get("roofline")
     line["roofline"] = None if roof is None else {
         **_pick(roof, "bound", "achieved", "peak", "unit", "frac"), "traffic": roof.get("traffic"),
-        **_pick(roof, "kernel", "avg_launch_ms", "algorithmic_flop_per_launch", "executed_flop_per_launch", "frac_executed", "peak_basis", "f32_instruction_peak", "traffic_source")}
+        **_pick(roof, "kernel", "avg_launch_ms", "algorithmic_flop_per_launch", "executed_flop_per_launch", "frac_executed", "peak_basis", "f32_instruction_peak",
+                "frac_on_the_six_product_basis_of_rounds_3_to_5", "traffic_source")}
     if out.get("cpu_baseline"):
         line["cpu_baseline"] = _pick(out["cpu_baseline"], "value", "unit", "cores", "kind", "sample", "median_samples_per_s", "host_cpus", "cpu_model", "pinned_bitwise")
         line.update(_pick(out, "speedup_vs_cpu_baseline"))
@@ -1021,10 +1031,10 @@ def headline_line(out: dict) -> dict:
             b = e["log_prob_batch_4096"]
             c["log_prob_4096"] = {**_pick(b, "ms"), **{"graph_" + k: v for k, v in _pick(b.get("hip_graph_replay"), "ms", "bitwise_equal_to_eager").items()},
                                   **{"one_launch_" + k: v for k, v in _pick(b.get("one_launch"), "ms", "bitwise_equal_to_eager").items()}}
-        for k in ("generated_split_kernels", "generic_split_kernel", "generic_f32_kernel"):
+        for k in ("two_part_kernels", "generated_split_kernels", "generic_split_kernel", "generic_f32_kernel"):
             if isinstance(e.get(k), dict):
                 c[k + "_ms"] = e[k].get("ms")
-        c.update(_pick(e, "generic_split_bitwise_equal_to_generated"))
+        c.update(_pick(e, "generic_split_bitwise_equal_to_generated", "two_part_max_rel_diff_vs_three_part"))
         paths[name] = c
     if paths:
         line["side_paths"] = paths
@@ -1223,6 +1233,8 @@ def main() -> None:
             tsp = static_ar.split_tables(st.plan, st.plan.layout.kind, st.act)[0]
             executed = (sum(tsp["NB"]) + tsp["GOFF"][-1] * st.plan.layout.nt) * 1024.0
         per_transform["split"] = split
+        # the launch the product makes for this flow: the two-part (f16 x 2, three partial products) kernel when the weights are eligible (zuko_amd/fused.py)
+        per_transform["half"] = bool(st is not None and hasattr(st, "_half_serves") and st._half_serves(torch.empty(4, features, device=dev)))
         last = [m for m in flow.transform.transforms[0].hyper.modules() if getattr(m, "weight", None) is not None][-1]
         lmask = getattr(last, "mask", None)
         per_transform["last_layer_nnz_frac"] = 1.0 if lmask is None else float(lmask.float().mean())
@@ -1243,9 +1255,13 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
-            **({"dtype_note": "f32 in, f32 out, f32 accumulation; the conditioner's products run on the bf16 matrix instruction with every f32 operand split into three bf16 numbers "
-                              "(six partial products: the rounding of an f32 dot product, see `parity`); ZUKO_AMD_EXACT_F32=1 selects the f32 matrix instruction"}
+            **({"dtype_note": ("f32 in, f32 out, f32 accumulation; the conditioner's products run on the f16 matrix instruction with every f32 operand as TWO f16 numbers scaled into range by "
+                               "exact powers of two (three partial products: the error of an f32 dot product, see `parity`); zuko_amd.set_matmul_precision('bf16x3') selects three bf16 parts / six "
+                               "products, ZUKO_AMD_EXACT_F32=1 the f32 matrix instruction") if "two-part" in (roof or {}).get("instantiation", "") else
+                              ("f32 in, f32 out, f32 accumulation; the conditioner's products run on the bf16 matrix instruction with every f32 operand split into three bf16 numbers "
+                               "(six partial products: the rounding of an f32 dot product, see `parity`); ZUKO_AMD_EXACT_F32=1 selects the f32 matrix instruction")}
                if (roof or {}).get("f32_instruction_peak") else {}),
+            "matmul_precision": zuko_amd.matmul_precision(),
             "data": "synthetic",
             "config": {
                 "workload": f"{workload}, batch=2^{args.batch_log2} per GPU, x~N(0,1), seed-0 init",
@@ -1372,8 +1388,16 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
                     (bool(flop_per_transform.get("split_coupling")) and parts[0] == "zk_coupling_forward")
             # operand-split kernels: every f32 product = 6 bf16 matrix products (csrc/fused_ar_split_impl.h), so the ceiling for f32-equivalent
             # FLOP is the dense bf16 peak / 6; the f32 matrix instruction's own peak stays on the line for comparison
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
+            half = bool(flop_per_transform.get("half")) and parts[0] == "zk_ar_forward" and "static" in rec.get("instantiation", "")
+            split = split and not half
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if half else (PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS)
             row.update(bound="mfma", achieved=float(B) * flop_per_transform["nnz"] / t / 1e12, peak=peak, unit="TFLOP/s")
+            if half:
+                # two-part kernels: every f32 product = 3 f16 matrix products (csrc/fused_ar_half_impl.h): ceiling = dense 16-bit peak / 3, f32-equivalent FLOP
+                row["instantiation"] = "static-shape, two-part operand split (2 x f16 per f32 operand scaled by exact powers of two, 3 partial products, f32 accumulate)"
+                row["peak_basis"] = f"{PEAK_BF16_MFMA_TFLOPS:g} TFLOP/s dense f16 / 3 matrix products per f32 product; f32-equivalent FLOP"
+                row["f32_instruction_peak"] = PEAK_F32_MFMA_TFLOPS
+                row["frac_on_the_six_product_basis_of_rounds_3_to_5"] = row["achieved"] / (PEAK_BF16_MFMA_TFLOPS / 6.0)
             if split:
                 row["instantiation"] = "static-shape, operand-split (3 x bf16 per f32 operand, 6 partial products, f32 accumulate)"
                 row["peak_basis"] = f"{PEAK_BF16_MFMA_TFLOPS:g} TFLOP/s dense bf16 / 6 matrix products per f32 product; f32-equivalent FLOP"
@@ -1385,7 +1409,7 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
                                                            "its conversion / spline / ring phases run beside idle matrix pipes (profiles/r05/headline.md)"}
             row["algorithmic_flop_per_launch"] = float(B) * flop_per_transform["nnz"]
             row["dense_equiv_tflops"] = float(B) * flop_per_transform["dense"] / t / 1e12
-            if executed_per_sample and parts[0] == "zk_ar_forward":
+            if executed_per_sample and parts[0] == "zk_ar_forward" and (split or half or not flop_per_transform.get("split")):
                 row["executed_flop_per_launch"] = float(B) * executed_per_sample
                 row["achieved_executed"] = float(B) * executed_per_sample / t / 1e12
                 row["frac_executed"] = row["achieved_executed"] / peak
@@ -1406,7 +1430,7 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
         roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                 "traffic": traffic, "traffic_source": (f"{src}: rocprofv3 --pmc passes of this same command, not re-measured in this run" if src else None),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]}
-        for k in ("instantiation", "peak_basis", "f32_instruction_peak", "instruction_form_ceiling", "frac_of_form_ceiling_executed", "algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
+        for k in ("instantiation", "peak_basis", "f32_instruction_peak", "frac_on_the_six_product_basis_of_rounds_3_to_5", "instruction_form_ceiling", "frac_of_form_ceiling_executed", "algorithmic_flop_per_launch", "executed_flop_per_launch", "achieved_executed", "frac_executed", "dense_equiv_tflops", "note"):
             if k in dom:
                 roof[k] = dom[k]
     return roof, table

@@ -116,3 +116,13 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def matmul():
+    """matmul("bf16x3" | "f16x2"): zuko_amd.set_matmul_precision for the duration of a test (the previous mode is restored)."""
+    import zuko_amd
+
+    keep = zuko_amd.matmul_precision()
+    yield zuko_amd.set_matmul_precision
+    zuko_amd.set_matmul_precision(keep)

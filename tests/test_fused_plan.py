@@ -515,9 +515,9 @@ def test_half_eligibility_follows_the_weights():
     base = fused.half_scales(lins)
     assert all(ok for ok, _ in base)
     with torch.no_grad():
-        lins[1].weight.mul_(2.0 ** -20)  # a whole layer far down: its own scale follows, still eligible
+        lins[1].weight.mul_(2.0 ** -12)  # a whole layer far down: its own scale follows, still eligible
     moved = fused.half_scales(lins)
-    assert moved[1] == (True, base[1][1] + 20) and moved[0] == base[0] and moved[2] == base[2]
+    assert moved[1] == (True, base[1][1] + 12) and moved[0] == base[0] and moved[2] == base[2]
     with torch.no_grad():
         lins = lins_of()
         g = torch.Generator().manual_seed(1)
@@ -530,8 +530,9 @@ def test_half_eligibility_follows_the_weights():
     assert [ok for ok, _ in fused.half_scales(lins)] == [True, True, False]
     with torch.no_grad():
         lins = lins_of()
-        lins[1].weight.mul_(2.0 ** -60)
-    assert [ok for ok, _ in fused.half_scales(lins)] == [True, False, True]
+        lins[1].weight.mul_(2.0 ** -30)
+        lins[2].weight.mul_(2.0 ** 45)
+    assert [ok for ok, _ in fused.half_scales(lins)] == [True, False, False]
     with torch.no_grad():
         lins = lins_of()
         lins[0].weight[lins[0].mask][0] = float("inf")

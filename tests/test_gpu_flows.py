@@ -732,14 +732,16 @@ def test_static_shape_kernel_is_bit_identical_to_the_generic_one(dev, case, N, m
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", STATIC_CASES, ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}" + (f"-{c[4]}" if len(c) > 4 else ""))
 @pytest.mark.parametrize("N", [1, 129, 1000, 40000])
-def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
-    """The operand-split kernels (csrc/fused_ar_split_impl.h: every f32 operand as three bf16 numbers, six partial products on the
-    bf16 matrix instruction, f32 accumulation) are the default static-shape kernels.  Against float64 they must be as close as the
-    f32-instruction kernel is (measured bar of tests/parity.py with the generic f32 kernel in the reference's place, C = 2), the NaN
-    pattern of poisoned rows must be identical, and `accumulate` must add to ladj."""
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_split_kernels_carry_f32_accuracy(dev, case, N, precision, monkeypatch, matmul):
+    """The operand-split kernels — three bf16 parts and six partial products (csrc/fused_ar_split_impl.h), two f16 parts scaled by exact powers
+    of two and three partial products (csrc/fused_ar_half_impl.h: the default inference launch) — on the 16-bit matrix instructions, f32
+    accumulation.  Against float64 they must be as close as the f32-instruction kernel is (measured bar of tests/parity.py with the generic f32
+    kernel in the reference's place, C = 2), the NaN pattern of poisoned rows must be identical, and `accumulate` must add to ladj."""
     from zuko_amd.flows import MAF, NSF
     from zuko_amd.nn import MaskedLinear
 
+    matmul(precision)
     kind, D, C, hidden = case[:4]
     kw = dict(activation=getattr(torch.nn, case[4])) if len(case) > 4 else {}
     monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
@@ -758,13 +760,17 @@ def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
         st = lazy.fused_state(dev)
         assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1, "an operand-split kernel must be selected"
         st.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
-        keep = st.static
+        keep = st.static, st.half
         y, ladj = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+        if precision == "f16x2" and max(hidden) <= 256 and len(hidden) <= 3:
+            assert st._half_serves(y), "seed-3 weights are eligible: the two-part kernel must serve the launch"
+        else:
+            assert not st._half_serves(y)
         st.run(inp, y, ladj, False)
-        st.static, st.gs_mode = None, "0"  # (the reference here: the generic kernel on the f32 matrix instruction)
+        st.static, st.half, st.gs_mode = None, None, "0"  # (the reference here: the generic kernel on the f32 matrix instruction)
         y0, ladj0 = torch.full((N, D), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
         st.run(inp, y0, ladj0, False)
-        st.static = keep
+        st.static, st.half = keep
         # float64: the oracle's masked MLP and univariate map in double on the same parameters
         lins = [m for m in lazy.hyper if isinstance(m, MaskedLinear)]
         act = {"ELU": torch.nn.functional.elu, "Tanh": torch.tanh}[case[4]] if len(case) > 4 else torch.relu
@@ -774,7 +780,7 @@ def test_split_kernels_carry_f32_accuracy(dev, case, N, monkeypatch):
                                 [l.mask.cpu() for l in lins], act=act)
             y64, l64 = O.univariate_forward(uni, phi.reshape(N, D, uni.total), x_cpu.double())
             l64 = l64.sum(dim=-1)
-        tag = f"split kernel {case} N={N} transform {i}"
+        tag = f"split kernel ({precision}) {case} N={N} transform {i}"
         assert_parity(y, y0, y64, f"{tag}: y", c=2.0)
         assert_parity(ladj, ladj0, l64, f"{tag}: ladj", c=2.0)
         l2 = ladj.clone()
@@ -789,7 +795,7 @@ GSPLIT_CASES = STATIC_CASES + [("nsf16", 64, 0, [256] * 3), ("nsf4", 8, 2, [48, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", GSPLIT_CASES, ids=lambda c: f"{c[0]}-{c[1]}-{c[2]}-{'x'.join(map(str, c[3]))}" + (f"-{c[4]}" if len(c) > 4 else ""))
 @pytest.mark.parametrize("N", [1, 129, 40000])
-def test_generic_split_kernel_equals_the_static_one(dev, case, N, monkeypatch):
+def test_generic_split_kernel_equals_the_static_one(dev, case, N, monkeypatch, matmul):
     """zk_ar_forward_split (csrc/fused_ar_gsplit.hip: ONE kernel for any conditioner up to 256 wide, run-time skip tests around the operand-split
     arithmetic) against the operand-split kernel GENERATED for the conditioner: every accumulator receives the same blocks in the same order (a
     block the generated kernel drops adds exact zeros), so y and ladj must agree bit for bit — both feature orders, ragged batches, poisoned rows,
@@ -797,6 +803,7 @@ def test_generic_split_kernel_equals_the_static_one(dev, case, N, monkeypatch):
     from zuko_amd.flows import MAF, NCSF, NSF
     from zuko_amd.nn import MaskedLinear
 
+    matmul("bf16x3")  # (both kernels of this test are three-part kernels)
     kind, D, C, hidden = case[:4]
     kw = dict(activation=getattr(torch.nn, case[4])) if len(case) > 4 else {}
     monkeypatch.setenv("ZUKO_AMD_JIT_MIN_ROWS", "1")
@@ -883,7 +890,8 @@ def _run_static(st, inp, N, D, dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("regime", ["trained", "wide-range", "denormal"])
 @pytest.mark.parametrize("kind", ["nsf", "maf"])
-def test_split_kernels_away_from_default_init(dev, kind, regime, monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_split_kernels_away_from_default_init(dev, kind, regime, precision, monkeypatch, matmul):
     """the 6-of-9 partial-product argument is relative, so it has to hold away from seed-3 Kaiming weights too.
     `trained`: weights x 30, inputs x 8 (activations in the hundreds to thousands, as a trained flow has them); `wide-range`: every
     weight multiplied by 2^u, u uniform in [-20, 4]; `denormal`: first-layer weights scaled into the f32 denormal range (bf16 shares
@@ -893,6 +901,7 @@ def test_split_kernels_away_from_default_init(dev, kind, regime, monkeypatch):
     from zuko_amd.flows import MAF, NSF
     from zuko_amd.nn import MaskedLinear
 
+    matmul(precision)
     D, N = 64, 4099
     torch.manual_seed(5)
     flow = (NSF(D, 0, transforms=1, bins=8, hidden_features=[256] * 3) if kind == "nsf" else MAF(D, 0, transforms=1, hidden_features=[256] * 3)).to(dev)
@@ -918,23 +927,27 @@ def test_split_kernels_away_from_default_init(dev, kind, regime, monkeypatch):
     st = lazy.fused_state(dev)
     assert st is not None and st.ready(1 << 20) and st.static is not None and st.static[0].meta.get("split") == 1
     st.refresh(lins)
+    # two f16 parts cover "trained" (per-layer / per-sample powers of two); magnitudes spread over 2^24 WITHIN a layer, or a layer 2^-120 down,
+    # are what fused.half_scales declines: those regimes stay on the three-part kernel whatever the mode
+    assert st._half_serves(torch.empty(N, D, device=dev)) == (precision == "f16x2" and regime == "trained")
     y, ladj = _run_static(st, inp, N, D, dev)
-    keep, st.static, st.gs_mode = st.static, None, "0"  # (the reference here: the generic kernel on the f32 matrix instruction)
+    keep, st.static, st.half, st.gs_mode = (st.static, st.half), None, None, "0"  # (the reference here: the generic kernel on the f32 matrix instruction)
     y0, ladj0 = _run_static(st, inp, N, D, dev)
-    st.static = keep
+    st.static, st.half = keep
     uni = O.uni_rqs(8) if kind == "nsf" else O.UNI_AFFINE
     with torch.no_grad():
         phi = O.mlp_forward(inp.cpu().double(), [l.weight.detach().cpu().double() for l in lins], [l.bias.detach().cpu().double() for l in lins], [l.mask.cpu() for l in lins], act=torch.relu)
         y64, l64 = O.univariate_forward(uni, phi.reshape(N, D, uni.total), inp.cpu().double())
         l64 = l64.sum(dim=-1)
     assert torch.isfinite(y).all() and torch.isfinite(ladj).all(), "the regime must stay finite in f32"
-    tag = f"split kernel, {kind}, {regime} weights"
+    tag = f"split kernel ({precision}), {kind}, {regime} weights"
     assert_parity(y, y0, y64, f"{tag}: y", c=2.0)
     assert_parity(ladj, ladj0, l64, f"{tag}: ladj", c=2.0)
 
 
 @pytest.mark.gpu
-def test_split_kernel_overflowing_activation_is_nan_not_inf(dev):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_split_kernel_overflowing_activation_is_nan_not_inf(dev, precision, matmul):
     """The documented difference of the operand split, as a test: a hidden activation that overflows f32 becomes NaN in the split
     kernels (h = bf16(inf) = inf, the remainder inf - inf = NaN enters the m / l parts) where the f32 matrix instruction carries
     inf x w.  The reference turns the same row into NaN one layer later (inf x 0 on its masked zeros, zuko/nn.py:217-218), so y / ladj of
@@ -942,6 +955,7 @@ def test_split_kernel_overflowing_activation_is_nan_not_inf(dev):
     from zuko_amd.flows import NSF
     from zuko_amd.nn import MaskedLinear
 
+    matmul(precision)
     D, N = 64, 256
     torch.manual_seed(5)
     flow = NSF(D, 0, transforms=1, bins=8, hidden_features=[256] * 3).to(dev)
@@ -967,13 +981,14 @@ def test_split_kernel_overflowing_activation_is_nan_not_inf(dev):
 
 
 @pytest.mark.gpu
-def test_split_kernel_geometries_agree(dev, monkeypatch):
+def test_split_kernel_geometries_agree(dev, monkeypatch, matmul):
     """ZUKO_AMD_SPLIT_GEOM: one workgroup of eight wavefronts (24-image chunks, the default) and two workgroups of four per CU (16-image
     chunks: chunk boundaries fall inside blocks, the stream's tail is not a whole number of blocks) run the same blocks in the same
     order: bit-identical y / ladj, on a batch of several passes per workgroup."""
     from zuko_amd.flows import NSF
     from zuko_amd.nn import MaskedLinear
 
+    matmul("bf16x3")
     N = 70000
     x = torch.randn(N, 64, generator=torch.Generator().manual_seed(2)).to(dev)
     outs = []

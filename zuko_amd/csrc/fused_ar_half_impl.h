@@ -17,7 +17,7 @@
 //                holds values of ONE sample; its four lanes agree on ea through two shuffles);
 // and the accumulator returns through ONE fma:  out = fma(acc, 2^-(ew_l + ea), bias)  — products and sums before it carry no rounding but
 // the f32 accumulation's.  Values more than 2^18 below their vector's maximum lose relative (not absolute) precision: an element's absolute
-// error stays below 2^-40 of the vector's maximum.  Measured against float64 next to the reference's own f32 evaluation (random-init, x30
+// error stays below 2^-40 of the vector's maximum.  Exponent bookkeeping: arh_scale.  Measured against float64 next to the reference's own f32 evaluation (random-init, x30
 // "trained", 2^-120 / 2^100 scaled weights: scripts/split_scheme_emulation.py, tests/test_gpu_flows.py): the same error as the f32 path;
 // weights whose magnitudes spread over more than the f16 range WITHIN a layer keep the three-part kernel (zuko_amd/fused.py: eligibility).
 // A hidden value that overflows f32 becomes NaN for its sample, as in fused_ar_split_impl.h (inf - inf in the low part).
@@ -34,13 +34,16 @@ struct ArhB {  // B operand of one pair of activation tiles
   f16x8 h, l;
 };
 
-// power-of-two scale of a sample: s = 2^ea with amax * s in [2^14, 2^15) (amax = 0, inf or NaN: s = 2^15 / 1 — zeros stay zeros, non-finite values poison the sample)
+// power-of-two scale of a sample: s = 2^ea with amax * s in [2^14, 2^15) for amax in [2^-75, 2^105]; ea stays in [-90, 90] so that the accumulator's
+// descale factor 2^-(ew + ea) (ew in [-25, 35]: zuko_amd/fused.py, half_scales) is a normal f32 number.  Beyond: a sample whose largest magnitude
+// exceeds 2^105 (4e31) overflows f16 and becomes NaN — as a non-finite value does (inf - inf in the low part) —, smaller ones than 2^-75 lose
+// relative precision (absolute error below 2^-100).  amax = 0: zeros stay zeros.
 __device__ __forceinline__ void arh_scale(float amax, float& s, float& inv_s) {
   amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
   amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
   int e = __builtin_amdgcn_frexp_expf(amax);  // amax = f 2^e, f in [0.5, 1); 0 for zero / inf / NaN
   int ea = 15 - e;
-  ea = ea > 60 ? 60 : (ea < -60 ? -60 : ea);
+  ea = ea > 90 ? 90 : (ea < -90 ? -90 : ea);
   s = __builtin_amdgcn_ldexpf(1.0f, ea);
   inv_s = __builtin_amdgcn_ldexpf(1.0f, -ea);
 }

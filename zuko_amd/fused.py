@@ -504,7 +504,8 @@ def set_matmul_precision(mode: str) -> None:
 HALF_SPREAD_LOG2 = 14        # a weight more than 2^14 below its layer's largest magnitude counts as "small" ...
 HALF_SMALL_FRACTION = 0.01   # ... and a layer with more than 1 % of them keeps the three-part kernel
 HALF_ROW_LOG2 = 12           # so does a layer with an out unit whose largest weight is more than 2^12 below the layer's
-HALF_MAX_LOG2 = 40           # or whose largest magnitude is outside [2^-40, 2^40]
+HALF_MIN_LOG2, HALF_MAX_LOG2 = -20, 40  # or whose largest magnitude is outside [2^-20, 2^40]: the weight scale 2^e then has e in [-25, 35], and with the kernel's
+                                        # per-sample exponent in [-90, 90] the descale factor 2^-(e + ea) of an accumulator stays a normal f32 number
 
 
 def half_scales(linears):
@@ -525,7 +526,7 @@ def half_scales(linears):
         if big == 0.0:
             out.append((True, 0))
             continue
-        ok = math.isfinite(big) and 2.0 ** -HALF_MAX_LOG2 <= big <= 2.0 ** HALF_MAX_LOG2 and small <= HALF_SMALL_FRACTION and minrow >= big * 2.0 ** -HALF_ROW_LOG2
+        ok = math.isfinite(big) and 2.0 ** HALF_MIN_LOG2 <= big <= 2.0 ** HALF_MAX_LOG2 and small <= HALF_SMALL_FRACTION and minrow >= big * 2.0 ** -HALF_ROW_LOG2
         out.append((bool(ok), 15 - math.frexp(big)[1] if math.isfinite(big) else 0))
     return out
 
