@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-KERNEL = "arx_kernel"  # dominant kernel: zk::arx_kernel<Shape, UniRqs<8, false>, false, false>
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "arh_kernel"  # dominant kernel: zk::arh_kernel<Shape, UniRqs<8, false>, false> (round 6; rounds 3-5: arx_kernel)
+HALF = KERNEL == "arh_kernel"
 
 
 def counters(name):
@@ -36,12 +37,13 @@ ks = os.path.join(src, "kernel_stats.csv")
 if os.path.exists(ks):
     shutil.copy(ks, os.path.join(dst, "kernel_trace_stats.csv"))
     for row in csv.DictReader(open(ks)):
-        if KERNEL in row["Name"] and "UniRqs<8, false>, false, false" in row["Name"]:
+        if KERNEL in row["Name"] and ("UniRqs<8, false>, false>" if HALF else "UniRqs<8, false>, false, false") in row["Name"]:
             stats = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6, "min_ms": float(row["MinNs"]) / 1e6}
 B, D = 1 << 20, 64
 alg = B * (2 * D * 4 + 4)
 out = {
-    "kernel": "zk::arx_kernel<Shape, zk::UniRqs<8, false>, false, false> (generated operand-split static-shape instantiation of zk_ar_forward)",
+    "kernel": ("zk::arh_kernel<Shape, zk::UniRqs<8, false>, false> (generated TWO-PART operand-split static-shape instantiation of zk_ar_forward: 2 x f16 per operand, 3 matrix products)" if HALF else
+               "zk::arx_kernel<Shape, zk::UniRqs<8, false>, false, false> (generated operand-split static-shape instantiation of zk_ar_forward)"),
     "workload": "NSF(64, T=8, K=8, H=[256]*3) log_prob, batch 2^20, one transform per launch",
     "source": f"rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1` (scripts/gpu_profile.sh {tag}), mean per dispatch; raw rows in pmc_*.txt",
     "FETCH_SIZE_KiB": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB": c.get("WRITE_SIZE"),
@@ -59,9 +61,10 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
                    "coexec_share_of_busy": None if not c.get("SQ_VALU_MFMA_COEXEC_CYCLES") else c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"],
                    "shader_clock_ghz_under_the_profiler": None if not (cyc and stats.get("avg_ms")) else cyc / (stats["avg_ms"] * 1e-3) / 1e9,
                    "real_cycles_per_matrix_instruction_and_simd": None if not (cyc and c.get("SQ_INSTS_MFMA")) else cyc / (c["SQ_INSTS_MFMA"] / 1024.0),
-                   "note": "launch_cycles = GRBM_GUI_ACTIVE / 8 (a MEASURED cycle count: summed over the 8 XCDs); 16 busy cycles per v_mfma_f32_16x16x32_bf16.  With two wavefronts per SIMD — "
-                           "this kernel's geometry — a SIMD issues the form every 16.2-16.5 real cycles (profiles/r05/mfma_clock_probe.txt); the kernel's ~26 are NOT the form's ceiling "
-                           "(round 4 said so from a one-wavefront probe): its conversion / spline / ring phases run beside idle matrix pipes (profiles/r05/headline.md)"}
+                   "note": ("launch_cycles = GRBM_GUI_ACTIVE / 8 (a MEASURED cycle count: summed over the 8 XCDs); 16 busy cycles per 16x16x32 16-bit matrix instruction.  The two-part kernel issues HALF "
+                           "the matrix instructions of the three-part one (1.18e8 against 2.36e8 per launch) and ~22 % fewer vector instructions; what remains of the launch is vector issue time and "
+                           "waits, which no schedule hides under the matrix instructions (profiles/r06/headline.md)" if HALF else
+                           "launch_cycles = GRBM_GUI_ACTIVE / 8 (a MEASURED cycle count: summed over the 8 XCDs); 16 busy cycles per v_mfma_f32_16x16x32_bf16 (profiles/r05/headline.md)")}
 out["waves"] = {k: c[k] for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_IFETCH") if k in c}
 out["lds"] = {k: c[k] for k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS") if k in c}
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from zuko_amd import static_ar as sa  # noqa: E402
 
-OUT = os.path.join(sa.ARS_DIR, "abl_" + "x".join(map(str, sa.split_geometry())) + os.environ.get("ABL_TAG", ""))
+HALF = os.environ.get("ABL_HALF", "0") == "1"  # the two-part (f16 x 2) kernel instead of the three-part one
+OUT = os.path.join(sa.ARS_DIR, ("ablh_" if HALF else "abl_") + "x".join(map(str, sa.split_geometry())) + os.environ.get("ABL_TAG", ""))
 NAMES = {0: "full kernel", 1: "no DMA into the ring", 2: "no MFMA", 3: "no spline arithmetic", 4: "no barrier at chunk boundaries", 5: "no LDS reads of the weights", 6: "no operand conversion"}
 
 
@@ -24,7 +25,7 @@ def plan():
 
 def build():
     pa, lay = plan()
-    t, _ = sa.split_tables(pa, lay.kind, 1)
+    t, _ = (sa.half_tables if HALF else sa.split_tables)(pa, lay.kind, 1)
     t = dict(t)
     for kv in filter(None, os.environ.get("ABL_SHAPE", "").split(",")):  # probe builds: ABL_SHAPE="NR=2,LAG=2,XLDS=0" overrides entries of the generated shape
         k, v = kv.split("=")
@@ -32,7 +33,7 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(OUT, "arx_cfg2.hip")
     with open(src, "w") as f:
-        f.write(sa.emit_split(t))
+        f.write((sa.emit_half if HALF else sa.emit_split)(t))
     procs = []
     for k in (NAMES if os.environ.get("ABL_ONLY0", "0") != "1" else [0]):
         cmd = [sa._hipcc(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-uninitialized", "-ffp-contract=off", f"-I{sa.CSRC}", f"-DARX_ABL={k}", "-shared",
@@ -63,17 +64,25 @@ def run():
     y, ladj = torch.empty(N, 64, device=dev), torch.empty(N, device=dev)
     p = st.plan
     only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+    import zuko_amd
+
+    zuko_amd.set_matmul_precision("f16x2" if HALF else "bf16x3")
     with torch.no_grad():  # the product kernel's result on the same rows: what variant 0 of a probe build has to reproduce bit for bit
         y_ref, l_ref = flow.transform.transforms[0]().call_and_ladj(x)
+    assert st._half_serves(y) == HALF
     for k, name in NAMES.items():
         so = os.path.join(OUT, f"arx_abl{k}.so")
         if not os.path.exists(so) or (only is not None and k not in only):
             continue
         lib = ctypes.CDLL(so)
         launcher = ctypes.cast(lib.zk_ars_launch, ctypes.c_void_p)
-        a = _C.args("zk_ar_args_v1", launcher=launcher, rev=0, uni_kind=p.layout.kind, N=N, D=64, DIN=64, x=_ptr(x), ldx=64, y=_ptr(y), ldy=64, ladj=_ptr(ladj), accumulate=0,
-                    wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap), n_layers=p.n_layers, n_groups=p.n_groups,
-                    n_chunks=st.fine_n_chunks, act=1, bound=st.bound, slope=st.slope)
+        if HALF:
+            a = st._half_args(N=N, DIN=64, x=_ptr(x), ldx=64, y=_ptr(y), ldy=64, ladj=_ptr(ladj), accumulate=0)
+            a.launcher = launcher.value
+        else:
+            a = _C.args("zk_ar_args_v1", launcher=launcher, rev=0, uni_kind=p.layout.kind, N=N, D=64, DIN=64, x=_ptr(x), ldx=64, y=_ptr(y), ldy=64, ladj=_ptr(ladj), accumulate=0,
+                        wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap), n_layers=p.n_layers, n_groups=p.n_groups,
+                        n_chunks=st.fine_n_chunks, act=1, bound=st.bound, slope=st.slope)
         fn = lambda: _C.check(_C.lib().zk_ar_forward_static(a, _stream()), "zk_ar_forward_static")
         for _ in range(3):
             fn()

@@ -12,7 +12,7 @@ import torch
 
 from conftest import T, golden
 from oracle import zuko_oracle as O
-from parity import assert_f64, assert_parity, d64
+from parity import C_ADVERSARIAL, assert_f64, assert_parity, d64
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +59,20 @@ def test_rqs_golden(dev, tag):
             w64, h64, dd64, x64 = (d64(g[n]) for n in ("widths", "heights", "derivatives", "x"))
             y64, l64 = O.rqs_forward(w64, h64, dd64, x64)
             assert_parity(y2, g["y"], y64, "rqs golden f32: y from parameters", where=same)
-            assert_parity(l2, g["ladj"], l64, "rqs golden f32: ladj from parameters", where=same)
+            assert_parity(l2, g["ladj"], l64, "rqs golden f32: ladj from parameters", where=same, c=C_ADVERSARIAL)
+            # elements whose bin flipped (x within rounding of a knot the two evaluations place an ulp apart) are COMPARED, not skipped:
+            # the spline is C1 at a knot, so y and log|dy/dx| of the neighbouring bin differ from the reference's by O(knot distance) — bars: y within
+            # 1e-5 (1 + |y|) + the largest slope around the knot x 4 ulps of the knot; ladj within 1e-3 (the second derivative jumps at a knot and the
+            # adversarial rows have bins 1e-3 wide: measured and printed below)
+            flip = ~same
+            if flip.any():
+                yv, yr, lv, lr = y2.cpu()[flip].double(), T(g["y"])[flip].double(), l2.cpu()[flip].double(), T(g["ladj"])[flip].double()
+                slope = T(g["slopes"]).double().abs().amax(dim=-1)[flip]
+                knot_ulp = 4 * 2.0 ** -23 * torch.maximum(x.cpu().abs().double()[flip], torch.tensor(1.0, dtype=torch.float64))
+                ey, el = (yv - yr).abs(), (lv - lr).abs()
+                print(f"rqs[f32] flipped elements: {int(flip.sum())}, max |dy| {ey.max():.2e}, max |dladj| {el.max():.2e}")
+                assert bool((ey <= 1e-5 * (1 + yr.abs()) + slope * knot_ulp).all()), f"y on bin-flipped elements: max |d| {ey.max():.3e}"
+                assert bool((el <= 1e-3).all()), f"ladj on bin-flipped elements: max |d| {el.max():.3e}"
         else:
             close(torch.where(same.to(dev), y2, T(g["y"], dev)), g["y"], "y", tol)
             close(torch.where(same.to(dev), l2, T(g["ladj"], dev)), g["ladj"], "ladj", tol)
@@ -233,7 +246,7 @@ def test_bernstein_golden(dev, tag, name):
         # polynomial by de Casteljau with the closed-form derivative.  Both against the float64 oracle:
         y64, l64 = O.bern_forward(d64(g["theta"]), d64(g["x"]), name == "bbern")
         assert_parity(y, g["y"], y64, f"{name} golden f32: y")
-        assert_parity(ladj, g["ladj"], l64, f"{name} golden f32: ladj")
+        assert_parity(ladj, g["ladj"], l64, f"{name} golden f32: ladj", **({"c": C_ADVERSARIAL} if name == "bern" else {}))
         assert_parity(xi, g["x_inv"], O.bern_inverse(d64(g["theta"]), d64(g["y"]), name == "bbern"), f"{name} golden f32: inverse (24-step bisection)")
     else:
         # float64: the closed form equals the reference's Beta-pdf form to 6e-14 on this set (measured in the build container

@@ -26,6 +26,13 @@
 #pragma once
 #include "fused_ar_split_impl.h"
 
+#ifndef ARH_LOOK
+#define ARH_LOOK 1  // blocks of weight images requested ahead of the matrix instructions that consume them
+#endif
+#ifndef ARH_RELU_INT
+#define ARH_RELU_INT 0  // probe builds: 1 = ReLU as an integer max (one instruction; a NaN with the sign bit set would become 0)
+#endif
+
 namespace zk {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -88,7 +95,7 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arh_hidden
     if constexpr (!P::tile_has_blocks(L, t)) out[t] = *reinterpret_cast<const f32x4*>(bias_q + t * 16);  // units that depend on nothing: bias only
   });
   if constexpr (NB > 0) {
-    constexpr int LOOK = ARX_LOOK < NB ? ARX_LOOK : NB;
+    constexpr int LOOK = ARH_LOOK < NB ? ARH_LOOK : NB;
     f32x4 a[LOOK + 1][2];
     f32x4 bs;  // the out tile's bias: a raw read in front of the look-ahead request of the tile's LAST block, whose counted wait settles it
     f32x4 acc;
@@ -106,9 +113,9 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arh_hidden
         constexpr int nx = (s + LOOK) % (LOOK + 1);
         ars_for<2>([&](auto p) ARS_ALWAYS_INLINE { a[nx][p] = ring.template read<BASE + 2 * (s + LOOK) + decltype(p)::value>(); });
       }
-      constexpr int ahead = (s + LOOK < NB ? LOOK : NB - 1 - s);  // blocks behind this one whose images may still be outstanding (LOOK <= 1: only this step's request is younger than the bias read)
-      static_assert(ARX_LOOK == 1, "counted waits of the two-part kernels are written for a look-ahead of one block");
-      if constexpr (last_of_tile) arh_settle<2 * ahead>(a[cur][0], a[cur][1], bs);
+      constexpr int ahead = (s + LOOK < NB ? LOOK : NB - 1 - s);  // blocks behind this one whose images may still be outstanding
+      // (a tile's last block: only THIS step's request is younger than the bias read — the wait that settles it also settles the blocks in between)
+      if constexpr (last_of_tile) arh_settle<(s + LOOK < NB ? 2 : 0)>(a[cur][0], a[cur][1], bs);
       else arh_settle<2 * ahead>(a[cur][0], a[cur][1]);
       if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
       arh_block(a[cur], in[ip], acc);
@@ -132,7 +139,8 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arh_hidden
       for (int t = 0; t < HTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          out[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
+          if (ARH_RELU_INT) out[t][r] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, out[t][r]), 0));
+          else out[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
           amax = fmaxf(amax, out[t][r]);                  // (non-negative after the ReLU; a NaN is skipped here and poisons through the split)
         }
     } else {
@@ -251,7 +259,7 @@ template <class S, typename Uni, bool DIAG = false> __global__ __launch_bounds__
     const float dl = a.wdescale[S::NH] * inv_s;
     float lacc = 0.f;
     constexpr int NBL = NSTEP * NT;                          // blocks of the last layer
-    constexpr int LOOKL = ARX_LOOK < NBL ? ARX_LOOK : NBL;
+    constexpr int LOOKL = ARH_LOOK < NBL ? ARH_LOOK : NBL;
     f32x4 w[LOOKL + 1][2];
     ars_for<LOOKL>([&](auto b_) ARS_ALWAYS_INLINE {
       constexpr int b = b_;
@@ -288,7 +296,8 @@ template <class S, typename Uni, bool DIAG = false> __global__ __launch_bounds__
             ars_for<2>([&](auto p) ARS_ALWAYS_INLINE { w[nx][p] = ring.template read<S::LAST_BASE + 2 * (blk + LOOKL) + decltype(p)::value>(); });
           }
           constexpr int ahead = (blk + LOOKL < NBL ? LOOKL : NBL - 1 - blk);
-          arh_settle<2 * ahead>(w[cur][0], w[cur][1]);
+          if constexpr (last_of_group) arh_settle<(blk + LOOKL < NBL ? 2 : 0)>(w[cur][0], w[cur][1]);
+          else arh_settle<2 * ahead>(w[cur][0], w[cur][1]);
           if constexpr (last_of_group) {  // (the bias tiles are older than this step's request: the same wait has settled them)
 #pragma unroll
             for (int u = 0; u < NT; ++u) arh_touch(bs[u]);
