@@ -79,10 +79,14 @@ def test_gradients_over_many_tiles(dev, name):
 @pytest.mark.parametrize("activation", ["Tanh", "ELU"])
 def test_gradients_smooth_activation_max_norm(dev, activation):
     """test_gradients_over_many_tiles holds the headline flow's gradients at 4 096 rows to float64 autograd only in the 1-norm,
-    arguing that a ReLU unit whose pre-activation lies within float32 rounding of zero flips between two correct evaluations and moves a whole
-    weight-gradient row by O(1 / rows).  That argument is testable: a Tanh / ELU conditioner has no kinks, so the SAME flow shape (NSF 64
-    features, 8 transforms, hidden [256] * 3) at the SAME 4 096 rows must agree with float64 autograd through the oracle in the MAX norm.  The
-    bar is 1e-5 of max |grad| per parameter tensor and for dx — if it held only with ReLU's excuse there would be a bug in the reduction."""
+    arguing with ReLU units that flip between two correct evaluations.  A Tanh / ELU conditioner has no kinks, so here the SAME flow shape
+    (NSF 64 features, 8 transforms, hidden [256] * 3) at the SAME 4 096 rows is held in the MAX norm.  Measured first (round 6): against float64
+    autograd the HIP gradients sit 1.1e-3 of max |grad| away with ELU as well — the kink story was not the whole story.  The float32 REFERENCE
+    (autograd through the oracle in float32, the reference's own arithmetic) is compared with the same float64 gradients here: the gradient of a
+    deep spline flow is ill-conditioned in its inputs (bins 0.1 wide: second derivatives of order 1e2 multiply the 1e-5 rounding of every
+    transform's input), for anyone's float32.  The bar, in the max norm and per parameter tensor: |hip - f64| <= 1e-5 of max |grad| (the verdict's
+    figure; Tanh measures 9.8e-6 at worst, the float32 reference 1.1e-6) OR <= 2 x |reference_f32 - f64| (the suite's measured bar: ELU, whose
+    float32 reference is itself 1e-3 away), and the same for dx."""
     import zuko_amd.flows as F
 
     act = getattr(torch.nn, activation)
@@ -91,38 +95,44 @@ def test_gradients_smooth_activation_max_norm(dev, activation):
     gen = torch.Generator().manual_seed(23)
     n = 4096
     x = torch.randn(n, 64, generator=gen)
-    sd = {k: (v.detach().double() if v.is_floating_point() else v.detach()) for k, v in flow.state_dict().items() if v is not None}
-    leaves = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and ("weight" in k or "bias" in k)}
-    sd.update(leaves)
-    spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(8), 64)
     fn = {"Tanh": torch.tanh, "ELU": torch.nn.functional.elu}[activation]
-    for layer in spec.layers:
-        assert hasattr(layer, "plan") and layer.plan is None
-    x64 = x.double().requires_grad_()
-    # (the oracle's mlp_forward takes the activation as an argument: evaluate the flow layer by layer with it)
-    z, ladj = x64, torch.zeros(n, dtype=torch.float64)
-    for layer in spec.layers:
-        phi = O.mlp_forward(z, layer.weights, layer.biases, layer.masks, act=fn).unflatten(-1, (-1, layer.uni.total))
-        z, lj = O.univariate_forward(layer.uni, phi, z)
-        ladj = ladj + lj.sum(-1)
-    ref_loss = -(O.diag_normal_log_prob(z, spec.loc, spec.scale) + ladj).mean()
-    ref_loss.backward()
+
+    def oracle(dtype):
+        sd = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach()) for k, v in flow.state_dict().items() if v is not None}
+        leaves = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and ("weight" in k or "bias" in k)}
+        sd.update(leaves)
+        spec = O.spec_from_state_dict(sd, "ar", O.uni_rqs(8), 64)
+        xr = x.detach().clone().to(dtype).requires_grad_()
+        # (the oracle's mlp_forward takes the activation as an argument: the flow layer by layer with it)
+        z, ladj = xr, torch.zeros(n, dtype=dtype)
+        for layer in spec.layers:
+            phi = O.mlp_forward(z, layer.weights, layer.biases, layer.masks, act=fn).unflatten(-1, (-1, layer.uni.total))
+            z, lj = O.univariate_forward(layer.uni, phi, z)
+            ladj = ladj + lj.sum(-1)
+        loss = -(O.diag_normal_log_prob(z, spec.loc, spec.scale) + ladj).mean()
+        loss.backward()
+        return loss.item(), {k: v.grad.double() for k, v in leaves.items()}, xr.grad.double()
+
+    l64, g64, gx64 = oracle(torch.float64)
+    l32, g32, gx32 = oracle(torch.float32)
 
     flow = flow.to(dev)
     xg = x.to(dev).requires_grad_()
     loss = -flow().log_prob(xg).mean()
     loss.backward()
-    assert abs(loss.item() - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
+    assert abs(loss.item() - l64) < 1e-5 * max(1.0, abs(l64))
     params = dict(flow.named_parameters())
-    worst = 0.0
-    for k, v in leaves.items():
-        g = v.grad
-        err = ((params[k].grad.cpu().double() - g).abs().max() / g.abs().max().clamp_min(1e-12)).item()
-        worst = max(worst, err)
-        assert err < 1e-5, f"{k}: max-norm distance from float64 autograd {err:.2e} of max |grad| ({activation}, {n} rows)"
-    gx = ((xg.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max()).item()
-    assert gx < 1e-5, f"grad x: {gx:.2e}"
-    print(f"NSF cfg2 shape with {activation} at {n} rows: max-norm distance from float64 oracle autograd {worst:.2e} of max |grad| (dx {gx:.2e})")
+    worst = (0.0, 0.0)
+    for k, g in g64.items():
+        scale = g.abs().max().clamp_min(1e-12)
+        e_hip = ((params[k].grad.cpu().double() - g).abs().max() / scale).item()
+        e_ref = ((g32[k] - g).abs().max() / scale).item()
+        worst = max(worst, (e_hip, e_ref))
+        assert e_hip <= max(1e-5, 2.0 * e_ref), f"{k}: |hip - f64| = {e_hip:.2e} of max |grad| against the float32 reference's own {e_ref:.2e} ({activation}, {n} rows)"
+    sx = gx64.abs().max()
+    ex_hip, ex_ref = ((xg.grad.cpu().double() - gx64).abs().max() / sx).item(), ((gx32 - gx64).abs().max() / sx).item()
+    assert ex_hip <= max(1e-5, 2.0 * ex_ref), f"grad x: {ex_hip:.2e} against the reference's {ex_ref:.2e}"
+    print(f"NSF cfg2 shape with {activation} at {n} rows, max norm, of max |grad|: worst parameter tensor hip {worst[0]:.2e} / float32 reference {worst[1]:.2e}; dx hip {ex_hip:.2e} / reference {ex_ref:.2e}")
 
 
 @pytest.mark.parametrize("name", ["nsf_cfg1", "maf_doc", "nice_small", "nsf_p2", "maf_cfg3", "nsf_cfg2"])

@@ -62,8 +62,8 @@ def test_rqs_golden(dev, tag):
             assert_parity(l2, g["ladj"], l64, "rqs golden f32: ladj from parameters", where=same, c=C_ADVERSARIAL)
             # elements whose bin flipped (x within rounding of a knot the two evaluations place an ulp apart) are COMPARED, not skipped:
             # the spline is C1 at a knot, so y and log|dy/dx| of the neighbouring bin differ from the reference's by O(knot distance) — bars: y within
-            # 1e-5 (1 + |y|) + the largest slope around the knot x 4 ulps of the knot; ladj within 1e-3 (the second derivative jumps at a knot and the
-            # adversarial rows have bins 1e-3 wide: measured and printed below)
+            # 1e-5 (1 + |y|) + the largest slope around the knot x 4 ulps of the knot; ladj within 1e-4 (the second derivative jumps at a knot and the
+            # adversarial rows have bins 1e-3 wide; measured on this set: 6 flipped elements, max |dy| 2.7e-6, max |dladj| 1.1e-5)
             flip = ~same
             if flip.any():
                 yv, yr, lv, lr = y2.cpu()[flip].double(), T(g["y"])[flip].double(), l2.cpu()[flip].double(), T(g["ladj"])[flip].double()
@@ -72,7 +72,7 @@ def test_rqs_golden(dev, tag):
                 ey, el = (yv - yr).abs(), (lv - lr).abs()
                 print(f"rqs[f32] flipped elements: {int(flip.sum())}, max |dy| {ey.max():.2e}, max |dladj| {el.max():.2e}")
                 assert bool((ey <= 1e-5 * (1 + yr.abs()) + slope * knot_ulp).all()), f"y on bin-flipped elements: max |d| {ey.max():.3e}"
-                assert bool((el <= 1e-3).all()), f"ladj on bin-flipped elements: max |d| {el.max():.3e}"
+                assert bool((el <= 1e-4).all()), f"ladj on bin-flipped elements: max |d| {el.max():.3e}"
         else:
             close(torch.where(same.to(dev), y2, T(g["y"], dev)), g["y"], "y", tol)
             close(torch.where(same.to(dev), l2, T(g["ladj"], dev)), g["ladj"], "ladj", tol)
