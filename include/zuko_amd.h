@@ -377,6 +377,11 @@ typedef struct zk_ar_inc_args_v1 {
   const int32_t* bias_off; /* HOST, n_hidden + 1 ints */
   const int32_t* featmap;  /* DEVICE [4 n_groups] */
   const int32_t* prog;     /* DEVICE [n_groups][36] */
+  int32_t half;            /* != 0: wstream is the plan's HALF stream (zuko_amd/incremental.py: half_stream) — the pull blocks (out tile x PAIR of final in tiles) as two */
+  int32_t pad_;            /* f16 images of the layer's weights times a power of two (zk_gather_split_f16), multiplied on v_mfma_f32_16x16x32_f16 with three partial */
+  double wdescale1;        /* products; wdescale_l = the inverse of that power of two for linear layer l = 1 .. n_hidden.  First layer and diagonal tiles: f32 as before */
+  double wdescale2;
+  double wdescale3;
 } zk_ar_inc_args_v1;
 int zk_ar_inverse_incremental(const zk_ar_inc_args_v1* args, void* stream);
 int zk_ar_inc_lds_bytes(int bias_floats, int nit);

@@ -133,6 +133,19 @@ def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bin
 
     xs, ls = inc.simulate(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn)
     assert np.abs(xs - xo.numpy()).max() < 1e-12 and np.abs(ls - lo.numpy()).max() < 1e-11
+    # the HALF stream (round 6: pulls as 16 x 32 blocks of two f16 images on the f16 matrix instruction, per-pair power-of-two scales): same groups,
+    # same diagonal tiles; its static length, and the walk with the kernel's operand split agrees with the oracle to the split's 2^-22
+    hs = inc.half_stream(plan, [l.mask for l in lins])
+    images = sum(inc.L1S + 2 * ((NH - 1) + NT) * ((j + 1) // 2) + inc.L1D + (NH - 1) + NT for j in range(plan.n_groups))
+    assert hs.n_images == -(-images // inc.CHUNK) * inc.CHUNK == hs.n_chunks * inc.CHUNK
+    assert sum(len(p) for p in hs.blk_pos[1:]) == sum(((NH - 1) + NT) * ((j + 1) // 2) for j in range(plan.n_groups))
+    taken = np.concatenate([np.concatenate([p, p + 1]) for p in hs.blk_pos[1:] if len(p)]) if any(len(p) for p in hs.blk_pos[1:]) else np.zeros(0, int)
+    assert len(set(taken.tolist())) == len(taken) and (hs.gather_f32.reshape(-1, 256)[taken] == -1).all(), "block images are disjoint and left to the block gathers"
+    from zuko_amd import fused as Fu
+
+    wexp = [0] + [e for _, e in Fu.half_scales(lins)][1:]
+    xh, lh = inc.simulate(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn, half=hs, wexp=wexp)
+    assert np.abs(xh - xo.numpy()).max() < 1e-6 * max(1.0, np.abs(xo.numpy()).max()) and np.abs(lh - lo.numpy()).max() < 1e-5, (np.abs(xh - xo.numpy()).max(), np.abs(lh - lo.numpy()).max())
 
 
 def test_incremental_plan_rejects_layouts_that_do_not_fit():

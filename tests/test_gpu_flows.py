@@ -590,10 +590,13 @@ def test_bf16_xcd_walk_equals_id_order_raster(dev, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["nsf_cfg2", "maf_cfg3"])
-def test_incremental_inverse_kernel(dev, name, monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_incremental_inverse_kernel(dev, name, precision, monkeypatch, matmul):
     """zk_ar_inverse_incremental (one launch, ~1.5x the multiply-adds of a density pass) against the partial sweeps
     (bit-identical to the reference's full `passes` loop) and the oracle; ragged batch; ladj from the same launch equals the
-    forward pass's; rsample_and_log_prob consistency (zuko/distributions.py:129-138)."""
+    forward pass's; rsample_and_log_prob consistency (zuko/distributions.py:129-138).  precision f16x2: the launch's pull phase runs on the
+    f16 matrix instruction with the two-part operand split (HALF instantiation, csrc/inc_inverse.hip); "bf16x3": every product on the f32 one."""
+    matmul(precision)
     flow, entry = build_flow(name)
     spec = oracle_spec(flow, entry)
     flow = flow.to(dev)
@@ -601,12 +604,13 @@ def test_incremental_inverse_kernel(dev, name, monkeypatch):
     with torch.no_grad():
         assert all(t.incremental_state(dev) is not None for t in flow.transform.transforms)
         x_inc = flow().transform.inv(z.to(dev))
+        assert all(t.incremental_state(dev).h_ok == (precision == "f16x2") for t in flow.transform.transforms)
         monkeypatch.setenv("ZUKO_AMD_NO_INCREMENTAL", "1")
         x_par = flow().transform.inv(z.to(dev))
         monkeypatch.delenv("ZUKO_AMD_NO_INCREMENTAL")
         x_or = O.flow_inverse(spec, z)
         x_64 = O.flow_inverse(to_f64(spec), d64(z))
-        assert_parity(x_inc, x_or, x_64, f"{name}: incremental inverse vs the oracle's sweep loop")
+        assert_parity(x_inc, x_or, x_64, f"{name} ({precision}): incremental inverse vs the oracle's sweep loop")
         assert_parity(x_par, x_or, x_64, f"{name}: partial-sweep inverse vs the oracle's sweep loop")
         # one transform: x and the forward log-determinant from the single launch
         t0 = flow.transform.transforms[0]()

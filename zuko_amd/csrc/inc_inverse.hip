@@ -25,10 +25,58 @@
 namespace zk {
 
 typedef float f32x4i __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8i __attribute__((ext_vector_type(8)));
+
+// HALF instantiation (round 6): the PULL phase — every off-diagonal weight tile, multiplied once per sample — runs on v_mfma_f32_16x16x32_f16 with
+// the two-part operand split of csrc/fused_ar_half_impl.h (operand = two f16 numbers after an exact power-of-two scaling, three partial products, f32
+// accumulation) instead of four v_mfma_f32_16x16x4_f32 per 16 x 16 tile: 48 matrix cycles per 16 x 32 block against 256.  The final activations of
+// a layer are held as PAIRS of tiles (2 p, 2 p + 1) — the B operand of a block: 4 values of either tile per lane, as h and l parts (the same 4
+// registers per tile as the f32 values) — converted when a tile becomes final with the pair's own scale (max over the sample's 32 values of the pair:
+// two shuffles; the even tile is converted alone first, and again with its partner).  A block's three products go to a zeroed temporary that enters
+// the pre-activation through ONE fma with 2^-(ew + ea) (ew: the layer's weight scale, host; ea: the pair's).  The first layer (inputs are x itself)
+// and the five passes over the diagonal tiles stay on the f32 instruction: their operands change every pass.
+struct IncPair { f16x8i h, l; };
+__device__ __forceinline__ void inc_pair_convert(const f32x4i& lo, const f32x4i& hi, float amax, float wdesc, IncPair& p, float& dd) {
+  amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+  int ea = 15 - __builtin_amdgcn_frexp_expf(amax);  // amax 2^ea in [2^14, 2^15); zero / inf / NaN: ea = 15 (zeros stay zeros, non-finite values become NaN)
+  ea = ea > 90 ? 90 : (ea < -90 ? -90 : ea);
+  const float s = __builtin_amdgcn_ldexpf(1.0f, ea);
+  dd = __builtin_amdgcn_ldexpf(1.0f, -ea) * wdesc;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = (e < 4 ? lo[e] : hi[e - 4]) * s;
+    const _Float16 h = (_Float16)v;
+    p.h[e] = h;
+    p.l[e] = (_Float16)(v - (float)h);
+  }
+}
+__device__ __forceinline__ float inc_amax4(const f32x4i& v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
+// acc += dd * (W' B'): the block's images wh / wl (h and l parts of the scaled weights) against the pair's parts.  The three matrix instructions and
+// the wait states behind them are ONE assembly block: hipcc (ROCm 7.2) leaves 8 wait states between a v_mfma_f32_16x16x32_f16 and the first vector
+// instruction that reads its result (v_accvgpr_read / v_pk_fma_f32) — too few on gfx950: with one wavefront per SIMD the product read stale registers
+// in a timing-dependent subset of wavefronts (whole 16-sample tiles off by 1e-2; 32 wait states: none; scripts/_dbg in profiles/r06/inverse.md).
+// Operands pinned to VGPRs; smallest partial product first.
+#define IN_HBLOCK(acc, wh, wl, P, dd)                                                                                               \
+  {                                                                                                                                  \
+    f32x4i t_;                                                                                                                       \
+    asm volatile("s_nop 1\n\t"                                                                                                      \
+                 "v_mfma_f32_16x16x32_f16 %0, %1, %3, 0\n\t"                                                                        \
+                 "v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"                                                                       \
+                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\t"                                                                       \
+                 "s_nop 15\n\ts_nop 3"                                                                                              \
+                 : "=&v"(t_) : "v"(wl), "v"(wh), "v"((P).h), "v"((P).l));                                                            \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (acc)[r_] = __builtin_fmaf(t_[r_], (dd), (acc)[r_]);                            \
+  }
 
 #define IN_T 17      /* tiles per hidden layer = feature groups (static unroll depth) */
 #define IN_CH 24     /* tiles per ring chunk */
+#ifndef IN_NR
 #define IN_NR 3      /* ring slots */
+#endif
+#ifndef INC_DBG
+#define INC_DBG 0    /* probe builds: 1 = wait states behind a block's matrix instructions, 2 = every counted wait drains */
+#endif
 #define IN_WAVES 4
 #define IN_MAXD 4    /* dynamic first-layer input tiles kept in registers per group (= IN_L1D) */
 #define IN_PROG (2 + 2 * IN_T)
@@ -50,6 +98,7 @@ struct IncArgs {
   float bound, ls;
   RqsLeanConst lc;
   int64_t n_tiles;
+  float wdescale[4];  // HALF: 2^-ew of linear layer 1 .. NH (the power of two its pull blocks were stored with); [0] unused
 };
 
 // (not inlined: the group step below exists 17 times; inline expansions of expm1f / tanhf / erff at every activation
@@ -85,10 +134,13 @@ __device__ __forceinline__ f32x4i inc_act4(f32x4i v, int act) {
 //   [IN_L1D first-layer diagonal tiles (padded)] [(NH-1) hidden diagonal tiles] [NT last-layer diagonal tiles]
 #define IN_L1S 4
 #define IN_L1D 4
-__host__ __device__ constexpr int inc_group_tiles(int NH, int NT, int j) { return IN_L1S + (NH - 1) * j + NT * j + IN_L1D + (NH - 1) + NT; }
-__host__ __device__ constexpr int inc_group_start(int NH, int NT, int j) {
+// HALF: a pull is a 16 x 32 BLOCK (out tile, pair of final in tiles: the pairs that hold a tile < j are (j + 1) / 2) of two images (h, l)
+__host__ __device__ constexpr int inc_group_tiles(int NH, int NT, int j, bool half = false) {
+  return half ? IN_L1S + 2 * ((NH - 1) + NT) * ((j + 1) / 2) + IN_L1D + (NH - 1) + NT : IN_L1S + (NH - 1) * j + NT * j + IN_L1D + (NH - 1) + NT;
+}
+__host__ __device__ constexpr int inc_group_start(int NH, int NT, int j, bool half = false) {
   int s = 0;
-  for (int i = 0; i < j; ++i) s += inc_group_tiles(NH, NT, i);
+  for (int i = 0; i < j; ++i) s += inc_group_tiles(NH, NT, i, half);
   return s;
 }
 
@@ -165,7 +217,7 @@ template <int K> struct IncRqs {
 
 extern __shared__ __attribute__((aligned(16))) float inc_lds[];
 
-template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_inverse_kernel(IncArgs a) {
+template <typename Uni, int NH, bool HALF = false> __global__ __launch_bounds__(256, 1) void inc_inverse_kernel(IncArgs a) {
   constexpr int NT = Uni::NT, TOTAL = Uni::TOTAL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,7 +271,13 @@ template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_in
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 
-    f32x4i h1[IN_T], h2[NH > 1 ? IN_T : 1], h3[NH > 2 ? IN_T : 1];
+    f32x4i h1[HALF ? 1 : IN_T], h2[NH > 1 && !HALF ? IN_T : 1], h3[NH > 2 && !HALF ? IN_T : 1];
+    // HALF: the final activations as pairs of tiles in two f16 parts, every pair with its descale factor; the even tile of the open pair in f32
+    constexpr int NPAIR = (IN_T + 1) / 2;
+    IncPair p1[HALF ? NPAIR : 1], p2[HALF && NH > 1 ? NPAIR : 1], p3[HALF && NH > 2 ? NPAIR : 1];
+    float dd1[HALF ? NPAIR : 1], dd2[HALF && NH > 1 ? NPAIR : 1], dd3[HALF && NH > 2 ? NPAIR : 1];
+    f32x4i ev1 = {0.f, 0.f, 0.f, 0.f}, ev2 = ev1, ev3 = ev1;
+    float am1 = 0.f, am2 = 0.f, am3 = 0.f;
     float lacc = 0.f;
 
     // one statically indexed copy of the group step per group (a generic lambda over integral constants: `#pragma unroll`
@@ -229,10 +287,11 @@ template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_in
       if (j < a.G) {
         const int* pg = prog_lds + j * IN_PROG;
         const int ns = __builtin_amdgcn_readfirstlane(pg[0]), nd = __builtin_amdgcn_readfirstlane(pg[1]);
-        constexpr int P_S = inc_group_start(NH, NT, j);            // first-layer tiles with final inputs
+        constexpr int NPR = (j + 1) / 2;                           // HALF: pairs that hold a final tile
+        constexpr int P_S = inc_group_start(NH, NT, j, HALF);      // first-layer tiles with final inputs
         constexpr int P_H = P_S + IN_L1S;                          // hidden pulls
-        constexpr int P_L = P_H + (NH - 1) * j;                    // last-layer pulls
-        constexpr int P_D = P_L + NT * j;                          // diagonal tiles
+        constexpr int P_L = P_H + (HALF ? 2 * (NH - 1) * NPR : (NH - 1) * j);  // last-layer pulls
+        constexpr int P_D = P_L + (HALF ? 2 * NT * NPR : NT * j);  // diagonal tiles
         // ---- pull: contributions of everything that is already final, then the diagonal tiles into registers -----------
         // One static sequence of NTOT consecutive stream tiles, three raw reads in flight: tile i + 2 is requested before tile i
         // is multiplied (or stored away, for the diagonal tiles that stay in registers over the five passes).
@@ -255,18 +314,33 @@ template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_in
         for (int i = 0; i < IN_MAXD; ++i) itd[i] = i < nd ? __builtin_amdgcn_readfirstlane(pg[2 + IN_T + i]) : 0;
         f32x4i wh2 = {0.f, 0.f, 0.f, 0.f}, wh3 = {0.f, 0.f, 0.f, 0.f};
         f32x4i wl[NT];
-        constexpr int N_H = (NH - 1) * j, N_L = NT * j, NPULL = IN_L1S + N_H + N_L, NTOT = NPULL + IN_L1D + (NH - 1) + NT;
+        constexpr int N_H = HALF ? 2 * (NH - 1) * NPR : (NH - 1) * j, N_L = HALF ? 2 * NT * NPR : NT * j, NPULL = IN_L1S + N_H + N_L, NTOT = NPULL + IN_L1D + (NH - 1) + NT;
         static_assert(P_D == P_S + NPULL, "pull tiles are consecutive in the stream");
-        f32x4i buf[3];
+        f32x4i buf[4];  // three raw reads in flight; HALF multiplies a block when its second image is in, so the first must outlive one more request
         buf[0] = ring.template read<P_S>();
         buf[1] = ring.template read<P_S + 1>();
         inc_for<NTOT>([&](auto i_) __attribute__((always_inline)) {
           constexpr int i = decltype(i_)::value;
-          if constexpr (i + 2 < NTOT) buf[(i + 2) % 3] = ring.template read<P_S + i + 2>();
-          inc_settle<(NTOT - 1 - i) < 2 ? (NTOT - 1 - i) : 2>(buf[i % 3]);
-          const f32x4i w = buf[i % 3];
+          if constexpr (i + 2 < NTOT) buf[(i + 2) % 4] = ring.template read<P_S + i + 2>();
+          inc_settle<INC_DBG == 2 ? 0 : ((NTOT - 1 - i) < 2 ? (NTOT - 1 - i) : 2)>(buf[i % 4]);
+          const f32x4i w = buf[i % 4];
           if constexpr (i < IN_L1S) {  // first-layer tiles whose inputs are final
             if (i < ns) IN_MFMA4(o1, w, l1b[i]);
+          } else if constexpr (HALF && i < NPULL) {  // blocks of two images: hidden pulls (layer 2 from the pairs of h1, layer 3 from h2), then the last layer's
+            if constexpr ((i - IN_L1S) % 2 == 1) {
+              constexpr int k = (i - IN_L1S) / 2;
+              const f32x4i wh = buf[(i + 3) % 4];  // the block's first image (h), settled one step ago
+              if constexpr (k < (NH - 1) * NPR) {
+                constexpr int layer = k / NPR, p = k % NPR;
+                if constexpr (layer == 0) { IN_HBLOCK(o2, wh, w, p1[p], dd1[p]); }
+                else { IN_HBLOCK(o3, wh, w, p2[p], dd2[p]); }
+              } else {
+                constexpr int kk = k - (NH - 1) * NPR, p = kk / NT, tt = kk % NT;
+                if constexpr (NH == 1) { IN_HBLOCK(po[tt], wh, w, p1[p], dd1[p]); }
+                else if constexpr (NH == 2) { IN_HBLOCK(po[tt], wh, w, p2[p], dd2[p]); }
+                else { IN_HBLOCK(po[tt], wh, w, p3[p], dd3[p]); }
+              }
+            }
           } else if constexpr (i < IN_L1S + N_H) {  // hidden pulls: layer 2 from h1, then layer 3 from h2
             constexpr int k = i - IN_L1S;
             if constexpr (k < j) { IN_MFMA4(o2, w, h1[k]); }
@@ -331,9 +405,25 @@ template <typename Uni, int NH> __global__ __launch_bounds__(256, 1) void inc_in
           asm volatile("" ::: "memory");
           __builtin_amdgcn_wave_barrier();
         }
-        h1[j] = h1j;
-        if constexpr (NH > 1) h2[j] = h2j;
-        if constexpr (NH > 2) h3[j] = h3j;
+        if constexpr (!HALF) {
+          h1[j] = h1j;
+          if constexpr (NH > 1) h2[j] = h2j;
+          if constexpr (NH > 2) h3[j] = h3j;
+        } else {
+          // tile j is final: pair j / 2 of every layer is (re)converted — the even tile alone against zeros, then together with its partner
+          const f32x4i zero = {0.f, 0.f, 0.f, 0.f};
+          auto fin = [&](const f32x4i& v, f32x4i& ev, float& am, IncPair& pr, float& dd, float wd) __attribute__((always_inline)) {
+            if constexpr (j % 2 == 0) {
+              ev = v; am = inc_amax4(v);
+              inc_pair_convert(v, zero, am, wd, pr, dd);
+            } else {
+              inc_pair_convert(ev, v, fmaxf(am, inc_amax4(v)), wd, pr, dd);
+            }
+          };
+          fin(h1j, ev1, am1, p1[j / 2], dd1[j / 2], a.wdescale[1]);
+          if constexpr (NH > 1) fin(h2j, ev2, am2, p2[j / 2], dd2[j / 2], a.wdescale[2]);
+          if constexpr (NH > 2) fin(h3j, ev3, am3, p3[j / 2], dd3[j / 2], a.wdescale[3]);
+        }
       }
     };
 #define ZK_INC_STEP(J) group_step(std::integral_constant<int, J>{});
@@ -399,14 +489,23 @@ int zk_ar_inverse_incremental(const zk_ar_inc_args_v1* args, void* stream) {
   a.n_tiles = (N + 63) / 64;
   const int lds = inc_lds_floats(bias_floats, n_groups, a.xs) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
+  const bool half = args->half != 0;
+  if (half) {  // wstream is the plan's HALF stream (zuko_amd/incremental.py: half_stream): pull blocks as two f16 images of the weights times 1 / wdescale_l
+    const double wd[4] = {1.0, args->wdescale1, args->wdescale2, args->wdescale3};
+    for (int l = 1; l <= n_hidden; ++l) {
+      if (!(wd[l] > 0.0) || !(wd[l] < 1e38)) return ZK_EINVAL;
+      a.wdescale[l] = (float)wd[l];
+    }
+  }
   const void* fn = nullptr;
 #ifdef ZK_INC_FAST_BUILD  /* development: the two benchmark instantiations only */
   if (n_hidden != 3) return ZK_EINVAL;
-  if (uni_kind == 0) fn = (const void*)inc_inverse_kernel<IncAffine, 3>;
-  else if (uni_kind == 1) fn = (const void*)inc_inverse_kernel<IncRqs<8>, 3>;
+  if (uni_kind == 0) fn = half ? (const void*)inc_inverse_kernel<IncAffine, 3, true> : (const void*)inc_inverse_kernel<IncAffine, 3>;
+  else if (uni_kind == 1) fn = half ? (const void*)inc_inverse_kernel<IncRqs<8>, 3, true> : (const void*)inc_inverse_kernel<IncRqs<8>, 3>;
   else return ZK_EINVAL;
 #else
-#define ZK_INC_PICK(UNI) (n_hidden == 1 ? (const void*)inc_inverse_kernel<UNI, 1> : (n_hidden == 2 ? (const void*)inc_inverse_kernel<UNI, 2> : (const void*)inc_inverse_kernel<UNI, 3>))
+#define ZK_INC_PICK1(UNI, H) (n_hidden == 1 ? (const void*)inc_inverse_kernel<UNI, 1, H> : (n_hidden == 2 ? (const void*)inc_inverse_kernel<UNI, 2, H> : (const void*)inc_inverse_kernel<UNI, 3, H>))
+#define ZK_INC_PICK(UNI) (half ? ZK_INC_PICK1(UNI, true) : ZK_INC_PICK1(UNI, false))
   if (uni_kind == 0) fn = ZK_INC_PICK(IncAffine);
   else if (uni_kind == 1) fn = ZK_INC_PICK(IncRqs<8>);
   else if (uni_kind == 2) fn = ZK_INC_PICK(IncRqs<4>);

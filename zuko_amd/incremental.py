@@ -283,15 +283,143 @@ def _build(M, features: int, order: np.ndarray, layout: UniLayout, chunk: int, f
     )
 
 
-def simulate(plan: IncPlan, weights, biases, masks, y: np.ndarray, ctx: np.ndarray | None, act, inv_fn):
+@dataclass
+class HalfStream:
+    """The HALF stream of an IncPlan (csrc/inc_inverse.hip, HALF instantiation): same groups, same first-layer and diagonal tiles (f32 images), the
+    PULLS as 16 x 32 blocks (out tile of group j, PAIR (2 p, 2 p + 1) of final in tiles, tile 2 p + 1 zero while it is not final) of two f16 images."""
+
+    gather_f32: np.ndarray       # int32 [n_images * 256] into the concatenated weights, -1 = zero (block images: -1, overwritten by the block gathers)
+    blk_gather: list             # per linear layer l = 1 .. NH: int32 [n_blocks_l * 512] (lane-major, 8 per lane) into the concatenated weights
+    blk_pos: list                # per linear layer l: int64 [n_blocks_l] image index of every block's first image
+    n_images: int
+    n_chunks: int
+
+
+def half_stream(plan: IncPlan, masks, chunk: int = CHUNK) -> HalfStream:
+    """Rebuilds the plan's stream in the HALF layout from the same tables (`masks` only for their shapes)."""
+    NH, L, nt, n_groups, din = plan.n_hidden, plan.n_hidden + 1, plan.nt, plan.n_groups, plan.din
+    shapes = [tuple(np.asarray(m.detach().cpu().numpy() if hasattr(m, "detach") else m).shape) for m in masks]
+    total = plan.layout.total
+    lane = np.arange(64)
+    li, lq = lane % 16, lane // 16
+    perms, featmap, w_offsets = plan.perms, plan.featmap.astype(np.int64), plan.w_offsets
+
+    def image(l: int, rows: np.ndarray, cols: np.ndarray) -> np.ndarray:  # [64, 4]: element (lane, r) <- W_l[rows[lane % 16], cols[4 (lane / 16) + r]]
+        r = rows[li][:, None]
+        c = cols[(4 * lq)[:, None] + np.arange(4)[None, :]]
+        idx = w_offsets[l] + r * shapes[l][1] + c
+        idx[(r < 0) | (c < 0)] = -1
+        return idx
+
+    def in_cols(it: int) -> np.ndarray:
+        c = np.arange(it * TILE, (it + 1) * TILE)
+        c[c >= din] = -1
+        return c
+
+    hid_rows = lambda l, j: perms[l][j * TILE : (j + 1) * TILE]
+    none = -np.ones(TILE, dtype=np.int64)
+
+    def last_rows(j: int, t: int) -> np.ndarray:
+        rows = -np.ones(TILE, dtype=np.int64)
+        for i in range(TILE):
+            pp = 4 * t + (i & 3)
+            f = featmap[j * 4 + (i >> 2)]
+            if pp < total and f >= 0:
+                rows[i] = f * total + pp
+        return rows
+
+    images: list = []                                      # per image: [256] indices, or None for a block image
+    blk = {l: [] for l in range(1, L)}
+    pos = {l: [] for l in range(1, L)}
+    zero = -np.ones(256, dtype=np.int64)
+
+    def pair_block(l: int, rows: np.ndarray, src_layer: int, p_: int, j: int) -> None:
+        lo = image(l, rows, hid_rows(src_layer, 2 * p_))
+        hi = image(l, rows, hid_rows(src_layer, 2 * p_ + 1) if 2 * p_ + 1 < j else none)  # (the pair's second tile joins once it is final)
+        blk[l].append(np.concatenate([lo, hi], axis=1).reshape(-1))
+        pos[l].append(len(images))
+        images.extend([None, None])
+
+    for j in range(n_groups):
+        ns, nd = int(plan.prog[j, 0]), int(plan.prog[j, 1])
+        stat = plan.prog[j, 2 : 2 + ns]
+        dyn = plan.prog[j, 2 + MAX_TILES : 2 + MAX_TILES + nd]
+        npr = (j + 1) // 2
+        for it in stat:
+            images.append(image(0, hid_rows(0, j), in_cols(int(it))).reshape(-1))
+        images += [zero] * (L1S - ns)
+        for l in range(1, NH):
+            for p_ in range(npr):
+                pair_block(l, hid_rows(l, j), l - 1, p_, j)
+        for p_ in range(npr):
+            for tt in range(nt):
+                pair_block(L - 1, last_rows(j, tt), NH - 1, p_, j)
+        for it in dyn:
+            images.append(image(0, hid_rows(0, j), in_cols(int(it))).reshape(-1))
+        images += [zero] * (L1D - nd)
+        for l in range(1, NH):
+            images.append(image(l, hid_rows(l, j), hid_rows(l - 1, j)).reshape(-1))
+        for tt in range(nt):
+            images.append(image(L - 1, last_rows(j, tt), hid_rows(NH - 1, j)).reshape(-1))
+    n_chunks = -(-len(images) // chunk)
+    images += [zero] * (n_chunks * chunk - len(images))
+    g32 = np.concatenate([zero if im is None else im for im in images]).astype(np.int32)
+    return HalfStream(gather_f32=g32, blk_gather=[None] + [np.concatenate(blk[l]).astype(np.int32) if blk[l] else np.zeros(0, np.int32) for l in range(1, L)],
+                      blk_pos=[None] + [np.asarray(pos[l], dtype=np.int64) for l in range(1, L)], n_images=len(images), n_chunks=n_chunks)
+
+
+def _f16_parts(v: np.ndarray):
+    h = v.astype(np.float32).astype(np.float16).astype(np.float32)
+    return h, (v.astype(np.float32) - h).astype(np.float16).astype(np.float32)
+
+
+def _pow2(amax) -> np.ndarray:
+    """2^ea with amax 2^ea in [2^14, 2^15) (ea clamped to [-90, 90]; amax = 0: ea = 15) — inc_pair_convert of the kernel."""
+    m, e = np.frexp(np.asarray(amax, dtype=np.float64))
+    return np.exp2(np.clip(15 - np.where(np.asarray(amax) > 0, e, 0), -90, 90).astype(np.float64))
+
+
+def simulate(plan: IncPlan, weights, biases, masks, y: np.ndarray, ctx: np.ndarray | None, act, inv_fn, half: HalfStream | None = None, wexp=None):
     """Numpy walk through the SAME stream / tables the kernel uses.  y [n, features] values to invert, ctx [n, context] or None;
     `inv_fn(phi[n, total], yv[n]) -> (x[n], ladj[n])`.  Returns (x [n, features], ladj [n])."""
     n = y.shape[0]
     NH, L = plan.n_hidden, plan.n_hidden + 1
     wcat = np.concatenate([(np.asarray(w) * np.asarray(m)).reshape(-1) for w, m in zip(weights, masks)])
     bcat = np.concatenate([np.asarray(b).reshape(-1) for b in biases])
-    stream = np.where(plan.gather >= 0, wcat[np.maximum(plan.gather, 0)], 0.0).reshape(-1, 64, 4)
     bias = np.where(plan.bias_gather >= 0, bcat[np.maximum(plan.bias_gather, 0)], 0.0)
+    if half is not None:  # the HALF stream: f32 images + pair blocks in two f16 parts of W 2^wexp[l]; walked below exactly as the kernel walks it
+        stream = np.where(half.gather_f32 >= 0, wcat[np.maximum(half.gather_f32, 0)], 0.0).reshape(-1, 64, 4)
+        blocks = {}
+        for l in range(1, L):
+            idx = half.blk_gather[l].reshape(-1, 64, 8)
+            vals = np.where(idx >= 0, wcat[np.maximum(idx, 0)], 0.0) * 2.0 ** wexp[l]
+            bh, bl = _f16_parts(vals)
+            for k, ps in enumerate(half.blk_pos[l]):
+                blocks[int(ps)] = (bh[k], bl[k], 2.0 ** -wexp[l])
+        pairs = [[None] * ((MAX_TILES + 1) // 2) for _ in range(NH)]  # per layer and pair: (h [n, 64 lanes.. as [n, 32]], l, 1 / s)
+
+        def block_mat(img):  # [64 lanes, 8] -> A[i][k]: k = kq-th group of 4 of tile 2 p (first 16) / of tile 2 p + 1 (last 16)
+            a4 = img.reshape(4, 16, 8)  # [kq, i, e]
+            lo = a4[:, :, :4].transpose(1, 0, 2).reshape(16, 16)
+            hi = a4[:, :, 4:].transpose(1, 0, 2).reshape(16, 16)
+            return np.concatenate([lo, hi], axis=1)  # [16, 32]
+
+        def pull(pos_, layer_src, p_):
+            bh, bl, wd = blocks[pos_]
+            ph, pl, inv_s = pairs[layer_src][p_]
+            A_h, A_l = block_mat(bh), block_mat(bl)
+            t = ph @ A_l.T + pl @ A_h.T + ph @ A_h.T  # (smallest first; f32 accumulation in the kernel)
+            return t * (inv_s * wd)[:, None]
+
+        def finalize(layer, j_, hj):
+            lo = hj if j_ % 2 == 0 else h[layer][:, (j_ - 1) * TILE : j_ * TILE]
+            hi = np.zeros_like(hj) if j_ % 2 == 0 else hj
+            both = np.concatenate([lo, hi], axis=1)
+            s_ = _pow2(np.abs(both).max(axis=1))
+            ph, pl = _f16_parts(both * s_[:, None])
+            pairs[layer][j_ // 2] = (ph, pl, 1.0 / s_)
+    else:
+        stream = np.where(plan.gather >= 0, wcat[np.maximum(plan.gather, 0)], 0.0).reshape(-1, 64, 4)
 
     def tile_mat(blk):  # [64 lanes, 4] -> A[i][k = 4q + r]
         return blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)
@@ -311,18 +439,29 @@ def simulate(plan: IncPlan, weights, biases, masks, y: np.ndarray, ctx: np.ndarr
         for i, it in enumerate(stat):
             off[0] += xin[:, it * TILE : (it + 1) * TILE] @ tile_mat(stream[pos + i]).T
         pos += L1S
-        for l in range(1, NH):
-            for t in range(j):
-                off[l] += h[l - 1][:, t * TILE : (t + 1) * TILE] @ tile_mat(stream[pos]).T
-                pos += 1
         poff = np.zeros((n, plan.nt, TILE))
         for tt in range(plan.nt):
             b0 = plan.bias_off[NH] + (j * plan.nt + tt) * TILE
             poff[:, tt, :] = bias[b0 : b0 + TILE][None, :]
-        for t in range(j):
-            for tt in range(plan.nt):
-                poff[:, tt, :] += h[NH - 1][:, t * TILE : (t + 1) * TILE] @ tile_mat(stream[pos]).T
-                pos += 1
+        if half is not None:
+            npr = (j + 1) // 2
+            for l in range(1, NH):
+                for p_ in range(npr):
+                    off[l] += pull(pos, l - 1, p_)
+                    pos += 2
+            for p_ in range(npr):
+                for tt in range(plan.nt):
+                    poff[:, tt, :] += pull(pos, NH - 1, p_)
+                    pos += 2
+        else:
+            for l in range(1, NH):
+                for t in range(j):
+                    off[l] += h[l - 1][:, t * TILE : (t + 1) * TILE] @ tile_mat(stream[pos]).T
+                    pos += 1
+            for t in range(j):
+                for tt in range(plan.nt):
+                    poff[:, tt, :] += h[NH - 1][:, t * TILE : (t + 1) * TILE] @ tile_mat(stream[pos]).T
+                    pos += 1
         wd = [tile_mat(stream[pos + i]) for i in range(nd)]
         pos += L1D
         wh = [tile_mat(stream[pos + i]) for i in range(NH - 1)]
@@ -339,6 +478,8 @@ def simulate(plan: IncPlan, weights, biases, masks, y: np.ndarray, ctx: np.ndarr
             if r == 4:
                 for l in range(NH):
                     h[l][:, j * TILE : (j + 1) * TILE] = hj[l]
+                    if half is not None:
+                        finalize(l, j, hj[l])
                 break
             p = poff.copy()
             for tt in range(plan.nt):
@@ -375,6 +516,17 @@ class IncAR:
         self.bias = torch.empty(len(plan.bias_gather), dtype=torch.float32, device=device)
         self.bias_off = (ctypes.c_int * (plan.n_hidden + 1))(*[int(v) for v in plan.bias_off])
         self._stamp = None
+        # the HALF stream (pulls on the f16 matrix instruction: csrc/inc_inverse.hip), built when the weights allow it (fused.half_scales) and
+        # zuko_amd.matmul_precision() is "f16x2"
+        hs = half_stream(plan, [l.mask for l in lins])
+        self.half = hs
+        self.h_gather = torch.from_numpy(hs.gather_f32).to(device)
+        self.h_blk = [None] + [torch.from_numpy(g).to(device) for g in hs.blk_gather[1:]]
+        self.h_pos = [None] + [torch.from_numpy(np.stack([p, p + 1], axis=1).reshape(-1)).to(device) for p in hs.blk_pos[1:]]  # both images of every block
+        self.h_stream = torch.empty(hs.n_images * 256, dtype=torch.float32, device=device)
+        self.h_ok = False
+        self.h_descale = None
+        self._h_stamp = None
 
     def refresh(self, lins) -> None:
         """(Re)build the weight stream / bias image if any parameter changed since the last call."""
@@ -384,15 +536,46 @@ class IncAR:
         from .nn import _param_stamp
         from .ops import _ptr, _stream
 
+        from . import fused
+
         stamp = _param_stamp(lins)
-        if stamp == self._stamp:
+        want_half = fused.matmul_precision() == "f16x2" and self._h_stamp != stamp  # (also when the mode was switched after the f32 stream was built)
+        if stamp == self._stamp and not want_half:
             return
         lib = _C.lib()
         wcat = torch.cat([l.weight.detach().reshape(-1) for l in lins])
-        bcat = torch.cat([(l.bias.detach() if l.bias is not None else torch.zeros(l.weight.shape[0], device=self.device)).reshape(-1) for l in lins])
-        _C.check(lib.zk_gather_f32(_ptr(wcat), _ptr(self.mask_cat), _ptr(self.gather), self.gather.numel(), _ptr(self.stream), _stream()), "zk_gather_f32")
-        _C.check(lib.zk_gather_f32(_ptr(bcat), None, _ptr(self.bias_gather), self.bias_gather.numel(), _ptr(self.bias), _stream()), "zk_gather_f32")
-        self._stamp = stamp
+        if stamp != self._stamp:
+            bcat = torch.cat([(l.bias.detach() if l.bias is not None else torch.zeros(l.weight.shape[0], device=self.device)).reshape(-1) for l in lins])
+            _C.check(lib.zk_gather_f32(_ptr(wcat), _ptr(self.mask_cat), _ptr(self.gather), self.gather.numel(), _ptr(self.stream), _stream()), "zk_gather_f32")
+            _C.check(lib.zk_gather_f32(_ptr(bcat), None, _ptr(self.bias_gather), self.bias_gather.numel(), _ptr(self.bias), _stream()), "zk_gather_f32")
+            self._stamp = stamp
+        if want_half:
+            self._refresh_half(lins, wcat, stamp)
+
+    def _refresh_half(self, lins, wcat, stamp) -> None:
+        import torch
+
+        from . import _C, fused
+        from .ops import _ptr, _stream
+
+        self._h_stamp, self.h_ok = stamp, False
+        if fused.matmul_precision() != "f16x2":
+            return
+        scales = fused.half_scales(lins)  # (one synchronisation per weight version; the first layer stays on the f32 instruction whatever its weights)
+        if not all(ok for ok, _ in scales[1:]):
+            return
+        lib = _C.lib()
+        _C.check(lib.zk_gather_f32(_ptr(wcat), _ptr(self.mask_cat), _ptr(self.h_gather), self.h_gather.numel(), _ptr(self.h_stream), _stream()), "zk_gather_f32")
+        images = self.h_stream.view(-1, 256)
+        for l in range(1, len(lins)):
+            nb = self.h_blk[l].numel() // 512
+            if nb == 0:
+                continue
+            tmp = torch.empty(nb * 512, dtype=torch.float32, device=self.device)
+            _C.check(lib.zk_gather_split_f16(_ptr(wcat), _ptr(self.mask_cat), _ptr(self.h_blk[l]), nb, _ptr(tmp), 2.0 ** scales[l][1], _stream()), "zk_gather_split_f16")
+            images.index_copy_(0, self.h_pos[l], tmp.view(-1, 256))
+        self.h_descale = [1.0] + [2.0 ** -e for _, e in scales[1:]] + [1.0] * (4 - len(scales))
+        self.h_ok = True
 
     def run(self, y, ctx, want_ladj: bool = False):
         """y [N, D] contiguous fp32 (values to invert), ctx [N, C] or None -> (x [N, D], ladj [N] or None)."""
@@ -406,10 +589,14 @@ class IncAR:
         x = torch.empty((N, p.features), dtype=torch.float32, device=y.device)
         ladj = torch.empty(N, dtype=torch.float32, device=y.device) if want_ladj else None
         C = 0 if ctx is None else ctx.shape[1]
+        from . import fused
+
+        half = self.h_ok and self._h_stamp == self._stamp and fused.matmul_precision() == "f16x2"
+        extra = dict(half=1, wdescale1=self.h_descale[1], wdescale2=self.h_descale[2], wdescale3=self.h_descale[3]) if half else {}
         a = _C.args("zk_ar_inc_args_v1", uni_kind=p.layout.kind, n_hidden=p.n_hidden, N=N, D=p.features, C=C, y=_ptr(y), ldy=y.stride(0), ctx=_ptr(ctx),
-                    ldc=0 if ctx is None else ctx.stride(0), x=_ptr(x), ldx=p.features, ladj=_ptr(ladj), wstream=_ptr(self.stream), bias=_ptr(self.bias),
-                    bias_floats=self.bias.numel(), bias_off=self.bias_off, featmap=_ptr(self.featmap), prog=_ptr(self.prog), n_groups=p.n_groups, n_chunks=p.n_chunks,
-                    act=self.act, bound=self.bound, slope=self.slope)
+                    ldc=0 if ctx is None else ctx.stride(0), x=_ptr(x), ldx=p.features, ladj=_ptr(ladj), wstream=_ptr(self.h_stream if half else self.stream), bias=_ptr(self.bias),
+                    bias_floats=self.bias.numel(), bias_off=self.bias_off, featmap=_ptr(self.featmap), prog=_ptr(self.prog), n_groups=p.n_groups,
+                    n_chunks=self.half.n_chunks if half else p.n_chunks, act=self.act, bound=self.bound, slope=self.slope, **extra)
         err = _C.lib().zk_ar_inverse_incremental(a, _stream())
         _C.check(err, "zk_ar_inverse_incremental")
         return x, ladj
