@@ -22,6 +22,8 @@ def _run(args, env_extra, timeout):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, f"expected ONE json line, got {len(lines)}:\n{p.stdout[-2000:]}"
+    assert p.stdout.rstrip().splitlines()[-1] == lines[0], "the JSON line is the LAST stdout line"
+    assert len(lines[0]) < 8192, f"the printed line must stay under 8 KB (round 5's 20 KB line was not parsed by the driver): {len(lines[0])} bytes"
     return json.loads(lines[0])
 
 
@@ -49,6 +51,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and len(out["per_rank_ms_per_step"]) == 2
     assert out["config"]["global_batch"] == 2 << 14 and out["value"] > 0
     assert out["roofline"]["frac"] <= 1.0
+    # the multi-rank line: rank 0's solo run before the group formed and the efficiency derived from it (the driver computes its own from per-N runs)
+    assert out["rank0_alone_before_group"]["value"] > 0 and 0.0 < out["weak_scaling_efficiency"] < 2.0 and out["scaling"] == "weak"
 
 
 @pytest.mark.gpu

@@ -169,10 +169,12 @@ def test_static_kernel_raw_lds_reads_are_never_touched_before_their_wait():
 
 
 @pytest.mark.parametrize("tu,prefix,extra,n_kernels", [
-    ("inc_inverse.hip", "_ZN2zk18inc_inverse_kernel", ("-DZK_INC_FAST_BUILD",), 2),
+    ("inc_inverse.hip", "_ZN2zk18inc_inverse_kernel", ("-DZK_INC_FAST_BUILD",), 4),  # (f32 pulls and, round 6, the HALF instantiations: blocks of two images, three matrix instructions)
     ("fused_coupling.hip", "_ZN2zk22coupling_kernel_static", ("-mllvm", "-pragma-unroll-threshold=1000000"), 1),
 ])
 def test_raw_lds_reads_of_the_other_ring_kernels(tu, prefix, extra, n_kernels):
     """Same guard for the incremental inverse (the two benchmark instantiations) and the static coupling kernel."""
     stats = _check_raw_reads(_isa_of(tu, extra), prefix)
-    assert len(stats) == n_kernels and all(r > 0 and m >= 4 * r for r, m in stats)
+    assert len(stats) == n_kernels and all(r > 0 and m >= (1.2 if n_kernels == 4 else 4) * r for r, m in stats)
+    if n_kernels == 4:
+        assert sum(m >= 4 * r for r, m in stats) >= 2  # (the f32-pull instantiations: four matrix instructions per image, as before)

@@ -217,6 +217,35 @@ def test_sampling_paths(dev, name):
         assert_parity(lp, O.flow_log_prob(spec, xs.cpu(), c), O.flow_log_prob(spec64, d64(xs), d64(c)), f"{name}: rsample_and_log_prob")
 
 
+def test_capture_replays_a_flow_call_as_a_graph(dev):
+    """zuko_amd.capture (round 6; zuko/lazy.py:119-128 chains T transforms: at small batches the launches are the time): the conditional cfg1 flow's
+    log_prob at BASELINE.json configs[0]'s batch as ONE replayed HIP graph — bit-identical to the eager call on new inputs, shapes are checked."""
+    import zuko_amd
+    import zuko_amd.flows as F
+
+    torch.manual_seed(0)
+    flow = F.NSF(3, 5, transforms=3, bins=8, hidden_features=[128] * 3).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x, c = torch.randn(4096, 3, device=dev, generator=g), torch.randn(4096, 5, device=dev, generator=g)
+    fn = zuko_amd.capture(flow, x, c)
+    for _ in range(3):
+        x2, c2 = torch.randn(4096, 3, device=dev, generator=g), torch.randn(4096, 5, device=dev, generator=g)
+        with torch.no_grad():
+            eager = flow(c2).log_prob(x2)
+        assert torch.equal(fn(x2, c2), eager)
+    fz = zuko_amd.capture(flow, x, c, call="transform")
+    with torch.no_grad():
+        assert torch.equal(fz(x2, c2), flow(c2).transform(x2))
+    with pytest.raises(ValueError):
+        fn(x2[:100], c2[:100])
+    # an unconditional flow, larger batch
+    flow2 = F.MAF(16, 0, transforms=2, hidden_features=[128, 128]).to(dev)
+    xb = torch.randn(10000, 16, device=dev, generator=g)
+    f2 = zuko_amd.capture(flow2, xb)
+    with torch.no_grad():
+        assert torch.equal(f2(xb * 0.5), flow2().log_prob(xb * 0.5))
+
+
 def test_inverse_with_a_per_unit_activation(dev):
     """MAF(6, hidden=[40], activation=lambda: nn.PReLU(40)) — a flow the reference supports (one slope per hidden unit): the inverse must not
     apply the activation to a subset of units (round-5 advisor finding: it raised inside wavefront_inverse); round trip and log_prob hold."""
@@ -597,6 +626,7 @@ def test_incremental_inverse_kernel(dev, name, precision, monkeypatch, matmul):
     forward pass's; rsample_and_log_prob consistency (zuko/distributions.py:129-138).  precision f16x2: the launch's pull phase runs on the
     f16 matrix instruction with the two-part operand split (HALF instantiation, csrc/inc_inverse.hip); "bf16x3": every product on the f32 one."""
     matmul(precision)
+    monkeypatch.setenv("ZUKO_AMD_INVERSE_HALF", "1")  # (off by default: no faster — profiles/r06/inverse.md; kept correct here)
     flow, entry = build_flow(name)
     spec = oracle_spec(flow, entry)
     flow = flow.to(dev)

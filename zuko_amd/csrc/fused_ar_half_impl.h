@@ -121,7 +121,6 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arh_hidden
       arh_block(a[cur], in[ip], acc);
       if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
       if constexpr (last_of_tile) {
-        arx_mfma_guard(acc);  // (wait states behind the tile's last matrix instruction: fused_ar_split_impl.h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[ot][r] = __builtin_fmaf(acc[r], d, bs[r]);
       }
@@ -309,7 +308,6 @@ template <class S, typename Uni, bool DIAG = false> __global__ __launch_bounds__
         });
       });
       float p[4 * NT];
-      if constexpr (GN > 0) arx_mfma_guard(acc[NT - 1]);
       ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE {
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(acc[t][r], dl, bs[t][r]);

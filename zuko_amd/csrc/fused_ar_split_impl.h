@@ -86,11 +86,16 @@ template <int OFF> __device__ __forceinline__ f32x4 arx_lds_raw(unsigned addr) {
 }
 __device__ __forceinline__ unsigned arx_lds_addr(const float* p) { return (unsigned)(size_t)((const __attribute__((address_space(3))) float*)p); }
 
-// Wait states between a layer's last matrix instruction and the first vector instruction that reads its accumulator.  hipcc (ROCm 7.2) leaves 8 behind a
-// v_mfma_f32_16x16x32_{bf16,f16}; the two-part inverse kernel (csrc/inc_inverse.hip, one wavefront per SIMD) read stale accumulators with that in a
-// timing-dependent subset of wavefronts, and none with 32 (profiles/r06/inverse.md).  With two wavefronts per SIMD the partner's instructions have
-// covered the gap in every run of rounds 3-6 (bit-identical results across builds and boxes) — these 16 states make it a property of the code.
-__device__ __forceinline__ void arx_mfma_guard(f32x4& acc) { asm volatile("s_nop 15" : "+v"(acc)); }
+// Wait states between a layer's last matrix instruction and the first vector instruction that reads its accumulator — for the ONE-wavefront-per-SIMD
+// instantiations only (Shape::OCC == 1: up to 512 registers, so accumulators may live in AGPRs).  Round 6 found that hipcc (ROCm 7.2) leaves 8 wait states
+// between a v_mfma_f32_16x16x32_* whose destination is an AGPR and the v_accvgpr_read of it, and that this is not enough on gfx950 (csrc/inc_inverse.hip's
+// two-part pull blocks read stale accumulators in a timing-dependent subset of wavefronts; with the destination in a VGPR the same 8 states suffice:
+// profiles/r06/inverse.md).  The two-wavefront kernels hold everything in the 256 architectural VGPRs (agpr_count 0): nothing to guard there.
+template <bool ON> __device__ __forceinline__ void arx_mfma_guard(f32x4& acc) {
+  if constexpr (ON) asm volatile("s_nop 15" : "+v"(acc));
+}
+template <class S, class = void> struct ArxOneWave : std::false_type {};  // (the dgrad chain shapes have no OCC: two wavefronts per SIMD)
+template <class S> struct ArxOneWave<S, std::void_t<decltype(S::OCC)>> : std::integral_constant<bool, S::OCC == 1> {};
 
 template <class S> struct ArxPat {
   static constexpr int ot(int l, int s) { return S::B_OT[S::BOFF[l] + s]; }
@@ -136,7 +141,7 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arx_hidden
       arx_block(a[cur], in[ip], out[ot]);
       if (ARX_FENCE) __builtin_amdgcn_sched_barrier(0);
     });
-    arx_mfma_guard(out[P::ot(L, NB - 1)]);  // (the layer's last accumulator is read by the activation next)
+    arx_mfma_guard<ArxOneWave<S>::value>(out[P::ot(L, NB - 1)]);  // (the layer's last accumulator is read by the activation next)
   }
 }
 
@@ -308,7 +313,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
         });
       });
       float p[4 * NT];
-      if constexpr (GN > 0) arx_mfma_guard(acc[NT - 1]);
+      if constexpr (GN > 0) arx_mfma_guard<ArxOneWave<S>::value>(acc[NT - 1]);
       ars_for<NT>([&](auto t) ARS_ALWAYS_INLINE {
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[4 * t + r] = acc[t][r];
@@ -445,7 +450,6 @@ template <class S, class Ring> __device__ __forceinline__ void arxd_first(Ring& 
     arx_block(a[s & 1], b, out[ot]);
     __builtin_amdgcn_sched_barrier(0);
   });
-  if constexpr (NB > 0) arx_mfma_guard(out[S::B_OT[NB - 1]]);
 }
 
 template <class S, int L, class Ring> __device__ __forceinline__ void arxd_stack(Ring& ring, const float* zero_q, int q, ArxB (&in)[S::TMAX / 2], f32x4 (&out)[S::TMAX], const ArArgs& a,
@@ -613,7 +617,6 @@ __device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const in
       }
     });
   });
-  if constexpr (NB > 0) arx_mfma_guard(out[S::B_OT[NB - 1]]);
 }
 
 template <class S, typename Uni> __global__ __launch_bounds__(512, 2) void arxb_kernel(ArArgs a) {

@@ -764,7 +764,7 @@ template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_ke
         cp_for<2>([&](auto b) CP_ALWAYS_INLINE { CP_XMFMA(w[k & 1][3 * b + 1], in.m(2 * k + b), cS[b]); });
         __builtin_amdgcn_sched_barrier(0);
       });
-      asm volatile("s_nop 15" : "+v"(cS[1]));  // wait states behind the group's last matrix instruction (hipcc leaves 8: see csrc/fused_ar_split_impl.h, arx_mfma_guard)
+      asm volatile("s_nop 15" : "+v"(cS[1]));  // wait states behind the group's last matrix instruction: one wavefront per SIMD, accumulators may sit in AGPRs (csrc/fused_ar_split_impl.h: arx_mfma_guard)
       const f32x4c p = ((cS[0] + cS[1]) + (cM[0] + cM[1])) + (cH[0] + cH[1]);  // (shift, scale) of slot 2 q, then of slot 2 q + 1
       float y0, y1, l0, l1;
       cp_affine(a, p[0], p[1], x0, y0, l0);

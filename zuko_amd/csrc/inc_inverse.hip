@@ -53,10 +53,10 @@ __device__ __forceinline__ void inc_pair_convert(const f32x4i& lo, const f32x4i&
 }
 __device__ __forceinline__ float inc_amax4(const f32x4i& v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
 // acc += dd * (W' B'): the block's images wh / wl (h and l parts of the scaled weights) against the pair's parts.  The three matrix instructions and
-// the wait states behind them are ONE assembly block: hipcc (ROCm 7.2) leaves 8 wait states between a v_mfma_f32_16x16x32_f16 and the first vector
-// instruction that reads its result (v_accvgpr_read / v_pk_fma_f32) — too few on gfx950: with one wavefront per SIMD the product read stale registers
-// in a timing-dependent subset of wavefronts (whole 16-sample tiles off by 1e-2; 32 wait states: none; scripts/_dbg in profiles/r06/inverse.md).
-// Operands pinned to VGPRs; smallest partial product first.
+// the wait states behind them are ONE assembly block with the accumulator pinned to VGPRs: compiled from the builtin, hipcc (ROCm 7.2) put the accumulator
+// in AGPRs and left 8 wait states between the last v_mfma_f32_16x16x32_f16 and the v_accvgpr_read of its result — not enough on gfx950: a timing-dependent
+// subset of wavefronts read stale registers (whole 16-sample tiles off by 1e-2).  With a VGPR destination 8 states are enough (6 are not): measured in
+// profiles/r06/inverse.md; 12 are used.  Smallest partial product first.
 #define IN_HBLOCK(acc, wh, wl, P, dd)                                                                                               \
   {                                                                                                                                  \
     f32x4i t_;                                                                                                                       \
@@ -64,7 +64,7 @@ __device__ __forceinline__ float inc_amax4(const f32x4i& v) { return fmaxf(fmaxf
                  "v_mfma_f32_16x16x32_f16 %0, %1, %3, 0\n\t"                                                                        \
                  "v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"                                                                       \
                  "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\t"                                                                       \
-                 "s_nop 15\n\ts_nop 3"                                                                                              \
+                 INC_NOPS                                                                                                            \
                  : "=&v"(t_) : "v"(wl), "v"(wh), "v"((P).h), "v"((P).l));                                                            \
     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) (acc)[r_] = __builtin_fmaf(t_[r_], (dd), (acc)[r_]);                            \
   }
@@ -73,6 +73,9 @@ __device__ __forceinline__ float inc_amax4(const f32x4i& v) { return fmaxf(fmaxf
 #define IN_CH 24     /* tiles per ring chunk */
 #ifndef IN_NR
 #define IN_NR 3      /* ring slots */
+#endif
+#ifndef INC_NOPS
+#define INC_NOPS "s_nop 11"  /* 12 wait states behind a block's last matrix instruction (8 needed: profiles/r06/inverse.md) */
 #endif
 #ifndef INC_DBG
 #define INC_DBG 0    /* probe builds: 1 = wait states behind a block's matrix instructions, 2 = every counted wait drains */

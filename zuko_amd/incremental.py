@@ -283,6 +283,15 @@ def _build(M, features: int, order: np.ndarray, layout: UniLayout, chunk: int, f
     )
 
 
+def inverse_half_enabled() -> bool:
+    """Whether the incremental inverse runs its pull phase on the f16 matrix instruction (HALF instantiation of csrc/inc_inverse.hip).  OFF by default:
+    measured on MI355X (profiles/r06/inverse.md) it moves the launch by +2 % (NSF) / -4 % (MAF) — the launch is bound by the serial chain of its five passes
+    per group, not by the pulls.  ZUKO_AMD_INVERSE_HALF=1 enables it (tests/test_gpu_flows.py runs both forms)."""
+    import os
+
+    return os.environ.get("ZUKO_AMD_INVERSE_HALF", "0") == "1"
+
+
 @dataclass
 class HalfStream:
     """The HALF stream of an IncPlan (csrc/inc_inverse.hip, HALF instantiation): same groups, same first-layer and diagonal tiles (f32 images), the
@@ -539,7 +548,7 @@ class IncAR:
         from . import fused
 
         stamp = _param_stamp(lins)
-        want_half = fused.matmul_precision() == "f16x2" and self._h_stamp != stamp  # (also when the mode was switched after the f32 stream was built)
+        want_half = fused.matmul_precision() == "f16x2" and inverse_half_enabled() and self._h_stamp != stamp  # (also when the mode was switched after the f32 stream was built)
         if stamp == self._stamp and not want_half:
             return
         lib = _C.lib()
@@ -559,7 +568,7 @@ class IncAR:
         from .ops import _ptr, _stream
 
         self._h_stamp, self.h_ok = stamp, False
-        if fused.matmul_precision() != "f16x2":
+        if fused.matmul_precision() != "f16x2" or not inverse_half_enabled():
             return
         scales = fused.half_scales(lins)  # (one synchronisation per weight version; the first layer stays on the f32 instruction whatever its weights)
         if not all(ok for ok, _ in scales[1:]):
@@ -591,7 +600,7 @@ class IncAR:
         C = 0 if ctx is None else ctx.shape[1]
         from . import fused
 
-        half = self.h_ok and self._h_stamp == self._stamp and fused.matmul_precision() == "f16x2"
+        half = self.h_ok and self._h_stamp == self._stamp and fused.matmul_precision() == "f16x2" and inverse_half_enabled()
         extra = dict(half=1, wdescale1=self.h_descale[1], wdescale2=self.h_descale[2], wdescale3=self.h_descale[3]) if half else {}
         a = _C.args("zk_ar_inc_args_v1", uni_kind=p.layout.kind, n_hidden=p.n_hidden, N=N, D=p.features, C=C, y=_ptr(y), ldy=y.stride(0), ctx=_ptr(ctx),
                     ldc=0 if ctx is None else ctx.stride(0), x=_ptr(x), ldx=p.features, ladj=_ptr(ladj), wstream=_ptr(self.h_stream if half else self.stream), bias=_ptr(self.bias),
