@@ -318,7 +318,7 @@ typedef struct zk_coupling_args_v1 {
   int32_t act;             /* activation code */
   int32_t bias_floats;
   int32_t accumulate;      /* != 0: ladj += */
-  int32_t static_ok;       /* != 0 allows the shape-specialised instantiation when the shapes match; 2 = wstream is the operand-split stream */
+  int32_t static_ok;       /* != 0 allows the shape-specialised instantiation when the shapes match; 2 = wstream is the operand-split stream; 3 = the two-part stream (below) */
   int64_t N;
   int64_t ldx;             /* row stride of `in` */
   int64_t ldc;             /* row stride of ctx */
@@ -335,6 +335,10 @@ typedef struct zk_coupling_args_v1 {
   const int32_t* fmap;     /* DEVICE [n_groups * 8] */
   const int32_t* tiles;    /* HOST, n_layers - 1 ints: 16-row output tiles of every hidden layer */
   const int32_t* widths;   /* HOST, n_layers - 1 ints: true width of every hidden layer */
+  double wdescale0;        /* static_ok == 3: wstream is the TWO-PART stream (the operand-split stream's blocks as two f16 images of the layer's weights times a power of two, */
+  double wdescale1;        /* zk_gather_split_f16; 16-image chunks) and wdescale_l the inverse of that power for linear layer l = 0 .. 3 (n_layers <= 4): three partial products on */
+  double wdescale2;        /* v_mfma_f32_16x16x32_f16, activations scaled per sample inside the kernel (csrc/fused_coupling.hip: coupling_kernel_half) */
+  double wdescale3;
 } zk_coupling_args_v1;
 int zk_coupling_forward(const zk_coupling_args_v1* args, void* stream);
 /* The inverse of the same coupling transform (CouplingTransform._inverse, zuko/transforms.py:1050-1056), same plan and arguments:

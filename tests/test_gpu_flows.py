@@ -666,11 +666,14 @@ def test_incremental_inverse_kernel(dev, name, precision, monkeypatch, matmul):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,ctx,hidden,N", [(256, 0, [512] * 3, 300), (5, 3, [32, 32], 1000), (12, 2, [40, 70, 24], 77), (64, 0, [256], 4096 + 5)])
-def test_fused_coupling_kernel(dev, D, ctx, hidden, N, monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_fused_coupling_kernel(dev, D, ctx, hidden, N, precision, monkeypatch, matmul):
     """zk_coupling_forward (conditioner + affine map + split / merge in one launch) against the layer-wise HIP path and the
-    oracle; ragged batches, context, widths that are not multiples of 16, non-finite inputs."""
+    oracle; ragged batches, context, widths that are not multiples of 16, non-finite inputs.  precision f16x2: cfg4's shape (128 conditioner
+    inputs, hidden [512] * 3) runs on the two-part kernel (coupling_kernel_half), the other shapes have no split stream and are not affected."""
     import zuko_amd.flows as F
 
+    matmul(precision)
     torch.manual_seed(D + N)
     flow = F.RealNVP(D, ctx, transforms=3, hidden_features=hidden)
     sd = {k: v.detach().clone() for k, v in flow.state_dict().items() if v is not None}
@@ -683,6 +686,8 @@ def test_fused_coupling_kernel(dev, D, ctx, hidden, N, monkeypatch):
     with torch.no_grad():
         assert all(t.fused_state(dev) is not None for t in flow.transform.transforms)
         z, ladj = flow(cg).transform.call_and_ladj(x.to(dev))
+        if hidden == [512] * 3 and D == 256:
+            assert all(t.fused_state(dev).half_ok == (precision == "f16x2") for t in flow.transform.transforms), "cfg4's shape: the two-part kernel serves exactly in f16x2 mode"
         lp = flow(cg).log_prob(x.to(dev))
         monkeypatch.setenv("ZUKO_AMD_NO_FUSED_COUPLING", "1")
         z_l, ladj_l = flow(cg).transform.call_and_ladj(x.to(dev))
@@ -692,7 +697,7 @@ def test_fused_coupling_kernel(dev, D, ctx, hidden, N, monkeypatch):
     spec64 = to_f64(spec)
     with torch.no_grad():
         z64, l64 = O.flow_forward(spec64, d64(x), d64(c))
-    tag = f"coupling D={D} ctx={ctx} N={N}"
+    tag = f"coupling ({precision}) D={D} ctx={ctx} N={N}"
     assert_parity(z, zo, z64, f"{tag}: z fused")
     assert_parity(ladj, lo, l64, f"{tag}: ladj fused")
     assert_parity(z_l, zo, z64, f"{tag}: z layer-wise")

@@ -15,6 +15,7 @@ import numpy as np
 
 TILE = 16
 CHUNK = 24
+HALF_CHUNK = 16  # images per ring chunk of the two-part kernel (csrc/fused_coupling.hip: CPH_CH)
 RING = 3     # CP_NR: ring slots
 MAX_T = 32    # CP_T: activation tiles (hidden width <= 512)
 MAX_IT = 16   # CP_IT: input tiles (conditioner inputs <= 256)
@@ -41,6 +42,7 @@ class CouplingPlan:
     # operand-split stream (csrc/fused_coupling.hip: coupling_kernel_split; only for the static shape: 128 inputs, hidden [512] * k)
     split_gather: np.ndarray = None  # int32 [split_blocks * 512] (lane-major, 8 per lane) into the concatenated weights (-1 -> 0)
     split_chunks: int = 0
+    split_layer_blocks: list = None  # blocks of every linear layer inside split_gather (the two-part stream scales each layer by its own power of two)
 
 
 def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk: int = CHUNK):
@@ -130,24 +132,28 @@ def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk
 
     # operand-split twin of the stream for the static shape: a block = (out tile, PAIR of in tiles) as three bf16 images; hidden layers
     # in steps of (4 out tiles, 1 in pair), the last layer group by group, pair by pair.  Every layer and every group fills whole chunks.
-    split_gather, split_chunks = None, 0
+    split_gather, split_chunks, split_layer_blocks = None, 0, None
     if nit == 8 and all(w == 512 for w in widths):
         def block(l, rows, ip, in_w):
             lo, hi = image(l, rows, span(2 * ip, in_w)).reshape(64, 4), image(l, rows, span(2 * ip + 1, in_w)).reshape(64, 4)
             return np.concatenate([lo, hi], axis=1).reshape(-1)
 
-        sblocks = []
+        sblocks, split_layer_blocks = [], []
         for l in range(L - 1):
             n_in, in_w = (nit, din) if l == 0 else (tiles[l - 1], widths[l - 1])
+            n0 = len(sblocks)
             for otg in range(tiles[l] // 4):
                 for ip in range(n_in // 2):
                     for t in range(4):
                         sblocks.append(block(l, span(otg * 4 + t, widths[l]), ip, in_w))
             assert (3 * len(sblocks)) % chunk == 0
+            split_layer_blocks.append(len(sblocks) - n0)
+        n0 = len(sblocks)
         for g in range(n_groups):
             for ip in range(tiles[-1] // 2):
                 sblocks.append(block(L - 1, last_rows(g), ip, widths[-1]))
         assert (3 * len(sblocks)) % chunk == 0
+        split_layer_blocks.append(len(sblocks) - n0)
         split_gather, split_chunks = np.concatenate(sblocks).astype(np.int32), 3 * len(sblocks) // chunk
 
     amap = -np.ones(nit * TILE, dtype=np.int64)
@@ -159,7 +165,7 @@ def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk
     return CouplingPlan(
         n_layers=L, din=din, nit=nit, widths=widths, tiles=tiles, moved=moved, n_groups=n_groups, gather=gather, n_blocks=len(blocks),
         n_chunks=len(blocks) // chunk, bias_gather=np.concatenate(bias_gather).astype(np.int32), bias_off=bias_off, amap=amap.astype(np.int32),
-        fmap=fmap.astype(np.int32), features=features, context=context, split_gather=split_gather, split_chunks=split_chunks,
+        fmap=fmap.astype(np.int32), features=features, context=context, split_gather=split_gather, split_chunks=split_chunks, split_layer_blocks=split_layer_blocks,
     )
 
 
@@ -235,6 +241,10 @@ class FusedCoupling:
             self.stream = torch.empty(plan.split_chunks * CHUNK * 256, dtype=torch.float32, device=device)
         else:
             self.stream = torch.empty(plan.n_blocks * 256, dtype=torch.float32, device=device)
+        # two-part (f16 x 2) twin of the split stream: the same blocks, two images each, 16-image chunks; used when the weights allow it (fused.half_scales)
+        self.half_able = self.split and plan.n_layers <= 4 and all((2 * b) % HALF_CHUNK == 0 for b in plan.split_layer_blocks)
+        self.half_stream = torch.empty(2 * (len(plan.split_gather) // 512) * 256, dtype=torch.float32, device=device) if self.half_able else None
+        self.half_ok, self.half_descale, self._half_stamp = False, None, None
         self.bias = torch.empty(len(plan.bias_gather), dtype=torch.float32, device=device)
         nl = plan.n_layers
         self.bias_off = (ctypes.c_int * nl)(*[int(v) for v in plan.bias_off])
@@ -249,11 +259,26 @@ class FusedCoupling:
         from .nn import _param_stamp
         from .ops import _ptr, _stream
 
+        from . import fused
+
         stamp = _param_stamp(lins)
-        if stamp == self._stamp:
+        want_half = self.half_able and fused.matmul_precision() == "f16x2" and self._half_stamp != stamp
+        if stamp == self._stamp and not want_half:
             return
         lib = _C.lib()
         wcat = torch.cat([l.weight.detach().reshape(-1) for l in lins])
+        if want_half:  # eligibility + per-layer powers of two (one synchronisation per weight version), then one gather per layer
+            self._half_stamp, self.half_ok = stamp, False
+            scales = fused.half_scales(lins)
+            if all(ok for ok, _ in scales):
+                b0 = 0
+                for (ok, e), nb in zip(scales, self.plan.split_layer_blocks):
+                    _C.check(lib.zk_gather_split_f16(_ptr(wcat), None, _ptr(self.gather[b0 * 512 :]), nb, _ptr(self.half_stream[b0 * 512 :]), 2.0 ** e, _stream()), "zk_gather_split_f16")
+                    b0 += nb
+                self.half_descale = [2.0 ** -e for _, e in scales] + [1.0] * (4 - len(scales))
+                self.half_ok = True
+        if stamp == self._stamp:
+            return
         bcat = torch.cat([(l.bias.detach() if l.bias is not None else torch.zeros(l.weight.shape[0], device=self.device)).reshape(-1) for l in lins])
         if self.split:
             _C.check(lib.zk_gather_split_bf16(_ptr(wcat), None, _ptr(self.gather), self.gather.numel() // 512, _ptr(self.stream), _stream()), "zk_gather_split_bf16")
@@ -275,6 +300,16 @@ class FusedCoupling:
         y = torch.empty((N, p.features), dtype=torch.float32, device=x.device)
         ladj = torch.empty(N, dtype=torch.float32, device=x.device)
         fn = _C.lib().zk_coupling_inverse if inverse else _C.lib().zk_coupling_forward
+        from . import fused
+
+        if self.half_able and self.half_ok and self._half_stamp == self._stamp and fused.matmul_precision() == "f16x2":
+            d = self.half_descale
+            a = _C.args("zk_coupling_args_v1", N=N, D=p.features, C=p.context, **{"in": _ptr(x)}, ldx=x.stride(0), ctx=_ptr(ctx), ldc=0 if ctx is None else ctx.stride(0), out=_ptr(y),
+                        ldy=p.features, ladj=_ptr(ladj), accumulate=0, wstream=_ptr(self.half_stream), bias=_ptr(self.bias), bias_floats=self.bias.numel(), bias_off=self.bias_off,
+                        amap=_ptr(self.amap), nit=p.nit, fmap=_ptr(self.fmap), n_groups=p.n_groups, n_layers=p.n_layers, tiles=self.tiles, widths=self.widths,
+                        n_chunks=2 * (len(p.split_gather) // 512) // HALF_CHUNK, act=self.act, slope=self.slope, static_ok=3, wdescale0=d[0], wdescale1=d[1], wdescale2=d[2], wdescale3=d[3])
+            _C.check(fn(a, _stream()), "zk_coupling_inverse" if inverse else "zk_coupling_forward")
+            return y, ladj
         a = _C.args("zk_coupling_args_v1", N=N, D=p.features, C=p.context, **{"in": _ptr(x)}, ldx=x.stride(0), ctx=_ptr(ctx), ldc=0 if ctx is None else ctx.stride(0), out=_ptr(y),
                     ldy=p.features, ladj=_ptr(ladj), accumulate=0, wstream=_ptr(self.stream), bias=_ptr(self.bias), bias_floats=self.bias.numel(), bias_off=self.bias_off,
                     amap=_ptr(self.amap), nit=p.nit, fmap=_ptr(self.fmap), n_groups=p.n_groups, n_layers=p.n_layers, tiles=self.tiles, widths=self.widths,

@@ -57,6 +57,7 @@ struct CpArgs {
   int inverse;                  // x holds y: the moved half is mapped back (x_b = (y_b - shift) exp(-scale)); ladj stays that of the forward map
   float ls;
   int64_t n_tiles;
+  float wdescale[CP_MAXL];      // two-part (f16) kernel: 2^-ew of every linear layer, the power of two its weights were stored with
 };
 
 __device__ __attribute__((noinline)) float cp_act_slow(float v, int act) {
@@ -786,6 +787,278 @@ template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_ke
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---- TWO-PART operand split (round 6; csrc/fused_ar_half_impl.h has the arithmetic's full description) ------------------------------
+// Every f32 operand as two f16 numbers after an exact power-of-two scaling (weights: per layer, host; activations: per SAMPLE and layer, from the
+// largest magnitude of the sample's input vector — a lane holds one sample, two shuffles), three partial products lh + hl + hh on
+// v_mfma_f32_16x16x32_f16, the accumulator back through one fma with 2^-(ew + ea) and the bias: half the matrix instructions of
+// coupling_kernel_split, two 1 KiB images per 16 x 32 block (16-image chunks: every layer and every group of the last layer fills whole chunks).
+// One wavefront per SIMD, more than 256 registers: the accumulators of a step are pinned to VGPRs and the step's matrix instructions are ONE
+// assembly block (hipcc under-counts the wait states behind a v_mfma_f32_16x16x32_f16 whose destination is an AGPR: profiles/r06/inverse.md),
+// with 12 wait states in front of the vector instructions that read them.
+typedef _Float16 cf16x8 __attribute__((ext_vector_type(8)));
+#define CPH_CH 16
+struct CpRingH {
+  float* lds;
+  const float* stream;
+  unsigned cur_off, lds_off;
+  int n_chunks, slot, load_chunk, load_slot, wave, lane;
+  static constexpr int kPerWave = CPH_CH / CP_WAVES;
+  template <int I> __device__ __forceinline__ void dma(const float* g, float* l) {
+    if constexpr (I < kPerWave) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, (I - 2) * 1024, 0);
+      dma<I + 1>(g, l);
+    }
+  }
+  __device__ __forceinline__ void issue() {
+    const int b2 = wave * kPerWave + 2;
+    dma<0>(stream + ((size_t)load_chunk * CPH_CH + b2) * 256 + lane * 4, lds + (load_slot * CPH_CH + b2) * 256);
+    load_chunk = (load_chunk + 1 == n_chunks) ? 0 : load_chunk + 1;
+    load_slot = (load_slot + 1 == CP_NR) ? 0 : load_slot + 1;
+  }
+  __device__ __forceinline__ void advance() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CP_NR - 2) * (CPH_CH / CP_WAVES)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue();
+    slot = (slot + 1 == CP_NR) ? 0 : slot + 1;
+    cur_off = lds_off + (unsigned)(slot * CPH_CH * 1024 + lane * 16);
+  }
+  template <int S> __device__ __forceinline__ f32x4c read() {
+    if constexpr (S % CPH_CH == 0) advance();
+    f32x4c v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(cur_off), "n"((S % CPH_CH) * 1024));
+    return v;
+  }
+};
+struct CpBh {  // B operands (h, l parts) of 16 activation pairs
+  cf16x8 (&hlo)[8]; cf16x8 (&hhi)[8]; cf16x8 (&llo)[8]; cf16x8 (&lhi)[8];
+  __device__ __forceinline__ cf16x8& h(int p) const { return p < 8 ? hlo[p & 7] : hhi[p & 7]; }
+  __device__ __forceinline__ cf16x8& l(int p) const { return p < 8 ? llo[p & 7] : lhi[p & 7]; }
+};
+__device__ __forceinline__ void cph_split(const f32x4c& lo, const f32x4c& hi, float s, cf16x8& h, cf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = (e < 4 ? lo[e] : hi[e - 4]) * s;
+    const _Float16 hh = (_Float16)v;
+    h[e] = hh; l[e] = (_Float16)(v - (float)hh);
+  }
+}
+// s = 2^ea with amax 2^ea in [2^14, 2^15) (|ea| <= 90; zero / non-finite amax: ea = 15), inv_s = 2^-ea   (arh_scale of fused_ar_half_impl.h)
+__device__ __forceinline__ void cph_scale(float amax, float& s, float& inv_s) {
+  amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+  int ea = 15 - __builtin_amdgcn_frexp_expf(amax);
+  ea = ea > 90 ? 90 : (ea < -90 ? -90 : ea);
+  s = __builtin_amdgcn_ldexpf(1.0f, ea);
+  inv_s = __builtin_amdgcn_ldexpf(1.0f, -ea);
+}
+template <int N> __device__ __forceinline__ void cph_settle8(f32x4c (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void cph_settle8o(f32x4c (&a)[8], f32x4c& o0, f32x4c& o1, f32x4c& o2, f32x4c& o3) {
+  asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void cph_settle4(f32x4c (&a)[4]) { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N)); }
+// the twelve matrix instructions of a step (4 out tiles x 3 partial products, term by term: an accumulator is touched every fourth instruction),
+// images a[2 t] = h, a[2 t + 1] = l of out tile t; FIRST: the accumulators start at zero; LAST: wait states for the vector instructions that follow
+template <bool FIRST, bool LAST> __device__ __forceinline__ void cph_step(f32x4c (&acc)[4], f32x4c (&a)[8], const cf16x8& bh, const cf16x8& bl) {
+  if constexpr (FIRST) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %5, %12, 0\n\tv_mfma_f32_16x16x32_f16 %1, %7, %12, 0\n\tv_mfma_f32_16x16x32_f16 %2, %9, %12, 0\n\tv_mfma_f32_16x16x32_f16 %3, %11, %12, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %4, %13, %0\n\tv_mfma_f32_16x16x32_f16 %1, %6, %13, %1\n\tv_mfma_f32_16x16x32_f16 %2, %8, %13, %2\n\tv_mfma_f32_16x16x32_f16 %3, %10, %13, %3\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %4, %12, %0\n\tv_mfma_f32_16x16x32_f16 %1, %6, %12, %1\n\tv_mfma_f32_16x16x32_f16 %2, %8, %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, %10, %12, %3"
+                 : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(bh), "v"(bl));
+  } else {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %5, %12, %0\n\tv_mfma_f32_16x16x32_f16 %1, %7, %12, %1\n\tv_mfma_f32_16x16x32_f16 %2, %9, %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, %11, %12, %3\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %4, %13, %0\n\tv_mfma_f32_16x16x32_f16 %1, %6, %13, %1\n\tv_mfma_f32_16x16x32_f16 %2, %8, %13, %2\n\tv_mfma_f32_16x16x32_f16 %3, %10, %13, %3\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %4, %12, %0\n\tv_mfma_f32_16x16x32_f16 %1, %6, %12, %1\n\tv_mfma_f32_16x16x32_f16 %2, %8, %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, %10, %12, %3"
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(bh), "v"(bl));
+  }
+  if constexpr (LAST) asm volatile("s_nop 11" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+
+// one dense layer: out[ot] = fma(W' in', d, bias) over (4 out tiles, 1 in pair) steps; NP in pairs, HT out tiles
+template <int NP, int HT> __device__ __forceinline__ void cph_layer(CpRingH& ring, const float* bias_q, const CpBh& in, const CpAct& out, float d) {
+  constexpr int STEPS = (HT / 4) * NP;
+  f32x4c a[2][8];
+  f32x4c acc[4], bs[4];
+  cp_for<8>([&](auto i) CP_ALWAYS_INLINE { a[0][i] = ring.template read<decltype(i)::value>(); });
+  const unsigned bias_addr = (unsigned)(size_t)((const __attribute__((address_space(3))) float*)bias_q);
+  cp_for<STEPS>([&](auto st_) CP_ALWAYS_INLINE {
+    constexpr int st = st_, otg = st / NP, ip = st % NP;
+    constexpr bool first = ip == 0, last = ip == NP - 1;
+    if constexpr (last) {  // the out-group's bias tiles: raw reads in front of the look-ahead request of the group's LAST step, whose counted wait settles them
+      cp_for<4>([&](auto t) CP_ALWAYS_INLINE { bs[t] = cp_lds_raw<(otg * 4 + decltype(t)::value) * 64>(bias_addr); });
+    }
+    if constexpr (st + 1 < STEPS) {
+      cp_for<8>([&](auto i) CP_ALWAYS_INLINE { a[(st + 1) & 1][i] = ring.template read<(st + 1) * 8 + decltype(i)::value>(); });
+      if constexpr (last) cph_settle8o<8>(a[st & 1], bs[0], bs[1], bs[2], bs[3]);
+      else cph_settle8<8>(a[st & 1]);
+    } else {
+      if constexpr (last) cph_settle8o<0>(a[st & 1], bs[0], bs[1], bs[2], bs[3]);
+      else cph_settle8<0>(a[st & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cph_step<first, last>(acc, a[st & 1], in.h(ip), in.l(ip));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (last) {
+      cp_for<4>([&](auto t) CP_ALWAYS_INLINE {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[otg * 4 + t][r] = __builtin_fmaf(acc[t][r], d, bs[t][r]);
+      });
+    }
+  });
+}
+
+// ReLU + per-sample scale + conversion of the HT out tiles into the next layer's B operands; returns 2^-ea
+template <int HT> __device__ __forceinline__ float cph_convert(const CpAct& out, const CpBh& in) {
+  float amax = 0.f;
+  cp_for<HT>([&](auto t_) CP_ALWAYS_INLINE {
+    constexpr int t = t_;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      out[t][r] = out[t][r] < 0.f ? 0.f : out[t][r];  // NaN stays NaN, as torch.relu
+      amax = fmaxf(amax, out[t][r]);
+    }
+  });
+  float s, inv_s;
+  cph_scale(amax, s, inv_s);
+  cp_for<HT / 2>([&](auto p_) CP_ALWAYS_INLINE {
+    constexpr int p = p_;
+    cph_split(out[2 * p], out[2 * p + 1], s, in.h(p), in.l(p));
+  });
+  return inv_s;
+}
+
+template <int NIT, int HT> __global__ __launch_bounds__(256, 1) void coupling_kernel_half(CpArgs a) {
+  static_assert(HT % 4 == 0 && HT <= CP_T && NIT <= CP_IT && NIT % 2 == 0 && (8 * (NIT / 2) * (HT / 4)) % CPH_CH == 0 && (8 * (HT / 2) * (HT / 4)) % CPH_CH == 0 && (2 * (HT / 2)) % CPH_CH == 0,
+                "every layer and every group of the last layer fills whole chunks");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & 15, q = lane >> 4;
+  float* bias_lds = cp_lds + CP_NR * CPH_CH * 256;
+  int* amap_lds = reinterpret_cast<int*>(bias_lds + a.bias_floats);
+  int* fmap_lds = amap_lds + CP_IT * 16;
+  int* lay_lds = fmap_lds + a.NG * 8;
+  float* xw = reinterpret_cast<float*>(lay_lds + 3 * CP_MAXL) + (size_t)wave * 16 * a.xs;
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < CP_MAXL; ++l) lay_lds[2 * CP_MAXL + l] = a.bias_off[l];
+  }
+  for (int i = tid; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+  for (int i = tid; i < NIT * 16; i += 256) amap_lds[i] = a.amap[i];
+  for (int i = tid; i < a.NG * 8; i += 256) fmap_lds[i] = a.fmap[i];
+  CpRingH ring;
+  ring.lds = cp_lds; ring.stream = a.stream; ring.n_chunks = a.n_chunks; ring.wave = wave; ring.lane = lane;
+  ring.load_chunk = 0; ring.load_slot = 0;
+#pragma unroll
+  for (int i = 0; i < CP_NR - 1; ++i) ring.issue();
+  ring.slot = CP_NR - 1;
+  ring.lds_off = (unsigned)(size_t)((__attribute__((address_space(3))) float*)cp_lds);
+  ring.cur_off = ring.lds_off;
+  __syncthreads();
+
+  const int xs = a.xs;
+  float* xrow = xw + jl * xs;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * 64 + wave * 16;
+    const int64_t n = n0 + jl;
+    const bool live = n < a.N;
+    cp_stage_rows(a, xw, xs, n0, lane);
+
+    f32x4c out_lo[16], out_hi[16];
+    cf16x8 bhl[8], bhh[8], bll[8], blh[8];
+    const CpAct out{out_lo, out_hi};
+    const CpBh in{bhl, bhh, bll, blh};
+    float inv_s;
+    {  // first layer: B operands gathered from the row image through idx_a, scaled by the sample's own power of two, converted pair by pair
+      f32x4c v[NIT];
+      float amax = 0.f;
+      cp_for<NIT>([&](auto t_) CP_ALWAYS_INLINE {
+        constexpr int t = t_;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int src = amap_lds[t * 16 + 4 * q + r];
+          v[t][r] = src >= 0 ? xrow[src] : (src <= -2 ? xrow[a.D + (-2 - src)] : 0.f);
+          amax = fmaxf(amax, fabsf(v[t][r]));
+        }
+      });
+      float s;
+      cph_scale(amax, s, inv_s);
+      cp_for<NIT / 2>([&](auto p_) CP_ALWAYS_INLINE { constexpr int p = p_; cph_split(v[2 * p], v[2 * p + 1], s, in.h(p), in.l(p)); });
+    }
+    cph_layer<NIT / 2, HT>(ring, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL]) + 4 * q, in, out, a.wdescale[0] * inv_s);
+    inv_s = cph_convert<HT>(out, in);
+    for (int l = 1; l < a.L - 1; ++l) {
+      cph_layer<HT / 2, HT>(ring, bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + l]) + 4 * q, in, out, a.wdescale[l] * inv_s);
+      inv_s = cph_convert<HT>(out, in);
+    }
+    // last layer + affine map: one group of 8 moved features = one out tile = HT / 2 blocks, two blocks per step on two accumulators
+    const float* bias_last = bias_lds + __builtin_amdgcn_readfirstlane(lay_lds[2 * CP_MAXL + a.L - 1]) + 4 * q;
+    const float dl = a.wdescale[a.L - 1] * inv_s;
+    float lacc = 0.f;
+    for (int g = 0; g < a.NG; ++g) {
+      const int f0 = fmap_lds[g * 8 + 2 * q], f1 = fmap_lds[g * 8 + 2 * q + 1];
+      const float x0 = xrow[f0 < 0 ? 0 : f0], x1 = xrow[f1 < 0 ? 0 : f1];
+      const f32x4c bg = *reinterpret_cast<const f32x4c*>(bias_last + g * 16);
+      f32x4c c0, c1;
+      f32x4c w[2][4];  // images of the step's two blocks: w[.][2 b + part]
+      constexpr int KS = HT / 4;  // steps per group
+      cp_for<4>([&](auto i) CP_ALWAYS_INLINE { w[0][i] = ring.template read<decltype(i)::value>(); });
+      cp_for<KS>([&](auto k_) CP_ALWAYS_INLINE {
+        constexpr int k = k_;
+        if constexpr (k + 1 < KS) {
+          cp_for<4>([&](auto i) CP_ALWAYS_INLINE { w[(k + 1) & 1][i] = ring.template read<(k + 1) * 4 + decltype(i)::value>(); });
+          cph_settle4<4>(w[k & 1]);
+        } else {
+          cph_settle4<0>(w[k & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k == 0) {
+          asm volatile("s_nop 1\n\t"
+                       "v_mfma_f32_16x16x32_f16 %0, %3, %6, 0\n\tv_mfma_f32_16x16x32_f16 %1, %5, %8, 0\n\t"
+                       "v_mfma_f32_16x16x32_f16 %0, %2, %7, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %9, %1\n\t"
+                       "v_mfma_f32_16x16x32_f16 %0, %2, %6, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %8, %1"
+                       : "=&v"(c0), "=&v"(c1)
+                       : "v"(w[0][0]), "v"(w[0][1]), "v"(w[0][2]), "v"(w[0][3]), "v"(in.h(0)), "v"(in.l(0)), "v"(in.h(1)), "v"(in.l(1)));
+        } else {
+          asm volatile("s_nop 1\n\t"
+                       "v_mfma_f32_16x16x32_f16 %0, %3, %6, %0\n\tv_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"
+                       "v_mfma_f32_16x16x32_f16 %0, %2, %7, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %9, %1\n\t"
+                       "v_mfma_f32_16x16x32_f16 %0, %2, %6, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %8, %1"
+                       : "+v"(c0), "+v"(c1)
+                       : "v"(w[k & 1][0]), "v"(w[k & 1][1]), "v"(w[k & 1][2]), "v"(w[k & 1][3]), "v"(in.h(2 * k)), "v"(in.l(2 * k)), "v"(in.h(2 * k + 1)), "v"(in.l(2 * k + 1)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_nop 11" : "+v"(c0), "+v"(c1));
+      f32x4c p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] = __builtin_fmaf(c0[r] + c1[r], dl, bg[r]);  // (shift, scale) of slot 2 q, then of slot 2 q + 1
+      float y0, y1, l0, l1;
+      cp_affine(a, p[0], p[1], x0, y0, l0);
+      cp_affine(a, p[2], p[3], x1, y1, l1);
+      if (f0 >= 0) { xrow[f0] = y0; lacc += l0; }
+      if (f1 >= 0) { xrow[f1] = y1; lacc += l1; }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    cp_store_rows(a, xw, xs, n0, lane);
+    if (a.ladj) {
+      lacc += __shfl_xor(lacc, 16, 64);
+      lacc += __shfl_xor(lacc, 32, 64);
+      if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -799,7 +1072,8 @@ extern "C" {
 // 4 * 16 * (D + C + 4) * 4 bytes of LDS beside the 72 KiB ring, conditioner inputs <= 256, hidden widths <= 512.
 static int cp_launch(int inverse, int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, void* y, int64_t ldy, void* ladj, int accumulate,
                         const void* wstream, const void* bias, int bias_floats, const int32_t* bias_off, const int32_t* amap, int nit, const int32_t* fmap,
-                        int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream) {
+                        int n_groups, int n_layers, const int32_t* tiles, const int32_t* widths, int n_chunks, int act, double slope, int static_ok, void* stream,
+                        const double* wdescale = nullptr) {
   if (N <= 0) return 0;
   if (n_layers < 2 || n_layers > CP_MAXL || nit < 1 || nit > CP_IT || n_groups < 1 || n_chunks < 1 || D < 2 || C < 0 || (C > 0 && !ctx)) return ZK_EINVAL;
   CpArgs a{};
@@ -832,6 +1106,21 @@ static int cp_launch(int inverse, int64_t N, int D, int C, const void* x, int64_
   // that its stream has the matching layout (every layer and every triple of groups starts on a chunk boundary)
   bool same = act == 1 && nit == 8;
   for (int l = 0; l < n_layers - 1; ++l) same = same && tiles[l] == 32 && widths[l] == 512;
+  if (static_ok == 3) {  // the plan's TWO-PART stream (coupling_plan.py: half stream): f16 images, 16-image chunks, per-layer descale factors
+    if (!same || n_layers > 4 || !wdescale) return ZK_EINVAL;
+    for (int l = 0; l < n_layers; ++l) {
+      if (!(wdescale[l] > 0.0) || !(wdescale[l] < 1e38)) return ZK_EINVAL;
+      a.wdescale[l] = (float)wdescale[l];
+    }
+    static bool attr4 = false;
+    if (!attr4) {
+      hipError_t e = hipFuncSetAttribute((const void*)coupling_kernel_half<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr4 = true;
+    }
+    hipLaunchKernelGGL((coupling_kernel_half<8, 32>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    return ZK_LAUNCH_CHECK();
+  }
   if (same && static_ok == 2) {  // the plan's stream is the operand-split one (coupling_plan.py: split_gather): bf16 images, (4 out tiles, in pair) steps
     static bool attr3 = false;
     if (!attr3) {
@@ -861,7 +1150,7 @@ static int cp_launch(int inverse, int64_t N, int D, int C, const void* x, int64_
 static int cp_launch_v1(int inverse, const zk_coupling_args_v1* p, void* stream) {
   if (!p || p->struct_size != sizeof(zk_coupling_args_v1) || p->version != 1) return ZK_EINVAL;
   return cp_launch(inverse, p->N, p->D, p->C, p->in, p->ldx, p->ctx, p->ldc, p->out, p->ldy, p->ladj, p->accumulate, p->wstream, p->bias, p->bias_floats, p->bias_off, p->amap,
-                   p->nit, p->fmap, p->n_groups, p->n_layers, p->tiles, p->widths, p->n_chunks, p->act, p->slope, p->static_ok, stream);
+                   p->nit, p->fmap, p->n_groups, p->n_layers, p->tiles, p->widths, p->n_chunks, p->act, p->slope, p->static_ok, stream, &p->wdescale0);
 }
 
 int zk_coupling_forward(const zk_coupling_args_v1* args, void* stream) { return cp_launch_v1(0, args, stream); }
