@@ -498,7 +498,7 @@ SIDE_RUNS = {  # config: (batch log2 = its per-GPU share, warm-up, timed steps)
 def side_parity(config: str, flow, flow_cpu, dev) -> dict:
     """cfg3 / cfg4 (fp32): a 2^12-row chunk through the GPU flow against the CPU oracle (the pinned restatement of the reference) on
     the same rows — north_star's bar, log_prob within 1e-5 relative — with each side's distance from the float64 oracle next to it.
-    cfg5 (bf16): SURVEY 9.1's bar on the FULL flow at 64 rows — against the fp32 oracle on the same bf16-valued weights the HIP bf16
+    cfg5 (bf16): SURVEY 9.1's bar on the FULL flow at 1 024 rows — against the fp32 oracle on the same bf16-valued weights the HIP bf16
     path must be no worse than the reference's own bf16 evaluation (the oracle run in torch.bfloat16) in mean / median / p99."""
     import dataclasses
 
@@ -550,7 +550,7 @@ def side_parity(config: str, flow, flow_cpu, dev) -> dict:
             rep["vs_float64_oracle"] = {"error": repr(exc)}
         return rep
     # bf16
-    K, n = kw["bins"], 64
+    K, n = kw["bins"], 1024  # (64 rows until round 5; the 16-thread oracle handles 1 024 in ~20 s)
     sdb = {k: v.detach().cpu() for k, v in flow.state_dict().items() if v is not None}
     xs = torch.randn(n, D, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16)
     with torch.no_grad():
@@ -1237,6 +1237,7 @@ def main() -> None:
         per_transform["split"] = split
         # the launch the product makes for this flow: the two-part (f16 x 2, three partial products) kernel when the weights are eligible (zuko_amd/fused.py)
         per_transform["half"] = bool(st is not None and hasattr(st, "_half_serves") and st._half_serves(torch.empty(4, features, device=dev)))
+        per_transform["half_coupling"] = bool(st is not None and getattr(st, "half_able", False) and getattr(st, "half_ok", False) and zuko_amd.matmul_precision() == "f16x2")
         last = [m for m in flow.transform.transforms[0].hyper.modules() if getattr(m, "weight", None) is not None][-1]
         lmask = getattr(last, "mask", None)
         per_transform["last_layer_nnz_frac"] = 1.0 if lmask is None else float(lmask.float().mean())
@@ -1390,7 +1391,8 @@ def zuko_amd_roofline(kernels: dict, B: int, flop_per_transform: dict, executed_
                     (bool(flop_per_transform.get("split_coupling")) and parts[0] == "zk_coupling_forward")
             # operand-split kernels: every f32 product = 6 bf16 matrix products (csrc/fused_ar_split_impl.h), so the ceiling for f32-equivalent
             # FLOP is the dense bf16 peak / 6; the f32 matrix instruction's own peak stays on the line for comparison
-            half = bool(flop_per_transform.get("half")) and parts[0] == "zk_ar_forward" and "static" in rec.get("instantiation", "")
+            half = (bool(flop_per_transform.get("half")) and parts[0] == "zk_ar_forward" and "static" in rec.get("instantiation", "")) or \
+                   (bool(flop_per_transform.get("half_coupling")) and parts[0] == "zk_coupling_forward")
             split = split and not half
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if half else (PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS)
             row.update(bound="mfma", achieved=float(B) * flop_per_transform["nnz"] / t / 1e12, peak=peak, unit="TFLOP/s")

@@ -510,13 +510,13 @@ def test_cfg5_layer_shape_bf16(dev, N, monkeypatch):
 @pytest.mark.gpu
 def test_cfg5_full_flow_bf16(dev):
     """BASELINE.json configs[4] IN FULL: NSF(features=1024, transforms=12, bins=16, hidden=[1024]*3) — 629 M parameters, twelve
-    1024 -> 48128 last layers — `flow.to(torch.bfloat16)`, N = 64 rows (zuko/flows/spline.py:48-62 with the module cast as
+    1024 -> 48128 last layers — `flow.to(torch.bfloat16)`, N = 1 024 rows (64 until round 5) (zuko/flows/spline.py:48-62 with the module cast as
     zuko/tests/test_flows.py:17-29 does).  SURVEY 9.1's bar on the whole flow: against the fp32 oracle on the same (bf16-valued)
     weights, z / ladj / log_prob of the HIP bf16 path are no worse than the reference's OWN bf16 path (the oracle evaluated in
     torch.bfloat16 on the CPU)."""
     import zuko_amd.flows as F
 
-    D, K, TR, N = 1024, 16, 12, 64
+    D, K, TR, N = 1024, 16, 12, 1024
     torch.manual_seed(0)
     flow = F.NSF(D, 0, transforms=TR, bins=K, hidden_features=[1024] * 3)
     sdb = {k: (v.detach().to(torch.bfloat16) if v.is_floating_point() else v.detach()) for k, v in flow.state_dict().items() if v is not None}

@@ -183,11 +183,13 @@ def live_tile_masks(mask: Tensor, rows: int = 256, cols: int = 64) -> Tensor:
     out_f, in_f = mask.shape
     kt = in_f // cols
     pad = (-out_f) % rows
+    dev = mask.device
+    mask = mask.detach().cpu()  # (bookkeeping on the host, once per module / parameter version: on the device these were boolean reduce launches in a product trace)
     t = mask != 0
     t = torch.nn.functional.pad(t, (0, 0, 0, pad)) if pad else t
     live = t.reshape(-1, rows, kt, cols).any(dim=3).any(dim=1)  # [panels, kt]
-    weights = torch.ones(kt, dtype=torch.int64, device=mask.device) << torch.arange(kt, dtype=torch.int64, device=mask.device)
-    return (live.to(torch.int64) * weights).sum(dim=1).contiguous()  # (bit 63 lands in the sign bit: the kernel reads raw bits)
+    weights = torch.ones(kt, dtype=torch.int64) << torch.arange(kt, dtype=torch.int64)
+    return (live.to(torch.int64) * weights).sum(dim=1).contiguous().to(dev)  # (bit 63 lands in the sign bit: the kernel reads raw bits)
 
 
 class _Bf16Plan:
@@ -201,16 +203,19 @@ class _Bf16Plan:
     def __init__(self, lins: Sequence["MaskedLinear"]):
         masks = [l.mask for l in lins]
         dev = masks[0].device
-        dep = torch.eye(masks[0].shape[1], dtype=torch.float64, device=dev)
+        # the dependency bookkeeping (boolean matrix products over the masks) runs on the HOST, once per module: on the device it would be a
+        # library float64 GEMM in a product trace for a few thousand integer operations
+        dep = torch.eye(masks[0].shape[1], dtype=torch.float64)
         self.perms: list[Tensor | None] = []
         prev = None
         self.live: list[Tensor | None] = []
         self.masks_p: list[Tensor] = []
         for i, m in enumerate(masks):
-            dep = ((m.double() @ dep) > 0).double()  # [units, inputs]: which inputs each unit can see
+            dep = ((m.detach().cpu().double() @ dep) > 0).double()  # [units, inputs]: which inputs each unit can see
             if i + 1 < len(masks):
-                perm = torch.argsort(dep.sum(dim=1), stable=True)
-                dep = dep[perm]
+                perm_c = torch.argsort(dep.sum(dim=1), stable=True)
+                dep = dep[perm_c]
+                perm = perm_c.to(dev)
             else:
                 perm = None  # the outputs keep the reference's column order f * total + j
             mp = m if perm is None else m[perm]
