@@ -84,3 +84,17 @@ def test_non_finite_numbers_do_not_break_json():
     out["nll"] = float("nan")
     text = json.dumps(bench.headline_line(out))
     assert "NaN" not in text and json.loads(text)["roofline"]["traffic"] is None
+
+
+def test_line_of_the_round_6_run_fits():
+    """The full object of a round-6 run (profiles/r06/bench_detail.json: two-part kernels, sampling at 2^20, cfg5 parity at 1 024 rows)."""
+    path = os.path.join(ROOT, "profiles", "r06", "bench_detail.json")
+    with open(path) as f:
+        out = json.load(f)
+    line = bench.headline_line(out)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_BUDGET
+    for k in CONTRACT:
+        assert k in line, k
+    assert line["matmul_precision"] == "f16x2" and "3 matrix products" in line["roofline"]["peak_basis"]
+    assert line["side_paths"]["nsf_cfg2"]["sample"]["batch_log2"] == 20 and line["side_configs"]["cfg5"]["parity_rows"] == 1024

@@ -576,7 +576,7 @@ class FusedAR:
         self._acquire_static(None)  # kernels already on disk (prebuilt or compiled earlier) are used whatever the batch size
         # the generic operand-split kernel (csrc/fused_ar_gsplit.hip): what run() launches while there is no static-shape kernel for the plan
         # (its tables are built on first use).  ZUKO_AMD_GSPLIT=0: keep such plans on the f32 matrix instruction; =force: even when there is one
-        self.gs_mode = os.environ.get("ZUKO_AMD_GSPLIT", "1")
+        self.gs_mode = os.environ.get("ZUKO_AMD_GSPLIT", "1")  # (read when the state object is made — once per transform and device; zuko_amd.invalidate(module) re-reads it)
         self.gs = None              # (gathers on the device, offsets, n_chunks, stream) | False: the plan has no generic split kernel
         self._gs_stamp = self._seen_stamp = None
 
