@@ -806,35 +806,39 @@ def side_paths_report() -> dict:
             rel = ((res["fused"][1] - res["layer_wise"][1]).abs().max() / res["layer_wise"][1].abs().max()).item()
             entry["log_prob"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) log_prob, batch 2^18", "ms": res["fused"][0] * 1e3, "samples_per_s": Bp / res["fused"][0],
                                  "layer_wise_ms": res["layer_wise"][0] * 1e3, "parity": {"log_prob_max_rel_vs_layer_wise_kernels": rel, "ok": bool(rel < 1e-5)}}
-            # sampling: the bisection inverse has no fused kernel; it runs layer by layer in wavefront form (FusedAutoregressiveTransform._ordered_inverse:
-            # per sweep the hidden layers, then the last layer's rows and the bisections of that sweep's feature only) — beside the reference's loop
-            # (zuko/transforms.py:994-1000: everything, every sweep; ZUKO_AMD_FULL_SWEEPS=1), which must give the same x bit for bit
-            Bs = 1 << 14
+            # sampling (round 6): ONE incremental launch per autoregressive layer with the reference's bisection (zuko/transforms.py:608-617) in the kernel's group
+            # epilogue — at 2^18, and at 2^14 beside what it replaces: the layer-wise wavefront form (ZUKO_AMD_NO_INCREMENTAL=1: per sweep the hidden layers, the last
+            # layer's rows and the bisections of that sweep's feature) and the reference's loop itself (ZUKO_AMD_FULL_SWEEPS=1), which must agree bit for bit
             with torch.no_grad():
                 tr = flow().transform
-                x0 = 0.8 * torch.randn(Bs, 64, device=dev)
-                z = tr(x0)  # (inside the maps' invertible range: the bisection works on [-B, B], as the reference's)
                 samp = {}
-                for mode in ("wavefront", "reference_loop"):
-                    keep = os.environ.get("ZUKO_AMD_FULL_SWEEPS")
-                    if mode == "reference_loop":
-                        os.environ["ZUKO_AMD_FULL_SWEEPS"] = "1"
-                    try:
-                        xs = tr.inv(z)
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        xs = tr.inv(z)
-                        torch.cuda.synchronize()
-                        samp[mode] = (time.perf_counter() - t0, xs)
-                    finally:
-                        if keep is None:
-                            os.environ.pop("ZUKO_AMD_FULL_SWEEPS", None)
-                        else:
-                            os.environ["ZUKO_AMD_FULL_SWEEPS"] = keep
-                back = (samp["wavefront"][1] - x0).abs().max().item()
-            entry["sampling"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) flow().transform.inv(z), batch 2^14", "ms": samp["wavefront"][0] * 1e3, "samples_per_s": Bs / samp["wavefront"][0],
-                                 "reference_loop_ms": samp["reference_loop"][0] * 1e3, "bitwise_equal_to_reference_loop": bool(torch.equal(samp["wavefront"][1], samp["reference_loop"][1])),
-                                 "round_trip_max_abs": back}
+                for lg, modes in ((18, ("incremental",)), (14, ("incremental", "wavefront", "reference_loop"))):
+                    Bs = 1 << lg
+                    x0 = 0.8 * torch.randn(Bs, 64, device=dev)
+                    z = tr(x0)  # (inside the maps' invertible range: the bisection works on [-B, B], as the reference's)
+                    for mode in modes:
+                        env = {"wavefront": {"ZUKO_AMD_NO_INCREMENTAL": "1"}, "reference_loop": {"ZUKO_AMD_NO_INCREMENTAL": "1", "ZUKO_AMD_FULL_SWEEPS": "1"}}.get(mode, {})
+                        keep = {k: os.environ.get(k) for k in env}
+                        os.environ.update(env)
+                        try:
+                            xs = tr.inv(z)
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            xs = tr.inv(z)
+                            torch.cuda.synchronize()
+                            samp[(lg, mode)] = (time.perf_counter() - t0, xs, (xs - x0).abs().max().item())
+                        finally:
+                            for k, v in keep.items():
+                                if v is None:
+                                    os.environ.pop(k, None)
+                                else:
+                                    os.environ[k] = v
+            t18, t14 = samp[(18, "incremental")], samp[(14, "incremental")]
+            entry["sampling"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) flow().transform.inv(z), batch 2^18: one incremental launch per layer, bisection in the kernel", "batch_log2": 18,
+                                 "ms": t18[0] * 1e3, "samples_per_s": (1 << 18) / t18[0], "round_trip_max_abs": t18[2], "ok": bool(t18[2] < 1e-3),
+                                 "at_2^14": {"incremental_ms": t14[0] * 1e3, "layer_wise_wavefront_ms": samp[(14, "wavefront")][0] * 1e3, "reference_loop_ms": samp[(14, "reference_loop")][0] * 1e3,
+                                             "incremental_max_abs_diff_vs_reference_loop": (t14[1] - samp[(14, "reference_loop")][1]).abs().max().item()},
+                                 "bitwise_equal_to_reference_loop": bool(torch.equal(samp[(14, "wavefront")][1], samp[(14, "reference_loop")][1]))}
         except Exception as exc:
             entry["error"] = repr(exc)
         entry["wall_s"] = round(time.perf_counter() - t_entry, 1)

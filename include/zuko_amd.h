@@ -386,6 +386,11 @@ typedef struct zk_ar_inc_args_v1 {
   double wdescale1;        /* products; wdescale_l = the inverse of that power of two for linear layer l = 1 .. n_hidden.  First layer and diagonal tiles: f32 as before */
   double wdescale2;
   double wdescale3;
+  const double* gl_nodes01;   /* uni_kind 5 (shifted SOS polynomial, 3 x 5 coefficients + constant): HOST arrays of the 5 Gauss-Legendre nodes / weights on [0, 1], as zk_sos_forward */
+  const double* gl_weights01;
+  double eps;              /* uni_kind 6 (bounded Bernstein polynomial of degree 16): continuation margin (0 = 1e-6) */
+  int32_t n_bisect;        /* uni_kind 5 / 6: steps of the bisection inverse (zuko/transforms.py:608-617: ceil(log2(2 bound / 1e-6))) */
+  int32_t pad2_;
 } zk_ar_inc_args_v1;
 int zk_ar_inverse_incremental(const zk_ar_inc_args_v1* args, void* stream);
 int zk_ar_inc_lds_bytes(int bias_floats, int nit);

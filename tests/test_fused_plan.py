@@ -93,7 +93,7 @@ def test_plan_simulation_on_random_adjacencies():
 
 
 @pytest.mark.parametrize("kind,D,hidden,bins", [("rqs", 64, [256] * 3, 8), ("affine", 64, [256] * 3, 0), ("rqs", 32, [128], 16), ("affine", 5, [24, 32], 0),
-                                                 ("rqs", 40, [160, 160], 4), ("affine", 64, [256, 256], 0)])
+                                                 ("rqs", 40, [160, 160], 4), ("affine", 64, [256, 256], 0), ("sos", 64, [256] * 3, 0), ("bern", 64, [256] * 3, 0)])
 def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bins):
     """The aligned-tile plan of the incremental inverse kernel, walked in numpy over the very tables / stream the kernel
     consumes, reproduces the oracle's `passes`-sweep inverse and the forward log-determinant at the solution (float64)."""
@@ -105,10 +105,17 @@ def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bin
 
     torch.manual_seed(D + len(hidden))
     ctx = 2 if D == 5 else 0
-    flow = F.MAF(D, ctx, transforms=2, hidden_features=hidden) if kind == "affine" else F.NSF(D, ctx, transforms=2, bins=bins, hidden_features=hidden)
-    lazy = flow.transform.transforms[1]  # descending order
+    if kind in ("sos", "bern"):  # the polynomial flows (round 6: bisection inverse in the incremental launch): 16 / 17 parameters per feature, 4 / 5 tiles per group
+        from zuko_amd.flows.autoregressive import MaskedAutoregressiveTransform
+
+        flow = (F.SOSPF if kind == "sos" else F.BPF)(D, ctx, transforms=2, hidden_features=hidden)
+        lazy = [t for t in flow.transform.transforms if isinstance(t, MaskedAutoregressiveTransform)][1]
+        lay = fused.UniLayout(5, 16, 1, 4) if kind == "sos" else fused.UniLayout(6, 17, 1, 5)
+    else:
+        flow = F.MAF(D, ctx, transforms=2, hidden_features=hidden) if kind == "affine" else F.NSF(D, ctx, transforms=2, bins=bins, hidden_features=hidden)
+        lazy = flow.transform.transforms[1]  # descending order
+        lay = fused.UniLayout(0, 2, 1, 1) if kind == "affine" else fused.UniLayout({8: 1, 4: 2, 16: 3}[bins], 3 * bins - 1, 1, (3 * bins - 1 + 3) // 4, bins)
     lins = [m for m in lazy.hyper if hasattr(m, "mask")]
-    lay = fused.UniLayout(0, 2, 1, 1) if kind == "affine" else fused.UniLayout({8: 1, 4: 2, 16: 3}[bins], 3 * bins - 1, 1, (3 * bins - 1 + 3) // 4, bins)
     plan = inc.build_inc_plan([l.mask for l in lins], D, lazy.order.numpy(), lay)
     assert plan is not None and plan.n_groups <= inc.MAX_TILES and plan.n_blocks % inc.CHUNK == 0
     # stream length = the static layout the kernel assumes
@@ -120,7 +127,7 @@ def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bin
     g = torch.Generator().manual_seed(1)
     y = torch.randn(30, D, generator=g, dtype=torch.float64)
     c = torch.randn(30, ctx, generator=g, dtype=torch.float64) if ctx else None
-    uni = O.UNI_AFFINE if kind == "affine" else O.uni_rqs(bins)
+    uni = O.UNI_AFFINE if kind == "affine" else (O.uni_sos() if kind == "sos" else (O.uni_bpf() if kind == "bern" else O.uni_rqs(bins)))
     layer = O.ARLayer(uni, [torch.from_numpy(w) for w in W], [torch.from_numpy(b) for b in B], [torch.from_numpy(m) for m in Mk], lazy.passes, D)
     xo = O.ar_inverse(layer, y, c)
     _, lo = O.ar_forward(layer, xo, c)
@@ -132,6 +139,9 @@ def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bin
         return x[:, 0].numpy(), l[:, 0].numpy()
 
     xs, ls = inc.simulate(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn)
+    if kind in ("sos", "bern"):  # (a bisection: both walks stop at the same 2^-24 bracket unless a comparison sits within rounding of the target)
+        assert np.abs(xs - xo.numpy()).max() < 1e-5 and np.abs(ls - lo.numpy()).max() < 1e-3
+        return
     assert np.abs(xs - xo.numpy()).max() < 1e-12 and np.abs(ls - lo.numpy()).max() < 1e-11
     # the HALF stream (round 6: pulls as 16 x 32 blocks of two f16 images on the f16 matrix instruction, per-pair power-of-two scales): same groups,
     # same diagonal tiles; its static length, and the walk with the kernel's operand split agrees with the oracle to the split's 2^-22

@@ -246,6 +246,43 @@ def test_capture_replays_a_flow_call_as_a_graph(dev):
         assert torch.equal(f2(xb * 0.5), flow2().log_prob(xb * 0.5))
 
 
+@pytest.mark.parametrize("name", ["sospf", "bpf"])
+def test_polynomial_flows_invert_in_one_incremental_launch(dev, name, monkeypatch):
+    """SOSPF / BPF layers (round 6): transform.inv = ONE zk_ar_inverse_incremental launch per autoregressive layer with the reference's bisection
+    (zuko/transforms.py:608-617, zuko/utils.py:170-178) in the kernel's group epilogue, instead of ~25 layer-wise launches per sweep.  Against the
+    oracle's `passes`-sweep loop with its own bisection, and against the layer-wise wavefront form (bit-identical to the reference's loop) on the same z:
+    a bisection stops at the same 2^-24 bracket unless a comparison sits within rounding of the target — a few 1e-6; the round trip through the forward map."""
+    import zuko_amd.flows as F
+    from zuko_amd.flows.autoregressive import MaskedAutoregressiveTransform
+
+    torch.manual_seed(5)
+    flow = (F.SOSPF if name == "sospf" else F.BPF)(64, 0, transforms=2, hidden_features=[256] * 3).to(dev)
+    lazies = [t for t in flow.transform.transforms if isinstance(t, MaskedAutoregressiveTransform)]
+    assert all(t.incremental_state(dev) is not None and t.incremental_state(dev).plan.layout.kind in (5, 6) for t in lazies)
+    N = 777
+    x = (0.8 * torch.randn(N, 64, generator=torch.Generator().manual_seed(2))).to(dev)
+    with torch.no_grad():
+        t = flow().transform
+        z = t(x)
+        xi = t.inv(z)
+        monkeypatch.setenv("ZUKO_AMD_NO_INCREMENTAL", "1")
+        xw = flow().transform.inv(z)
+        monkeypatch.delenv("ZUKO_AMD_NO_INCREMENTAL")
+    assert (xi - x).abs().max().item() < 5e-5, "round trip through the forward map"
+    assert (xi - xw).abs().max().item() < 5e-5, "against the layer-wise wavefront form (= the reference's loop, bit for bit)"
+    sd = {k: v.detach().cpu() for k, v in flow.state_dict().items() if v is not None}
+    spec = O.spec_from_state_dict(sd, "ar", O.uni_sos() if name == "sospf" else O.uni_bpf(), 64, **({"softclip": 11.0} if name == "sospf" else {}))
+    with torch.no_grad():
+        xo = O.flow_inverse(spec, z.cpu())
+    assert (xi.cpu() - xo).abs().max().item() < 5e-5, f"{name}: incremental inverse vs the oracle's sweep loop: {(xi.cpu() - xo).abs().max().item():.2e}"
+    # a non-finite input poisons its own row only
+    zz = z[:8].clone()
+    zz[1, 3] = float("nan")
+    with torch.no_grad():
+        xb = flow().transform.inv(zz).cpu()
+    assert torch.isnan(xb[1]).any() and torch.isfinite(xb[0]).all() and torch.isfinite(xb[2:]).all()
+
+
 def test_inverse_with_a_per_unit_activation(dev):
     """MAF(6, hidden=[40], activation=lambda: nn.PReLU(40)) — a flow the reference supports (one slope per hidden unit): the inverse must not
     apply the activation to a subset of units (round-5 advisor finding: it raised inside wavefront_inverse); round trip and log_prob hold."""
@@ -1345,6 +1382,8 @@ def test_layer_wise_inverse_in_wavefront_form_equals_the_reference_loop(dev, nam
         C = 3
         flow = F.NSF(D, C, transforms=2, hidden_features=[300, 300])
     flow = flow.to(dev)
+    if name in ("sospf", "bpf"):  # (since round 6 the incremental launch inverts these layers; the wavefront form stays their fallback and is what this test is about)
+        monkeypatch.setenv("ZUKO_AMD_NO_INCREMENTAL", "1")
     N = 1000
     x = (0.8 * torch.randn(N, D)).to(dev)
     c = torch.randn(N, C).to(dev) if C else None

@@ -102,6 +102,9 @@ struct IncArgs {
   RqsLeanConst lc;
   int64_t n_tiles;
   float wdescale[4];  // HALF: 2^-ew of linear layer 1 .. NH (the power of two its pull blocks were stored with); [0] unused
+  SosConst<float> sos;  // polynomial maps (uni_kind 5): quadrature nodes / weights, bound, slope
+  float eps;            // uni_kind 6: continuation margin of the Bernstein map
+  int nbis;             // uni_kind 5 / 6: bisection steps (ceil(log2(2 B / 1e-6)), zuko/transforms.py:615)
 };
 
 // (not inlined: the group step below exists 17 times; inline expansions of expm1f / tanhf / erff at every activation
@@ -215,6 +218,39 @@ template <int K> struct IncRqs {
   template <typename A> static __device__ __forceinline__ void inv(const float* p, const A& a, float y, float& x, float& lj) {
     int k;
     rqs_lean<K, true, true>([&](int j) { return p[j]; }, [&](int j) { return p[K + j]; }, [&](int j) { return p[2 * K + j]; }, a.lc, y, x, lj, k);
+  }
+};
+
+// The polynomial maps (round 6): their inverse is the reference's fixed-count bisection on [-B, B] (zuko/transforms.py:608-617, zuko/utils.py:170-178), here in the
+// group's epilogue on the parameters the lane already holds — the layer-wise form launched ~25 kernels per sweep of the reference's loop (SOSPF 0.25 M, BPF 0.56 M
+// samples/s).  Same expression trees as zk_sos_inverse / zk_bernstein_inverse (csrc/zk_univariate.h); log|dy/dx| of the forward map at the solution as for the others.
+struct IncSos3x5 {  // ShiftedSOSPolynomialTransform, 3 polynomials of degree 4 + the learned constant (zuko/flows/polynomial.py:51-70)
+  static constexpr int TOTAL = 16, NT = 4;
+  template <typename A> static __device__ __forceinline__ void inv(const float* p, const A& a, float y, float& x, float& lj) {
+    auto ld = [&](int j) { return p[j]; };
+    const float yy = y - p[15];
+    float lo = -a.sos.bound, hi = a.sos.bound;
+#pragma unroll 1
+    for (int it = 0; it < a.nbis; ++it) {
+      const float mid = (lo + hi) / 2.f;
+      const bool below = sos_f_static<float, 3, 5>(a.sos, ld, mid) < yy;
+      lo = below ? mid : lo;
+      hi = below ? hi : mid;
+    }
+    x = (lo + hi) / 2.f;
+    lj = t_log(sos_g_static<float, 3, 5>(a.sos, ld, x));
+  }
+};
+struct IncBern17 {  // BoundedBernsteinTransform of degree 16: 17 unconstrained parameters -> 22 constrained coefficients (zuko/transforms.py:779-831)
+  static constexpr int TOTAL = 17, NT = 5;
+  template <typename A> static __device__ __forceinline__ void inv(const float* p, const A& a, float y, float& x, float& lj) {
+    float th[22];
+    bern_theta_bounded<float, 22>([&](int j) { return p[j]; }, a.bound, th);
+    const BernTails<float> t = bern_tails<float, 22>(th, true, a.bound, a.eps);
+    x = bern_inv<float, 22>(th, t, a.bound, y, a.nbis, a.eps);
+    float fy, d;
+    bern_fwd<float, 22>(th, t, a.bound, x, fy, d, a.eps);
+    lj = t_log(d);
   }
 };
 
@@ -489,6 +525,16 @@ int zk_ar_inverse_incremental(const zk_ar_inc_args_v1* args, void* stream) {
   for (int l = 0; l <= n_hidden; ++l) a.bias_off[l] = bias_off[l];
   a.xs = a.nit * 16 + 4;
   a.bound = (float)bound; a.ls = (float)log(slope); a.lc = rqs_lean_const(bound, log(slope));
+  if (uni_kind == 5 || uni_kind == 6) {  // polynomial maps: bisection inverse in the group epilogue
+    if (args->half || args->n_bisect < 1 || args->n_bisect > 64) return ZK_EINVAL;
+    a.nbis = args->n_bisect;
+    a.eps = (float)(args->eps > 0.0 ? args->eps : 1e-6);
+    if (uni_kind == 5) {
+      if (!args->gl_nodes01 || !args->gl_weights01) return ZK_EINVAL;
+      a.sos.bound = (float)bound; a.sos.slope = (float)slope; a.sos.P = 3; a.sos.L1 = 5;
+      for (int i = 0; i < 5; ++i) { a.sos.node[i] = (float)args->gl_nodes01[i]; a.sos.weight[i] = (float)args->gl_weights01[i]; }
+    }
+  }
   a.n_tiles = (N + 63) / 64;
   const int lds = inc_lds_floats(bias_floats, n_groups, a.xs) * (int)sizeof(float);
   if (lds > 160 * 1024) return ZK_EINVAL;
@@ -513,6 +559,8 @@ int zk_ar_inverse_incremental(const zk_ar_inc_args_v1* args, void* stream) {
   else if (uni_kind == 1) fn = ZK_INC_PICK(IncRqs<8>);
   else if (uni_kind == 2) fn = ZK_INC_PICK(IncRqs<4>);
   else if (uni_kind == 3) fn = ZK_INC_PICK(IncRqs<16>);
+  else if (uni_kind == 5) fn = ZK_INC_PICK1(IncSos3x5, false);
+  else if (uni_kind == 6) fn = ZK_INC_PICK1(IncBern17, false);
   else return ZK_EINVAL;
 #endif
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -294,11 +294,12 @@ class MaskedAutoregressiveTransform(LazyTransform):
             mods = list(self.hyper)
             simple = all(isinstance(a, MaskedLinear) != (i % 2 == 1) for i, a in enumerate(mods))
             codes = {_act_code(a) for a in mods if not isinstance(a, MaskedLinear)}
-            if lay is not None and lay[0].kind in (0, 1, 2, 3) and simple and len(codes) == 1 and None not in codes and all(l.weight.dtype == torch.float32 for l in lins):
+            if lay is not None and lay[0].kind in (0, 1, 2, 3, 5, 6) and simple and len(codes) == 1 and None not in codes and all(l.weight.dtype == torch.float32 for l in lins):
                 layout = fused.UniLayout(lay[0].kind, lay[0].total, 1, (lay[0].total + 3) // 4, lay[0].bins)
                 plan = inc.build_inc_plan([l.mask for l in lins], self.features, self.order.cpu().numpy(), layout)
                 if plan is not None:
-                    state = inc.IncAR(plan, lins, device, codes.pop(), lay[1], lay[2])
+                    # (kind 6, the Bernstein map: the layout's third slot is its continuation margin, it has no slope)
+                    state = inc.IncAR(plan, lins, device, codes.pop(), lay[1], 1e-3 if lay[0].kind == 6 else lay[2], eps=lay[2] if lay[0].kind == 6 else None)
             cache[key] = (structure, state)
         return cache[key][1]
 
@@ -513,7 +514,8 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
         conditioner fits the aligned-tile plan, else one fused launch per (partial) sweep, updating the buffer in place."""
         st = self._fused(y, need_generic=True)  # (the sweeps below run on the generic kernel)
         if st is None:
-            return self._ordered_inverse(y)
+            out = self._poly_incremental(y, want_ladj)  # the polynomial maps: no generic kernel, but the incremental launch inverts them (round 6)
+            return out if out is not None else self._ordered_inverse(y)
         self._check_widths(y, st)
         lazy, c = self.lazy, self.c
         D = lazy.features
@@ -548,6 +550,33 @@ class FusedAutoregressiveTransform(AutoregressiveTransform):
                 st.run_inverse_sweep(buf, y2)
         return buf[:, :D].reshape(batch + (D,)).contiguous() if buf.shape[1] != D else buf.reshape(batch + (D,))
 
+
+    def _poly_incremental(self, y: Tensor, want_ladj: bool):
+        """SOSPF / BPF layers (uni kinds 5, 6): x = f^{-1}(y) in ONE incremental launch with the bisection of zuko/transforms.py:608-617 in the kernel's group
+        epilogue (csrc/inc_inverse.hip: IncSos3x5, IncBern17), or None when the layer is something else / does not fit the aligned-tile plan / autograd is on."""
+        lazy, c = self.lazy, self.c
+        if not (y.is_cuda and y.dtype == torch.float32 and y.dim() >= 1 and _incremental_enabled() and _partial_inverse_enabled()) or want_ladj:
+            return None
+        if torch.is_grad_enabled() and (y.requires_grad or (c is not None and c.requires_grad) or any(p.requires_grad for p in lazy.hyper.parameters())):
+            return None
+        lay = lazy._fusable_layout()
+        if lay is None or lay[0].kind not in (5, 6) or os.environ.get("ZUKO_AMD_FULL_SWEEPS", "0") == "1":
+            return None
+        inc_state = lazy.incremental_state(y.device)
+        if inc_state is None:
+            return None
+        D = lazy.features
+        if y.shape[-1] != D:
+            return None
+        if c is not None:
+            yb, cb = broadcast(y, c, ignore=1)
+        else:
+            yb, cb = y, None
+        batch = yb.shape[:-1]
+        inc_state.refresh([m for m in lazy.hyper if isinstance(m, MaskedLinear)])
+        c2 = None if cb is None else cb.reshape(-1, cb.shape[-1]).contiguous()
+        x2, _ = inc_state.run(yb.reshape(-1, D).contiguous(), c2, False)
+        return x2.reshape(batch + (D,))
 
     def _ordered_inverse(self, y: Tensor) -> Tensor:
         """The reference's loop (zuko/transforms.py:994-1000: `passes` times x <- meta(x).inv(y) from x = 0) for layers that have no fused

@@ -510,12 +510,14 @@ def simulate(plan: IncPlan, weights, biases, masks, y: np.ndarray, ctx: np.ndarr
 class IncAR:
     """Runs zk_ar_inverse_incremental for one MaskedAutoregressiveTransform on one device."""
 
-    def __init__(self, plan: IncPlan, lins, device, act: int, bound: float, slope: float) -> None:
+    def __init__(self, plan: IncPlan, lins, device, act: int, bound: float, slope: float, eps: float | None = None) -> None:
         import ctypes
 
         import torch
 
         self.plan, self.device, self.act, self.bound, self.slope = plan, device, act, bound, slope
+        self.eps = eps  # (Bernstein map: continuation margin)
+        self._gl = None  # (SOS map: ctypes arrays of the Gauss-Legendre nodes / weights, kept alive here)
         self.gather = torch.from_numpy(plan.gather).to(device)
         self.bias_gather = torch.from_numpy(plan.bias_gather).to(device)
         self.featmap = torch.from_numpy(plan.featmap.copy()).to(device)
@@ -600,8 +602,22 @@ class IncAR:
         C = 0 if ctx is None else ctx.shape[1]
         from . import fused
 
-        half = self.h_ok and self._h_stamp == self._stamp and fused.matmul_precision() == "f16x2" and inverse_half_enabled()
+        half = self.h_ok and self._h_stamp == self._stamp and fused.matmul_precision() == "f16x2" and inverse_half_enabled() and p.layout.kind <= 3
         extra = dict(half=1, wdescale1=self.h_descale[1], wdescale2=self.h_descale[2], wdescale3=self.h_descale[3]) if half else {}
+        if p.layout.kind in (5, 6):  # the polynomial maps: bisection inverse in the launch (zuko/transforms.py:608-617: n = ceil(log2(2 B / 1e-6)) steps)
+            import ctypes
+            import math
+
+            eps = 1e-6 if self.eps is None else float(self.eps)
+            extra["n_bisect"] = math.ceil(math.log2(2 * self.bound / (1e-6 if p.layout.kind == 5 else eps)))
+            if p.layout.kind == 5:
+                if self._gl is None:
+                    from .ops import _leggauss01
+
+                    self._gl = _leggauss01(5)
+                extra.update(gl_nodes01=ctypes.cast(self._gl[0], ctypes.c_void_p), gl_weights01=ctypes.cast(self._gl[1], ctypes.c_void_p))
+            else:
+                extra["eps"] = eps
         a = _C.args("zk_ar_inc_args_v1", uni_kind=p.layout.kind, n_hidden=p.n_hidden, N=N, D=p.features, C=C, y=_ptr(y), ldy=y.stride(0), ctx=_ptr(ctx),
                     ldc=0 if ctx is None else ctx.stride(0), x=_ptr(x), ldx=p.features, ladj=_ptr(ladj), wstream=_ptr(self.h_stream if half else self.stream), bias=_ptr(self.bias),
                     bias_floats=self.bias.numel(), bias_off=self.bias_off, featmap=_ptr(self.featmap), prog=_ptr(self.prog), n_groups=p.n_groups,
