@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import zuko_oracle as O
+from plan_emulators import simulate_ar, simulate_coupling, simulate_inc
 
 
 @pytest.mark.parametrize(
@@ -36,7 +37,7 @@ def test_plan_simulation_matches_masked_mlp(name, kind, total, bins, D, C, kw):
         B = [m.bias.detach().double().numpy() for m in lins]
         x = torch.randn(19, D + C, dtype=torch.float64)
         ref = O.mlp_forward(x, [torch.tensor(w) for w in W], [torch.tensor(b) for b in B], masks).reshape(19, D, total).numpy()
-        phi = fused.simulate(plan, W, B, [m.numpy() for m in masks], x.numpy(), lambda v: np.maximum(v, 0))
+        phi = simulate_ar(plan, W, B, [m.numpy() for m in masks], x.numpy(), lambda v: np.maximum(v, 0))
         assert np.abs(phi - ref).max() < 1e-12
     if name == "nsf64":
         assert plan.kept_tiles < 0.6 * plan.dense_tiles  # degree sort exposes the block-triangular structure
@@ -86,7 +87,7 @@ def test_plan_simulation_on_random_adjacencies():
         B = [m.bias.detach().double().numpy() for m in lins]
         x = torch.randn(5, D + C, dtype=torch.float64)
         ref = O.mlp_forward(x, [torch.tensor(w) for w in W], [torch.tensor(b) for b in B], masks).reshape(5, D, 2).numpy()
-        phi = fused.simulate(plan, W, B, [m.numpy() for m in masks], x.numpy(), lambda v: np.maximum(v, 0))
+        phi = simulate_ar(plan, W, B, [m.numpy() for m in masks], x.numpy(), lambda v: np.maximum(v, 0))
         assert np.abs(phi - ref).max() < 1e-12, (trial, D, C, hidden)
         done += 1
     assert done >= 25
@@ -138,7 +139,7 @@ def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bin
         _, l = O.univariate_forward(uni, ph, x)
         return x[:, 0].numpy(), l[:, 0].numpy()
 
-    xs, ls = inc.simulate(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn)
+    xs, ls = simulate_inc(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn)
     if kind in ("sos", "bern"):  # (a bisection: both walks stop at the same 2^-24 bracket unless a comparison sits within rounding of the target)
         assert np.abs(xs - xo.numpy()).max() < 1e-5 and np.abs(ls - lo.numpy()).max() < 1e-3
         return
@@ -154,7 +155,7 @@ def test_incremental_inverse_plan_simulation_matches_oracle(kind, D, hidden, bin
     from zuko_amd import fused as Fu
 
     wexp = [0] + [e for _, e in Fu.half_scales(lins)][1:]
-    xh, lh = inc.simulate(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn, half=hs, wexp=wexp)
+    xh, lh = simulate_inc(plan, W, B, Mk, y.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), inv_fn, half=hs, wexp=wexp)
     assert np.abs(xh - xo.numpy()).max() < 1e-6 * max(1.0, np.abs(xo.numpy()).max()) and np.abs(lh - lo.numpy()).max() < 1e-5, (np.abs(xh - xo.numpy()).max(), np.abs(lh - lo.numpy()).max())
 
 
@@ -191,14 +192,14 @@ def test_coupling_plan_simulation_matches_oracle(D, ctx, hidden):
     c = torch.randn(n, ctx, generator=g, dtype=torch.float64) if ctx else None
     layer = O.CouplingLayer(O.UNI_AFFINE, [torch.from_numpy(w) for w in W], [torch.from_numpy(b) for b in B], t.mask)
     yo, lo = O.coupling_forward(layer, x, c)
-    ys, ls = cp.simulate(plan, W, B, x.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), float(np.log(1e-3)))
+    ys, ls = simulate_coupling(plan, W, B, x.numpy(), None if c is None else c.numpy(), lambda v: np.maximum(v, 0), float(np.log(1e-3)))
     assert np.abs(ys - yo.numpy()).max() < 1e-12 and np.abs(ls - lo.numpy()).max() < 1e-12
 
 
 def _walk_static_tables(t, stream, bias_img, inp, rev_l0=None):
     """Pure-numpy walk of the weight stream exactly as csrc/fused_ar_static_impl.h does it from the GENERATED tables (step lists,
     stream positions from the popcounts of the tile masks, last-layer groups): returns the accumulators of every feature group
-    [n, NG, NT, 16].  A wrong table shows up as a difference from fused.simulate(), which walks the plan itself."""
+    [n, NG, NT, 16].  A wrong table shows up as a difference from simulate_ar(), which walks the plan itself."""
     n = inp.shape[0]
     tiles = stream.reshape(-1, 64, 4)  # [tile][lane][r]
     A = lambda b: tiles[b].reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)  # lane (i, q), r -> A[i][4 q + r]
@@ -237,7 +238,7 @@ def _walk_static_tables(t, stream, bias_img, inp, rev_l0=None):
 def test_static_kernel_tables_describe_the_plan(cfg):
     """zuko_amd/static_ar.py:tables() — what a generated static-shape kernel is compiled from — against the plan it came from, for
     both feature orders zuko alternates between (zuko/flows/autoregressive.py:121-125): the table-driven walk of the per-tile stream
-    reproduces phi of fused.simulate() (which walks the plan) and of the masked network itself, including widths that are not
+    reproduces phi of simulate_ar() (which walks the plan) and of the masked network itself, including widths that are not
     multiples of 16 / 64, a context, a single hidden layer and the 512-wide plan only the static kernels cover."""
     from zuko_amd import fused, static_ar
 

@@ -4,7 +4,7 @@ One `GeneralCouplingTransform` (zuko/flows/coupling.py:25-139) = dense MLP on th
 the affine map of the other half.  The kernel streams the MLP's weights as 1 KiB MFMA A-operand images in consumption
 order; this module builds that order (gather indices into the concatenated layer weights), the bias image and the two
 index maps that implement `CouplingTransform`'s split / merge (zuko/transforms.py:1037-1048) inside the kernel.
-`simulate` walks the same tables in numpy (CPU tests).
+(tests/plan_emulators.py walks the same tables in numpy for the CPU tests.)
 """
 
 from __future__ import annotations
@@ -167,56 +167,6 @@ def build_coupling_plan(shapes, idx_a, idx_b, features: int, context: int, chunk
         n_chunks=len(blocks) // chunk, bias_gather=np.concatenate(bias_gather).astype(np.int32), bias_off=bias_off, amap=amap.astype(np.int32),
         fmap=fmap.astype(np.int32), features=features, context=context, split_gather=split_gather, split_chunks=split_chunks, split_layer_blocks=split_layer_blocks,
     )
-
-
-def simulate(plan: CouplingPlan, weights, biases, x: np.ndarray, ctx: np.ndarray | None, act, ls: float):
-    """Numpy walk through the kernel's tables: returns (y [n, D], ladj [n])."""
-    n = x.shape[0]
-    wcat = np.concatenate([np.asarray(w).reshape(-1) for w in weights])
-    bcat = np.concatenate([np.asarray(b).reshape(-1) for b in biases])
-    stream = np.where(plan.gather >= 0, wcat[np.maximum(plan.gather, 0)], 0.0).reshape(-1, 64, 4)
-    bias = np.where(plan.bias_gather >= 0, bcat[np.maximum(plan.bias_gather, 0)], 0.0)
-
-    def tile_mat(blk):
-        return blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)
-
-    cur = np.zeros((n, plan.nit * TILE))
-    for i, src in enumerate(plan.amap):
-        if src >= 0:
-            cur[:, i] = x[:, src]
-        elif src <= -2:
-            cur[:, i] = ctx[:, -2 - src]
-    pos = 0
-    L = plan.n_layers
-    for l in range(L - 1):
-        n_in = plan.nit if l == 0 else plan.tiles[l - 1]
-        out = np.zeros((n, MAX_T * TILE))
-        for otg in range(-(-plan.tiles[l] // 4)):
-            for t in range(4):
-                out[:, (otg * 4 + t) * TILE : (otg * 4 + t + 1) * TILE] = bias[plan.bias_off[l] + (otg * 4 + t) * TILE : plan.bias_off[l] + (otg * 4 + t + 1) * TILE]
-            for it in range(n_in):
-                for t in range(4):
-                    out[:, (otg * 4 + t) * TILE : (otg * 4 + t + 1) * TILE] += cur[:, it * TILE : (it + 1) * TILE] @ tile_mat(stream[pos]).T
-                    pos += 1
-        pos = -(-pos // CHUNK) * CHUNK
-        cur = act(out)
-        cur[:, plan.widths[l] :] = 0.0
-    y = x.copy()
-    ladj = np.zeros(n)
-    for g in range(plan.n_groups):
-        acc = np.zeros((n, TILE)) + bias[plan.bias_off[L - 1] + g * TILE : plan.bias_off[L - 1] + (g + 1) * TILE]
-        for it in range(plan.tiles[-1]):
-            acc += cur[:, it * TILE : (it + 1) * TILE] @ tile_mat(stream[pos]).T
-            pos += 1
-        for qq in range(4):
-            for fi in range(2):
-                f = plan.fmap[g * 8 + qq * 2 + fi]
-                if f >= 0:
-                    shift, scale = acc[:, 4 * qq + 2 * fi], acc[:, 4 * qq + 2 * fi + 1]
-                    lsc = scale / (1 + np.abs(scale / ls))
-                    y[:, f] = x[:, f] * np.exp(lsc) + shift
-                    ladj += lsc
-    return y, ladj
 
 
 class FusedCoupling:

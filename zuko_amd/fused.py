@@ -338,65 +338,6 @@ def partial_schedule(plan: ArPlan, g_lo: int, g_hi: int):
     return sched, olim
 
 
-def simulate(plan: ArPlan, weights: list[np.ndarray], biases: list[np.ndarray], masks: list[np.ndarray], inp: np.ndarray, act) -> np.ndarray:
-    """Pure-numpy walk through the SAME stream / tables the kernel uses (tile order, skip bits,
-    chunk padding, feature regrouping) for a [n, din] input; returns phi[n, features, total].
-    Used by the CPU tests to validate the plan without a GPU."""
-    stream = []
-    for l, g in enumerate(plan.gather):
-        w = (weights[l] * masks[l]).reshape(-1)
-        s = np.where(g >= 0, w[np.maximum(g, 0)], 0.0)
-        stream.append(s)
-    stream = np.concatenate(stream).reshape(-1, 64, 4)  # [block][lane][r]
-    bias_img = []
-    for l, g in enumerate(plan.bias_gather):
-        bias_img.append(np.where(g >= 0, biases[l][np.maximum(g, 0)], 0.0))
-    n = inp.shape[0]
-    MW = plan.max_width
-    n_otg, n_itile = MW // TILE // GROUP_HIDDEN, MW // TILE
-    cur = np.zeros((n, MW))
-    cur[:, : plan.din] = inp
-    lay = plan.layout
-    for l in range(plan.n_layers - 1):
-        b = plan.layer_block0[l]
-        out = np.zeros((n, MW))
-        for otg in range(n_otg):
-            bits = int(plan.skip[l * n_otg + otg])
-            for it in range(n_itile):
-                if bits >> it & 1:
-                    for t in range(GROUP_HIDDEN):
-                        ot = otg * GROUP_HIDDEN + t
-                        blk = stream[b]
-                        b += 1
-                        # lane (i, q), r: A[i][k = 4q + r]
-                        A = blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)  # [i][4q+r]
-                        out[:, ot * 16 : ot * 16 + 16] += cur[:, it * 16 : it * 16 + 16] @ A.T
-        cur = act(out + bias_img[l][None, :])
-    b = plan.layer_block0[-1]
-    phi = np.zeros((n, plan.features, lay.total))
-    per_group = 4 * lay.fpl
-    for g in range(plan.n_groups):
-        acc = np.zeros((n, lay.nt, 16))
-        bits = int(plan.skip[(plan.n_layers - 1) * n_otg + g])
-        for it in range(n_itile):
-            if bits >> it & 1:
-                for t in range(lay.nt):
-                    blk = stream[b]
-                    b += 1
-                    A = blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)
-                    acc[:, t, :] += cur[:, it * 16 : it * 16 + 16] @ A.T
-        acc += bias_img[-1].reshape(plan.n_groups, lay.nt, 16)[g][None]
-        for t in range(lay.nt):
-            for i in range(16):
-                m = 4 * t + (i & 3)
-                fi, p = divmod(m, lay.total)
-                if fi < lay.fpl:
-                    f = plan.featmap[g * per_group + (i >> 2) * lay.fpl + fi]
-                    if f >= 0:
-                        phi[:, f, p] = acc[:, t, i]
-    return phi
-
-
 # --------------------------------------------------------------------------------------------------
 # device-side state: plan tables + the gathered weight stream, refreshed when parameters change
 # --------------------------------------------------------------------------------------------------

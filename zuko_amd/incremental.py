@@ -19,7 +19,7 @@ Per sample this is ~1.5x the multiply-adds of ONE density evaluation instead of 
 reference loop).  Layouts that do not fit (a tile would need more than 16 units, more than 16 tiles per layer, residual
 blocks, D > 128) return None and the caller falls back to the partial sweeps.
 
-Everything here is integer bookkeeping on the CPU, done once per module; `simulate` walks the same tables in numpy and is
+Everything here is integer bookkeeping on the CPU, done once per module; tests/plan_emulators.py walks the same tables in numpy and is
 what the CPU tests check against the oracle.
 """
 
@@ -375,131 +375,6 @@ def half_stream(plan: IncPlan, masks, chunk: int = CHUNK) -> HalfStream:
     g32 = np.concatenate([zero if im is None else im for im in images]).astype(np.int32)
     return HalfStream(gather_f32=g32, blk_gather=[None] + [np.concatenate(blk[l]).astype(np.int32) if blk[l] else np.zeros(0, np.int32) for l in range(1, L)],
                       blk_pos=[None] + [np.asarray(pos[l], dtype=np.int64) for l in range(1, L)], n_images=len(images), n_chunks=n_chunks)
-
-
-def _f16_parts(v: np.ndarray):
-    h = v.astype(np.float32).astype(np.float16).astype(np.float32)
-    return h, (v.astype(np.float32) - h).astype(np.float16).astype(np.float32)
-
-
-def _pow2(amax) -> np.ndarray:
-    """2^ea with amax 2^ea in [2^14, 2^15) (ea clamped to [-90, 90]; amax = 0: ea = 15) — inc_pair_convert of the kernel."""
-    m, e = np.frexp(np.asarray(amax, dtype=np.float64))
-    return np.exp2(np.clip(15 - np.where(np.asarray(amax) > 0, e, 0), -90, 90).astype(np.float64))
-
-
-def simulate(plan: IncPlan, weights, biases, masks, y: np.ndarray, ctx: np.ndarray | None, act, inv_fn, half: HalfStream | None = None, wexp=None):
-    """Numpy walk through the SAME stream / tables the kernel uses.  y [n, features] values to invert, ctx [n, context] or None;
-    `inv_fn(phi[n, total], yv[n]) -> (x[n], ladj[n])`.  Returns (x [n, features], ladj [n])."""
-    n = y.shape[0]
-    NH, L = plan.n_hidden, plan.n_hidden + 1
-    wcat = np.concatenate([(np.asarray(w) * np.asarray(m)).reshape(-1) for w, m in zip(weights, masks)])
-    bcat = np.concatenate([np.asarray(b).reshape(-1) for b in biases])
-    bias = np.where(plan.bias_gather >= 0, bcat[np.maximum(plan.bias_gather, 0)], 0.0)
-    if half is not None:  # the HALF stream: f32 images + pair blocks in two f16 parts of W 2^wexp[l]; walked below exactly as the kernel walks it
-        stream = np.where(half.gather_f32 >= 0, wcat[np.maximum(half.gather_f32, 0)], 0.0).reshape(-1, 64, 4)
-        blocks = {}
-        for l in range(1, L):
-            idx = half.blk_gather[l].reshape(-1, 64, 8)
-            vals = np.where(idx >= 0, wcat[np.maximum(idx, 0)], 0.0) * 2.0 ** wexp[l]
-            bh, bl = _f16_parts(vals)
-            for k, ps in enumerate(half.blk_pos[l]):
-                blocks[int(ps)] = (bh[k], bl[k], 2.0 ** -wexp[l])
-        pairs = [[None] * ((MAX_TILES + 1) // 2) for _ in range(NH)]  # per layer and pair: (h [n, 64 lanes.. as [n, 32]], l, 1 / s)
-
-        def block_mat(img):  # [64 lanes, 8] -> A[i][k]: k = kq-th group of 4 of tile 2 p (first 16) / of tile 2 p + 1 (last 16)
-            a4 = img.reshape(4, 16, 8)  # [kq, i, e]
-            lo = a4[:, :, :4].transpose(1, 0, 2).reshape(16, 16)
-            hi = a4[:, :, 4:].transpose(1, 0, 2).reshape(16, 16)
-            return np.concatenate([lo, hi], axis=1)  # [16, 32]
-
-        def pull(pos_, layer_src, p_):
-            bh, bl, wd = blocks[pos_]
-            ph, pl, inv_s = pairs[layer_src][p_]
-            A_h, A_l = block_mat(bh), block_mat(bl)
-            t = ph @ A_l.T + pl @ A_h.T + ph @ A_h.T  # (smallest first; f32 accumulation in the kernel)
-            return t * (inv_s * wd)[:, None]
-
-        def finalize(layer, j_, hj):
-            lo = hj if j_ % 2 == 0 else h[layer][:, (j_ - 1) * TILE : j_ * TILE]
-            hi = np.zeros_like(hj) if j_ % 2 == 0 else hj
-            both = np.concatenate([lo, hi], axis=1)
-            s_ = _pow2(np.abs(both).max(axis=1))
-            ph, pl = _f16_parts(both * s_[:, None])
-            pairs[layer][j_ // 2] = (ph, pl, 1.0 / s_)
-    else:
-        stream = np.where(plan.gather >= 0, wcat[np.maximum(plan.gather, 0)], 0.0).reshape(-1, 64, 4)
-
-    def tile_mat(blk):  # [64 lanes, 4] -> A[i][k = 4q + r]
-        return blk.reshape(4, 16, 4).transpose(1, 0, 2).reshape(16, 16)
-
-    xin = np.zeros((n, plan.nit * TILE))
-    if ctx is not None:
-        xin[:, plan.features : plan.features + ctx.shape[1]] = ctx
-    h = [np.zeros((n, MAX_TILES * TILE)) for _ in range(NH)]
-    ladj = np.zeros(n)
-    pos = 0
-    total = plan.layout.total
-    for j in range(plan.n_groups):
-        ns, nd = int(plan.prog[j, 0]), int(plan.prog[j, 1])
-        stat = plan.prog[j, 2 : 2 + ns]
-        dyn = plan.prog[j, 2 + MAX_TILES : 2 + MAX_TILES + nd]
-        off = [bias[plan.bias_off[l] + j * TILE : plan.bias_off[l] + (j + 1) * TILE][None, :].repeat(n, 0).copy() for l in range(NH)]
-        for i, it in enumerate(stat):
-            off[0] += xin[:, it * TILE : (it + 1) * TILE] @ tile_mat(stream[pos + i]).T
-        pos += L1S
-        poff = np.zeros((n, plan.nt, TILE))
-        for tt in range(plan.nt):
-            b0 = plan.bias_off[NH] + (j * plan.nt + tt) * TILE
-            poff[:, tt, :] = bias[b0 : b0 + TILE][None, :]
-        if half is not None:
-            npr = (j + 1) // 2
-            for l in range(1, NH):
-                for p_ in range(npr):
-                    off[l] += pull(pos, l - 1, p_)
-                    pos += 2
-            for p_ in range(npr):
-                for tt in range(plan.nt):
-                    poff[:, tt, :] += pull(pos, NH - 1, p_)
-                    pos += 2
-        else:
-            for l in range(1, NH):
-                for t in range(j):
-                    off[l] += h[l - 1][:, t * TILE : (t + 1) * TILE] @ tile_mat(stream[pos]).T
-                    pos += 1
-            for t in range(j):
-                for tt in range(plan.nt):
-                    poff[:, tt, :] += h[NH - 1][:, t * TILE : (t + 1) * TILE] @ tile_mat(stream[pos]).T
-                    pos += 1
-        wd = [tile_mat(stream[pos + i]) for i in range(nd)]
-        pos += L1D
-        wh = [tile_mat(stream[pos + i]) for i in range(NH - 1)]
-        pos += NH - 1
-        wl = [tile_mat(stream[pos + i]) for i in range(plan.nt)]
-        pos += plan.nt
-        for r in range(5):
-            cur = off[0].copy()
-            for i, it in enumerate(dyn):
-                cur += xin[:, it * TILE : (it + 1) * TILE] @ wd[i].T
-            hj = [act(cur)]
-            for l in range(1, NH):
-                hj.append(act(off[l] + hj[l - 1] @ wh[l - 1].T))
-            if r == 4:
-                for l in range(NH):
-                    h[l][:, j * TILE : (j + 1) * TILE] = hj[l]
-                    if half is not None:
-                        finalize(l, j, hj[l])
-                break
-            p = poff.copy()
-            for tt in range(plan.nt):
-                p[:, tt, :] += hj[NH - 1] @ wl[tt].T
-            f = int(plan.featmap[j * 4 + r])
-            if f >= 0:
-                phi = np.stack([p[:, pp // 4, 4 * r + (pp & 3)] for pp in range(total)], axis=1)  # lane q = r: rows 4 r .. 4 r + 3 of every tile
-                xv, lj = inv_fn(phi, y[:, f])
-                xin[:, f] = xv
-                ladj += lj
-    return xin[:, : plan.features], ladj
 
 
 # --------------------------------------------------------------------------------------------------
