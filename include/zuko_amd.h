@@ -530,6 +530,46 @@ int zk_wgrad_multi(int n_layers, const zk_wgrad_layer_v1* layers, int64_t N, voi
 int zk_colsum_slices(int64_t N);
 int zk_colsum_f32(int64_t N, int C, const void* x, int64_t ld, float* workspace, void* out, int accumulate, void* stream);
 
+/* ---- DENSE conditioner GEMMs on the f16 matrix instruction with two-part f32 operands (csrc/gemm_half.hip) ------------------------- *
+ * Forward and dgrad of the coupling conditioner `MLP` (zuko/nn.py:15 F.linear + activation, zuko/flows/coupling.py:128-136) under training:
+ * every f32 operand is scaled by a power of two that puts its TENSOR's largest magnitude in [2^14, 2^15) and written as h + l in f16; a
+ * product is three v_mfma_f32_16x16x32_f16 with f32 accumulation (22 significand bits for elements within 2^-18 of the maximum, an
+ * absolute error of 2^-40 of the maximum below).  A maximum travels as a DEVICE array of ZK_AMAX_WORDS uint32 — 64 partial maxima, bit
+ * patterns of non-negative floats, one per 128-byte line so that the atomicMax of a few thousand wavefronts do not queue on one address;
+ * the caller zeroes it, the readers fold it: no host synchronisation between the layers of a chain.
+ *
+ * zk_amax_f32:    folds max |src[r, c]| into `out` for any number of [rows, cols] (row stride ld) tensors, eight per launch.
+ * zk_wsplit_f16:  the lane images of a weight operand W'[unit u, k] = src[u * unit_stride + k * k_stride] (mask likewise, or NULL) for
+ *                 `units` x `k`, scaled from *amax: dst receives ceil(units / 128) * ceil(k / 32) * 16 KiB, zero padded.  (unit_stride, k_stride) =
+ *                 (in, 1) on a row-major [out, in] weight gives the forward operand, (1, in) with units = in, k = out the dgrad operand W^T.
+ * zk_gemm_f16x2:  c[M, N] = act(a[M, K] W'^T + bias) (* (gate > 0) when gate != NULL and gate_act == 1); act in {NONE, RELU}.  a_amax >= max |a|
+ *                 and w_amax (the scalar the images were made with) are read on the device; c_amax (or NULL) receives max |c| by atomicMax. */
+#define ZK_AMAX_WORDS 2048
+typedef struct zk_amax_desc_v1 {
+  uint32_t struct_size;    /* sizeof(zk_amax_desc_v1) */
+  int32_t cols;
+  int64_t rows;
+  int64_t ld;
+  const void* src;         /* f32 */
+  uint32_t* out;           /* DEVICE [ZK_AMAX_WORDS] */
+} zk_amax_desc_v1;
+int zk_amax_f32(int n, const zk_amax_desc_v1* descs, void* stream);
+typedef struct zk_wsplit_desc_v1 {
+  uint32_t struct_size;    /* sizeof(zk_wsplit_desc_v1) */
+  int32_t units;
+  int32_t k;
+  int32_t pad_;
+  int64_t unit_stride;
+  int64_t k_stride;
+  const void* src;         /* f32 */
+  const uint8_t* mask;     /* or NULL; indexed like src */
+  const uint32_t* amax;    /* DEVICE [ZK_AMAX_WORDS]: >= max |src| */
+  void* dst;
+} zk_wsplit_desc_v1;
+int zk_wsplit_f16(int n, const zk_wsplit_desc_v1* descs, void* stream);
+int zk_gemm_f16x2(int64_t M, int K, int N, const void* a, int64_t lda, const uint32_t* a_amax, const void* w_images, const uint32_t* w_amax,
+                  const void* bias, int act, const void* gate, int64_t ldg, int gate_act, void* c, int64_t ldc, uint32_t* c_amax, void* stream);
+
 /* ---- base density + final reduction (zuko/distributions.py:115-119, 337-363) ---------------------- *
  * out[n] = sum_d Normal(loc[d], scale[d]).log_prob(z[n, d]) (+ ladj[n] if ladj != NULL). */
 int zk_diag_normal_log_prob(int dtype, int64_t N, int64_t D, const void* z, const void* loc, const void* scale,

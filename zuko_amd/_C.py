@@ -123,6 +123,9 @@ SIGNATURES = {
     "zk_wgrad_bias_f32": [L, I, I, P, L, P, L, P, I, P, P, P, I, P, P, P, P, P, P],
     "zk_colsum_slices": [L],
     "zk_colsum_f32": [L, I, P, L, P, P, I, P],
+    "zk_amax_f32": [I, P, P],
+    "zk_wsplit_f16": [I, P, P],
+    "zk_gemm_f16x2": [L, I, I, P, L, P, P, P, P, I, P, L, I, P, L, P, P],
     "zk_ar_lds_bytes": [I, I],
     "zk_ar_forward_static": [_AR, P],
     "zk_ar_forward_train": [_AR, P],

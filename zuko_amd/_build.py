@@ -33,6 +33,7 @@ SOURCES = {
     "fused_ar_gsplit.hip": ["-ffp-contract=off"],
     "backward.hip": [],
     "train.hip": [],
+    "gemm_half.hip": [],
     # (pragma-unroll-threshold: the 8 x 32 tile loop of a 512-wide layer exceeds the default cap of forced unrolling; a
     #  partially unrolled loop indexes the activation arrays dynamically, which puts them in scratch memory: 4x slower)
     "fused_coupling.hip": ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000"],
