@@ -172,8 +172,27 @@ class FusedCouplingTransform(CouplingTransform):
         y, ladj = st.run(x2, c2, inverse)
         return y.reshape(batch + (D,)), ladj.reshape(batch)
 
+    def _trained(self, x: Tensor):
+        """(y, ladj) through the one-node training path (zuko_amd/coupling_train.py), or None."""
+        from .. import coupling_train
+
+        lazy, c = self.lazy, self.c
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1 and torch.is_grad_enabled()):
+            return None
+        if c is not None:
+            xb, cb = broadcast(x, c, ignore=1)
+        else:
+            xb, cb = x, None
+        batch = xb.shape[:-1]
+        out = coupling_train.coupling(lazy, xb.reshape(-1, xb.shape[-1]), None if cb is None else cb.reshape(-1, cb.shape[-1]))
+        if out is None:
+            return None
+        return out[0].reshape(batch + (xb.shape[-1],)), out[1].reshape(batch)
+
     def call_and_ladj(self, x: Tensor):
         out = self._fused(x, False)
+        if out is None:
+            out = self._trained(x)
         return super().call_and_ladj(x) if out is None else out
 
     def _call(self, x: Tensor) -> Tensor:
