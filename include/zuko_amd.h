@@ -525,6 +525,8 @@ typedef struct zk_wgrad_layer_v1 {
   void* db;                /* [out], written through rows */
   const int32_t* rows;     /* sorted row -> the module's row, or NULL */
   const int32_t* cols;
+  const uint32_t* g_amax;  /* DEVICE [ZK_AMAX_WORDS] maxima of |g| and |h| (see zk_gemm_f16x2 below), or NULL; given for EVERY layer: the products */
+  const uint32_t* h_amax;  /* run as two-part f16 operands with per-tensor power-of-two scales (three partial products instead of six) */
 } zk_wgrad_layer_v1;
 int zk_wgrad_multi(int n_layers, const zk_wgrad_layer_v1* layers, int64_t N, void* stream);
 int zk_colsum_slices(int64_t N);

@@ -145,7 +145,9 @@ class CouplingFn(torch.autograd.Function):
                 gs[l - 1] = g
         res = {}
         for l0 in range(0, L, 4):  # (zk_wgrad_multi: up to four layers per pair of launches)
-            res.update(plan.wgrad_multi([(l, gs[l], hs[l]) for l in range(l0, min(L, l0 + 4))]))
+            ls = range(l0, min(L, l0 + 4))
+            # (maxima: of g_l — g_phi for the last layer — and of the layer's input h_l, all left on the device by the GEMM epilogues)
+            res.update(plan.wgrad_multi([(l, gs[l], hs[l]) for l in ls], amax={l: (am[2 * L + (L - 1 - l)], am[l]) for l in ls}))
         grads = []
         for l in range(L):
             grads += list(res[l])

@@ -14,6 +14,7 @@
 // Operand layout notes are next to each kernel.  fp32 MFMA is bitwise an fmaf chain: results differ from any other fp32
 // GEMM by summation order only.
 #include "zk_common.h"
+#include "zk_half.h"
 #include <stdlib.h>
 
 #include "../../include/zuko_amd.h"
@@ -239,6 +240,10 @@ struct WgradArgs {
   const uint8_t* cs_flag;
   float* cs_partial;
   int cs_ld;
+  // optional (operand-split kernel): the maxima of |g| and |h| on the device (zk_half.h) — both given = TWO-part f16 operands with per-tensor
+  // power-of-two scales (three partial products) instead of three-part bf16 (six)
+  const unsigned* g_amax;
+  const unsigned* h_amax;
 };
 
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
@@ -363,7 +368,22 @@ __device__ __forceinline__ void wsplit8(const float (&v)[8], wbf16x8& h, wbf16x8
   }
 }
 
-__device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, int work, uint4* Gs, uint4* Hs) {
+__device__ __forceinline__ void wsplit8_half(const float (&v)[8], float sc, gh16x8& h, gh16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = v[e] * sc;
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh; l[e] = (_Float16)(x - (float)hh);
+  }
+}
+
+// HALF: two-part f16 operands (a.g_amax / a.h_amax given; a rows-contraction has no per-row scale to factor out: one power of two per tensor, an
+// element 2^-18 below its tensor's maximum still carries 22 bits, and the sum over rows is dominated by the large ones), images [unit block][h, l][lane]
+template <bool HALF> __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, int work, uint4* Gs, uint4* Hs) {
+  constexpr int NPART = HALF ? 2 : 3;
+  int eg = 0, eh = 0;
+  if constexpr (HALF) { eg = gh_exp(a.g_amax); eh = gh_exp(a.h_amax); }
+  const float sg = __builtin_amdgcn_ldexpf(1.0f, eg), sh = __builtin_amdgcn_ldexpf(1.0f, eh);
   const int p = work % a.npairs, s = work / a.npairs;
   const int ob = a.pairs[2 * p], ib = a.pairs[2 * p + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -396,17 +416,25 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, int work, u
   };
   const bool do_cs = a.cs_flag && a.cs_flag[p];
   float csum = 0.f;
-  const int img = (u >> 4) * 3 * 64 + (u & 15);  // + part * 64 + octet * 16
+  const int img = (u >> 4) * NPART * 64 + (u & 15);  // + part * 64 + octet * 16
   gload(n_begin);
   for (int64_t n0 = n_begin; n0 < n_end; n0 += 32) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      wbf16x8 hh, mm, ll;
-      wsplit8(rg[t], hh, mm, ll);
       const int at = img + (oc0 + 2 * t) * 16;
-      Gs[at] = __builtin_bit_cast(uint4, hh); Gs[at + 64] = __builtin_bit_cast(uint4, mm); Gs[at + 128] = __builtin_bit_cast(uint4, ll);
-      wsplit8(rh[t], hh, mm, ll);
-      Hs[at] = __builtin_bit_cast(uint4, hh); Hs[at + 64] = __builtin_bit_cast(uint4, mm); Hs[at + 128] = __builtin_bit_cast(uint4, ll);
+      if constexpr (HALF) {
+        gh16x8 hh, ll;
+        wsplit8_half(rg[t], sg, hh, ll);
+        Gs[at] = __builtin_bit_cast(uint4, hh); Gs[at + 64] = __builtin_bit_cast(uint4, ll);
+        wsplit8_half(rh[t], sh, hh, ll);
+        Hs[at] = __builtin_bit_cast(uint4, hh); Hs[at + 64] = __builtin_bit_cast(uint4, ll);
+      } else {
+        wbf16x8 hh, mm, ll;
+        wsplit8(rg[t], hh, mm, ll);
+        Gs[at] = __builtin_bit_cast(uint4, hh); Gs[at + 64] = __builtin_bit_cast(uint4, mm); Gs[at + 128] = __builtin_bit_cast(uint4, ll);
+        wsplit8(rh[t], hh, mm, ll);
+        Hs[at] = __builtin_bit_cast(uint4, hh); Hs[at + 64] = __builtin_bit_cast(uint4, mm); Hs[at + 128] = __builtin_bit_cast(uint4, ll);
+      }
       if (do_cs) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum += rg[t][e];
@@ -414,6 +442,22 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, int work, u
     }
     __syncthreads();
     if (n0 + 32 < n_end) gload(n0 + 32);
+    if constexpr (HALF) {
+      gh16x8 A[4][2], B[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          A[i][part] = __builtin_bit_cast(gh16x8, Gs[((wr * 4 + i) * 2 + part) * 64 + lane]);
+          B[i][part] = __builtin_bit_cast(gh16x8, Hs[((wc * 4 + i) * 2 + part) * 64 + lane]);
+        }
+      // three partial products, smallest first: (l, h) (h, l) (h, h)
+#define ZK_HTERM(PA, PB)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i][PA], B[j][PB], acc[i][j], 0, 0, 0);
+      ZK_HTERM(1, 0) ZK_HTERM(0, 1) ZK_HTERM(0, 0)
+#undef ZK_HTERM
+    } else {
     wbf16x8 A[4][3], B[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -429,6 +473,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, int work, u
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][PA], B[j][PB], acc[i][j], 0, 0, 0);
     ZK_WTERM(2, 0) ZK_WTERM(0, 2) ZK_WTERM(1, 1) ZK_WTERM(1, 0) ZK_WTERM(0, 1) ZK_WTERM(0, 0)
 #undef ZK_WTERM
+    }
     __syncthreads();
   }
   if (a.cs_flag) {  // (uniform per block: cs_flag[p])
@@ -440,13 +485,14 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, int work, u
     }
   }
   // acc[i][j][r] = D[row 4 (lane >> 4) + r][col lane & 15] of tile (i, j)
+  const float dg = __builtin_amdgcn_ldexpf(1.0f, -eg), dh = __builtin_amdgcn_ldexpf(1.0f, -eh);
   float* dst = a.partial + ((size_t)s * a.npairs + p) * (128 * 128);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(wr * 64 + i * 16 + 4 * (lane >> 4) + r) * 128 + wc * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) dst[(wr * 64 + i * 16 + 4 * (lane >> 4) + r) * 128 + wc * 64 + j * 16 + (lane & 15)] = HALF ? acc[i][j][r] * dg * dh : acc[i][j][r];
 }
 
 // XCD-aware walk: workgroups go round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  XCD x takes a CONTIGUOUS range of the
@@ -463,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 Hs[8 * 3 * 64];
   const int work = wgrad_work(a.nslices * a.npairs);
   if (work < 0) return;
-  wgrad_split_body(a, work, Gs, Hs);
+  wgrad_split_body<false>(a, work, Gs, Hs);
 }
 
 // The weight gradients of ALL layers of a conditioner in one launch (up to four: the layers' work lists follow each other; a layer with two
@@ -473,7 +519,7 @@ struct WgradMulti {
   int start[5];  // first work item of every layer, start[n] = total
   WgradArgs a[4];
 };
-__global__ __launch_bounds__(256, 2) void wgrad_split_multi_kernel(WgradMulti m) {
+template <bool HALF> __global__ __launch_bounds__(256, 2) void wgrad_split_multi_kernel(WgradMulti m) {
   __shared__ __attribute__((aligned(16))) uint4 Gs[8 * 3 * 64];
   __shared__ __attribute__((aligned(16))) uint4 Hs[8 * 3 * 64];
   const int work = wgrad_work(m.start[m.n]);
@@ -484,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_multi_kernel(WgradMulti m)
   if (m.n > 1 && work >= m.start[1]) { a = m.a[1]; base = m.start[1]; }
   if (m.n > 2 && work >= m.start[2]) { a = m.a[2]; base = m.start[2]; }
   if (m.n > 3 && work >= m.start[3]) { a = m.a[3]; base = m.start[3]; }
-  wgrad_split_body(a, work - base, Gs, Hs);
+  wgrad_split_body<HALF>(a, work - base, Gs, Hs);
 }
 
 // dW[o, i] (+)= mask[o, i] * sum_s partial[s][p][...] in slice order (deterministic); 64 blocks of 256 elements per pair
@@ -731,6 +777,7 @@ int zk_wgrad_multi(int n, const zk_wgrad_layer_v1* layers, int64_t N, void* stre
   WredMulti r{};
   m.n = r.n = n;
   int work = 0, red = 0, cs = 0;
+  bool half = true;  // every layer comes with the maxima of its operands: two-part f16 products
   // ONE slice length for all layers, so that every block of the launch runs equally long and the blocks fill a whole number of rounds:
   // about zk_wgrad_slices' blocks-per-CU target over the live blocks of ALL layers (never more slices than a layer's own launch would use:
   // the callers size `partial` for that)
@@ -745,6 +792,8 @@ int zk_wgrad_multi(int n, const zk_wgrad_layer_v1* layers, int64_t N, void* stre
     a.N = N; a.OUT = d.out_features; a.IN = d.in_features; a.g = (const float*)d.g; a.ldg = d.ldg; a.h = (const float*)d.h; a.ldh = d.ldh;
     a.pairs = d.pairs; a.npairs = d.npairs; a.partial = (float*)d.partial;
     a.cs_flag = d.cs_flag; a.cs_partial = (float*)d.cs_partial; a.cs_ld = (d.out_features + 127) / 128 * 128;
+    a.g_amax = d.g_amax; a.h_amax = d.h_amax;
+    half = half && d.g_amax && d.h_amax;
     a.nslices = zk_wgrad_slices(N, d.npairs);
     a.nslices = a.nslices < common ? a.nslices : common;
     a.S = (((N + a.nslices - 1) / a.nslices) + 31) / 32 * 32;
@@ -758,7 +807,8 @@ int zk_wgrad_multi(int n, const zk_wgrad_layer_v1* layers, int64_t N, void* stre
   }
   m.start[n] = work; r.start[n] = red; r.cs_start[n] = cs;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_split_multi_kernel, dim3((unsigned)(8 * ((work + 7) / 8))), dim3(256), 0, st, m);
+  if (half) hipLaunchKernelGGL(wgrad_split_multi_kernel<true>, dim3((unsigned)(8 * ((work + 7) / 8))), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL(wgrad_split_multi_kernel<false>, dim3((unsigned)(8 * ((work + 7) / 8))), dim3(256), 0, st, m);
   hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)(red + cs)), dim3(256), 0, st, r);
   return ZK_LAUNCH_CHECK();
 }

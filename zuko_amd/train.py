@@ -185,7 +185,7 @@ class SortedPlan:
         _C.check(err, "zk_wgrad_f32")
         return (dw, None) if want_bias else dw
 
-    def wgrad_multi(self, items, packed_last=None):
+    def wgrad_multi(self, items, packed_last=None, amax=None):
         """Weight and bias gradients of several layers in two launches (zk_wgrad_multi).  items: [(layer, g, h)] with every layer's
         cs_flag present; returns {layer: (dW in the module's order, db in the module's order)}.  packed_last (PackedRows): the LAST layer's g
         has its columns in the fused kernels' packed order (padding slots included) — the row tables of that order are used for it."""
@@ -224,6 +224,8 @@ class SortedPlan:
             for name, t in (("g", g), ("h", h), ("pairs", pairs), ("partial", work[op:]), ("mask", mask_s), ("dw", dw), ("cs_flag", cs_flag),
                             ("cs_partial", work[oc:]), ("db", db), ("rows", rows), ("cols", self.cols_dev[l])):
                 setattr(d, name, None if t is None else t.data_ptr())
+            if amax is not None:  # {layer: (maxima of |g|, of |h|)} on the device: two-part f16 products (csrc/train.hip: wgrad_split_body<true>)
+                d.g_amax, d.h_amax = amax[l][0].data_ptr(), amax[l][1].data_ptr()
             out[l] = (dw, db)
             ow += sizes_w[i]; ob += sizes_b[i]; op += sizes_p[i]; oc += sizes_c[i]
         _C.check(lib.zk_wgrad_multi(n, ctypes.cast(arr, ctypes.c_void_p), N, _stream()), "zk_wgrad_multi")
