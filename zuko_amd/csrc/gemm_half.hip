@@ -100,6 +100,9 @@ struct GhArgs {
   int nbm, nbn, nks;
 };
 
+#ifndef GH_ABL
+#define GH_ABL 0  // probe builds only (wrong results): 1 no conversion arithmetic, 2 no matrix instructions, 3 no raw-tile DMA, 4 no weight DMA, 5 no stores, 6 no fragment reads
+#endif
 #define GH_IMG 64  /* uint4 per image */
 #define GH_WR 2    /* LDS slots of weight images: step s + 1 is requested while step s is multiplied (the weights sit in L2) */
 #define GH_AR 3    /* LDS slots of raw f32 activation tiles: step s + 3 is requested while step s is multiplied (they come from HBM) */
@@ -165,7 +168,7 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
     const int kk = k < a.K ? k : 0;
     uint4* l = gh_lds + OFF_RAW + slot * RAW + wave * GH_IMG;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) gh_dma16(a_src[p] + kk, l + p * (NT / 64) * GH_IMG);
+    for (int p = 0; p < NP; ++p) if (GH_ABL != 3) gh_dma16(a_src[p] + kk, l + p * (NT / 64) * GH_IMG);
   };
   // weights: wavefront w moves images NW w .. NW w + NW - 1 of the step
   //          (the images are laid out per 128-unit tile: [tile][k step][16 images]; a tile past the last one is clamped — its outputs are never stored)
@@ -176,7 +179,7 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
     const uint4* g = wsrc + (int64_t)ks * 16 * GH_IMG;
     uint4* l = gh_lds + slot * WIMG * GH_IMG + wave * NW * GH_IMG;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) gh_dma16(g + i * GH_IMG, l + i * GH_IMG);
+    for (int i = 0; i < NW; ++i) if (GH_ABL != 4) gh_dma16(g + i * GH_IMG, l + i * GH_IMG);
   };
   // (raw ds_write: behind an ordinary LDS store hipcc drains every LDS-DMA in flight — vmcnt(0) — as a possible alias)
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) uint4*)gh_lds);
@@ -194,6 +197,7 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
       gh16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if (GH_ABL == 1) { h[e] = __builtin_bit_cast(_Float16, (unsigned short)__builtin_bit_cast(unsigned, raw[p][e])); l[e] = h[e]; continue; }
         const float x = kin ? raw[p][e] * sa : 0.f;
         const _Float16 hh = (_Float16)x;
         h[e] = hh;
@@ -239,26 +243,26 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
     gh16x8 wh[4], wl[4], ah[4], al[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      wh[u] = __builtin_bit_cast(gh16x8, wcur[((wn * 4 + u) * 2) * GH_IMG + lane]);
-      wl[u] = __builtin_bit_cast(gh16x8, wcur[((wn * 4 + u) * 2 + 1) * GH_IMG + lane]);
+      wh[u] = __builtin_bit_cast(gh16x8, wcur[GH_ABL == 6 ? lane : ((wn * 4 + u) * 2) * GH_IMG + lane]);
+      wl[u] = __builtin_bit_cast(gh16x8, wcur[GH_ABL == 6 ? lane : ((wn * 4 + u) * 2 + 1) * GH_IMG + lane]);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      ah[s] = __builtin_bit_cast(gh16x8, acur[((wm * 4 + s) * 2) * GH_IMG + a_rd]);
-      al[s] = __builtin_bit_cast(gh16x8, acur[((wm * 4 + s) * 2 + 1) * GH_IMG + a_rd]);
+      ah[s] = __builtin_bit_cast(gh16x8, acur[GH_ABL == 6 ? lane : ((wm * 4 + s) * 2) * GH_IMG + a_rd]);
+      al[s] = __builtin_bit_cast(gh16x8, acur[GH_ABL == 6 ? lane : ((wm * 4 + s) * 2 + 1) * GH_IMG + a_rd]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], ah[s], acc[u][s], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) if (GH_ABL == 2) { asm volatile("" ::"v"(wl[u]), "v"(ah[s])); } else acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], ah[s], acc[u][s], 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], al[s], acc[u][s], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) if (GH_ABL == 2) { asm volatile("" ::"v"(wh[u]), "v"(al[s])); } else acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], al[s], acc[u][s], 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], ah[s], acc[u][s], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) if (GH_ABL == 2) { asm volatile("" ::"v"(wh[u]), "v"(ah[s])); } else acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], ah[s], acc[u][s], 0, 0, 0);
     if (more) convert(ks + 1, (ks + 1) & 1);
     // the weights of step ks + 1 and the raw tile of step ks + 2 have landed once only this step's raw request is outstanding
     if (req) gh_wait_vm<NP>(); else gh_wait_vm<0>();
@@ -281,7 +285,7 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int64_t row = m0 + wm * 64 + s * 16 + j;
-      if (row >= a.M || col >= a.N) continue;
+      if (row >= a.M || col >= a.N || (GH_ABL == 5 && acc[u][s][0] != 123.f)) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
