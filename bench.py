@@ -703,7 +703,7 @@ def side_paths_report() -> dict:
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             entry["training"] = {"workload": f"{ctor} Adam step of -log_prob(x).mean(), batch 2^{B.bit_length() - 1}", "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "loss_before_after": [float(l0), float(l)],
-                                 "one_autograd_node_per_transform": "AutoregressiveFnBackward" in names,
+                                 "one_autograd_node_per_transform": ("CouplingFnBackward" if coupling else "AutoregressiveFnBackward") in names,
                                  "parity": {"rows": prows, "against": "float64 autograd through the oracle (oracle/zuko_oracle.py) on the same rows and weights",
                                             "grad_l1_rel_vs_oracle_autograd": rel1, "grad_max_rel_vs_oracle_autograd": rel, "loss_abs_diff": abs(l1 - l2),
                                             "bar": "1-norm distance per parameter tensor < 2e-3 (tests/test_gpu_backward.py::test_gradients_over_many_tiles: the max-norm moves by O(1 / rows) per "

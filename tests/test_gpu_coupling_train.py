@@ -1,0 +1,164 @@
+"""GPU: the dense training GEMM on two-part f16 operands (csrc/gemm_half.hip, C ABI zk_amax_f32 / zk_wsplit_f16 / zk_gemm_f16x2) and the
+one-node training path of a coupling transform built on it (zuko_amd/coupling_train.py), against float64 products and against autograd
+through the CPU oracle — which is how the reference obtains its gradients (tests/test_flows.py:22-29, zuko/flows/coupling.py:128-136)."""
+
+import os
+
+import pytest
+import torch
+
+from oracle import zuko_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize(
+    "M,K,N,act,gate,sa,sw",
+    [
+        (4096, 512, 512, 1, False, 1.0, 1.0),  # 256-wide tiles
+        (4096, 512, 512, 0, True, 1.0, 1.0),
+        (16384, 512, 256, 0, False, 1.0, 1.0),  # 128-wide tiles, 4 wavefronts
+        (16384, 512, 128, 0, True, 1.0, 1.0),  # 64-row tiles
+        (1000, 72, 40, 1, False, 1.0, 1.0),  # ragged in every direction (K % 32, N % 16, M % 64)
+        (129, 8, 4, 1, False, 1.0, 1.0),
+        (1, 512, 512, 1, False, 1.0, 1.0),
+        (300, 200, 132, 0, True, 1.0, 1.0),
+        (2048, 512, 512, 1, False, 1e-6, 1e3),  # operand magnitudes far from 1: the per-tensor powers of two absorb them
+        (2048, 512, 512, 0, True, 1e5, 1e-4),
+    ],
+)
+def test_two_part_gemm_against_float64(dev, M, K, N, act, gate, sa, sw):
+    """c = act(a W^T + b) (* (gate > 0)): every output within 1e-6 of max |c| of the float64 product (the f32 matrix instruction it replaces:
+    5e-7 .. 9e-7 on the same inputs, profiles/r06/gemm_half_check.txt), and the maximum it leaves on the device equals max |c| bit for bit."""
+    from zuko_amd import coupling_train as ct
+
+    g = torch.Generator().manual_seed(M + K + N)
+    a = (torch.randn(M, K, generator=g) * sa).to(dev)
+    a = a.clamp_min(0) if act else a
+    w = (torch.randn(N, K, generator=g) * sw / K**0.5).to(dev)
+    b = (torch.randn(N, generator=g) * sa * sw).to(dev)
+    gt = torch.randn(M, N, generator=g).to(dev) if gate else None
+    am = torch.zeros(3, ct.AMAX_WORDS, dtype=torch.int32, device=dev)
+    ct.amax([(a, am[0]), (w, am[1])])
+    assert am[0].max().item() == torch.tensor([a.abs().max().item()]).view(torch.int32).item()
+    img = torch.empty(ct.image_words(N, K), dtype=torch.int32, device=dev)
+    ct.wsplit([(w, False, am[1], img)])
+    c = ct.gemm(a, am[0], img, am[1], N, b, act, gt, am[2])
+    ref = a.double() @ w.double().t() + b.double()
+    ref = ref.clamp_min(0) if act else ref
+    ref = ref * (gt > 0) if gate else ref
+    err = ((c.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 1e-6, err
+    assert am[2].max().item() == torch.tensor([c.abs().max().item()]).view(torch.int32).item()
+    # the dgrad operand: the same weight read transposed
+    imgt = torch.empty(ct.image_words(K, N), dtype=torch.int32, device=dev)
+    ct.wsplit([(w, True, am[1], imgt)])
+    gy = torch.randn(M, N, generator=g).to(dev)
+    am2 = torch.zeros(1, ct.AMAX_WORDS, dtype=torch.int32, device=dev)
+    ct.amax([(gy, am2[0])])
+    if N % 4 == 0:
+        gx = ct.gemm(gy, am2[0], imgt, am[1], K, None, 0, None, None)
+        refx = gy.double() @ w.double()
+        assert ((gx.double() - refx).abs().max() / refx.abs().max()).item() < 1e-6
+
+
+def _oracle_grads(flow, features, x, c):
+    sd = {k: v.detach().cpu().clone() for k, v in flow.state_dict().items() if v is not None}
+    leaves = {k: v.double().requires_grad_() for k, v in sd.items() if v.is_floating_point() and ("weight" in k or "bias" in k)}
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    sd.update(leaves)
+    spec = O.spec_from_state_dict(sd, "coupling", O.UNI_AFFINE, features)
+    xr = x.double().clone().requires_grad_()
+    cr = None if c is None else c.double().clone().requires_grad_()
+    loss = -O.flow_log_prob(spec, xr, cr).mean()
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in leaves.items()}, xr.grad, None if cr is None else cr.grad
+
+
+@pytest.mark.parametrize(
+    "ctor,kw,rows",
+    [
+        ("RealNVP", dict(features=16, context=0, transforms=3, hidden_features=[64, 64]), 1000),
+        ("NICE", dict(features=16, context=4, transforms=2, hidden_features=[128] * 3), 4096),
+        ("RealNVP", dict(features=256, context=0, transforms=16, hidden_features=[512] * 3), 96),  # BASELINE config 4
+        ("RealNVP", dict(features=256, context=0, transforms=4, hidden_features=[512] * 3), 4096),
+    ],
+)
+def test_coupling_transform_trains_as_one_autograd_node(dev, ctor, kw, rows):
+    """d(-log_prob.mean()) / d(parameters, x, context) of a coupling flow whose every transform is ONE autograd node (CouplingFn) against float64
+    autograd through the oracle.  Up to 1 000 rows: 2e-4 of max |grad| per tensor (the bar of test_gradients_match_reference_autograd); at 4 096 rows
+    the 1-norm bar of test_gradients_over_many_tiles (2e-3: ReLU units within float32 rounding of zero) plus the max-norm gate 5e-2 — and, on the
+    same rows, of the size of the layer-wise path's own distance from float64 (f32 matrix instruction; within x 3: which units flip is a coin toss per path)."""
+    from zuko_amd import flows as F
+
+    torch.manual_seed(7)
+    flow = getattr(F, ctor)(**kw)
+    D, C = kw["features"], kw["context"]
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(rows, D, generator=g)
+    c = torch.randn(rows, C, generator=g) if C else None
+    ref_loss, ref_grads, ref_gx, ref_gc = _oracle_grads(flow, D, x, c)
+    flow = flow.to(dev)
+
+    def run(off):
+        os.environ["ZUKO_AMD_NO_COUPLING_FN"] = "1" if off else "0"
+        try:
+            flow.zero_grad(set_to_none=True)
+            xg = x.to(dev).requires_grad_()
+            cg = None if c is None else c.to(dev).requires_grad_()
+            loss = -flow(cg).log_prob(xg).mean()
+            names = set()
+
+            def walk(fn):
+                if fn is not None and fn not in names:
+                    names.add(fn)
+                    for nxt, _ in fn.next_functions:
+                        walk(nxt)
+
+            walk(loss.grad_fn)
+            loss.backward()
+            return loss.item(), {type(f).__name__ for f in names}, {k: p.grad.detach().cpu().double() for k, p in flow.named_parameters()}, xg.grad.cpu().double(), None if cg is None else cg.grad.cpu().double()
+        finally:
+            os.environ.pop("ZUKO_AMD_NO_COUPLING_FN", None)
+
+    loss, names, grads, gx, gc = run(False)
+    assert "CouplingFnBackward" in names, "the one-node path did not serve this flow"
+    assert abs(loss - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
+    _, names0, grads0, gx0, _ = run(True)
+    assert "CouplingFnBackward" not in names0
+    mx = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+    l1 = lambda a, b: ((a - b).abs().sum() / b.abs().sum().clamp_min(1e-12)).item()
+    worst_mx = max(mx(grads[k], ref_grads[k]) for k in ref_grads)
+    worst_l1 = max(l1(grads[k], ref_grads[k]) for k in ref_grads)
+    old_l1 = max(l1(grads0[k], ref_grads[k]) for k in ref_grads)
+    if rows <= 1000:
+        assert worst_mx < 2e-4, worst_mx
+        assert mx(gx, ref_gx) < 2e-4
+    else:
+        assert worst_l1 < 2e-3 and worst_mx < 5e-2, (worst_l1, worst_mx)
+        assert worst_l1 < 3.0 * old_l1 + 1e-6, (worst_l1, old_l1)
+        assert l1(gx, ref_gx) < 1e-5
+    if gc is not None:
+        assert l1(gc, ref_gc) < 1e-5
+    print(f"{ctor}{kw} rows {rows}: parameter gradients vs float64 oracle autograd: max-norm {worst_mx:.2e}, 1-norm {worst_l1:.2e} (layer-wise path {old_l1:.2e}); dx 1-norm {l1(gx, ref_gx):.2e}")
+
+
+def test_coupling_node_falls_back_when_not_covered(dev):
+    """Widths that are not multiples of 4, a frozen parameter, a non-ReLU activation: the layer-wise autograd path serves the call (same values)."""
+    from zuko_amd import flows as F
+
+    torch.manual_seed(0)
+    x = torch.randn(64, 5, device=dev)
+    c = torch.randn(64, 3, device=dev)
+    flow = F.NICE(5, 3, transforms=2, hidden_features=[32, 32]).to(dev)  # 2 or 3 kept features + 3 context columns: not a multiple of 4
+    loss = -flow(c).log_prob(x).mean()
+    loss.backward()
+    assert all(p.grad is not None for p in flow.parameters())
+    flow2 = F.RealNVP(16, 0, transforms=2, hidden_features=[64, 64], activation=torch.nn.ELU).to(dev)
+    x2 = torch.randn(64, 16, device=dev)
+    (-flow2().log_prob(x2).mean()).backward()
+    assert all(p.grad is not None for p in flow2.parameters())
+    flow3 = F.RealNVP(16, 0, transforms=2, hidden_features=[64, 64]).to(dev)
+    next(flow3.parameters()).requires_grad_(False)
+    (-flow3().log_prob(x2).mean()).backward()
+    assert sum(p.grad is not None for p in flow3.parameters()) == len(list(flow3.parameters())) - 1
