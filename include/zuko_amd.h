@@ -571,6 +571,16 @@ typedef struct zk_wsplit_desc_v1 {
 int zk_wsplit_f16(int n, const zk_wsplit_desc_v1* descs, void* stream);
 int zk_gemm_f16x2(int64_t M, int K, int N, const void* a, int64_t lda, const uint32_t* a_amax, const void* w_images, const uint32_t* w_amax,
                   const void* bias, int act, const void* gate, int64_t ldg, int gate_act, void* c, int64_t ldc, uint32_t* c_amax, void* stream);
+/* The split / merge of a coupling transform around its conditioner under training (zuko/transforms.py:1037-1073 `x[..., idx_a]`, `x[..., idx_b]`, merge;
+ * autograd's backward of the two index operations is a sort-based scatter: 1.7 ms of a RealNVP training step).  fp32, contiguous outputs.
+ * zk_coupling_split:  inp[N, na + C] = [x[:, idx_a] | ctx], xb[N, nb] = x[:, idx_b]; folds max |inp| into inp_amax (the first GEMM's operand scale).
+ * zk_coupling_merge:  out[n, d] = half[d] >= 0 ? b[n, half[d]] : base[n, d] (+ add[n, -1 - half[d]] if add != NULL), base == NULL reading as zero;
+ *                     half [D] int32: slot of a moved feature in the b half, or -1 - (slot of a kept feature in the a half).  Forward: y = merge(x, y_b);
+ *                     backward: g_x = merge(g_y, g_xb, add = the conditioner's input gradient). */
+int zk_coupling_split(int64_t N, int D, int C, const void* x, int64_t ldx, const void* ctx, int64_t ldc, const int32_t* idx_a, int na, const int32_t* idx_b, int nb,
+                      void* inp, void* xb, uint32_t* inp_amax, void* stream);
+int zk_coupling_merge(int64_t N, int D, const void* base, int64_t ldbase, const void* b, int nb, const void* add, int64_t ldadd, const int32_t* half, void* out,
+                      void* stream);
 
 /* ---- base density + final reduction (zuko/distributions.py:115-119, 337-363) ---------------------- *
  * out[n] = sum_d Normal(loc[d], scale[d]).log_prob(z[n, d]) (+ ladj[n] if ladj != NULL). */

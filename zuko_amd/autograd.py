@@ -34,7 +34,7 @@ def _ptr(t):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _C.stream()
 
 
 def _require_f32(*ts) -> None:

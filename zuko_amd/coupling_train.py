@@ -35,7 +35,7 @@ def _ptr(t):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _C.stream()
 
 
 def image_words(units: int, k: int) -> int:
@@ -76,24 +76,37 @@ def gemm(a: Tensor, a_amax: Tensor, images: Tensor, w_amax: Tensor, n_out: int, 
     return c
 
 
+def _maps(lazy):
+    """(idx_a, idx_b, half) as int32 device tensors for zk_coupling_split / zk_coupling_merge, cached per version of the mask."""
+    idx_a, idx_b = lazy.split_indices()
+    cached = lazy.__dict__.get("_train_maps")
+    if cached is None or cached[0] is not idx_a:
+        half = torch.empty(idx_a.shape[0] + idx_b.shape[0], dtype=torch.int32, device=idx_a.device)
+        half[idx_b] = torch.arange(idx_b.shape[0], dtype=torch.int32, device=idx_a.device)
+        half[idx_a] = -1 - torch.arange(idx_a.shape[0], dtype=torch.int32, device=idx_a.device)
+        cached = (idx_a, idx_a.to(torch.int32), idx_b.to(torch.int32), half)
+        lazy.__dict__["_train_maps"] = cached
+    return cached[1], cached[2], cached[3]
+
+
 class CouplingFn(torch.autograd.Function):
     """(y, ladj) of one affine coupling transform.  Inputs after `c`: weight_0, bias_0, weight_1, ... of the conditioner."""
 
     @staticmethod
     def forward(ctx, lazy, plan, slope: float, x: Tensor, c, *params):
-        from .autograd import _fwd_any
-
-        idx_a, idx_b = lazy.split_indices()
+        ia, ib, half = _maps(lazy)
         ws, bs = params[0::2], params[1::2]
         L = len(ws)
-        N = x.shape[0]
+        N, D = x.shape
         dev = x.device
-        xa = x.index_select(1, idx_a)
-        inp = xa if c is None else torch.cat((xa, c), dim=1)
-        xb = x.index_select(1, idx_b)
+        na, nb, C = ia.shape[0], ib.shape[0], 0 if c is None else c.shape[1]
         am = torch.zeros((3 * L + 1, AMAX_WORDS), dtype=torch.int32, device=dev)  # [input, h_1..h_{L-1}, (unused) | W_0..W_{L-1} | g_phi, g_{L-1}..g_1]
+        inp = torch.empty((N, na + C), dtype=torch.float32, device=dev)
+        xb = torch.empty((N, nb), dtype=torch.float32, device=dev)
+        _C.check(_C.lib().zk_coupling_split(N, D, C, x.data_ptr(), x.stride(0), None if c is None else c.data_ptr(), 0 if c is None else c.stride(0), ia.data_ptr(), na, ib.data_ptr(), nb,
+                                            inp.data_ptr(), xb.data_ptr(), am[0].data_ptr(), _stream()), "zk_coupling_split")
         wd = [w.detach() if w.is_contiguous() else w.detach().contiguous() for w in ws]
-        amax([(inp, am[0])] + [(wd[l], am[L + l]) for l in range(L)])
+        amax([(wd[l], am[L + l]) for l in range(L)])
         sizes = [image_words(*w.shape) for w in wd] + [image_words(w.shape[1], w.shape[0]) for w in wd]  # forward operands, then the dgrad operands W^T
         pool = torch.empty(sum(sizes), dtype=torch.int32, device=dev)
         offs = [0]
@@ -110,9 +123,14 @@ class CouplingFn(torch.autograd.Function):
             hs.append(h)
         phi = hs[-1].view(N, xb.shape[1], 2)
         meta = (0, 5.0, slope, (1, 1), ())
-        yb, ladj = _fwd_any(meta, xb, phi, True)
-        y = x.clone()
-        y.index_copy_(1, idx_b, yb)
+        # (zk_affine_forward straight on the packed parameters — shift = phi[.., 0], scale = phi[.., 1], strides (2 nb, 2) — instead of ops.affine_forward's
+        #  general broadcasting front end: 55 us of host time per transform)
+        yb = torch.empty_like(xb)
+        ladj = torch.empty(N, dtype=torch.float32, device=dev)
+        pp = phi.data_ptr()
+        _C.check(_C.lib().zk_affine_forward(0, N, nb, slope, xb.data_ptr(), pp, 2 * nb, 2, pp + 4, 2 * nb, 2, yb.data_ptr(), ladj.data_ptr(), 1, _stream()), "zk_affine_forward")
+        y = torch.empty_like(x)
+        _C.check(_C.lib().zk_coupling_merge(N, D, x.data_ptr(), x.stride(0), yb.data_ptr(), nb, None, 0, half.data_ptr(), y.data_ptr(), _stream()), "zk_coupling_merge")
         ctx.lazy, ctx.plan, ctx.meta, ctx.L, ctx.has_c = lazy, plan, meta, L, c is not None
         ctx.save_for_backward(xb, *hs, *img_t, am)
         return y, ladj
@@ -126,6 +144,7 @@ class CouplingFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         xb, hs, img_t, am = saved[0], saved[1 : L + 2], saved[L + 2 : 2 * L + 2], saved[2 * L + 2]
         idx_a, idx_b = ctx.lazy.split_indices()
+        ia, ib, half = _maps(ctx.lazy)
         N, dev = xb.shape[0], xb.device
         phi = hs[L].view(N, xb.shape[1], 2)
         gyb = torch.zeros_like(xb) if gy is None else gy.index_select(1, idx_b)
@@ -152,50 +171,76 @@ class CouplingFn(torch.autograd.Function):
         for l in range(L):
             grads += list(res[l])
         gx = gc = None
-        if need_in:
-            na = idx_a.shape[0]
-            if ctx.needs_input_grad[3]:
-                gx = torch.zeros((N, int(idx_a.shape[0] + idx_b.shape[0])), dtype=torch.float32, device=dev) if gy is None else gy.clone()
-                gx.index_copy_(1, idx_b, gxb)
-                gx.index_add_(1, idx_a, g[:, :na])
-            if ctx.has_c and ctx.needs_input_grad[4]:
-                gc = g[:, na:].contiguous()
-        elif ctx.needs_input_grad[3]:
-            gx = torch.zeros((N, int(idx_a.shape[0] + idx_b.shape[0])), dtype=torch.float32, device=dev) if gy is None else gy.clone()
-            gx.index_copy_(1, idx_b, gxb)
+        na, nb = ia.shape[0], ib.shape[0]
+        if ctx.needs_input_grad[3]:  # g_x = g_y on the kept half (+ the conditioner's input gradient), the adjoint's g_xb on the moved half: one pass
+            gx = torch.empty((N, na + nb), dtype=torch.float32, device=dev)
+            gyc = None if gy is None else (gy if gy.stride(1) == 1 else gy.contiguous())
+            _C.check(_C.lib().zk_coupling_merge(N, na + nb, None if gyc is None else gyc.data_ptr(), 0 if gyc is None else gyc.stride(0), gxb.data_ptr(), nb,
+                                                g.data_ptr() if need_in else None, g.stride(0) if need_in else 0, half.data_ptr(), gx.data_ptr(), _stream()), "zk_coupling_merge")
+        if need_in and ctx.has_c and ctx.needs_input_grad[4]:
+            gc = g[:, na:].contiguous()
         return (None, None, None, gx, gc, *grads)
+
+
+_STATE: "weakref.WeakKeyDictionary" = None  # lazy -> {key: (verdict, plan, params, slope)}
+
+
+def _static_verdict(lazy, device, n_ctx: int):
+    """(plan, params, slope) when `lazy` is covered on `device` with n_ctx context columns, else None.  Cached per module and per what the verdict
+    depends on (parameter identities / requires_grad flags / mask version): the checks walk the conditioner, and a training step calls this once
+    per transform."""
+    import weakref
+
+    from . import train
+    from .nn import Linear, _act_code
+    from .transforms import MonotonicAffineTransform
+
+    global _STATE
+    if _STATE is None:
+        _STATE = weakref.WeakKeyDictionary()
+    mods = list(lazy.hyper)
+    lins = mods[0::2]
+    key = (str(device), n_ctx, lazy.mask._version, lazy.mask.data_ptr(), id(lazy.univariate), len(mods),
+           tuple((id(l.weight), id(l.bias), l.weight.requires_grad, l.bias is not None and l.bias.requires_grad, l.weight.data_ptr()) for l in lins if hasattr(l, "weight")))
+    per = _STATE.setdefault(lazy, {})
+    if per.get("key") == key:
+        return per["value"]
+    value = None
+    u = lazy.univariate
+    f, kw = (u.func, dict(u.keywords)) if isinstance(u, partial) else (u, {})
+    slope = kw.pop("slope", 1e-3)
+    acts = mods[1::2]
+    ok = f is MonotonicAffineTransform and not kw and not (isinstance(u, partial) and u.args) and [tuple(s) for s in lazy.shapes] == [(), ()]
+    ok = ok and len(mods) == 2 * len(lins) - 1 and all(type(m) is Linear for m in lins) and not any(_act_code(m) != 1 for m in acts) and len(lins) <= 8
+    ok = ok and all(l.weight.dtype == torch.float32 and l.bias is not None and l.weight.requires_grad and l.bias.requires_grad and l.weight.shape[1] % 4 == 0 and l.weight.shape[0] % 4 == 0
+                    for l in lins)
+    if ok:
+        kept = int(lazy.split_indices()[0].shape[0])  # (cached indices: mask.sum() would be a device -> host synchronisation per call)
+        ok = lins[0].weight.shape[1] == kept + n_ctx
+    if ok:
+        plan, _ = train.plan_for(lazy.hyper, device)
+        ok = plan is not None and all(plan.cs_flag[i] is not None and plan.pairs[i].shape[0] > 0 for i in range(len(lins)))
+    if ok:
+        params = []
+        for l in lins:
+            params += [l.weight, l.bias]
+        value = (plan, tuple(params), float(slope))
+    per["key"], per["value"] = key, value
+    return value
 
 
 def coupling(lazy, x: Tensor, c):
     """(y, ladj) of `lazy` (a GeneralCouplingTransform) at x [N, features] (c [N, context] or None) under autograd through CouplingFn, or None when
     the layer / batch is not covered."""
-    from . import train
-    from .nn import Linear, _act_code
-    from .transforms import MonotonicAffineTransform
-
     if os.environ.get("ZUKO_AMD_NO_COUPLING_FN", "0") == "1" or os.environ.get("ZUKO_AMD_EXACT_F32", "0") == "1":
         return None
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0) or (c is not None and (c.dim() != 2 or c.dtype != torch.float32 or c.shape[0] != x.shape[0])):
         return None
-    u = lazy.univariate
-    f, kw = (u.func, dict(u.keywords)) if isinstance(u, partial) else (u, {})
-    slope = kw.pop("slope", 1e-3)
-    if f is not MonotonicAffineTransform or kw or (isinstance(u, partial) and u.args) or [tuple(s) for s in lazy.shapes] != [(), ()]:
+    if x.shape[1] != lazy.mask.shape[0]:
         return None
-    mods = list(lazy.hyper)
-    lins, acts = mods[0::2], mods[1::2]
-    if len(mods) != 2 * len(lins) - 1 or not all(type(m) is Linear for m in lins) or any(_act_code(m) != 1 for m in acts) or len(lins) > 8:
+    st = _static_verdict(lazy, x.device, 0 if c is None else c.shape[1])
+    if st is None:
         return None
-    if not all(l.weight.dtype == torch.float32 and l.bias is not None and l.weight.requires_grad and l.bias.requires_grad and l.weight.shape[1] % 4 == 0 and l.weight.shape[0] % 4 == 0
-               for l in lins):
-        return None
-    if x.shape[1] != lazy.mask.numel() or lins[0].weight.shape[1] != int(lazy.mask.sum()) + (0 if c is None else c.shape[1]):
-        return None
-    plan, _ = train.plan_for(lazy.hyper, x.device)
-    if plan is None or not all(plan.cs_flag[i] is not None and plan.pairs[i].shape[0] > 0 for i in range(len(lins))):
-        return None
-    params = []
-    for l in lins:
-        params += [l.weight, l.bias]
+    plan, params, slope = st
     xc = x if x.is_contiguous() else x.contiguous()
-    return CouplingFn.apply(lazy, plan, float(slope), xc, None if c is None else c.contiguous(), *params)
+    return CouplingFn.apply(lazy, plan, slope, xc, None if c is None else c.contiguous(), *params)

@@ -81,7 +81,7 @@ def _no_grad_only(*ts: Tensor) -> None:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _C.stream()
 
 
 def _ptr(t: Tensor | None):

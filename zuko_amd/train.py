@@ -35,7 +35,7 @@ def _ptr(t):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _C.stream()
 
 
 class SortedPlan:
