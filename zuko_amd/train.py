@@ -206,7 +206,7 @@ class SortedPlan:
         sides = [side(l) for l, _, _ in items]
         sizes_w = [self.shapes[l][0] * self.shapes[l][1] for l, _, _ in items]
         sizes_b = [self.shapes[l][0] for l, _, _ in items]
-        ns = [max(1, lib.zk_wgrad_slices(N, sd[1].shape[0])) for sd in sides]
+        ns = [_wgrad_slices(N, sd[1].shape[0]) for sd in sides]
         sizes_p = [ns[i] * sd[1].shape[0] * 128 * 128 for i, sd in enumerate(sides)]
         sizes_c = [ns[i] * (-(-sd[0] // 128) * 128) for i, sd in enumerate(sides)]
         flat = torch.zeros(sum(sizes_w) + sum(sizes_b), dtype=torch.float32, device=dev)  # (dW: only the live blocks are written)
@@ -238,6 +238,18 @@ class SortedPlan:
         out = torch.empty(C, dtype=torch.float32, device=g.device)
         _C.check(lib.zk_colsum_f32(N, C, _ptr(g), g.stride(0), _ptr(ws), _ptr(out), 0, _stream()), "zk_colsum_f32")
         return out
+
+
+_SLICES: dict = {}
+
+
+def _wgrad_slices(N: int, npairs: int) -> int:
+    """max(1, zk_wgrad_slices(N, npairs)), remembered (a pure function of its arguments; four library calls per transform and step otherwise)."""
+    key = (N, npairs)
+    v = _SLICES.get(key)
+    if v is None:
+        v = _SLICES[key] = max(1, _C.lib().zk_wgrad_slices(N, npairs))
+    return v
 
 
 class PackedRows:
