@@ -342,15 +342,16 @@ template <int WM, int WN> static int gh_launch(GhArgs& g, hipStream_t st) {
 // half[d] >= 0: feature d is moved (slot half[d] of the b half); half[d] < 0: kept (slot -1 - half[d] of the a half)
 struct SplitArgs { int64_t N; int D, C, na, nb; const float* x; int64_t ldx; const float* ctx; int64_t ldc; const int* idx_a; const int* idx_b; float* inp; float* xb; unsigned* amax; };
 __global__ __launch_bounds__(256) void coupling_split_kernel(SplitArgs a) {
+  // a block walks rows, its threads the columns of [inp | xb] (no 64-bit division per element)
   const int wi = a.na + a.C, w = wi + a.nb;
-  const int64_t total = a.N * w;
   float mx = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t n = i / w;
-    const int col = (int)(i - n * w);
-    if (col < a.na) { const float v = a.x[n * a.ldx + a.idx_a[col]]; a.inp[n * wi + col] = v; mx = fmaxf(mx, fabsf(v)); }
-    else if (col < wi) { const float v = a.ctx[n * a.ldc + (col - a.na)]; a.inp[n * wi + col] = v; mx = fmaxf(mx, fabsf(v)); }
-    else a.xb[n * a.nb + (col - wi)] = a.x[n * a.ldx + a.idx_b[col - wi]];
+  for (int64_t n = blockIdx.x; n < a.N; n += gridDim.x) {
+    const float* xr = a.x + n * a.ldx;
+    for (int col = threadIdx.x; col < w; col += 256) {
+      if (col < a.na) { const float v = xr[a.idx_a[col]]; a.inp[n * wi + col] = v; mx = fmaxf(mx, fabsf(v)); }
+      else if (col < wi) { const float v = a.ctx[n * a.ldc + (col - a.na)]; a.inp[n * wi + col] = v; mx = fmaxf(mx, fabsf(v)); }
+      else a.xb[n * a.nb + (col - wi)] = xr[a.idx_b[col - wi]];
+    }
   }
   mx = gh_wave_max(mx);
   if ((threadIdx.x & 63) == 0) gh_amax_put(a.amax, blockIdx.x * 4 + (threadIdx.x >> 6), mx);
@@ -358,18 +359,17 @@ __global__ __launch_bounds__(256) void coupling_split_kernel(SplitArgs a) {
 // out[n, d] = half[d] >= 0 ? b[n, half[d]] : base[n, d] (+ add[n, -1 - half[d]] when add != null); base == null reads as zero
 struct MergeArgs { int64_t N; int D; const float* base; int64_t ldbase; const float* b; int nb; const float* add; int64_t ldadd; const int* half; float* out; };
 __global__ __launch_bounds__(256) void coupling_merge_kernel(MergeArgs a) {
-  const int64_t total = a.N * a.D;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t n = i / a.D;
-    const int d = (int)(i - n * a.D);
+  for (int d = threadIdx.x; d < a.D; d += 256) {
     const int h = a.half[d];
-    float v;
-    if (h >= 0) v = a.b[n * a.nb + h];
-    else {
-      v = a.base ? a.base[n * a.ldbase + d] : 0.f;
-      if (a.add) v += a.add[n * a.ldadd + (-1 - h)];
+    for (int64_t n = blockIdx.x; n < a.N; n += gridDim.x) {
+      float v;
+      if (h >= 0) v = a.b[n * a.nb + h];
+      else {
+        v = a.base ? a.base[n * a.ldbase + d] : 0.f;
+        if (a.add) v += a.add[n * a.ldadd + (-1 - h)];
+      }
+      a.out[n * a.D + d] = v;
     }
-    a.out[i] = v;
   }
 }
 
@@ -456,7 +456,7 @@ int zk_coupling_split(int64_t N, int D, int C, const void* x, int64_t ldx, const
   if (N < 0 || D <= 0 || C < 0 || na <= 0 || nb <= 0 || na + nb != D || !idx_a || !idx_b || !inp || !xb || !inp_amax || (N > 0 && !x) || (C > 0 && !ctx)) return ZK_EINVAL;
   if (N == 0) return 0;
   SplitArgs a{N, D, C, na, nb, (const float*)x, ldx, (const float*)ctx, ldc, idx_a, idx_b, (float*)inp, (float*)xb, inp_amax};
-  coupling_split_kernel<<<dim3((unsigned)grid_for((N * (na + C + nb) + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a);
+  coupling_split_kernel<<<dim3((unsigned)grid_for(N)), 256, 0, (hipStream_t)stream>>>(a);
   return ZK_LAUNCH_CHECK();
 }
 
@@ -464,7 +464,7 @@ int zk_coupling_merge(int64_t N, int D, const void* base, int64_t ldbase, const 
   if (N < 0 || D <= 0 || nb <= 0 || !b || !half || !out) return ZK_EINVAL;
   if (N == 0) return 0;
   MergeArgs a{N, D, (const float*)base, ldbase, (const float*)b, nb, (const float*)add, ldadd, half, (float*)out};
-  coupling_merge_kernel<<<dim3((unsigned)grid_for((N * D + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a);
+  coupling_merge_kernel<<<dim3((unsigned)grid_for(N)), 256, 0, (hipStream_t)stream>>>(a);
   return ZK_LAUNCH_CHECK();
 }
 

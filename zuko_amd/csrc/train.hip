@@ -403,45 +403,45 @@ template <bool HALF> __device__ __forceinline__ void wgrad_split_body(const Wgra
   const int go = ob * 128 + u, hc = ib * 128 + u;
   const bool g_ok = go < a.OUT, h_ok = hc < a.IN;
   float rg[2][8], rh[2][8];
-  auto gload = [&](int64_t n0) {
+  auto gload_to = [&](float (&rg_)[2][8], float (&rh_)[2][8], int64_t n0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int64_t n = n0 + (oc0 + 2 * t) * 8 + e;
         const bool in = n < n_end;
-        rg[t][e] = (ZK_WG_ABL != 2 && in && g_ok) ? a.g[n * a.ldg + go] : (ZK_WG_ABL == 2 ? (float)n : 0.f);
-        rh[t][e] = (ZK_WG_ABL != 2 && in && h_ok) ? a.h[n * a.ldh + hc] : (ZK_WG_ABL == 2 ? (float)e : 0.f);
+        rg_[t][e] = (ZK_WG_ABL != 2 && in && g_ok) ? a.g[n * a.ldg + go] : (ZK_WG_ABL == 2 ? (float)n : 0.f);
+        rh_[t][e] = (ZK_WG_ABL != 2 && in && h_ok) ? a.h[n * a.ldh + hc] : (ZK_WG_ABL == 2 ? (float)e : 0.f);
       }
   };
   const bool do_cs = a.cs_flag && a.cs_flag[p];
   float csum = 0.f;
   const int img = (u >> 4) * NPART * 64 + (u & 15);  // + part * 64 + octet * 16
-  gload(n_begin);
-  for (int64_t n0 = n_begin; n0 < n_end; n0 += 32) {
+  // registers of one k tile -> operand images in LDS
+  auto stage = [&](float (&rg_)[2][8], float (&rh_)[2][8]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int at = img + (oc0 + 2 * t) * 16;
       if constexpr (HALF) {
         gh16x8 hh, ll;
-        wsplit8_half(rg[t], sg, hh, ll);
+        wsplit8_half(rg_[t], sg, hh, ll);
         Gs[at] = __builtin_bit_cast(uint4, hh); Gs[at + 64] = __builtin_bit_cast(uint4, ll);
-        wsplit8_half(rh[t], sh, hh, ll);
+        wsplit8_half(rh_[t], sh, hh, ll);
         Hs[at] = __builtin_bit_cast(uint4, hh); Hs[at + 64] = __builtin_bit_cast(uint4, ll);
       } else {
         wbf16x8 hh, mm, ll;
-        wsplit8(rg[t], hh, mm, ll);
+        wsplit8(rg_[t], hh, mm, ll);
         Gs[at] = __builtin_bit_cast(uint4, hh); Gs[at + 64] = __builtin_bit_cast(uint4, mm); Gs[at + 128] = __builtin_bit_cast(uint4, ll);
-        wsplit8(rh[t], hh, mm, ll);
+        wsplit8(rh_[t], hh, mm, ll);
         Hs[at] = __builtin_bit_cast(uint4, hh); Hs[at + 64] = __builtin_bit_cast(uint4, mm); Hs[at + 128] = __builtin_bit_cast(uint4, ll);
       }
       if (do_cs) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) csum += rg[t][e];
+        for (int e = 0; e < 8; ++e) csum += rg_[t][e];
       }
     }
-    __syncthreads();
-    if (n0 + 32 < n_end) gload(n0 + 32);
+  };
+  auto mma = [&]() {
     if constexpr (HALF) {
       gh16x8 A[4][2], B[4][2];
 #pragma unroll
@@ -458,22 +458,30 @@ template <bool HALF> __device__ __forceinline__ void wgrad_split_body(const Wgra
       ZK_HTERM(1, 0) ZK_HTERM(0, 1) ZK_HTERM(0, 0)
 #undef ZK_HTERM
     } else {
-    wbf16x8 A[4][3], B[4][3];
+      wbf16x8 A[4][3], B[4][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int part = 0; part < 3; ++part) {
-        A[i][part] = __builtin_bit_cast(wbf16x8, Gs[ZK_WG_ABL == 4 ? lane : ((wr * 4 + i) * 3 + part) * 64 + lane]);
-        B[i][part] = __builtin_bit_cast(wbf16x8, Hs[ZK_WG_ABL == 4 ? lane : ((wc * 4 + i) * 3 + part) * 64 + lane]);
-      }
-    // six partial products, smallest first: (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
+        for (int part = 0; part < 3; ++part) {
+          A[i][part] = __builtin_bit_cast(wbf16x8, Gs[ZK_WG_ABL == 4 ? lane : ((wr * 4 + i) * 3 + part) * 64 + lane]);
+          B[i][part] = __builtin_bit_cast(wbf16x8, Hs[ZK_WG_ABL == 4 ? lane : ((wc * 4 + i) * 3 + part) * 64 + lane]);
+        }
+      // six partial products, smallest first: (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
 #define ZK_WTERM(PA, PB)                                                                                                            \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
       if (ZK_WG_ABL == 3) { asm volatile("" ::"v"(A[i][PA]), "v"(B[j][PB])); } else                                                  \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][PA], B[j][PB], acc[i][j], 0, 0, 0);
-    ZK_WTERM(2, 0) ZK_WTERM(0, 2) ZK_WTERM(1, 1) ZK_WTERM(1, 0) ZK_WTERM(0, 1) ZK_WTERM(0, 0)
+      ZK_WTERM(2, 0) ZK_WTERM(0, 2) ZK_WTERM(1, 1) ZK_WTERM(1, 0) ZK_WTERM(0, 1) ZK_WTERM(0, 0)
 #undef ZK_WTERM
     }
+  };
+  // (a second k tile of look-ahead in registers — tried for the two-part operands, whose fragments take 64 registers instead of 96 — still spills: 151 VGPRs)
+  gload_to(rg, rh, n_begin);
+  for (int64_t n0 = n_begin; n0 < n_end; n0 += 32) {
+    stage(rg, rh);
+    __syncthreads();
+    if (n0 + 32 < n_end) gload_to(rg, rh, n0 + 32);
+    mma();
     __syncthreads();
   }
   if (a.cs_flag) {  // (uniform per block: cs_flag[p])
