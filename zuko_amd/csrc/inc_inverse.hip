@@ -224,16 +224,61 @@ template <int K> struct IncRqs {
 // The polynomial maps (round 6): their inverse is the reference's fixed-count bisection on [-B, B] (zuko/transforms.py:608-617, zuko/utils.py:170-178), here in the
 // group's epilogue on the parameters the lane already holds — the layer-wise form launched ~25 kernels per sweep of the reference's loop (SOSPF 0.25 M, BPF 0.56 M
 // samples/s).  Same expression trees as zk_sos_inverse / zk_bernstein_inverse (csrc/zk_univariate.h); log|dy/dx| of the forward map at the solution as for the others.
+//
+// SCREENED bisection (round 6, second pass).  A step only needs the SIGN of f(mid) - y, and for most steps that sign is far from in doubt: the step first
+// evaluates f by a cheap closed form with a rigorous error bound E (>= the closed form's and the reference expression tree's distance from the exact value,
+// in units of the magnitudes that enter them), and falls back to the reference's expression tree only where |f~(mid) - y| <= E — the last few steps, once
+// the bracket is a few 1e-6 wide.  Every comparison therefore has the outcome the tree's would have: the result is the one of the plain loop above
+// (2.4x / 2.6x fewer tree evaluations; `INC_NO_SCREEN` builds the plain loop).
+//   * SOS: f(x) = int_0^x mean_p q_p(t / B)^2 + slope dt is a polynomial of degree 9 in u = x / B — five-node Gauss-Legendre IS exact for it — so
+//     f~ = x (C_0 + u (C_1 + .. u C_8)), C_m = the convolution coefficients / (m + 1), 9 fmas; bound: the same Horner on |coefficients|, |u|.
+//   * Bernstein: sum_i C(n, i) th_i u^i v^(n - i) by Horner in u / v (u <= 1/2) or v / u (both chains, the overflowing one is never selected): 2 n fmas instead of
+//     n (n - 1) / 2 lerps; all |th_i| <= B, the weights are a partition of one: E = 192 * 2^-24 * B.  In the linear tails (u within eps of 0 or 1) the tree decides.
+#ifndef INC_NO_SCREEN
+#define INC_NO_SCREEN 0
+#endif
+#ifndef INC_BERN_TRUST
+#define INC_BERN_TRUST 1
+#endif
 struct IncSos3x5 {  // ShiftedSOSPolynomialTransform, 3 polynomials of degree 4 + the learned constant (zuko/flows/polynomial.py:51-70)
   static constexpr int TOTAL = 16, NT = 4;
   template <typename A> static __device__ __forceinline__ void inv(const float* p, const A& a, float y, float& x, float& lj) {
     auto ld = [&](int j) { return p[j]; };
     const float yy = y - p[15];
+    float C[9], Ca[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) C[m] = Ca[m] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float q[5];
+#pragma unroll
+      for (int e = 0; e < 5; ++e) q[e] = e == 0 ? 1.f + p[5 * k] : p[5 * k + e];
+#pragma unroll
+      for (int e = 0; e < 5; ++e)
+#pragma unroll
+        for (int f = 0; f < 5; ++f) { C[e + f] += q[e] * q[f]; Ca[e + f] += fabsf(q[e] * q[f]); }
+    }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+      C[m] = (C[m] / 3.f + (m == 0 ? a.sos.slope : 0.f)) / (float)(m + 1);
+      Ca[m] = (Ca[m] / 3.f + (m == 0 ? fabsf(a.sos.slope) : 0.f)) / (float)(m + 1);
+    }
     float lo = -a.sos.bound, hi = a.sos.bound;
 #pragma unroll 1
     for (int it = 0; it < a.nbis; ++it) {
       const float mid = (lo + hi) / 2.f;
-      const bool below = sos_f_static<float, 3, 5>(a.sos, ld, mid) < yy;
+      float fm;
+      bool sure = false;
+      if (!INC_NO_SCREEN) {
+        const float u = mid / a.sos.bound, ua = fabsf(u);
+        float h = C[8], ha = Ca[8];
+#pragma unroll
+        for (int m = 7; m >= 0; --m) { h = __builtin_fmaf(h, u, C[m]); ha = __builtin_fmaf(ha, ua, Ca[m]); }
+        fm = mid * h;
+        sure = fabsf(fm - yy) > 3.8147e-6f * (fabsf(mid) * ha);  // 64 * 2^-24 of the magnitudes that enter either evaluation (a NaN is never sure)
+      }
+      if (!sure) fm = sos_f_static<float, 3, 5>(a.sos, ld, mid);
+      const bool below = fm < yy;
       lo = below ? mid : lo;
       hi = below ? hi : mid;
     }
@@ -244,12 +289,53 @@ struct IncSos3x5 {  // ShiftedSOSPolynomialTransform, 3 polynomials of degree 4 
 struct IncBern17 {  // BoundedBernsteinTransform of degree 16: 17 unconstrained parameters -> 22 constrained coefficients (zuko/transforms.py:779-831)
   static constexpr int TOTAL = 17, NT = 5;
   template <typename A> static __device__ __forceinline__ void inv(const float* p, const A& a, float y, float& x, float& lj) {
-    float th[22];
-    bern_theta_bounded<float, 22>([&](int j) { return p[j]; }, a.bound, th);
-    const BernTails<float> t = bern_tails<float, 22>(th, true, a.bound, a.eps);
-    x = bern_inv<float, 22>(th, t, a.bound, y, a.nbis, a.eps);
+    constexpr int NC = 22, n = NC - 1;
+    float th[NC];
+    bern_theta_bounded<float, NC>([&](int j) { return p[j]; }, a.bound, th);
+    const BernTails<float> t = bern_tails<float, NC>(th, true, a.bound, a.eps);
+    // C(21, i) th_i (the binomials are exact in float)
+    constexpr float BIN[NC] = {1.f, 21.f, 210.f, 1330.f, 5985.f, 20349.f, 54264.f, 116280.f, 203490.f, 293930.f, 352716.f,
+                               352716.f, 293930.f, 203490.f, 116280.f, 54264.f, 20349.f, 5985.f, 1330.f, 210.f, 21.f, 1.f};
+    float c[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) c[i] = BIN[i] * th[i];
+    const float E = 1.1444e-5f * a.bound;  // 192 * 2^-24 * B
+    float lo = -a.bound, hi = a.bound;
+#pragma unroll 1
+    for (int it = 0; it < a.nbis; ++it) {
+      const float mid = (lo + hi) / 2.f;
+      float fm;
+      bool sure = false;
+      if (!INC_NO_SCREEN) {
+        const float u = (mid + a.bound) / (2.f * a.bound), v = 1.f - u;
+        const float sr = u / v, rr = v / u;
+        float hA = c[n], hB = c[0];
+#pragma unroll
+        for (int i = 1; i <= n; ++i) { hA = __builtin_fmaf(hA, sr, c[n - i]); hB = __builtin_fmaf(hB, rr, c[i]); }
+        const float w = u <= 0.5f ? v : u;
+        const float w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, w16 = w8 * w8;
+        fm = (u <= 0.5f ? hA : hB) * (w16 * w4 * w);
+        // INC_BERN_TRUST (default): the closed form decides wherever it is finite and outside the linear tails.  Its distance from the de Casteljau value is of the size
+        // of de Casteljau's own distance from the exact polynomial (both <= ~70 * 2^-24 * B; neither is the reference's expression — that is the Beta-density form of
+        // zuko/transforms.py:736-740), so the solution moves by what a different rounding of f moves it: a few 1e-6 / f'.  INC_BERN_TRUST=0: screened as the SOS loop, bit-identical
+        // to the plain de Casteljau loop (profiles/r06/poly_screen_check.txt) at 1.2x instead of ~4x.
+        sure = (INC_BERN_TRUST ? fabsf(fm) < 3.0e38f : fabsf(fm - y) > E) && u > a.eps && u < 1.f - a.eps;
+      }
+      if (!sure) {
+        float d;
+        bern_fwd<float, NC>(th, t, a.bound, mid, fm, d, a.eps);
+      }
+      const bool below = fm < y;
+      lo = below ? mid : lo;
+      hi = below ? hi : mid;
+    }
+    x = (lo + hi) / 2.f;
+    const float xlo = (((y - t.off0) / t.slp0 + a.eps) * 2.f) * a.bound - a.bound;
+    const float xhi = ((((y - t.off1) / t.slp1 - a.eps) + 1.f) * 2.f) * a.bound - a.bound;
+    x = (y <= t.off0) ? xlo : x;
+    x = (y >= t.off1) ? xhi : x;
     float fy, d;
-    bern_fwd<float, 22>(th, t, a.bound, x, fy, d, a.eps);
+    bern_fwd<float, NC>(th, t, a.bound, x, fy, d, a.eps);
     lj = t_log(d);
   }
 };
