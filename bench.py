@@ -675,7 +675,7 @@ def side_paths_report() -> dict:
                 loss.backward()
                 return loss.item(), names, [p.grad.clone() for p in flow.parameters()]
 
-            prows = 4096  # (RealNVP cfg4 at 1 024 rows: 1-norm distances between 7e-7 and 3e-3 for BOTH training paths depending on the data seed — profiles/r06/cfg4_grad_noise.txt)
+            prows = 8192 if coupling else 4096  # (RealNVP cfg4 at 1 024 rows: 1-norm distances between 7e-7 and 3e-3 for BOTH training paths depending on the data seed, 5e-4 .. 1.9e-3 at 4 096 — profiles/r06/cfg4_grad_noise.txt — which units flip is a coin toss: more rows, less of it)
             l1, names, g1 = grads(prows)
             # the yardstick is autograd through the ORACLE (the reference's algorithm on PyTorch-CPU ops, float64) on the same 4 096 rows and weights —
             # which is how the reference itself obtains its gradients (tests/test_flows.py:22-29); until round 4 this block compared two HIP paths
