@@ -771,6 +771,42 @@ def side_paths_report() -> dict:
                     entry["log_prob_batch_4096"]["hip_graph_replay"] = {"ms": dg * 1e3, "samples_per_s": 4096 / dg, "bitwise_equal_to_eager": same}
                 except Exception as exc:
                     entry["log_prob_batch_4096"]["hip_graph_replay"] = {"error": repr(exc)[:200]}
+                # one optimisation step at that batch, eager and as a replayed HIP graph (zuko_amd.capture_step) on a COPY of the flow
+                try:
+                    import copy
+
+                    import zuko_amd
+
+                    f2 = copy.deepcopy(flow)
+                    o2 = torch.optim.Adam(f2.parameters(), lr=1e-3, capturable=True)
+                    xs4, cs4 = x[:4096].clone(), ctx[:4096].clone()
+
+                    def eager_step():
+                        loss = -f2(cs4).log_prob(xs4).mean()
+                        o2.zero_grad(set_to_none=False)
+                        loss.backward()
+                        o2.step()
+
+                    for _ in range(3):
+                        eager_step()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        eager_step()
+                    torch.cuda.synchronize()
+                    de = (time.perf_counter() - t0) / 20
+                    stepg = zuko_amd.capture_step(f2, o2, xs4, cs4)
+                    stepg()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        stepg()
+                    torch.cuda.synchronize()
+                    dgs = (time.perf_counter() - t0) / 50
+                    entry["training_step_batch_4096"] = {"workload": "Adam(capturable) step of -flow(c).log_prob(x).mean(), batch 4096", "eager_ms": de * 1e3, "hip_graph_replay_ms": dgs * 1e3,
+                                                         "loss_finite": bool(torch.isfinite(stepg.loss).item())}
+                except Exception as exc:
+                    entry["training_step_batch_4096"] = {"error": repr(exc)[:200]}
         except Exception as exc:  # never let a side measurement break the headline line
             entry["error"] = repr(exc)
         entry["wall_s"] = round(time.perf_counter() - t_entry, 1)
@@ -1037,6 +1073,8 @@ def headline_line(out: dict) -> dict:
             b = e["log_prob_batch_4096"]
             c["log_prob_4096"] = {**_pick(b, "ms"), **{"graph_" + k: v for k, v in _pick(b.get("hip_graph_replay"), "ms", "bitwise_equal_to_eager").items()},
                                   **{"one_launch_" + k: v for k, v in _pick(b.get("one_launch"), "ms", "bitwise_equal_to_eager").items()}}
+        if isinstance(e.get("training_step_batch_4096"), dict):
+            c["train_step_4096"] = _pick(e["training_step_batch_4096"], "eager_ms", "hip_graph_replay_ms")
         for k in ("two_part_kernels", "generated_split_kernels", "generic_split_kernel", "generic_f32_kernel"):
             if isinstance(e.get(k), dict):
                 c[k + "_ms"] = e[k].get("ms")

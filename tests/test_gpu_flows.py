@@ -246,6 +246,49 @@ def test_capture_replays_a_flow_call_as_a_graph(dev):
         assert torch.equal(f2(xb * 0.5), flow2().log_prob(xb * 0.5))
 
 
+@pytest.mark.parametrize("which", ["nsf_conditional", "realnvp", "maf"])
+def test_capture_step_replays_an_optimisation_step(dev, which):
+    """zuko_amd.capture_step (round 6): forward + backward (one-node training paths) + Adam of the README loop (tests/test_flows.py:22-29) as ONE replayed HIP
+    graph.  Two flows from the same seed, the same batches in the same order: the eager loop and the replayed graph leave the same parameters (the kernels and
+    their order are the same; every reduction in them is ordered) and report the same losses."""
+    import copy
+
+    import zuko_amd
+    import zuko_amd.flows as F
+
+    torch.manual_seed(3)
+    if which == "nsf_conditional":
+        flow, D, C, N = F.NSF(3, 5, transforms=3, bins=8, hidden_features=[128] * 3), 3, 5, 4096
+    elif which == "realnvp":
+        flow, D, C, N = F.RealNVP(16, 0, transforms=3, hidden_features=[64, 64]), 16, 0, 2048
+    else:
+        flow, D, C, N = F.MAF(8, 0, transforms=2, hidden_features=[64, 64]), 8, 0, 1024
+    flow = flow.to(dev)
+    twin = copy.deepcopy(flow)
+    g = torch.Generator(device=dev).manual_seed(4)
+    batches = [(torch.randn(N, D, device=dev, generator=g), torch.randn(N, C, device=dev, generator=g) if C else None) for _ in range(4)]
+    opt_a = torch.optim.Adam(flow.parameters(), lr=1e-3, capturable=True)
+    opt_b = torch.optim.Adam(twin.parameters(), lr=1e-3, capturable=True)
+    WARM = 2
+    step = zuko_amd.capture_step(flow, opt_a, *batches[0], warmup=WARM)  # (WARM eager steps on batch 0 happen in here)
+    losses_a = [step(*b).item() for b in batches]
+    losses_b = []
+    for i, (x, c) in enumerate([batches[0]] * WARM + batches):
+        loss = -(twin(c) if c is not None else twin()).log_prob(x).mean()
+        opt_b.zero_grad(set_to_none=False)
+        loss.backward()
+        opt_b.step()
+        if i >= WARM:
+            losses_b.append(loss.item())
+    assert losses_a == pytest.approx(losses_b, rel=1e-6, abs=1e-6), (losses_a, losses_b)
+    worst = max((p.detach() - q.detach()).abs().max().item() for p, q in zip(flow.parameters(), twin.parameters()))
+    assert worst < 1e-6, worst
+    with pytest.raises(ValueError):
+        step(batches[0][0][:10])
+    with pytest.raises(ValueError):
+        zuko_amd.capture_step(flow, torch.optim.Adam(flow.parameters(), lr=1e-3), *batches[0])
+
+
 @pytest.mark.parametrize("name", ["sospf", "bpf"])
 def test_polynomial_flows_invert_in_one_incremental_launch(dev, name, monkeypatch):
     """SOSPF / BPF layers (round 6): transform.inv = ONE zk_ar_inverse_incremental launch per autoregressive layer with the reference's bisection

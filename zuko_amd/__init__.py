@@ -12,10 +12,10 @@ _C.lib()  # fail loudly at import time if libzuko_amd.so is missing or stale
 
 from . import distributions, flows, lazy, nn, ops, transforms, utils  # noqa: E402
 from .fused import matmul_precision, set_matmul_precision  # noqa: E402
-from .graph import capture  # noqa: E402
+from .graph import capture, capture_step  # noqa: E402
 
 __version__ = "0.2.0"
-__all__ = ["capture", "distributions", "flows", "invalidate", "lazy", "matmul_precision", "nn", "ops", "set_matmul_precision", "transforms", "utils"]
+__all__ = ["capture", "capture_step", "distributions", "flows", "invalidate", "lazy", "matmul_precision", "nn", "ops", "set_matmul_precision", "transforms", "utils"]
 
 
 def invalidate(module) -> None:
