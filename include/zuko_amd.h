@@ -544,7 +544,8 @@ int zk_colsum_f32(int64_t N, int C, const void* x, int64_t ld, float* workspace,
  * zk_wsplit_f16:  the lane images of a weight operand W'[unit u, k] = src[u * unit_stride + k * k_stride] (mask likewise, or NULL) for
  *                 `units` x `k`, scaled from *amax: dst receives ceil(units / 128) * ceil(k / 32) * 16 KiB, zero padded.  (unit_stride, k_stride) =
  *                 (in, 1) on a row-major [out, in] weight gives the forward operand, (1, in) with units = in, k = out the dgrad operand W^T.
- * zk_gemm_f16x2:  c[M, N] = act(a[M, K] W'^T + bias) (* (gate > 0) when gate != NULL and gate_act == 1); act in {NONE, RELU}.  a_amax >= max |a|
+ * zk_gemm_f16x2:  c[M, N] = act(a[M, K] W'^T + bias) (* act'_{gate_act}(gate[M, N]) when gate != NULL, the derivative in terms of the activation OUTPUT as for
+ *                 zk_gemm_f32_skip); act / gate_act in {NONE, RELU, ELU, TANH, SIGMOID, LEAKY}.  a_amax >= max |a|
  *                 and w_amax (the scalar the images were made with) are read on the device; c_amax (or NULL) receives max |c| by atomicMax. */
 #define ZK_AMAX_WORDS 2048
 typedef struct zk_amax_desc_v1 {

@@ -143,7 +143,7 @@ def test_coupling_transform_trains_as_one_autograd_node(dev, ctor, kw, rows):
 
 
 def test_coupling_node_falls_back_when_not_covered(dev):
-    """Widths that are not multiples of 4, a frozen parameter, a non-ReLU activation: the layer-wise autograd path serves the call (same values)."""
+    """Widths that are not multiples of 4, a frozen parameter, an activation outside the epilogue's set: the layer-wise autograd path serves the call."""
     from zuko_amd import flows as F
 
     torch.manual_seed(0)
@@ -153,7 +153,7 @@ def test_coupling_node_falls_back_when_not_covered(dev):
     loss = -flow(c).log_prob(x).mean()
     loss.backward()
     assert all(p.grad is not None for p in flow.parameters())
-    flow2 = F.RealNVP(16, 0, transforms=2, hidden_features=[64, 64], activation=torch.nn.ELU).to(dev)
+    flow2 = F.RealNVP(16, 0, transforms=2, hidden_features=[64, 64], activation=torch.nn.GELU).to(dev)  # (its derivative is not a function of its output)
     x2 = torch.randn(64, 16, device=dev)
     (-flow2().log_prob(x2).mean()).backward()
     assert all(p.grad is not None for p in flow2.parameters())
@@ -161,3 +161,63 @@ def test_coupling_node_falls_back_when_not_covered(dev):
     next(flow3.parameters()).requires_grad_(False)
     (-flow3().log_prob(x2).mean()).backward()
     assert sum(p.grad is not None for p in flow3.parameters()) == len(list(flow3.parameters())) - 1
+
+
+@pytest.mark.parametrize("act", ["ELU", "Tanh", "Sigmoid", "LeakyReLU"])
+def test_coupling_node_with_other_activations(dev, act):
+    """ELU / Tanh / Sigmoid / LeakyReLU conditioners (activation and its derivative in the GEMM epilogues) against float64 autograd through the same formulas in
+    plain torch ops (zuko/flows/coupling.py:128-136, zuko/transforms.py:436-446, 1037-1073 — the oracle's conditioner is ReLU-only).  The smooth ones have no kinks:
+    2e-5 of max |grad| per tensor at 2 048 rows (the bar of test_gradients_smooth_activation_max_norm)."""
+    import math
+
+    from zuko_amd import flows as F
+
+    torch.manual_seed(11)
+    flow = F.RealNVP(16, 4, transforms=3, hidden_features=[64, 128], activation=getattr(torch.nn, act)).to(dev)
+    g = torch.Generator().manual_seed(12)
+    x, c = torch.randn(2048, 16, generator=g), torch.randn(2048, 4, generator=g)
+    xg, cg = x.to(dev).requires_grad_(), c.to(dev).requires_grad_()
+    loss = -flow(cg).log_prob(xg).mean()
+    names = set()
+
+    def walk(fn):
+        if fn is not None and fn not in names:
+            names.add(fn)
+            for nxt, _ in fn.next_functions:
+                walk(nxt)
+
+    walk(loss.grad_fn)
+    assert "CouplingFnBackward" in {type(f).__name__ for f in names}
+    loss.backward()
+    # float64 reference
+    xs, cs = x.double().requires_grad_(), c.double().requires_grad_()
+    ps = [p.detach().cpu().double().requires_grad_() for p in flow.parameters()]
+    it = iter(ps)
+    fn64 = {"ELU": torch.nn.functional.elu, "Tanh": torch.tanh, "Sigmoid": torch.sigmoid, "LeakyReLU": torch.nn.functional.leaky_relu}[act]
+    z, ladj = xs, 0.0
+    for t in flow.transform.transforms:
+        mask = t.mask.cpu()
+        ia, ib = mask.nonzero().squeeze(-1), (~mask).nonzero().squeeze(-1)
+        a, b = z[:, ia], z[:, ib]
+        h = torch.cat((a, cs), 1)
+        n_lin = len(list(t.hyper)[0::2])
+        for i in range(n_lin):
+            w, bias = next(it), next(it)
+            h = h @ w.t() + bias
+            if i + 1 < n_lin:
+                h = fn64(h)
+        phi = h.unflatten(-1, (-1, 2))
+        shift, scale = phi[..., 0], phi[..., 1]
+        ls = scale / (1 + (scale / math.log(1e3)).abs())
+        out = torch.empty_like(z)
+        out[:, ia], out[:, ib] = a, b * ls.exp() + shift
+        z, ladj = out, ladj + ls.sum(-1)
+    ref = -((-0.5 * z.pow(2) - 0.5 * math.log(2 * math.pi)).sum(-1) + ladj).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    mx = lambda u, v: ((u.detach().cpu().double() - v).abs().max() / v.abs().max().clamp_min(1e-12)).item()
+    worst = max(mx(p.grad, q.grad) for p, q in zip(flow.parameters(), ps))
+    bar = 2e-5 if act != "LeakyReLU" else 2e-4  # (LeakyReLU has the kink)
+    assert worst < bar, worst
+    assert mx(xg.grad, xs.grad) < bar and mx(cg.grad, cs.grad) < bar
+    print(f"RealNVP(16, context 4) with {act}: parameter gradients vs float64 autograd, max-norm {worst:.2e}; dx {mx(xg.grad, xs.grad):.2e}, dc {mx(cg.grad, cs.grad):.2e}")

@@ -11,7 +11,8 @@ Here (y, ladj) = CouplingFn(x, c, weights...) with
     backward  zk_univariate_backward (adjoint of the affine map) -> L x zk_gemm_f16x2 on W^T with the ReLU gate in the epilogue ->
               zk_wgrad_multi (weight + bias gradients of all layers in two launches) -> g_x assembled in place.
 The weights are re-split into f16 lane images once per call (zk_amax_f32 + zk_wsplit_f16: two launches for all layers, both orientations).
-Covered: affine univariate with the default shapes, a plain (Linear, ReLU)* conditioner in float32 whose layer widths are multiples of 4,
+Covered: affine univariate with the default shapes, a plain (Linear, activation)* conditioner in float32 — one of ReLU, ELU, Tanh, Sigmoid, LeakyReLU
+(their derivatives are functions of their outputs) — whose layer widths are multiples of 4,
 every parameter trainable.  Anything else returns None and the caller keeps the layer-wise autograd path.  ZUKO_AMD_NO_COUPLING_FN=1 switches it off.
 """
 
@@ -66,11 +67,11 @@ def wsplit(items) -> None:
     _C.check(_C.lib().zk_wsplit_f16(len(items), ctypes.cast(arr, ctypes.c_void_p), _stream()), "zk_wsplit_f16")
 
 
-def gemm(a: Tensor, a_amax: Tensor, images: Tensor, w_amax: Tensor, n_out: int, bias, act: int, gate, c_amax) -> Tensor:
-    """act(a W'^T + bias) (* (gate > 0)); a [M, K] fp32 with 16-byte aligned rows."""
+def gemm(a: Tensor, a_amax: Tensor, images: Tensor, w_amax: Tensor, n_out: int, bias, act: int, gate, c_amax, gate_act: int = 1) -> Tensor:
+    """act(a W'^T + bias) (* act'_{gate_act}(gate), the derivative from the activation's output); a [M, K] fp32 with 16-byte aligned rows."""
     M, K = a.shape
     c = torch.empty((M, n_out), dtype=torch.float32, device=a.device)
-    err = _C.lib().zk_gemm_f16x2(M, K, n_out, _ptr(a), a.stride(0), _ptr(a_amax), _ptr(images), _ptr(w_amax), _ptr(bias), act, _ptr(gate), 0 if gate is None else gate.stride(0), 1,
+    err = _C.lib().zk_gemm_f16x2(M, K, n_out, _ptr(a), a.stride(0), _ptr(a_amax), _ptr(images), _ptr(w_amax), _ptr(bias), act, _ptr(gate), 0 if gate is None else gate.stride(0), gate_act,
                                  _ptr(c), c.stride(0), _ptr(c_amax), _stream())
     _C.check(err, "zk_gemm_f16x2")
     return c
@@ -93,7 +94,7 @@ class CouplingFn(torch.autograd.Function):
     """(y, ladj) of one affine coupling transform.  Inputs after `c`: weight_0, bias_0, weight_1, ... of the conditioner."""
 
     @staticmethod
-    def forward(ctx, lazy, plan, slope: float, x: Tensor, c, *params):
+    def forward(ctx, lazy, plan, slope: float, act: int, x: Tensor, c, *params):
         ia, ib, half = _maps(lazy)
         ws, bs = params[0::2], params[1::2]
         L = len(ws)
@@ -119,7 +120,7 @@ class CouplingFn(torch.autograd.Function):
         h = inp
         for l in range(L):
             last = l + 1 == L
-            h = gemm(h, am[l], img_f[l], am[L + l], wd[l].shape[0], None if bs[l] is None else bs[l].detach(), 0 if last else 1, None, None if last else am[l + 1])
+            h = gemm(h, am[l], img_f[l], am[L + l], wd[l].shape[0], None if bs[l] is None else bs[l].detach(), 0 if last else act, None, None if last else am[l + 1])
             hs.append(h)
         phi = hs[-1].view(N, xb.shape[1], 2)
         meta = (0, 5.0, slope, (1, 1), ())
@@ -131,7 +132,7 @@ class CouplingFn(torch.autograd.Function):
         _C.check(_C.lib().zk_affine_forward(0, N, nb, slope, xb.data_ptr(), pp, 2 * nb, 2, pp + 4, 2 * nb, 2, yb.data_ptr(), ladj.data_ptr(), 1, _stream()), "zk_affine_forward")
         y = torch.empty_like(x)
         _C.check(_C.lib().zk_coupling_merge(N, D, x.data_ptr(), x.stride(0), yb.data_ptr(), nb, None, 0, half.data_ptr(), y.data_ptr(), _stream()), "zk_coupling_merge")
-        ctx.lazy, ctx.plan, ctx.meta, ctx.L, ctx.has_c = lazy, plan, meta, L, c is not None
+        ctx.lazy, ctx.plan, ctx.meta, ctx.L, ctx.has_c, ctx.act = lazy, plan, meta, L, c is not None, act
         ctx.save_for_backward(xb, *hs, *img_t, am)
         return y, ladj
 
@@ -154,12 +155,12 @@ class CouplingFn(torch.autograd.Function):
         amax([(g, am[2 * L])])
         gs = [None] * L  # gradient of layer l's pre-activation output
         gs[L - 1] = g
-        need_in = ctx.needs_input_grad[3] or (ctx.has_c and ctx.needs_input_grad[4])
+        need_in = ctx.needs_input_grad[4] or (ctx.has_c and ctx.needs_input_grad[5])
         for l in range(L - 1, -1, -1):
             if l == 0 and not need_in:
                 break
             # g_{l-1} = (g_l W_l) * relu'(h_l): W_l^T plays the weight, the saved activation h_l (hs[l], the layer's INPUT) the gate
-            g = gemm(g, am[2 * L + (L - 1 - l)], img_t[l], am[L + l], hs[l].shape[1], None, 0, hs[l] if l > 0 else None, am[2 * L + (L - l)] if l > 0 else None)
+            g = gemm(g, am[2 * L + (L - 1 - l)], img_t[l], am[L + l], hs[l].shape[1], None, 0, hs[l] if l > 0 else None, am[2 * L + (L - l)] if l > 0 else None, gate_act=ctx.act)
             if l > 0:
                 gs[l - 1] = g
         res = {}
@@ -172,14 +173,14 @@ class CouplingFn(torch.autograd.Function):
             grads += list(res[l])
         gx = gc = None
         na, nb = ia.shape[0], ib.shape[0]
-        if ctx.needs_input_grad[3]:  # g_x = g_y on the kept half (+ the conditioner's input gradient), the adjoint's g_xb on the moved half: one pass
+        if ctx.needs_input_grad[4]:  # g_x = g_y on the kept half (+ the conditioner's input gradient), the adjoint's g_xb on the moved half: one pass
             gx = torch.empty((N, na + nb), dtype=torch.float32, device=dev)
             gyc = None if gy is None else (gy if gy.stride(1) == 1 else gy.contiguous())
             _C.check(_C.lib().zk_coupling_merge(N, na + nb, None if gyc is None else gyc.data_ptr(), 0 if gyc is None else gyc.stride(0), gxb.data_ptr(), nb,
                                                 g.data_ptr() if need_in else None, g.stride(0) if need_in else 0, half.data_ptr(), gx.data_ptr(), _stream()), "zk_coupling_merge")
-        if need_in and ctx.has_c and ctx.needs_input_grad[4]:
+        if need_in and ctx.has_c and ctx.needs_input_grad[5]:
             gc = g[:, na:].contiguous()
-        return (None, None, None, gx, gc, *grads)
+        return (None, None, None, None, gx, gc, *grads)
 
 
 _STATE: "weakref.WeakKeyDictionary" = None  # lazy -> {key: (verdict, plan, params, slope)}
@@ -211,7 +212,7 @@ def _static_verdict(lazy, device, n_ctx: int):
     slope = kw.pop("slope", 1e-3)
     acts = mods[1::2]
     ok = f is MonotonicAffineTransform and not kw and not (isinstance(u, partial) and u.args) and [tuple(s) for s in lazy.shapes] == [(), ()]
-    ok = ok and len(mods) == 2 * len(lins) - 1 and all(type(m) is Linear for m in lins) and not any(_act_code(m) != 1 for m in acts) and len(lins) <= 8
+    ok = ok and len(mods) == 2 * len(lins) - 1 and all(type(m) is Linear for m in lins) and len({_act_code(m) for m in acts}) <= 1 and all(_act_code(m) in train.TRAIN_ACTS and _act_code(m) != 0 for m in acts) and len(lins) <= 8
     ok = ok and all(l.weight.dtype == torch.float32 and l.bias is not None and l.weight.requires_grad and l.bias.requires_grad and l.weight.shape[1] % 4 == 0 and l.weight.shape[0] % 4 == 0
                     for l in lins)
     if ok:
@@ -224,7 +225,7 @@ def _static_verdict(lazy, device, n_ctx: int):
         params = []
         for l in lins:
             params += [l.weight, l.bias]
-        value = (plan, tuple(params), float(slope))
+        value = (plan, tuple(params), float(slope), (_act_code(acts[0]) if acts else 0))
     per["key"], per["value"] = key, value
     return value
 
@@ -241,6 +242,6 @@ def coupling(lazy, x: Tensor, c):
     st = _static_verdict(lazy, x.device, 0 if c is None else c.shape[1])
     if st is None:
         return None
-    plan, params, slope = st
+    plan, params, slope, act = st
     xc = x if x.is_contiguous() else x.contiguous()
-    return CouplingFn.apply(lazy, plan, slope, xc, None if c is None else c.contiguous(), *params)
+    return CouplingFn.apply(lazy, plan, slope, act, xc, None if c is None else c.contiguous(), *params)

@@ -93,8 +93,8 @@ struct GhArgs {
   const uint4* w;                // images of zk_wsplit_f16 for (N units, K)
   const unsigned* w_amax;        // the maximum the images were scaled with
   const float* bias;             // [N] or null
-  int act;                       // 0 / 1 (ReLU)
-  const float* gate; int64_t ldg; int gate_act;  // optional [M, N]: result *= act'(gate) (ReLU: gate > 0)
+  int act;                       // NONE, RELU, ELU, TANH, SIGMOID, LEAKY
+  const float* gate; int64_t ldg; int gate_act;  // optional [M, N]: result *= act'(gate), the derivative written in the activation's OUTPUT (ReLU: gate > 0)
   float* c; int64_t ldc;
   unsigned* c_amax;              // or null: atomicMax of |c|
   int nbm, nbn, nks;
@@ -121,7 +121,9 @@ template <int N> __device__ __forceinline__ void gh_wait_vm() { asm volatile("s_
 // an LDS-DMA (hipcc cannot keep an ordinary load in flight across the loop without copying its destination registers, and drains every DMA at
 // the first use of one): the f32 activation tile travels global -> LDS as it is, is read back (ordinary LDS loads), scaled, split and stored as
 // lane images while the step before it is multiplied.
-template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_half_kernel(GhArgs a) {
+// OTHER: an activation beyond NONE / RELU is in play (a separate instantiation: their inline expansions, unrolled over the 64 outputs of a lane, do not belong in
+// the instruction stream of the ReLU kernel)
+template <int WM, int WN, bool OTHER> __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_half_kernel(GhArgs a) {
   constexpr int NT = 64 * WM * WN;     // threads
   constexpr int NP = 8 / WN;           // 16-byte pieces of the activation tile per thread and step
   constexpr int NW = 8 / WM;           // weight images per wavefront and step
@@ -291,6 +293,7 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[u][s][r] * d0 * d1 + bv[r];
         if (a.act == 1) v[r] = v[r] < 0.f ? 0.f : v[r];  // NaN stays NaN, as torch.relu
+        else if (OTHER && a.act > 1) v[r] = gh_act_fwd(v[r], a.act);
       }
       if (a.gate) {
         float gv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -303,6 +306,9 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
         if (a.gate_act == 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] *= gv[r] > 0.f ? 1.f : 0.f;
+        } else if (OTHER && a.gate_act > 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gh_act_grad_out(gv[r], a.gate_act);
         }
       }
       float* dst = a.c + row * a.ldc + col;
@@ -322,11 +328,11 @@ template <int WM, int WN> __global__ __launch_bounds__(64 * WM * WN, 2) void gem
   }
 }
 
-template <int WM, int WN> static int gh_launch(GhArgs& g, hipStream_t st) {
+template <int WM, int WN, bool OTHER> static int gh_launch_(GhArgs& g, hipStream_t st) {
   constexpr int LDS = (GH_WR * 8 * WN + (GH_AR + 2) * 8 * WM) * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute((const void*)gemm_half_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const hipError_t e = hipFuncSetAttribute((const void*)gemm_half_kernel<WM, WN, OTHER>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -334,8 +340,11 @@ template <int WM, int WN> static int gh_launch(GhArgs& g, hipStream_t st) {
   g.nbn = (g.N + 64 * WN - 1) / (64 * WN);
   const int64_t blocks = (int64_t)g.nbm * g.nbn;
   if (blocks > 0x7fffffff) return ZK_EINVAL;
-  gemm_half_kernel<WM, WN><<<dim3((unsigned)blocks), 64 * WM * WN, LDS, st>>>(g);
+  gemm_half_kernel<WM, WN, OTHER><<<dim3((unsigned)blocks), 64 * WM * WN, LDS, st>>>(g);
   return ZK_LAUNCH_CHECK();
+}
+template <int WM, int WN> static int gh_launch(GhArgs& g, hipStream_t st) {
+  return (g.act > 1 || (g.gate && g.gate_act > 1)) ? gh_launch_<WM, WN, true>(g, st) : gh_launch_<WM, WN, false>(g, st);
 }
 
 // ---- the glue of a coupling transform around its conditioner (zuko/transforms.py:1037-1073: split, merge) -----------------------------------
@@ -430,7 +439,8 @@ int zk_wsplit_f16(int n, const zk_wsplit_desc_v1* descs, void* stream) {
 int zk_gemm_f16x2(int64_t M, int K, int N, const void* a, int64_t lda, const uint32_t* a_amax, const void* w_images, const uint32_t* w_amax, const void* bias, int act,
                   const void* gate, int64_t ldg, int gate_act, void* c, int64_t ldc, uint32_t* c_amax, void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || !a_amax || !w_images || !w_amax || !c || (M > 0 && !a)) return ZK_EINVAL;
-  if ((act != 0 && act != 1) || (gate && gate_act != 0 && gate_act != 1)) return ZK_EINVAL;  // (other activations: zk_gemm_f32_skip)
+  auto known = [](int c) { return c == 0 || c == 1 || c == 2 || c == 3 || c == 6 || c == 7; };  // NONE, RELU, ELU, TANH, SIGMOID, LEAKY (derivative from the output)
+  if (!known(act) || (gate && !known(gate_act))) return ZK_EINVAL;
   if (lda < K || ldc < N || (gate && ldg < N)) return ZK_EINVAL;
   if (K % 4 != 0 || lda % 4 != 0 || (((uintptr_t)a) & 15) != 0) return ZK_EINVAL;  // 16-byte pieces of a row (zk_gemm_f32_skip has no such limit)
   if (M == 0) return 0;

@@ -26,4 +26,26 @@ __device__ __forceinline__ int gh_exp(const unsigned* slots) {
   return __builtin_amdgcn_readfirstlane(e > 90 ? 90 : (e < -90 ? -90 : e));
 }
 
+// activations of the training GEMMs (codes of zuko_amd/ops.py: ACTIVATIONS; those whose derivative is a function of their OUTPUT v, as csrc/train.hip)
+__device__ __forceinline__ float gh_act_fwd(float v, int act) {
+  switch (act) {
+    case 1: return v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
+    case 2: return v > 0.f ? v : expm1f(v);
+    case 3: return tanhf(v);
+    case 6: return 1.f / (1.f + expf(-v));
+    case 7: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+__device__ __forceinline__ float gh_act_grad_out(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? 1.f : 0.f;
+    case 2: return v > 0.f ? 1.f : v + 1.f;
+    case 3: return 1.f - v * v;
+    case 6: return v * (1.f - v);
+    case 7: return v > 0.f ? 1.f : 0.01f;
+    default: return 1.f;
+  }
+}
+
 }  // namespace zk
