@@ -246,7 +246,9 @@ def test_bernstein_golden(dev, tag, name):
         # polynomial by de Casteljau with the closed-form derivative.  Both against the float64 oracle:
         y64, l64 = O.bern_forward(d64(g["theta"]), d64(g["x"]), name == "bbern")
         assert_parity(y, g["y"], y64, f"{name} golden f32: y")
-        assert_parity(ladj, g["ladj"], l64, f"{name} golden f32: ladj", **({"c": C_ADVERSARIAL} if name == "bern" else {}))
+        # (round 6: the derivative is a de Casteljau sweep over the positive coefficient differences — 1.3e-6 from float64 on the adversarial `bern` set, where the
+        #  float32 reference itself sits 1.6e-5 away; until then the comparison needed its own constant, ratio 2.93)
+        assert_parity(ladj, g["ladj"], l64, f"{name} golden f32: ladj")
         assert_parity(xi, g["x_inv"], O.bern_inverse(d64(g["theta"]), d64(g["y"]), name == "bbern"), f"{name} golden f32: inverse (24-step bisection)")
     else:
         # float64: the closed form equals the reference's Beta-pdf form to 6e-14 on this set (measured in the build container

@@ -494,19 +494,26 @@ template <typename T, int NC, typename Ld> __device__ __forceinline__ void bern_
   cum += edge; th[n + 4] = cum;
 }
 
-// de Casteljau: value B(u) = sum_i C(M,i) u^i (1-u)^(M-i) theta_i and derivative dB/du in one sweep
-// (closed form of transforms.py:736-740; equality with the Beta-pdf form verified in SURVEY 9.1)
+// de Casteljau: value B(u) = sum_i C(M,i) u^i (1-u)^(M-i) theta_i (closed form of transforms.py:736-740; equality with the Beta-pdf form verified in
+// SURVEY 9.1) and derivative dB/du = M sum_i C(M-1,i) u^i (1-u)^(M-1-i) (theta_{i+1} - theta_i): a second de Casteljau sweep over the DIFFERENCES, which are
+// all positive (theta is a cumulative sum of positive increments) — every step a convex combination of positive numbers, no cancellation.  (Until round 5 the
+// derivative was M (b_1 - b_0) of the value sweep's last two points: two numbers of size |theta| that agree in their leading digits wherever the polynomial is
+// flat — the one comparison of the golden sets whose log-derivative sat 2.9x further from float64 than the float32 reference's.)
 template <typename T, int NC> __device__ __forceinline__ void bern_eval(const T (&th)[NC], T u, T& val, T& dval) {
-  T b[NC];
+  T b[NC], d[NC - 1];
 #pragma unroll
   for (int i = 0; i < NC; ++i) b[i] = th[i];
+#pragma unroll
+  for (int i = 0; i < NC - 1; ++i) d[i] = th[i + 1] - th[i];
   const T v = T(1) - u;
 #pragma unroll
   for (int r = 1; r < NC - 1; ++r) {
 #pragma unroll
     for (int i = 0; i < NC - r; ++i) b[i] = v * b[i] + u * b[i + 1];
+#pragma unroll
+    for (int i = 0; i < NC - 1 - r; ++i) d[i] = v * d[i] + u * d[i + 1];
   }
-  dval = T(NC - 1) * (b[1] - b[0]);
+  dval = T(NC - 1) * d[0];
   val = v * b[0] + u * b[1];
 }
 
