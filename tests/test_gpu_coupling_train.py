@@ -221,3 +221,57 @@ def test_coupling_node_with_other_activations(dev, act):
     assert worst < bar, worst
     assert mx(xg.grad, xs.grad) < bar and mx(cg.grad, cs.grad) < bar
     print(f"RealNVP(16, context 4) with {act}: parameter gradients vs float64 autograd, max-norm {worst:.2e}; dx {mx(xg.grad, xs.grad):.2e}, dc {mx(cg.grad, cs.grad):.2e}")
+
+
+def test_coupling_node_one_launch_equals_the_sum_of_row_chunks(dev):
+    """BASELINE config 4's conditioner shape at the bench's training batch (2^14 rows): the gradients of ONE call against the float64 sum of the gradients of its 16
+    chunks of 1 024 rows (the loss is a sum over rows; the chunks see other per-tensor maxima, hence other operand scales, other tiles, other reduction slices) —
+    the size-independent property that holds the many-tile GEMMs and the cross-slice weight-gradient reduction of the one-node path: 1e-5 of max |grad| per tensor."""
+    from zuko_amd import flows as F
+
+    torch.manual_seed(21)
+    flow = F.RealNVP(256, 0, transforms=2, hidden_features=[512] * 3).to(dev)
+    N, CH = 1 << 14, 1 << 10
+    x = torch.randn(N, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(22))
+
+    def grads(rows):
+        flow.zero_grad(set_to_none=True)
+        xg = rows.clone().requires_grad_()
+        (-flow().log_prob(xg).sum() / N).backward()
+        return [p.grad.detach().double() for p in flow.parameters()], xg.grad.detach().double()
+
+    whole, gx_whole = grads(x)
+    acc, gx_parts = None, []
+    for i in range(0, N, CH):
+        g, gx = grads(x[i : i + CH])
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        gx_parts.append(gx)
+    worst = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item() for a, b in zip(whole, acc))
+    gx_err = ((gx_whole - torch.cat(gx_parts)).abs().max() / gx_whole.abs().max()).item()
+    assert worst < 1e-5, worst
+    assert gx_err < 1e-5, gx_err
+    print(f"RealNVP(256, [512] x 3) 2^14 rows in one call vs 16 chunks: parameter gradients {worst:.2e}, dx {gx_err:.2e} of max |grad|")
+
+
+def test_two_part_gemm_at_2_to_the_20_rows(dev):
+    """Size-independent properties at the headline batch (2^20 rows x 512 x 512, 8 192 workgroups): rows are independent — a permutation of the rows permutes the
+    outputs bit for bit (same per-tensor maximum, hence the same scale) — and three slices of 4 096 rows agree with the float64 product."""
+    from zuko_amd import coupling_train as ct
+
+    M, K, N = 1 << 20, 512, 512
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randn(M, K, device=dev, generator=g).clamp_min(0)
+    w = torch.randn(N, K, device=dev, generator=g) / K**0.5
+    b = torch.randn(N, device=dev, generator=g)
+    am = torch.zeros(3, ct.AMAX_WORDS, dtype=torch.int32, device=dev)
+    ct.amax([(a, am[0]), (w, am[1])])
+    img = torch.empty(ct.image_words(N, K), dtype=torch.int32, device=dev)
+    ct.wsplit([(w, False, am[1], img)])
+    c = ct.gemm(a, am[0], img, am[1], N, b, 1, None, am[2])
+    perm = torch.randperm(M, device=dev, generator=g)
+    cp = ct.gemm(a[perm].contiguous(), am[0], img, am[1], N, b, 1, None, None)
+    assert torch.equal(cp, c[perm])
+    for lo in (0, M // 2 - 2048, M - 4096):
+        ref = (a[lo : lo + 4096].double() @ w.double().t() + b.double()).clamp_min(0)
+        assert ((c[lo : lo + 4096].double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    assert am[2].max().item() == torch.tensor([c.abs().max().item()]).view(torch.int32).item()
