@@ -233,6 +233,10 @@ typedef struct zk_ar_args_v1 {
   double wdescale1;        /* of two zk_gather_split_f16 stored that layer's weights with (0 = not given: such a kernel declines the launch) */
   double wdescale2;
   double wdescale3;
+  uint32_t* amax0;         /* zk_ar_forward_train / zk_ar_backward_full (operand-split kernels), optional: DEVICE [ZK_AMAX_WORDS] each (see zk_gemm_f16x2), zeroed by the */
+  uint32_t* amax1;         /* caller — forward: the maximum of h1 / h2 / h3 is folded into amax0 / 1 / 2 and of x into amax3; backward: of gh_l into amax_{l-1}... in the order the kernel */
+  uint32_t* amax2;         /* writes them (amax_c for chain layer c: the gradient of hidden layer n - 1 - c) and of the packed parameter gradient x_out into amax3.  They let */
+  uint32_t* amax3;         /* zk_wgrad_multi form its products from two-part f16 operands (zk_wgrad_layer_v1.g_amax / h_amax) */
 } zk_ar_args_v1;
 
 /* y, ladj of one layer on the generic tile-skipping kernel.  Reads: uni_kind, N, D, DIN, x, ldx, y, ldy, ladj, accumulate, wstream,

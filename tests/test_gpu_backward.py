@@ -534,3 +534,26 @@ def test_conditional_flow_with_the_stand_alone_adjoint(dev, monkeypatch):
             assert ((ref[2][k] - g).abs().max() / g.abs().max().clamp_min(1e-6)).item() < 2e-5, (env, k)
         assert ((ref[3] - got[3]).abs().max() / got[3].abs().max()).item() < 2e-5, env
         assert ((ref[4] - got[4]).abs().max() / got[4].abs().max()).item() < 2e-5, env
+
+
+@pytest.mark.parametrize("name", ["nsf_cfg2", "maf_cfg3"])
+def test_weight_gradients_on_two_part_operands_equal_the_three_part_ones(dev, name, monkeypatch):
+    """Round 6: the training launches leave the maxima of h_l / g_l / g_phi on the device and zk_wgrad_multi forms its products from two-part f16 operands with
+    per-tensor power-of-two scales (three matrix instructions per block) instead of three-part bf16 ones (six).  Same flow, same rows, both modes
+    (ZUKO_AMD_NO_WGRAD_HALF=1 selects the three-part one): every parameter gradient within 2e-6 of max |grad| — the size of either mode's own rounding."""
+    flow, entry = build_flow(name)
+    flow = flow.to(dev)
+    x = torch.randn(1 << 14, entry[1]["features"], generator=torch.Generator().manual_seed(31)).to(dev)
+
+    def grads():
+        flow.zero_grad(set_to_none=True)
+        (-flow().log_prob(x).mean()).backward()
+        return [p.grad.detach().clone() for p in flow.parameters()]
+
+    half = grads()
+    monkeypatch.setenv("ZUKO_AMD_NO_WGRAD_HALF", "1")
+    three = grads()
+    worst = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(half, three))
+    assert worst < 2e-6, worst
+    assert any(not torch.equal(a, b) for a, b in zip(half, three)), "the switch changed nothing: the two-part mode did not run"
+    print(f"{name}: two-part vs three-part weight gradients, worst tensor {worst:.2e} of max |grad|")

@@ -527,6 +527,7 @@ struct ArPartial {  // optional: evaluate only last-layer groups [g0, g1) and th
   int32_t* bin_out = nullptr;  // diagnostic launch (forward, spline maps): bin index + search knots
   float* knots_out = nullptr;
   double wdescale[4] = {0.0, 0.0, 0.0, 0.0};  // two-part split kernels: 1 / (the power of two every layer's weights were stored with)
+  unsigned* amax[4] = {nullptr, nullptr, nullptr, nullptr};  // training launches: maxima of the stored tensors (ArArgs::amax)
   const int* sched = nullptr;
   int n_sched = 0;
   const int* olim = nullptr;  // host array, one entry per hidden layer
@@ -575,6 +576,7 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
     }
     a.eps = (float)(part.eps > 0.0 ? part.eps : 1e-6);
     for (int l = 0; l < 4; ++l) a.wdescale[l] = (float)part.wdescale[l];
+    for (int l = 0; l < 4; ++l) a.amax[l] = part.amax[l];
     return ((ars_launch_fn)part.static_fn)(&a, ARS_ABI, (int)sizeof(ArArgs), part.phi_out != nullptr, stream);
   }
   // stage x / results through LDS when rows are float4-addressable and the tiles fit beside the ring
@@ -691,6 +693,7 @@ int zk_ar_forward_train(const zk_ar_args_v1* args, void* stream) {
   part.static_fn = args->launcher; part.rev = args->rev;
   part.act_out[0] = (float*)args->h1; part.act_out[1] = (float*)args->h2; part.act_out[2] = (float*)args->h3; part.phi_out = (float*)args->phi; part.ldphi = args->ldphi;
   part.phi_packed = args->phi_packed;
+  part.amax[0] = args->amax0; part.amax[1] = args->amax1; part.amax[2] = args->amax2; part.amax[3] = args->amax3;
   zk_ar_args_v1 p = *args;
   p.act = 1; p.skip = nullptr;
   if (!p.y) {  // conditioner only
@@ -770,6 +773,7 @@ int zk_ar_backward_full(const zk_ar_args_v1* args, void* stream) {
     a.gate[c] = (const float*)hs[n - 2 - c];
     a.act_out[c] = (float*)gs[n - 2 - c];
   }
+  a.amax[0] = args->amax0; a.amax[1] = args->amax1; a.amax[2] = args->amax2; a.amax[3] = args->amax3;
   return ((ars_dgrad_fn)args->launcher)(&a, ARS_ABI, (int)sizeof(ArArgs), stream);
 }
 

@@ -25,6 +25,7 @@
 //   Shape::GOFF[g], G_IP                last layer: kept in pairs of every feature group (each with Uni::NT blocks)
 #pragma once
 #include "fused_ar_static_impl.h"
+#include "zk_half.h"
 #include "zk_univariate_bwd.h"
 
 #ifndef ARX_LOOK
@@ -145,8 +146,17 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arx_hidden
   }
 }
 
+__device__ __forceinline__ void arx_amax_flush(const ArArgs& a, const float (&mx)[4], unsigned which, int lane) {
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (a.amax[l]) {  // (wave-uniform)
+      const float m = gh_wave_max(mx[l]);
+      if (lane == 0) gh_amax_put(a.amax[l], which, m);
+    }
+}
+// mx[l]: running maximum magnitude of what this lane stored to act_out[l] (training launches with ArArgs::amax; folded into the device maxima at the kernel's end)
 template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ void arx_hidden_stack(Ring& ring, const float* bias_lds, int q, ArxB (&in)[S::TMAX / 2], f32x4 (&out)[S::TMAX],
-                                                                                                 const ArArgs& a, int64_t n, bool live) {
+                                                                                                 const ArArgs& a, int64_t n, bool live, float (&mx)[4]) {
   if constexpr (L < S::NH) {
     arx_hidden<S, L>(ring, bias_lds + L * S::BIAS_STRIDE + 4 * q, in, out);
     constexpr int HTL = S::HT[L];
@@ -169,12 +179,18 @@ template <class S, int L, class Ring, bool TRAIN> __device__ __forceinline__ voi
       if (live) {
 #pragma unroll
         for (int t = 0; t < HTL; ++t) *reinterpret_cast<f32x4*>(a.act_out[L < 3 ? L : 2] + n * (HTL * 16) + t * 16 + 4 * q) = out[t];
+        if (a.amax[L < 3 ? L : 2]) {
+#pragma unroll
+          for (int t = 0; t < HTL; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx[L < 3 ? L : 2] = fmaxf(mx[L < 3 ? L : 2], fabsf(out[t][r]));
+        }
       }
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < (HTL + 1) / 2; ++p) arx_split(out[2 * p], 2 * p + 1 < HTL ? out[2 * p + 1] : zero, in[p]);
-    arx_hidden_stack<S, L + 1, Ring, TRAIN>(ring, bias_lds, q, in, out, a, n, live);
+    arx_hidden_stack<S, L + 1, Ring, TRAIN>(ring, bias_lds, q, in, out, a, n, live, mx);
   }
 }
 
@@ -225,6 +241,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
   }
 
   const bool uni_on = !TRAIN || a.y != nullptr;  // (training launch: y, ladj beside phi and the activations when the caller passes y)
+  float mx[4] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n = tile * (16 * WAVES) + wave * 16 + j;
     const bool live = n < a.N;
@@ -241,6 +258,12 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if ((it + 1) * 16 <= S::DIN || it * 16 + 4 * q < S::DIN) v = *reinterpret_cast<const f32x4*>(xrow + it * 16 + 4 * q);
         xin[it] = v;
+        if constexpr (TRAIN) {
+          if (live && a.amax[3]) {  // (training: the maximum of the conditioner's input, the first layer's operand of the weight gradients)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx[3] = fmaxf(mx[3], fabsf(v[r]));
+          }
+        }
       }
       xin[S::NIT] = f32x4{0.f, 0.f, 0.f, 0.f};
       // a NaN / inf input turns ALL parameters of its sample into NaN in the reference (x * 0 = NaN, zuko/nn.py:217-218)
@@ -264,7 +287,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
     }
 
     // ---- hidden layers ---------------------------------------------------------------------------------------------
-    arx_hidden_stack<S, 0, Ring, TRAIN>(ring, bias_lds, q, in, out, a, n, live);
+    arx_hidden_stack<S, 0, Ring, TRAIN>(ring, bias_lds, q, in, out, a, n, live, mx);
 
     // ---- last layer + univariate transform, one group of 4 * FPL features at a time --------------------------------
     float lacc = 0.f;
@@ -384,6 +407,7 @@ template <class S, typename Uni, bool TRAIN, bool DIAG = false> __global__ __lau
       if (live && q == 0) a.ladj[n] = a.accumulate ? a.ladj[n] + lacc : lacc;
     }
   }
+  if constexpr (TRAIN) arx_amax_flush(a, mx, blockIdx.x * WAVES + wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must land before the LDS is released
 }
 
@@ -453,7 +477,7 @@ template <class S, class Ring> __device__ __forceinline__ void arxd_first(Ring& 
 }
 
 template <class S, int L, class Ring> __device__ __forceinline__ void arxd_stack(Ring& ring, const float* zero_q, int q, ArxB (&in)[S::TMAX / 2], f32x4 (&out)[S::TMAX], const ArArgs& a,
-                                                                                 int64_t n, int64_t nc, bool live, const float* xadd_q = nullptr) {
+                                                                                 int64_t n, int64_t nc, bool live, float (&mx)[4], const float* xadd_q = nullptr) {
   if constexpr (L < S::NH) {
     if constexpr (L > 0) arx_hidden<S, L>(ring, zero_q, in, out);
     constexpr int HTL = S::HT[L];
@@ -468,11 +492,17 @@ template <class S, int L, class Ring> __device__ __forceinline__ void arxd_stack
       if (live && ARXB_ABL != 5 && ARXB_ABL != 7 && ARXB_ABL != 8) {
 #pragma unroll
         for (int t = 0; t < HTL; ++t) *reinterpret_cast<f32x4*>(a.act_out[L] + n * (HTL * 16) + t * 16 + 4 * q) = out[t];
+        if (a.amax[L < 3 ? L : 2]) {
+#pragma unroll
+          for (int t = 0; t < HTL; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx[L < 3 ? L : 2] = fmaxf(mx[L < 3 ? L : 2], fabsf(out[t][r]));
+        }
       }
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int p = 0; p < (HTL + 1) / 2; ++p) arx_split(out[2 * p], 2 * p + 1 < HTL ? out[2 * p + 1] : zero, in[p]);
-      arxd_stack<S, L + 1, Ring>(ring, zero_q, q, in, out, a, n, nc, live, xadd_q);
+      arxd_stack<S, L + 1, Ring>(ring, zero_q, q, in, out, a, n, nc, live, mx, xadd_q);
     } else if (live) {  // gradient w.r.t. the conditioner's input: module column order, DOUT columns (accumulate: added to what the buffer holds)
 #pragma unroll
       for (int t = 0; t < HTL; ++t)
@@ -503,6 +533,7 @@ template <class S> __global__ __launch_bounds__(512, 2) void arxd_kernel(ArArgs 
   float* zero_lds = ars_lds + ARS_NR * S::CH * AR_TF;  // "bias image" of a layer without bias
   for (int i = tid; i < S::TMAX * 16 + 16; i += 512) zero_lds[i] = 0.f;
   __syncthreads();
+  float mx[4] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n = tile * 128 + wave * 16 + j;
     const bool live = n < a.N;
@@ -510,8 +541,9 @@ template <class S> __global__ __launch_bounds__(512, 2) void arxd_kernel(ArArgs 
     ArxB in[S::TMAX / 2];
     f32x4 out[S::TMAX];
     arxd_first<S>(ring, a.x + nc * a.ldx + 4 * q, q, out);
-    arxd_stack<S, 0, Ring>(ring, zero_lds + 4 * q, q, in, out, a, n, nc, live);
+    arxd_stack<S, 0, Ring>(ring, zero_lds + 4 * q, q, in, out, a, n, nc, live, mx);
   }
+  arx_amax_flush(a, mx, blockIdx.x * 8 + wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -532,7 +564,7 @@ template <typename Uni, typename A> __device__ __forceinline__ void arxb_adjoint
 }
 
 template <class S, typename Uni, class Ring>
-__device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const int* fmap_lds, float* xr, int q, int64_t n, int64_t nc, bool live, f32x4 (&out)[S::TMAX]) {
+__device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const int* fmap_lds, float* xr, int q, int64_t n, int64_t nc, bool live, f32x4 (&out)[S::TMAX], float (&mx)[4]) {
   constexpr int NT = Uni::NT, FPL = Uni::FPL, TOTAL = Uni::TOTAL;
   constexpr int SG = (NT % 2) ? 2 : 1;  // groups per step: a step ends on a pair boundary
   constexpr int NSTEP = S::NG / SG, PPS = SG * NT / 2, NF = SG * FPL;
@@ -596,6 +628,10 @@ __device__ __forceinline__ void arxb_first(Ring& ring, const ArArgs& a, const in
     if (live && ARXB_ABL != 1 && ARXB_ABL != 3 && ARXB_ABL != 8) {  // the gradient in the same packed order (padding slots zero), for the weight gradients
 #pragma unroll
       for (int t = 0; t < SG * NT; ++t) *reinterpret_cast<f32x4*>(gphirow + (s * SG * NT + t) * 16) = f32x4{gq[4 * t], gq[4 * t + 1], gq[4 * t + 2], gq[4 * t + 3]};
+      if (a.amax[3]) {
+#pragma unroll
+        for (int t = 0; t < 4 * SG * NT; ++t) mx[3] = fmaxf(mx[3], fabsf(gq[t]));
+      }
     }
     ars_for<PPS>([&](auto pl_) ARS_ALWAYS_INLINE {
       constexpr int pl = pl_, pp = s * PPS + pl, B0 = S::PB[pp], B1 = S::PB[pp + 1];
@@ -641,6 +677,7 @@ template <class S, typename Uni> __global__ __launch_bounds__(512, 2) void arxb_
   for (int i = tid; i < S::TMAX * 16 + 16; i += 512) zero_lds[i] = 0.f;
   for (int i = tid; i < S::NG * 4 * Uni::FPL; i += 512) fmap_lds[i] = a.featmap[i];
   __syncthreads();
+  float mx[4] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n = tile * 128 + wave * 16 + j;
     const bool live = n < a.N;
@@ -651,13 +688,14 @@ template <class S, typename Uni> __global__ __launch_bounds__(512, 2) void arxb_
 #pragma unroll 1
       for (int i = a.D + q; i < a.xs - 4; i += 4) xr[i] = 0.f;
     }
-    arxb_first<S, Uni>(ring, a, fmap_lds, xr, q, n, nc, live, out);
+    arxb_first<S, Uni>(ring, a, fmap_lds, xr, q, n, nc, live, out, mx);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    arxd_stack<S, 0, Ring>(ring, zero_lds + 4 * q, q, in, out, a, n, nc, live, xr + 4 * q);
+    arxd_stack<S, 0, Ring>(ring, zero_lds + 4 * q, q, in, out, a, n, nc, live, mx, xr + 4 * q);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+  arx_amax_flush(a, mx, blockIdx.x * 8 + wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

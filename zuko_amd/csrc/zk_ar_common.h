@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AR_TF 256 /* floats per tile image */
 #define AR_WAVES 8
 #define AR_T 16   /* activation tiles (256 units) */
-#define ARS_ABI 8 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
+#define ARS_ABI 9 /* contract between this library and the generated static-shape kernels (zuko_amd/static_ar.py): bump on any change of ArArgs */
 
 struct ArArgs {
   int64_t N;
@@ -60,6 +60,10 @@ struct ArArgs {
   float eps;
   // two-part (f16) operand-split kernels (fused_ar_half_impl.h): 2^-ew_l of every linear layer, the power of two its weights were stored with
   float wdescale[4];
+  // training launches (operand-split static-shape kernels): where to fold the maximum magnitude of every tensor the launch stores for the weight
+  // gradients (zk_half.h: 64 slots) — forward: amax[l] for act_out[l]; backward: amax[l] for act_out[l] (gradient of a hidden layer), amax[3] for
+  // gphi_out.  null = not wanted.  With them the weight gradients run on two-part f16 operands (csrc/train.hip: wgrad_split_body<true>).
+  unsigned* amax[4];
 };
 
 __device__ __forceinline__ float act_f32(float v, int act) {

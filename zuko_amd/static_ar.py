@@ -36,12 +36,12 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ARS_DIR = os.path.join(HERE, "lib", "ars")  # kernels built ahead of time (prebuild()); also the JIT's directory unless ZUKO_AMD_CACHE_DIR is set
-ARS_ABI = 8  # == ARS_ABI of csrc/zk_ar_common.h
+ARS_ABI = 9  # == ARS_ABI of csrc/zk_ar_common.h
 UNI_TYPES = {0: "zk::UniAffine", 1: "zk::UniRqs8", 2: "zk::UniRqs4", 3: "zk::UniRqs16", 4: "zk::UniCircRqs8", 5: "zk::UniSos3x5", 6: "zk::UniBern17"}
 # 16 bins: the twelve accumulator tiles of a feature group do not fit the f32-instruction template's double-buffered last layer (it would
 # spill), but the operand-split template holds them (255 VGPRs, no scratch): that kind exists as a split kernel only, forward only
 SPLIT_ONLY_KINDS = {3, 5, 6}
-_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_univariate_bwd.h", "zk_common.h")
+_HEADERS = ("fused_ar_static_impl.h", "fused_ar_split_impl.h", "zk_ar_common.h", "zk_univariate.h", "zk_univariate_bwd.h", "zk_common.h", "zk_half.h")
 
 
 def _hipcc() -> str | None:

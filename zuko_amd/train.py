@@ -17,6 +17,7 @@ Only integer bookkeeping (permutations, gather / scatter indices, skip maps) is 
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -356,7 +357,7 @@ def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0, featur
     return st
 
 
-def _fused_forward(st, x: Tensor, out_features: int, uni=None, packed_width: int = 0):
+def _fused_forward(st, x: Tensor, out_features: int, uni=None, packed_width: int = 0, amax=None):
     """([h_1, ...] sorted-domain hidden activations, phi) from one launch of zk_ar_forward_train (a static-shape kernel of
     zuko_amd/static_ar.py in its training instantiation).  uni = (bound, slope) (operand-split kernels): the launch also evaluates the
     univariate map, and (hs, phi, y, ladj) is returned.  packed_width: phi [N, packed_width] in the kernels' packed order instead."""
@@ -367,9 +368,12 @@ def _fused_forward(st, x: Tensor, out_features: int, uni=None, packed_width: int
     kern, rev = st.static
     hp = [_ptr(h) for h in hs] + [None] * (3 - len(hs))
     extra = {}
+    if amax is not None:  # [maxima of x, h_1, h_2, ..] (device, zeroed): the launch folds max |x|, max |h_l| into them (operand-split kernels)
+        extra.update({f"amax{i}": _ptr(t) for i, t in enumerate(amax[1:4])})
+        extra["amax3"] = _ptr(amax[0])  # (x)
     if uni is not None:
         y, ladj = torch.empty((N, p.features), dtype=torch.float32, device=x.device), torch.empty(N, dtype=torch.float32, device=x.device)
-        extra = dict(y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), bound=float(uni[0]), slope=float(uni[1]))
+        extra.update(dict(y=_ptr(y), ldy=y.stride(0), ladj=_ptr(ladj), bound=float(uni[0]), slope=float(uni[1])))
     a = _C.args("zk_ar_args_v1", launcher=kern.launcher, rev=rev, uni_kind=p.layout.kind, N=N, D=p.features, DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
                 phi=_ptr(phi), ldphi=phi.stride(0), phi_packed=int(packed_width > 0), wstream=_ptr(st.fine_stream), bias=_ptr(st.bias), bias_floats=st.bias_floats, featmap=_ptr(st.featmap),
                 n_layers=p.n_layers, n_groups=p.n_groups, n_chunks=st.fine_n_chunks, act=1, **extra)
@@ -427,7 +431,7 @@ class DgradChain:
         return gs + [g_in], gx
 
 
-    def run_backward(self, plan: SortedPlan, stream: Tensor, st, uni, x: Tensor, phi: Tensor, gy: Tensor, gl: Tensor, hs):
+    def run_backward(self, plan: SortedPlan, stream: Tensor, st, uni, x: Tensor, phi: Tensor, gy: Tensor, gl: Tensor, hs, amax=None):
         """Fused chains: (g_phi [N, packed width] in the packed order of phi, [g_1, ..], gx) from d loss / d (y, ladj) in one launch
         (zk_ar_backward_full); phi: the forward's, packed; st = the forward's FusedAR (feature grouping), uni = (kind, bound, slope, ..)."""
         n = len(plan.shapes)
@@ -440,7 +444,8 @@ class DgradChain:
         gp = [_ptr(g) for g in gs] + [None] * 3
         a = _C.args("zk_ar_args_v1", launcher=self.kernel.launcher, uni_kind=uni[0], N=N, D=st.plan.features, DIN=x.shape[1], x=_ptr(x), ldx=x.stride(0), h1=hp[0], h2=hp[1], h3=hp[2],
                     gh1=gp[0], gh2=gp[1], gh3=gp[2], y=_ptr(gx), ldy=gx.stride(0), y_in=_ptr(gy), ldo=gy.stride(0), ladj=_ptr(gl), phi=_ptr(phi), x_out=_ptr(gphi), ldphi=phi.stride(0),
-                    wstream=_ptr(stream), featmap=_ptr(st.featmap), n_layers=n, n_groups=st.plan.n_groups, n_chunks=self.t["NCHUNK"], act=1, bound=float(uni[1]), slope=float(uni[2]))
+                    wstream=_ptr(stream), featmap=_ptr(st.featmap), n_layers=n, n_groups=st.plan.n_groups, n_chunks=self.t["NCHUNK"], act=1, bound=float(uni[1]), slope=float(uni[2]),
+                    **({} if amax is None else {"amax3": _ptr(amax["gphi"]), **{f"amax{c}": _ptr(amax["g"][n - 2 - c]) for c in range(n - 1)}}))
         _C.check(_C.lib().zk_ar_backward_full(a, _stream()), "zk_ar_backward_full")
         return gphi, gs, gx
 
@@ -630,8 +635,16 @@ class AutoregressiveFn(torch.autograd.Function):
         n = len(lins)
         st.refresh(lins, fine_only=True)
         stream = chain.gather(plan, lins)
-        acts, phi, y, ladj = _fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]), packed_width=chain.packed.width if chain.fused else 0)
-        ctx.plan, ctx.n, ctx.chain, ctx.uni, ctx.st = plan, n, chain, uni, st
+        # maxima of the tensors the weight gradients multiply — x, h_1.., g_1.., g_phi — on the device (coupling_train.AMAX_WORDS each): the two launches leave them,
+        # zk_wgrad_multi then forms its products from two-part f16 operands (three matrix instructions per block instead of six)
+        am = None
+        if chain.fused and os.environ.get("ZUKO_AMD_NO_WGRAD_HALF", "0") != "1":
+            from . import coupling_train as ct
+
+            am = torch.zeros((2 * n, ct.AMAX_WORDS), dtype=torch.int32, device=x.device)  # [x, h_1 .. h_{n-1} | g_1 .. g_{n-1}, g_phi]
+        acts, phi, y, ladj = _fused_forward(st, x, plan.shapes[-1][0], uni=(uni[1], uni[2]), packed_width=chain.packed.width if chain.fused else 0,
+                                            amax=None if am is None else [am[l] for l in range(n)])  # [x, h_1 ..]
+        ctx.plan, ctx.n, ctx.chain, ctx.uni, ctx.st, ctx.am = plan, n, chain, uni, st, am
         ctx.save_for_backward(x, *acts, phi, stream)
         return y, ladj
 
@@ -648,8 +661,10 @@ class AutoregressiveFn(torch.autograd.Function):
         N, D = x.shape[0], ctx.st.plan.features
         gy = torch.zeros((N, D), dtype=torch.float32, device=x.device) if gy is None else gy.contiguous()
         gl = torch.zeros(N, dtype=torch.float32, device=x.device) if gl is None else gl.contiguous()
+        am = ctx.am
         if chain.fused:
-            gphi, gs, gx = chain.run_backward(plan, stream, ctx.st, ctx.uni, x, phi, gy, gl, hs)
+            gphi, gs, gx = chain.run_backward(plan, stream, ctx.st, ctx.uni, x, phi, gy, gl, hs,
+                                              amax=None if am is None else {"g": [am[n + l] for l in range(n - 1)], "gphi": am[2 * n - 1]})
         else:
             xf = x if x.shape[1] == D else x[:, :D].contiguous()
             gxf, gphi = _adj_any((kind, bound, slope, sizes, ()), xf, phi.view(N, D, -1), gy, gl, True)
@@ -660,7 +675,8 @@ class AutoregressiveFn(torch.autograd.Function):
                 gx = torch.zeros_like(x)
                 gx[:, :D] = gxf
             gs, gx = chain.run(plan, stream, gphi, hs, gx_add=gx)
-        res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else gphi, hs[l]) for l in range(n)], packed_last=chain.packed if chain.fused else None)
+        res = plan.wgrad_multi([(l, gs[l] if l + 1 < n else gphi, hs[l]) for l in range(n)], packed_last=chain.packed if chain.fused else None,
+                               amax=None if (am is None or not chain.fused) else {l: (am[n + l] if l + 1 < n else am[2 * n - 1], am[l]) for l in range(n)})
         grads = []
         for l in range(n):
             grads += list(res[l])
