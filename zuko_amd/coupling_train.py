@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from functools import partial
 
 import torch
@@ -183,22 +184,17 @@ class CouplingFn(torch.autograd.Function):
         return (None, None, None, None, gx, gc, *grads)
 
 
-_STATE: "weakref.WeakKeyDictionary" = None  # lazy -> {key: (verdict, plan, params, slope)}
+_STATE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()  # lazy -> {"key": .., "value": (plan, params, slope, activation code) or None}
 
 
 def _static_verdict(lazy, device, n_ctx: int):
     """(plan, params, slope) when `lazy` is covered on `device` with n_ctx context columns, else None.  Cached per module and per what the verdict
     depends on (parameter identities / requires_grad flags / mask version): the checks walk the conditioner, and a training step calls this once
     per transform."""
-    import weakref
-
     from . import train
     from .nn import Linear, _act_code
     from .transforms import MonotonicAffineTransform
 
-    global _STATE
-    if _STATE is None:
-        _STATE = weakref.WeakKeyDictionary()
     mods = list(lazy.hyper)
     lins = mods[0::2]
     key = (str(device), n_ctx, lazy.mask._version, lazy.mask.data_ptr(), id(lazy.univariate), len(mods),

@@ -12,13 +12,15 @@
 //   atomicMax): a GEMM reads the maxima of its operands and — optionally — leaves the maximum of its own output for its consumer, so a
 //   chain of layers needs no host synchronisation.
 //
-// Layout: 128 rows x 128 out units per workgroup (4 wavefronts: 2 x 2 of 64 x 64 = 4 x 4 MFMA tiles each), K in steps of 32.
+// Layout: workgroup tile (64 WM) x (64 WN) out of WM x WN wavefronts of 64 rows x 64 units (4 x 4 MFMA tiles) each — (2, 4), (2, 2) or (1, 2), the widest that
+// still gives every CU a workgroup (a 256-wide tile converts every activation once per 256 outputs) — K in steps of 32.
 //   * the weights come PRE-SPLIT (zk_wsplit_f16, once per optimiser step) as the 1 KiB lane images the matrix instruction reads
-//     ([n tile][k step][16-unit tile][h | l][lane][8 halves]) and are moved global -> LDS by `global_load_lds_dwordx4`, no VGPR round trip;
-//   * the activations are read as f32 (32 contiguous bytes per lane), scaled + split in registers, and stored as the same kind of image;
-//     image slot of (row j, k-quarter kq) = 4 j + (kq ^ ((-(j >> 2)) & 3)): the 8 lanes of a ds_write_b128 group cover 128 contiguous bytes
-//     and the 16 lanes of every ds_read_b128 group 16 distinct slots of the 256-byte bank row (MI355X_MICROARCH.md, LDS table);
-//   * double-buffered LDS (2 x 32 KiB), one barrier per k step, two workgroups per CU (the second hides the first's staging).
+//     ([128-unit tile][k step][16-unit tile][h | l][lane][8 halves]) and are moved global -> LDS by `global_load_lds_dwordx4`, no VGPR round trip;
+//   * the f32 activation tile travels global -> LDS by the same DMA as it is (three slots, requested three steps ahead), is read back with ordinary LDS
+//     loads, scaled + split in registers and stored as the same kind of image (raw ds_write_b64) while the step before it is multiplied;
+//     image slot of (row j, k-quarter kq) = 4 j + (kq ^ ((-(j >> 2)) & 3)): the 16 lanes of a ds_write_b64 group cover 128 contiguous bytes
+//     and the 16 lanes of every ds_read_b128 group 16 distinct slots of the 256-byte bank row (MI355X_MICROARCH.md, LDS table; counters: 0 conflicts);
+//   * one barrier per k step.  Why everything in flight is a DMA, what the counters and removal probes say: DESIGN.md 3.7, profiles/r06/.
 //   Lane (j = lane & 15, q = lane >> 4) of an accumulator tile owns out units 4 q .. 4 q + 3 of row j: 16-byte stores.
 #include "zk_common.h"
 #include "zk_half.h"
