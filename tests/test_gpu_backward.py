@@ -557,3 +557,41 @@ def test_weight_gradients_on_two_part_operands_equal_the_three_part_ones(dev, na
     assert worst < 2e-6, worst
     assert any(not torch.equal(a, b) for a, b in zip(half, three)), "the switch changed nothing: the two-part mode did not run"
     print(f"{name}: two-part vs three-part weight gradients, worst tensor {worst:.2e} of max |grad|")
+
+
+@pytest.mark.parametrize("which", ["sos", "bern_bounded", "bern_unbounded"])
+def test_hand_written_polynomial_adjoints_equal_the_dual_number_kernels(dev, which, monkeypatch):
+    """Round 6: zk_sos_backward / zk_bernstein_backward are reverse-mode adjoints written out (7 ms -> sub-millisecond per SOSPF layer, 38 ms -> ~1 ms per BPF
+    layer at 2^16 x 64 elements); the forward-mode dual-number kernels they replace stay in the library (ZUKO_AMD_POLY_ADJOINT=dual) as the yardstick: same inputs, linear
+    tails included, gradients within 2e-5 of the largest one (the dual kernels differentiate the float32 forward, rounding included)."""
+    from zuko_amd import ops
+
+    gen = torch.Generator().manual_seed(41)
+    N, D = 4096, 8
+    gy, gl = torch.randn(N, D, generator=gen).to(dev), torch.randn(N, generator=gen).to(dev)
+
+    def run():
+        if which == "sos":
+            a = (torch.randn(N, D, 3, 5, generator=torch.Generator().manual_seed(1)) * 0.5).to(dev).requires_grad_()
+            c = torch.randn(N, D, generator=torch.Generator().manual_seed(2)).to(dev).requires_grad_()
+            x = (torch.randn(N, D, generator=torch.Generator().manual_seed(3)) * 3).to(dev).requires_grad_()
+            y, l = ops.sos_forward(x, a, c, reduce=True)
+            leaves = (a, c, x)
+        else:
+            bounded = which == "bern_bounded"
+            th = torch.randn(N, D, 17 if bounded else 16, generator=torch.Generator().manual_seed(4)).to(dev).requires_grad_()
+            xv = torch.randn(N, D, generator=torch.Generator().manual_seed(5)) * 2.5
+            xv[0, 0], xv[0, 1], xv[1, 0] = 7.0, -7.0, 4.9999999
+            x = xv.to(dev).requires_grad_()
+            y, l = ops.bernstein_forward(x, th, bounded, reduce=True)
+            leaves = (th, x)
+        ((y * gy).sum() + (l * gl).sum()).backward()
+        return [t.grad.detach().clone() for t in leaves]
+
+    hand = run()
+    monkeypatch.setenv("ZUKO_AMD_POLY_ADJOINT", "dual")
+    dual = run()
+    for h, d in zip(hand, dual):
+        err = ((h - d).abs().max() / d.abs().max()).item()
+        assert err < 2e-5, err
+    assert any(not torch.equal(h, d) for h, d in zip(hand, dual)), "the switch changed nothing"
