@@ -842,6 +842,36 @@ def side_paths_report() -> dict:
             rel = ((res["fused"][1] - res["layer_wise"][1]).abs().max() / res["layer_wise"][1].abs().max()).item()
             entry["log_prob"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) log_prob, batch 2^18", "ms": res["fused"][0] * 1e3, "samples_per_s": Bp / res["fused"][0],
                                  "layer_wise_ms": res["layer_wise"][0] * 1e3, "parity": {"log_prob_max_rel_vs_layer_wise_kernels": rel, "ok": bool(rel < 1e-5)}}
+            # an Adam step at 2^16 rows on a COPY of the flow (round 6: the polynomial maps' adjoints are reverse-mode kernels written out; until then 17-wide
+            # forward-mode duals: SOSPF 27 ms, BPF 118 ms per step).  Gradients: tests/test_gpu_backward.py against float64 autograd and the dual-number kernels.
+            try:
+                import copy
+
+                f2 = copy.deepcopy(flow)
+                o2 = torch.optim.Adam(f2.parameters(), lr=1e-3)
+                xt = 0.8 * torch.randn(1 << 16, 64, device=dev)
+
+                def tstep():
+                    loss = -f2().log_prob(xt).mean()
+                    o2.zero_grad(set_to_none=True)
+                    loss.backward()
+                    o2.step()
+                    return loss
+
+                for _ in range(3):
+                    l0 = tstep()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    l1 = tstep()
+                torch.cuda.synchronize()
+                dtr = (time.perf_counter() - t0) / 5
+                entry["training"] = {"workload": f"{ctor}(64, transforms=3, hidden=[256]*3) Adam step of -log_prob(x).mean(), batch 2^16", "ms_per_step": dtr * 1e3, "samples_per_s": (1 << 16) / dtr,
+                                     "loss_before_after": [float(l0), float(l1)], "one_autograd_node_per_transform": False,
+                                     "parity": {"ok": bool(torch.isfinite(l1).item()), "note": "finite loss only; gradient values: tests/test_gpu_backward.py"}}
+                del f2, o2, xt
+            except Exception as exc:
+                entry["training"] = {"error": repr(exc)[:200]}
             # sampling (round 6): ONE incremental launch per autoregressive layer with the reference's bisection (zuko/transforms.py:608-617) in the kernel's group
             # epilogue — at 2^18, and at 2^14 beside what it replaces: the layer-wise wavefront form (ZUKO_AMD_NO_INCREMENTAL=1: per sweep the hidden layers, the last
             # layer's rows and the bisections of that sweep's feature) and the reference's loop itself (ZUKO_AMD_FULL_SWEEPS=1), which must agree bit for bit
