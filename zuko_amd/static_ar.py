@@ -993,7 +993,7 @@ def prebuild(verbose: bool = True, jobs: int = 4) -> list[str]:
 
         act = _act_code(getattr(torch.nn, entry[5])()) if len(entry) > 5 else 1
         (pa, layout, lins_a), (pd, _, lins_d) = _plans_for(kind, features, context, hidden, bins)
-        if act == 1 and layout.kind not in SPLIT_ONLY_KINDS:  # the training backward of the same conditioners (one kernel per feature order)
+        if act == 1:  # the training backward of the same conditioners (one kernel per feature order; the polynomial flows — SPLIT_ONLY_KINDS — train on the two-node path: chains without the packed variant)
             for lins, pl in ((lins_a, pa), (lins_d, pd)):
                 cands = [chain_tables_for(lins), chain_tables_for(lins, full=True)]
                 if (features + context) % 4 == 0 and layout.kind in (0, 1) and layout.total in (2, 23) and pl is not None:  # what zuko_amd/train.py:autoregressive() covers
