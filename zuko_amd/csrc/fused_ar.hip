@@ -570,9 +570,11 @@ static int ar_launch(const ArPartial& part, bool inverse, int uni_kind, int64_t 
     for (int l = 0; l < 3; ++l) a.act_out[l] = part.act_out[l];
     a.phi_out = part.phi_out; a.ldphi = part.ldphi; a.phi_packed = part.phi_packed;
     if (uni_kind == 5) {  // shifted SOS polynomial, 3 x 5 coefficients (zuko/transforms.py:905-963): MonotonicTransform's bound 10 unless given
-      if (!part.gl_nodes01 || !part.gl_weights01) return ZK_EINVAL;
+      const bool conditioner_only = part.phi_out != nullptr && y == nullptr;  // (training launch without the map: no quadrature needed)
+      if ((!part.gl_nodes01 || !part.gl_weights01) && !conditioner_only) return ZK_EINVAL;
       a.sos.bound = (float)bound; a.sos.slope = (float)slope; a.sos.P = 3; a.sos.L1 = 5;
-      for (int i = 0; i < 5; ++i) { a.sos.node[i] = (float)part.gl_nodes01[i]; a.sos.weight[i] = (float)part.gl_weights01[i]; }
+      if (part.gl_nodes01 && part.gl_weights01)
+        for (int i = 0; i < 5; ++i) { a.sos.node[i] = (float)part.gl_nodes01[i]; a.sos.weight[i] = (float)part.gl_weights01[i]; }
     }
     a.eps = (float)(part.eps > 0.0 ? part.eps : 1e-6);
     for (int l = 0; l < 4; ++l) a.wdescale[l] = (float)part.wdescale[l];

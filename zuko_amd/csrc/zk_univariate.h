@@ -518,27 +518,29 @@ template <typename T> __device__ __forceinline__ T zk_ipow(T w, int n) {  // w^n
 // at no cost.)
 template <typename T, int NC> __device__ __forceinline__ void bern_eval(const T (&th)[NC], T u, T& val, T& dval) {
   constexpr int M = NC - 1;
-  T b[NC], d[M];
+  const T v = T(1) - u;
+  // the derivative first, straight from theta (no array of differences: with one the fused Bernstein layer spilled 30 registers, and a spilled
+  // accumulator of the matrix instruction came back wrong in 1 launch of 8 — tests/test_gpu_flows.py::test_polynomial_flows_run_on_a_fused_split_kernel)
+  {
+    const T sr = u / v, rr = v / u;
+    T hA = (th[M] - th[M - 1]) * T(zk_binom(M - 1, M - 1)), hB = (th[1] - th[0]) * T(zk_binom(M - 1, 0));
+#pragma unroll
+    for (int i = 1; i < M; ++i) {
+      hA = hA * sr + (th[M - i] - th[M - 1 - i]) * T(zk_binom(M - 1, M - 1 - i));
+      hB = hB * rr + (th[i + 1] - th[i]) * T(zk_binom(M - 1, i));
+    }
+    const bool low = u <= T(0.5);
+    dval = T(M) * ((low ? hA : hB) * zk_ipow<T>(low ? v : u, M - 1));
+  }
+  T b[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) b[i] = th[i];
-#pragma unroll
-  for (int i = 0; i < M; ++i) d[i] = (th[i + 1] - th[i]) * T(zk_binom(M - 1, i));
-  const T v = T(1) - u;
 #pragma unroll
   for (int r = 1; r < NC - 1; ++r) {
 #pragma unroll
     for (int i = 0; i < NC - r; ++i) b[i] = v * b[i] + u * b[i + 1];
   }
   val = v * b[0] + u * b[1];
-  const T sr = u / v, rr = v / u;
-  T hA = d[M - 1], hB = d[0];
-#pragma unroll
-  for (int i = 1; i < M; ++i) {
-    hA = hA * sr + d[M - 1 - i];
-    hB = hB * rr + d[i];
-  }
-  const bool low = u <= T(0.5);
-  dval = T(M) * ((low ? hA : hB) * zk_ipow<T>(low ? v : u, M - 1));
 }
 
 template <typename T> struct BernTails { T off0, off1, slp0, slp1; };

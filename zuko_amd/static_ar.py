@@ -222,7 +222,7 @@ def tables(plan, uni_kind: int, act: int = 1) -> dict | None:
         "uni": int(uni_kind), "ACT": int(act), "D": int(D), "DIN": int(din4), "NIT": int(NIT), "NH": int(NH), "HT": HT, "TMAX": int(TMAX), "NG": int(plan.n_groups),
         "NCHUNK": int(plan.fine_n_chunks), "BIAS_STRIDE": int(plan.max_width), "NS": NS, "S_OTG": S_OTG, "S_IT": S_IT, "S_MASK": S_MASK,
         "BASE": [int(b) for b in plan.fine_layer_block0[:NH]], "LAST_BASE": int(plan.fine_layer_block0[NH]), "GOFF": GOFF, "G_IT": G_IT,
-        "WAVES": waves, "XLDS": xlds, "TRAIN_OK": int(act == 1 and NH <= 3 and waves == 8 and all(w % 16 == 0 for w in widths) and uni_kind not in SPLIT_ONLY_KINDS),
+        "WAVES": waves, "XLDS": xlds, "TRAIN_OK": int(act == 1 and NH <= 3 and waves == 8 and all(w % 16 == 0 for w in widths) and uni_kind != 3),  # (kinds 5, 6 — split kernels only: the conditioner-only training forward of SOSPF / BPF)
     }
 
 

@@ -309,11 +309,12 @@ def _fused_forward_state(plan: "SortedPlan", lins, device, rows: int = 0, featur
             din = shapes[0][1]
             if features is None:
                 # (not told: no context — the conditioner's inputs are the features; affine head = 2, 8-bin spline head = 23 parameters per feature)
-                total = {2 * din: 2, 23 * din: 23}.get(shapes[-1][0], 0)
+                # (also the polynomial heads, round 6: 16 = shifted SOS, 17 = bounded Bernstein — their conditioner-only forward, the maps keep their own autograd node)
+                total = {2 * din: 2, 23 * din: 23, 16 * din: 16, 17 * din: 17}.get(shapes[-1][0], 0)
                 features = din
-            elif total not in (2, 23) or features * total != shapes[-1][0] or features > din:
+            elif total not in (2, 23, 16, 17) or features * total != shapes[-1][0] or features > din:
                 total = 0
-            layout = fused.uni_layout("affine", 2) if total == 2 else fused.uni_layout("rqs", 23, 8)
+            layout = {2: fused.uni_layout("affine", 2), 23: fused.uni_layout("rqs", 23, 8), 16: fused.uni_layout("sos", 16), 17: fused.uni_layout("bern", 17)}.get(total) or fused.uni_layout("affine", 2)
             ok = (total and 2 <= len(lins) <= 4 and plan.act == 1 and din % 4 == 0
                   and all(getattr(l, "mask", None) is not None for l in lins) and all(s[0] % 16 == 0 and s[0] <= fused.MAX_WIDTH for s in shapes[:-1]))
             if ok:
